@@ -1,0 +1,223 @@
+"""Pin the CPU oracle against fixtures generated from the imported reference
+(tests/golden/make_golden.py).  CPU-only; this is what makes oracle-vs-HIP parity meaningful."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gssd_oracle as O
+from gssd import synth
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_priors_bit_exact(golden):
+    g = golden('priors')
+    p = O.prior_box(O.V2)
+    assert p.shape == (8732, 4) and p.dtype == np.float32
+    assert np.array_equal(p, g['v2'])
+    assert hashlib.sha256(p.tobytes()).hexdigest().startswith('a962243ddb360b31')
+    p512 = O.prior_box(O.V2_512)
+    assert p512.shape == (24564, 4)
+    assert sha(p512) == g['v2_512_sha'].tobytes()
+    assert np.array_equal(p512[g['v2_512_sample_idx']], g['v2_512_sample'])
+
+
+def test_match_indices_bit_exact(golden):
+    g = golden('match')
+    pri = O.prior_box()
+    for i in range(int(g['n'])):
+        t = g[f't{i}']
+        loc, conf, _ = O.match(0.5, t[:, :-1], pri, (0.1, 0.2), t[:, -1])
+        assert np.array_equal(conf.astype(np.int8), g[f'conf{i}']), f'case {i}'
+        pos = conf > 0
+        ref = g[f'locpos{i}']
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(loc[pos]), fin)
+        # log() may differ in the last ulp between torch (SLEEF) and numpy
+        assert np.allclose(loc[pos][fin], ref[fin], rtol=2e-6, atol=2e-6), f'case {i}'
+    # SURVEY.md 8(c) known answers
+    loc, conf, _ = O.match(0.5, g['t0'][:, :-1], pri, (0.1, 0.2), g['t0'][:, -1])
+    assert np.nonzero(conf)[0].tolist() == [6257, 6263, 6371, 6377, 6485, 6491, 8068, 8069, 8074, 8075, 8077,
+                                             8134, 8137]
+    assert np.allclose(loc[6257], [0.36760753, 2.2056446, 0.48936203, 1.927772], rtol=1e-6)
+
+
+def test_multibox_loss(golden):
+    g = golden('loss')
+    m = golden('match')
+    pri = O.prior_box()
+    P = pri.shape[0]
+    ll, lc = O.multibox_loss(np.zeros((2, P, 4), np.float32), np.zeros((2, P, 2), np.float32), pri,
+                             [m['t0'], m['t1']])
+    assert abs(ll - g['zero_loss'][0]) < 1e-6 and abs(lc - g['zero_loss'][1]) < 1e-6
+    assert abs(lc - 4 * np.log(2)) < 1e-6
+    for ci in range(3):
+        rng = np.random.default_rng(int(g[f'seed{ci}']))
+        loc = rng.normal(0, 1.0, size=(4, P, 4)).astype(np.float32)
+        conf = rng.normal(0, 2.0, size=(4, P, 2)).astype(np.float32)
+        tg = [g[f'tg{ci}_{b}'] for b in range(4)]
+        ll, lc, d = O.multibox_loss(loc, conf, pri, tg, details=True)
+        assert rel(ll, g[f'loss{ci}'][0]) < 1e-5 and rel(lc, g[f'loss{ci}'][1]) < 1e-5
+        assert np.array_equal(np.packbits(d['pos']), g[f'pos{ci}'])
+        neg_ref = np.unpackbits(g[f'neg{ci}'])[:4 * P].reshape(4, P).astype(bool)
+        # mining ranks are integer work: identical unless two losses tie to the last ulp at the cut
+        assert (d['neg'] != neg_ref).sum() <= 2
+        assert d['neg'].sum() == neg_ref.sum()
+
+
+def test_detect_and_nms(golden):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from make_golden import closed_form_detect_inputs
+    g = golden('detect')
+    pri = O.prior_box()
+    loc, logit = closed_form_detect_inputs(pri.shape[0], 2)
+    # Detect's contract takes the already-softmaxed scores (detection_pytorch_ver_1point5.py:33): same inputs
+    out, keeps = O.detect(2, 0, 200, 0.01, 0.45, loc, g['conf_sm'], pri, return_keep=True)
+    assert np.array_equal(keeps[(0, 1)], g['keep0']) and np.array_equal(keeps[(1, 1)], g['keep1'])   # bit-exact
+    assert keeps[(0, 1)].shape[0] == 190
+    assert np.allclose(out, g['out'], rtol=0, atol=2e-6)
+    assert np.all(out[:, 0] == 0)
+    rng = np.random.default_rng(5)
+    loc_r = rng.normal(0, 0.5, size=(2, pri.shape[0], 4)).astype(np.float32)
+    rng.normal(0, 1.5, size=(2, pri.shape[0], 2))
+    out_r = O.detect(2, 0, 200, 0.01, 0.45, loc_r, g['conf_sm_rand'], pri)
+    assert np.abs(O.softmax_scores(logit) - g['conf_sm']).max() <= 1.2e-7      # K15: 1 ulp vs torch
+    assert np.array_equal(out_r[..., 0] > 0, g['out_rand'][..., 0] > 0)
+    assert np.allclose(out_r, g['out_rand'], rtol=0, atol=3e-6)
+    with pytest.raises(ValueError):
+        O.detect(2, 0, 200, 0.01, 0.0, loc, logit, pri)
+
+
+def test_small_ops(golden):
+    g = golden('ops')
+    y = O.l2norm(torch.from_numpy(g['l2_x']), torch.from_numpy(g['l2_w'])).numpy()
+    assert rel(y, g['l2_y']) < 1e-6
+    from torch import nn
+    shapes = {}
+    C = 64
+    for n, (co, ci) in dict(theta=(C // 8, C), phi=(C // 8, C), g=(C // 2, C), attn=(C, C // 2)).items():
+        p = f'snconv1x1_{n}'
+        shapes[p + '.bias'] = (co,)
+        shapes[p + '.weight_orig'] = (co, ci, 1, 1)
+        shapes[p + '.weight_u'] = (co,)
+        shapes[p + '.weight_v'] = (ci,)
+    shapes['sigma'] = (1,)
+    for mode in ('eval', 'train'):
+        sd = {'sa.' + k: v for k, v in synth.synth_state_dict(shapes, seed=21).items()}
+        upd = {}
+        out, ag, attn = O.self_attn(torch.from_numpy(g[f'sa_{mode}_x']), sd, 'sa', mode == 'train', 1, upd)
+        assert rel(out.numpy(), g[f'sa_{mode}_out']) < 1e-5
+        assert rel(ag.numpy(), g[f'sa_{mode}_ag']) < 1e-5
+        assert rel(attn.numpy(), g[f'sa_{mode}_attn']) < 1e-5
+        if mode == 'train':
+            for k, v in upd.items():
+                assert rel(v.numpy(), g['sa_train_after.' + k[3:]]) < 1e-5
+
+
+def test_dcn_known_answers():
+    """DCN parity is unpinned (no reference arithmetic in-tree); these are the identities the
+    reference's own wrapper guarantees (dcn_v2_custom.py:75-77 zero-init)."""
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.normal(size=(2, 16, 9, 9)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(size=(8, 16, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(8,)).astype(np.float32))
+    dg = 4
+    off = torch.zeros(2, dg * 18, 9, 9)
+    mask = torch.full((2, dg * 9, 9, 9), 0.5)
+    y = O.dcn_v2_conv(x, off, mask, w, b, 1, 1, 1, dg)
+    ref = 0.5 * torch.nn.functional.conv2d(x, w, None, 1, 1) + b.view(1, -1, 1, 1)
+    assert rel(y.numpy(), ref.numpy()) < 1e-5
+    # integer offset (+1 row, -1 col on every tap) == conv over the shifted, zero-padded map
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = -1.0
+    y = O.dcn_v2_conv(x, off, torch.ones_like(mask), w, b, 1, 1, 1, dg)
+    xs = torch.zeros_like(x)
+    xs[:, :, :-1, 1:] = x[:, :, 1:, :-1]
+    ref = torch.nn.functional.conv2d(xs, w, b, 1, 1)
+    # border taps differ (the shifted map loses one row/col of real data): compare the interior
+    assert rel(y[:, :, 2:-2, 2:-2].numpy(), ref[:, :, 2:-2, 2:-2].numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('name,flags', [
+    ('gssd', dict()),
+    ('gssd_sa', dict(use_self_attention=True, use_self_attention_base=True)),
+    ('gssdpp', dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                    dcn_cat_sab=True)),
+])
+def test_end_to_end_vs_reference(golden, name, flags):
+    g = golden('e2e')
+    keys = [str(k) for k in g[f'{name}.keys']]
+    shapes = {k: eval(s) for k, s in zip(keys, g[f'{name}.shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    x = synth.synth_images(2, seed=5)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        loc, conf, upd = O.gssd_forward(sd, x, **flags)
+    assert loc.shape == (2, 8732, 4) and conf.shape == (2, 8732, 2)
+    l, c = loc.numpy().reshape(-1), conf.numpy().reshape(-1)
+    assert np.abs(l[g[f'{name}.loc_idx']] - g[f'{name}.loc_val']).max() / g[f'{name}.loc_absmax'] < 1e-5
+    assert np.abs(c[g[f'{name}.conf_idx']] - g[f'{name}.conf_val']).max() / g[f'{name}.conf_absmax'] < 1e-5
+    ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), O.prior_box(), [t.numpy() for t in synth.synth_targets(2, 5)])
+    assert rel(ll, g[f'{name}.loss'][0]) < 1e-4 and rel(lc, g[f'{name}.loss'][1]) < 1e-4
+    for k in ('vgg.1.running_mean', 'vgg.1.running_var', 'bn_fuse_11.running_mean', 'extras.15.running_var'):
+        assert rel(upd[k].numpy(), g[f'{name}.after.{k}']) < 1e-5, k
+    if name != 'gssd':
+        k = 'self_attn_list.0.snconv1x1_theta.weight_u'
+        assert rel(upd[k].numpy(), g[f'{name}.after.{k}']) < 1e-5
+    # test phase twin: eval-mode forward with the post-step state, then Detect
+    sd2 = dict(sd)
+    sd2.update(upd)
+    # the reference's state after the train forward carries ALL running stats; rebuild them
+    with torch.no_grad():
+        loc_e, conf_e, _ = O.gssd_forward(sd2_full(sd, x, flags), x, training=False, **flags)
+    det = O.detect(2, 0, 200, 0.01, 0.45, loc_e.numpy(), O.softmax_scores(conf_e.numpy()), O.prior_box())
+    assert np.array_equal(det[..., 0] > 0, g[f'{name}.det'][..., 0] > 0)
+    # scores saturate near 1.0 -> exact fp32 ties, whose visiting order in the reference is an accident of
+    # torch's unstable sort: compare the rows as a set (canonical order), values to 2e-5
+    assert np.allclose(canon_rows(det), canon_rows(g[f'{name}.det']), rtol=0, atol=2e-5)
+
+
+def canon_rows(det):
+    out = det.copy()
+    for b in range(det.shape[0]):
+        for c in range(det.shape[1]):
+            r = det[b, c]
+            key = np.lexsort((np.round(r[:, 2], 4), np.round(r[:, 1], 4), -np.round(r[:, 0], 5)))
+            out[b, c] = r[key]
+    return out
+
+
+def sd2_full(sd, x, flags):
+    with torch.no_grad():
+        _, _, upd = O.gssd_forward(sd, x, **flags)
+    out = dict(sd)
+    out.update(upd)
+    return out
+
+
+def test_vanilla_ssd_config0(golden):
+    """BASELINE.json configs[0]: vanilla VGG-SSD300, 1 phase, batch 2, CPU forward + MultiBoxLoss."""
+    g = golden('e2e')
+    keys = [str(k) for k in g['ssd.keys']]
+    shapes = {k: eval(s) for k, s in zip(keys, g['ssd.shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    x = synth.synth_images(2, seed=6, channels=3)
+    with torch.no_grad():
+        loc, conf = O.vanilla_ssd_forward(sd, x)
+    l, c = loc.numpy().reshape(-1), conf.numpy().reshape(-1)
+    assert rel(l[g['ssd.loc_idx']], g['ssd.loc_val']) < 1e-5
+    assert rel(c[g['ssd.conf_idx']], g['ssd.conf_val']) < 1e-5
+    ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), O.prior_box(), [t.numpy() for t in synth.synth_targets(2, 5)])
+    assert rel(ll, g['ssd.loss'][0]) < 1e-5 and rel(lc, g['ssd.loss'][1]) < 1e-5
+    assert bool(g['ssd.grad_finite'])
