@@ -1,0 +1,93 @@
+"""ctypes binding of libgssd_hip.so (the C ABI declared in include/gssd_hip.h).
+
+The library is built in-tree by ``make -C grouped-ssd-pytorch_amd/gssd/csrc`` (or
+``__graft_entry__.build()``).  There is NO fallback: if the shared object is missing or does
+not export every symbol of the header, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libgssd_hip.so')
+
+c_fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+c_i = C.c_int
+c_f = C.c_float
+c_d = C.c_double
+c_i64 = C.c_int64
+
+
+class ConvDesc(C.Structure):
+    """struct gssd_conv_desc (include/gssd_hip.h)."""
+    _fields_ = [
+        ('in_', c_fp), ('wgt', c_fp), ('bias', c_fp), ('out', c_fp), ('out_b', c_fp), ('alpha', c_fp),
+        ('gate', c_fp), ('resid', c_fp), ('out2', c_fp), ('stats', c_fp),
+        ('B', c_i), ('H', c_i), ('W', c_i), ('in_stride', c_i), ('in_ch_off', c_i), ('Ho', c_i), ('Wo', c_i),
+        ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
+        ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
+        ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i),
+        ('in_batch_stride', c_i64), ('wgt_batch_stride', c_i64), ('out_batch_stride', c_i64),
+        ('outb_batch_stride', c_i64), ('out_off', c_i64), ('outb_off', c_i64),
+    ]
+
+
+class SnItem(C.Structure):
+    """struct gssd_sn_item."""
+    _fields_ = [('w', c_fp), ('u', c_fp), ('v', c_fp), ('inv_sigma', c_fp), ('rows', c_i), ('cols', c_i)]
+
+
+OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS = 0, 1, 2
+
+# name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
+SIGNATURES = {
+    'gssd_abi_version': (c_i, []),
+    'gssd_last_error': (C.c_char_p, []),
+    'gssd_build_arch': (C.c_char_p, []),
+    'gssd_pack_input_nhwc': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_unpack_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_pack_conv_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_conv2d_nhwc_f32': (c_i, [C.POINTER(ConvDesc), c_fp]),
+    'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
+                                    c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
+    'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
+    'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
+    'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
+    'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),
+    'gssd_dcn_im2col_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
+    'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_fp]),
+    'gssd_hnm_loss': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_loss_finalize': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp]),
+    'gssd_loss_backward': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    'gssd_detect': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_softmax_lastdim_f32': (c_i, [c_fp, c_fp, c_i64, c_i, c_fp]),
+}
+
+
+class GssdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise GssdError(
+            f'{LIB_PATH} is missing: the HIP kernels are not built.  Run `make -C '
+            f'{os.path.join(_HERE, "csrc")}` (needs hipcc, --offload-arch=gfx950) or '
+            f'`python -c "import __graft_entry__ as g; g.build()"`.  There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GssdError(f'{LIB_PATH} does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise GssdError(f'libgssd_hip: error {rc}: {lib.gssd_last_error().decode()}')

@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of libgssd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "gssd_hip.h"
+
+void gssd_set_error(const char* fmt, ...);
+
+#define GSSD_CHECK_ARG(cond)                                                          \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            gssd_set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond); \
+            return GSSD_EINVAL;                                                       \
+        }                                                                             \
+    } while (0)
+
+#define GSSD_CHECK_LAUNCH()                                                                     \
+    do {                                                                                        \
+        hipError_t e__ = hipGetLastError();                                                     \
+        if (e__ != hipSuccess) {                                                                \
+            gssd_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return GSSD_ELAUNCH;                                                                \
+        }                                                                                       \
+    } while (0)
+
+static inline hipStream_t as_stream(gssd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// 64-lane wavefront reductions (gfx950: wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,387 @@
+// MultiBoxLoss on gfx950: batched prior matching, hard-negative mining and the two loss sums.
+// Compiled with -ffp-contract=off: the IoU / encode arithmetic must round exactly like the
+// reference's separate fp32 torch ops (layers/box_utils.py:28-67,114-135) so that every integer
+// output (conf_t, positive / negative masks) is bit-identical.
+//
+//   gssd_match_batch : one 256-thread workgroup per image (box_utils.py:70-111)
+//   gssd_hnm_loss    : one workgroup per image; mining scores live in LDS, the per-row
+//                      "rank < num_neg" of the reference's double sort (multibox_loss.py:101-106) is an
+//                      8-bit x 4-pass radix select of the num_neg-th largest score, ties by lower index
+//   gssd_loss_finalize / gssd_loss_backward
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_GT = 64;
+constexpr int LT = 256;
+
+__device__ __forceinline__ float iou_pf(float ax1, float ay1, float ax2, float ay2, float area_a, float bx1, float by1,
+                                        float bx2, float by2) {
+    // intersect(): clamp(min(max_xy) - max(min_xy), 0) ; jaccard(): inter / (area_a + area_b - inter)
+    const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f);
+    const float h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+    const float inter = w * h;
+    const float area_b = (bx2 - bx1) * (by2 - by1);
+    const float uni = (area_a + area_b) - inter;
+    return __fdiv_rn(inter, uni);
+}
+
+__global__ __launch_bounds__(LT) void match_kernel(const float* __restrict__ targets, const int* __restrict__ gt_off,
+                                                   const float* __restrict__ priors, int P, float thr,
+                                                   float var0, float var1, float* __restrict__ loc_t,
+                                                   int64_t* __restrict__ conf_t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    __shared__ float gt[MAX_GT][5];
+    __shared__ float gt_area[MAX_GT];
+    __shared__ int best_prior[MAX_GT];
+    __shared__ float red_v[LT / 64];
+    __shared__ int red_i[LT / 64];
+    short* forced = reinterpret_cast<short*>(smraw);  // [P]: gt index forced onto this prior, -1 none
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g0 = gt_off[b];
+    int n = gt_off[b + 1] - g0;
+    if (n > MAX_GT) n = MAX_GT;
+    if (tid < 5) gt[0][tid] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < n * 5; i += LT) gt[i / 5][i % 5] = targets[(size_t)g0 * 5 + i];
+    for (int p = tid; p < P; p += LT) forced[p] = -1;
+    __syncthreads();
+    if (tid < n) gt_area[tid] = (gt[tid][2] - gt[tid][0]) * (gt[tid][3] - gt[tid][1]);
+    __syncthreads();
+
+    // best prior for each ground truth (overlaps.max(1)): max value, lowest index on ties
+    for (int j = 0; j < n; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        bool any_nan = false;
+        for (int p = tid; p < P; p += LT) {
+            const float4 pr = reinterpret_cast<const float4*>(priors)[p];
+            const float hx = pr.z / 2.f, hy = pr.w / 2.f;
+            const float v = iou_pf(gt[j][0], gt[j][1], gt[j][2], gt[j][3], gt_area[j], pr.x - hx, pr.y - hy, pr.x + hx,
+                                   pr.y + hy);
+            if (v > bv) {
+                bv = v;
+                bi = p;
+            }
+        }
+        (void)any_nan;
+        // wave then block reduce on (value desc, index asc)
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            red_v[tid >> 6] = bv;
+            red_i[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < LT / 64; ++w)
+                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) {
+                    bv = red_v[w];
+                    bi = red_i[w];
+                }
+            best_prior[j] = (bi == 0x7fffffff) ? 0 : bi;
+        }
+        __syncthreads();
+    }
+    // "for j: best_truth_idx[best_prior_idx[j]] = j" -- sequential, later ground truth wins
+    if (tid == 0)
+        for (int j = 0; j < n; ++j) forced[best_prior[j]] = (short)j;
+    __syncthreads();
+
+    for (int p = tid; p < P; p += LT) {
+        const float4 pr = reinterpret_cast<const float4*>(priors)[p];
+        const float hx = pr.z / 2.f, hy = pr.w / 2.f;
+        const float px1 = pr.x - hx, py1 = pr.y - hy, px2 = pr.x + hx, py2 = pr.y + hy;
+        float bv = -INFINITY;
+        int bj = 0;
+        for (int j = 0; j < n; ++j) {
+            const float v = iou_pf(gt[j][0], gt[j][1], gt[j][2], gt[j][3], gt_area[j], px1, py1, px2, py2);
+            if (v > bv) {   // overlaps.max(0): first maximum wins
+                bv = v;
+                bj = j;
+            }
+        }
+        const int f = forced[p];
+        if (f >= 0) {       // index_fill_(0, best_prior_idx, 2)
+            bv = 2.f;
+            bj = f;
+        }
+        int64_t conf = (int64_t)(gt[bj][4] + 1.f);
+        if (bv < thr) conf = 0;
+        conf_t[(size_t)b * P + p] = conf;
+        // encode(): ((g_min + g_max)/2 - p_c) / (var0 * p_wh) ; log((g_max - g_min) / p_wh) / var1
+        const float gx1 = gt[bj][0], gy1 = gt[bj][1], gx2 = gt[bj][2], gy2 = gt[bj][3];
+        float4 o;
+        o.x = __fdiv_rn(((gx1 + gx2) / 2.f) - pr.x, var0 * pr.z);
+        o.y = __fdiv_rn(((gy1 + gy2) / 2.f) - pr.y, var0 * pr.w);
+        o.z = __fdiv_rn((float)log((double)__fdiv_rn(gx2 - gx1, pr.z)), var1);
+        o.w = __fdiv_rn((float)log((double)__fdiv_rn(gy2 - gy1, pr.w)), var1);
+        reinterpret_cast<float4*>(loc_t)[(size_t)b * P + p] = o;
+    }
+}
+
+// k-th largest (1-based) of n non-negative floats in LDS via 4 x 8-bit radix passes on the bit pattern.
+// Returns the value's bits; *n_greater = how many are strictly greater.
+__device__ unsigned radix_select_desc(const float* vals, int n, int k, unsigned* hist /*[256]*/, int* bcast /*[2]*/,
+                                      int* n_greater) {
+    unsigned prefix = 0, mask = 0;
+    int greater = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned u = __float_as_uint(vals[i]);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = greater, bin = 255;
+            for (; bin > 0; --bin) {
+                if (acc + (int)hist[bin] >= k) break;
+                acc += (int)hist[bin];
+            }
+            bcast[0] = bin;
+            bcast[1] = acc;
+        }
+        __syncthreads();
+        prefix |= ((unsigned)bcast[0]) << shift;
+        mask |= 255u << shift;
+        greater = bcast[1];
+        __syncthreads();
+    }
+    *n_greater = greater;
+    return prefix;
+}
+
+__global__ __launch_bounds__(LT) void hnm_loss_kernel(const float* __restrict__ loc, const float* __restrict__ conf,
+                                                      const float* __restrict__ loc_t,
+                                                      const int64_t* __restrict__ conf_t,
+                                                      const float* __restrict__ xmax_p, int P, int C, int negpos_ratio,
+                                                      uint8_t* __restrict__ sel, double* __restrict__ partial,
+                                                      float* __restrict__ lca_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* lca = reinterpret_cast<float*>(smraw);  // [P]
+    __shared__ unsigned hist[256];
+    __shared__ int bcast[2];
+    __shared__ int s_cnt[LT / 64];
+    __shared__ double s_red[LT / 64][2];
+    __shared__ int s_tie_base;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float xmax = *xmax_p;
+    const float* cb = conf + (size_t)b * P * C;
+    const int64_t* tb = conf_t + (size_t)b * P;
+
+    // loss_c = log_sum_exp(conf) - conf[target], positives zeroed (multibox_loss.py:93-98)
+    int npos = 0;
+    for (int p = tid; p < P; p += LT) {
+        const int t = (int)tb[p];
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += (float)exp((double)(cb[(size_t)p * C + c] - xmax));
+        float v = ((float)log((double)s) + xmax) - cb[(size_t)p * C + t];
+        if (t > 0) {
+            v = 0.f;
+            ++npos;
+        }
+        if (!(v > 0.f)) v = 0.f;   // -0 / tiny negative rounding -> +0 keeps the uint ordering monotone
+        lca[p] = v;
+    }
+    npos = wave_sum(npos);
+    if (lane == 0) s_cnt[wave] = npos;
+    __syncthreads();
+    npos = 0;
+    for (int w = 0; w < LT / 64; ++w) npos += s_cnt[w];
+    int num_neg = negpos_ratio * npos;
+    if (num_neg > P - 1) num_neg = P - 1;
+    if (lca_out)
+        for (int p = tid; p < P; p += LT) lca_out[(size_t)b * P + p] = lca[p];
+
+    unsigned kth_bits = 0xffffffffu;
+    int n_greater = 0;
+    if (num_neg > 0) kth_bits = radix_select_desc(lca, P, num_neg, hist, bcast, &n_greater);
+    const int ties_needed = num_neg - n_greater;   // how many values == kth to take, lowest index first
+
+    // neg = rank < num_neg ; stable descending order => among equal scores the lower index ranks first
+    double sum_l = 0.0, sum_c = 0.0;
+    if (tid == 0) s_tie_base = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < P; p0 += LT) {
+        const int p = p0 + tid;
+        bool is_tie = false, take = false, pos = false;
+        if (p < P) {
+            const unsigned u = __float_as_uint(lca[p]);
+            pos = tb[p] > 0;
+            if (num_neg > 0) {
+                if (u > kth_bits) take = true;
+                else if (u == kth_bits) is_tie = true;
+            }
+        }
+        // ordered compaction of ties across the block (index order)
+        const unsigned long long bal = __ballot(is_tie);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int base = s_tie_base;
+        for (int w = 0; w < wave; ++w) base += s_cnt[w];
+        if (is_tie && base + before < ties_needed) take = true;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < LT / 64; ++w) t += s_cnt[w];
+            s_tie_base += t;
+        }
+        if (p < P) {
+            // a positive can never be mined: its score is 0 and ranks after every positive-loss prior; if the
+            // cut reaches the zeros the reference would mark it too (rank < num_neg) -- keep that behaviour
+            const uint8_t code = pos ? 1 : (take ? 2 : 0);
+            const bool neg_flag = take;
+            sel[(size_t)b * P + p] = pos ? (uint8_t)(neg_flag ? 3 : 1) : code;
+            if (pos) {
+                const float4 a = reinterpret_cast<const float4*>(loc)[(size_t)b * P + p];
+                const float4 t4 = reinterpret_cast<const float4*>(loc_t)[(size_t)b * P + p];
+                const float d[4] = {a.x - t4.x, a.y - t4.y, a.z - t4.z, a.w - t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ad = fabsf(d[e]);
+                    sum_l += (double)(ad < 1.f ? 0.5f * d[e] * d[e] : ad - 0.5f);
+                }
+            }
+            if (pos || take) {   // cross_entropy(sum) over pos | neg (multibox_loss.py:109-113)
+                const int t = (int)tb[p];
+                float m = cb[(size_t)p * C];
+                for (int c = 1; c < C; ++c) m = fmaxf(m, cb[(size_t)p * C + c]);
+                double s = 0.0;
+                for (int c = 0; c < C; ++c) s += exp((double)(cb[(size_t)p * C + c] - m));
+                sum_c += (log(s) + (double)m) - (double)cb[(size_t)p * C + t];
+            }
+        }
+        __syncthreads();
+    }
+    sum_l = wave_sum(sum_l);
+    sum_c = wave_sum(sum_c);
+    if (lane == 0) {
+        s_red[wave][0] = sum_l;
+        s_red[wave][1] = sum_c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double l = 0.0, c = 0.0;
+        for (int w = 0; w < LT / 64; ++w) {
+            l += s_red[w][0];
+            c += s_red[w][1];
+        }
+        partial[(size_t)b * 4 + 0] = l;
+        partial[(size_t)b * 4 + 1] = c;
+        partial[(size_t)b * 4 + 2] = (double)npos;
+        partial[(size_t)b * 4 + 3] = (double)num_neg;
+    }
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ partial, int B, float* __restrict__ losses,
+                                     double* __restrict__ n_total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double l = 0.0, c = 0.0, n = 0.0;
+        for (int b = 0; b < B; ++b) {
+            l += partial[b * 4 + 0];
+            c += partial[b * 4 + 1];
+            n += partial[b * 4 + 2];
+        }
+        losses[0] = (float)(l / n);   // N == 0 -> inf/nan, like the reference (multibox_loss.py:117-119)
+        losses[1] = (float)(c / n);
+        if (n_total) *n_total = n;
+    }
+}
+
+__global__ void loss_backward_kernel(const float* __restrict__ loc, const float* __restrict__ conf,
+                                     const float* __restrict__ loc_t, const int64_t* __restrict__ conf_t,
+                                     const uint8_t* __restrict__ sel, const double* __restrict__ n_total,
+                                     const float* __restrict__ gl_p, const float* __restrict__ gc_p, long long BP, int C,
+                                     float* __restrict__ dloc, float* __restrict__ dconf) {
+    const float invN = (float)(1.0 / *n_total);
+    const float gl = (gl_p ? *gl_p : 1.f) * invN, gc = (gc_p ? *gc_p : 1.f) * invN;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < BP;
+         i += (long long)gridDim.x * blockDim.x) {
+        const uint8_t s = sel[i];
+        float4 g = {0.f, 0.f, 0.f, 0.f};
+        if (s & 1) {
+            const float4 a = reinterpret_cast<const float4*>(loc)[i];
+            const float4 t = reinterpret_cast<const float4*>(loc_t)[i];
+            const float d[4] = {a.x - t.x, a.y - t.y, a.z - t.z, a.w - t.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (fabsf(d[e]) < 1.f ? d[e] : (d[e] > 0.f ? 1.f : -1.f)) * gl;
+            g = {o[0], o[1], o[2], o[3]};
+        }
+        reinterpret_cast<float4*>(dloc)[i] = g;
+        if (s) {
+            const int t = (int)conf_t[i];
+            float m = conf[i * C];
+            for (int c = 1; c < C; ++c) m = fmaxf(m, conf[i * C + c]);
+            float z = 0.f;
+            for (int c = 0; c < C; ++c) z += __expf(conf[i * C + c] - m);
+            for (int c = 0; c < C; ++c) dconf[i * C + c] = (__expf(conf[i * C + c] - m) / z - (c == t ? 1.f : 0.f)) * gc;
+        } else {
+            for (int c = 0; c < C; ++c) dconf[i * C + c] = 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gssd_match_batch(const float* targets, const int* gt_off, const float* priors, int B, int P,
+                                float threshold, float var0, float var1, float* loc_t, int64_t* conf_t,
+                                gssd_stream_t stream) {
+    GSSD_CHECK_ARG(targets && gt_off && priors && loc_t && conf_t);
+    GSSD_CHECK_ARG(B > 0 && P > 0 && P < 32768);
+    GSSD_CHECK_ARG(((uintptr_t)priors % 16) == 0 && ((uintptr_t)loc_t % 16) == 0);
+    hipLaunchKernelGGL(match_kernel, dim3(B), dim3(LT), (size_t)P * sizeof(short), as_stream(stream), targets, gt_off,
+                       priors, P, threshold, var0, var1, loc_t, conf_t);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t,
+                             const float* xmax, int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial,
+                             float* loss_c_all, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(loc && conf && loc_t && conf_t && xmax && sel && partial);
+    GSSD_CHECK_ARG(B > 0 && P > 0 && P <= 36000 && C >= 2 && negpos_ratio >= 0);
+    GSSD_CHECK_ARG(((uintptr_t)loc % 16) == 0 && ((uintptr_t)loc_t % 16) == 0);
+    static bool attr_set = false;
+    const size_t smem = (size_t)P * sizeof(float);
+    if (!attr_set && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hnm_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(hnm_loss_kernel, dim3(B), dim3(LT), smem, as_stream(stream), loc, conf, loc_t, conf_t, xmax, P, C,
+                       negpos_ratio, sel, partial, loss_c_all);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_loss_finalize(const double* partial, int B, float* losses, double* n_total, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(partial && losses && B > 0);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, B, losses, n_total);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_loss_backward(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t,
+                                  const uint8_t* sel, const double* n_total, const float* grad_l, const float* grad_c,
+                                  int B, int P, int C, float* dloc, float* dconf, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(loc && conf && loc_t && conf_t && sel && n_total && dloc && dconf && B > 0 && P > 0 && C >= 2);
+    const long long BP = (long long)B * P;
+    int blocks = (int)((BP + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(loss_backward_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), loc, conf, loc_t, conf_t, sel,
+                       n_total, grad_l, grad_c, BP, C, dloc, dconf);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

@@ -1,0 +1,432 @@
+"""Forward engine of the GSSD / GSSD++ detector on MI355X.
+
+``GssdEngine`` turns the module tree built by ``build_ssd`` into a flat launch plan: a list of
+(C-ABI function, prebuilt argument tuple) pairs over preallocated NHWC buffers.  Running the plan
+is a tight loop of ctypes calls on the current HIP stream -- no tensor ops, no allocation -- so it
+can be captured into a hipGraph (``use_graph=True``).
+
+Dataflow restated from models/ssd_multiphase_custom_group.py:217-400:
+
+  x[B,12,300,300] -> pack NHWC(16 ch: 3->4 per phase) -> grouped VGG (conv -> raw + batch stats; BN+ReLU(+pool))
+  conv4_3 -> [SA-base0] -> [slice_and_cat] -> [DCN]* -> x ; s = L2Norm(x) -> [SA0] -> fuse_11+BN+ReLU = source0
+  pool4 -> conv5_x -> pool5 -> conv6(dil 6) -> conv7 -> [SA-base1] ; -> [SA1] -> fuse_21 = source1
+  extras (conv+BN+ReLU)x8, every second one: [SA-base] ; [SA] -> fuse -> source2..5
+  heads: one merged (loc|conf) 3x3 conv per source writing straight into loc[B,8732,4] / conf[B,8732,C]
+
+Weights are re-packed (OIHW -> K-major rows) only when a parameter's version counter changed.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import lib
+
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'C', 512, 512, 512, 'M', 512, 512, 512]
+EXTRAS_CFG = [256, 'S', 512, 128, 'S', 256, 128, 256, 128, 256]
+MBOX = [4, 6, 6, 6, 4, 4]
+FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
+
+
+class _Step:
+    __slots__ = ('fn', 'args', 'keep')
+
+    def __init__(self, fn, args, keep=None):
+        self.fn, self.args, self.keep = fn, args, keep
+
+
+class GssdEngine:
+    def __init__(self, net):
+        self.net = net
+        self._plans = {}
+        self._packed = {}        # name -> packed weight tensor
+        self._pack_jobs = []     # (callable) refreshers
+        self._versions = None
+
+    # ------------------------------------------------------------------------------------------
+    def _param_versions(self):
+        return tuple((p._version, p.data_ptr()) for p in self.net.parameters())
+
+    def invalidate(self):
+        self._plans.clear()
+        self._packed.clear()
+        self._pack_jobs = []
+        self._versions = None
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, training, want_attn=False):
+        net = self.net
+        if not x.is_cuda:
+            raise _lib.GssdError('GSSD HIP engine: input must live on the MI355X (cuda/ROCm tensor); there is no '
+                                 'CPU fallback')
+        p0 = next(net.parameters())
+        if p0.device != x.device:
+            raise _lib.GssdError(f'model is on {p0.device}, input on {x.device}')
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (12, 300, 300):
+            raise _lib.GssdError(f'expected input [B,12,300,300], got {tuple(x.shape)}')
+        key = (B, bool(training), x.device.index, p0.data_ptr())
+        plan = self._plans.get(key)
+        if plan is None:
+            if self._plans and next(iter(self._plans))[3] != p0.data_ptr():
+                self.invalidate()          # parameters moved (e.g. .cuda()): rebuild everything
+            plan = self._build(B, bool(training), x.device)
+            self._plans[key] = plan
+        vers = self._param_versions()
+        if vers != self._versions:
+            for job in self._pack_jobs:
+                job()
+            self._versions = vers
+        return plan.run(x)
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, name, build):
+        """Register a packed weight: ``build(out_or_None) -> tensor`` fills/refreshes it in place."""
+        if name not in self._packed:
+            t = build(None)
+            self._packed[name] = t
+            self._pack_jobs.append(lambda: build(self._packed[name]))
+        return self._packed[name]
+
+    def _build(self, B, training, dev):
+        return _Plan(self, B, training, dev)
+
+
+class _Plan:
+    def __init__(self, eng, B, training, dev):
+        self.eng, self.B, self.training, self.dev = eng, B, training, dev
+        net = eng.net
+        self.steps = []
+        self.bufs = []
+        self.head_descs = []
+        self.P = 8732
+        self.nc = net.num_classes
+        g = net.groups_vgg
+        f32 = torch.float32
+
+        def buf(*shape):
+            t = torch.empty(*shape, device=dev, dtype=f32)
+            self.bufs.append(t)
+            return t
+
+        # ---- batch-stat arena ------------------------------------------------------------------
+        bn_mods = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        seen, uniq = set(), []
+        for m in bn_mods:
+            if id(m) not in seen:
+                seen.add(id(m))
+                uniq.append(m)
+        total = sum(2 * m.num_features for m in uniq)
+        self.stats = torch.zeros(max(total, 2), device=dev, dtype=torch.float64)
+        off = 0
+        self.stat_of = {}
+        for m in uniq:
+            self.stat_of[id(m)] = self.stats[off:off + 2 * m.num_features]
+            off += 2 * m.num_features
+        self.nbt = [m.num_batches_tracked for m in uniq]
+
+        # ---- spectral norm -----------------------------------------------------------------------
+        self.sn_items = []
+        self.sa_state = {}
+        for lst_name in ('self_attn_base_list', 'self_attn_list'):
+            lst = getattr(net, lst_name, None)
+            if lst is None:
+                continue
+            for i, sa in enumerate(lst):
+                Cc = sa.in_channels
+                a_tp = buf(Cc // 4)
+                a_g = buf(Cc // 2)
+                a_o = buf(Cc)
+                self.sn_items += [
+                    (sa.snconv1x1_theta.weight_orig, sa.snconv1x1_theta.weight_u, sa.snconv1x1_theta.weight_v, a_tp[:Cc // 8]),
+                    (sa.snconv1x1_phi.weight_orig, sa.snconv1x1_phi.weight_u, sa.snconv1x1_phi.weight_v, a_tp[Cc // 8:]),
+                    (sa.snconv1x1_g.weight_orig, sa.snconv1x1_g.weight_u, sa.snconv1x1_g.weight_v, a_g),
+                    (sa.snconv1x1_attn.weight_orig, sa.snconv1x1_attn.weight_u, sa.snconv1x1_attn.weight_v, a_o),
+                ]
+                self.sa_state[(lst_name, i)] = (a_tp, a_g, a_o)
+        if self.sn_items:
+            self.sn_dev = ops.sn_items_tensor([(w.detach(), u, v, s) for (w, u, v, s) in self.sn_items], dev)
+            self._add(lib.gssd_spectral_norm_f32, (self.sn_dev.data_ptr(), len(self.sn_items), int(training), 1e-12))
+
+        # ---- input pack ------------------------------------------------------------------------------
+        self.x_in = None   # set per run
+        x16 = buf(B, 300, 300, 4 * g)
+        self._pack_step = len(self.steps)
+        self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, 4])
+
+        # ---- trunk -------------------------------------------------------------------------------------
+        cur, H, Cc = x16, 300, 4 * g
+        vi = 0
+        cfg = list(VGG_CFG)
+        i = 0
+        x43 = None
+        while i < len(cfg):
+            v = cfg[i]
+            assert v not in ('M', 'C')
+            conv, bn = net.vgg[vi], net.vgg[vi + 1]
+            pool = None
+            nxt = cfg[i + 1] if i + 1 < len(cfg) else None
+            is_conv4_3 = (vi == 30)
+            last = (i == len(cfg) - 1)
+            if nxt in ('M', 'C') and not is_conv4_3:
+                pool = (2, 2, 0, nxt == 'C')
+            if last:
+                pool = (3, 1, 1, False)               # pool5
+            cur, H, Cc = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, pool=pool)
+            vi += 3
+            if nxt in ('M', 'C'):
+                vi += 1
+                i += 1
+            i += 1
+            if is_conv4_3:
+                x43 = cur
+                cur, H, Cc, src0 = self._after_conv4_3(cur, H, Cc)
+        vi += 1   # pool5 module
+        for _ in range(2):                                  # conv6, conv7
+            conv, bn = net.vgg[vi], net.vgg[vi + 1]
+            cur, H, Cc = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True)
+            vi += 3
+        sources = [src0]
+        sab_i, sa_i = 1, 1
+        if net.use_self_attention_base:
+            cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)
+            sab_i += 1
+        sources.append(self._branch(cur, H, Cc, sa_i, '21'))
+        sa_i += 1
+        # ---- extras --------------------------------------------------------------------------------------
+        ge = net.groups_extra
+        n_ex = len(net.extras)
+        fi = 2
+        for k in range(0, n_ex, 2):
+            conv, bn = net.extras[k], net.extras[k + 1]
+            cur, H, Cc = self._conv_bn(f'extras.{k}', conv, bn, cur, H, Cc, ge, relu=True)
+            if (k + 1) % 4 == 3:
+                if net.use_self_attention_base:
+                    cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)
+                    sab_i += 1
+                sources.append(self._branch(cur, H, Cc, sa_i, FUSE_NAMES[fi]))
+                sa_i += 1
+                fi += 1
+        self.sources = sources
+        # ---- heads ------------------------------------------------------------------------------------------
+        off = 0
+        for i, (s, Hs, Cs) in enumerate(sources):
+            A = MBOX[i]
+            nloc, nconf = A * 4, A * self.nc
+            lw, cw = net.loc[i], net.conf[i]
+            cin_pad, K = ops.packed_k(Cs, 3, 3)
+
+            def build_w(out, lw=lw, cw=cw, nloc=nloc, nconf=nconf, K=K):
+                if out is None:
+                    out = torch.empty(nloc + nconf, K, device=dev, dtype=f32)
+                ops.pack_weight(lw.weight, out, 0)
+                ops.pack_weight(cw.weight, out, nloc)
+                return out
+
+            def build_b(out, lw=lw, cw=cw, nloc=nloc):
+                if out is None:
+                    out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
+                out[:nloc].copy_(lw.bias.detach())
+                out[nloc:].copy_(cw.bias.detach())
+                return out
+            wp = eng._pack(f'heads.{i}.w', build_w)
+            bp = eng._pack(f'heads.{i}.b', build_b)
+            d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
+                                         pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
+                                         out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
+                                         out_off=off * 4, outb_off=off * self.nc)
+            self.head_descs.append(d)
+            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+            off += Hs * Hs * A
+        assert off == self.P, off
+
+    # ------------------------------------------------------------------------------------------------
+    def _add(self, fn, args, keep=None):
+        self.steps.append(_Step(fn, args, keep))
+
+    def _buf(self, *shape):
+        t = torch.empty(*shape, device=self.dev, dtype=torch.float32)
+        self.bufs.append(t)
+        return t
+
+    def _packed_conv(self, name, conv):
+        eng = self.eng
+
+        def build(out, conv=conv):
+            return ops.pack_weight(conv.weight, out)
+        return eng._pack(name + '.w', build)
+
+    def _conv_bn(self, name, conv, bn, x, H, Cin, groups, relu=True, pool=None):
+        """conv (raw output + fp64 batch sums) -> BN + ReLU (+ max-pool)."""
+        B = self.B
+        k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+        Cout = conv.out_channels
+        cin_g = Cin // groups
+        wp = self._packed_conv(name, conv)
+        Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
+        raw = self._buf(B, Ho, Ho, Cout)
+        st = self.eng_stat(bn)
+        d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
+                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(),
+                                     stats=st if self.training else None)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        if pool:
+            pk, ps, pp, ceil = pool
+            Hp = ops.pool_out_size(Ho, pk, ps, pp, ceil)
+        else:
+            pk, ps, pp, Hp = 0, 1, 0, Ho
+        act = self._buf(B, Hp, Hp, Cout)
+        self._add(lib.gssd_bn_relu_pool_f32,
+                  (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
+                   bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                   float(bn.momentum), float(bn.eps), int(self.training), int(relu)))
+        return act, Hp, Cout
+
+    def eng_stat(self, bn):
+        return self.stat_of[id(bn)]
+
+    def _pool_only(self, x, H, Cc, k, s, p):
+        B = self.B
+        Hp = ops.pool_out_size(H, k, s, p, False)
+        out = self._buf(B, Hp, Hp, Cc)
+        self._add(lib.gssd_bn_relu_pool_f32, (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0,
+                                              0.1, 1e-5, 0, 0))
+        return out, Hp
+
+    def _after_conv4_3(self, x, H, Cc):
+        """models/...group.py:261-298: [SA-base] -> [slice_and_cat] -> [DCN]* -> L2Norm -> [SA] -> fuse_11; pool4."""
+        net, B = self.eng.net, self.B
+        attn_g = None
+        if net.use_self_attention_base:
+            x, attn_g = self._self_attn('self_attn_base_list', 0, x, H, Cc, need_out2=bool(net.dcn_cat_sab))
+        if net.use_dcn:
+            xin, Cin = x, Cc
+            if net.dcn_cat_sab:
+                xc = self._buf(B, H, H, 2 * Cc)
+                self._add(lib.gssd_slice_and_cat_f32, (x.data_ptr(), attn_g.data_ptr(), xc.data_ptr(), B * H * H, Cc, Cc,
+                                                       net.groups_vgg))
+                xin, Cin = xc, 2 * Cc
+            for li in range(net.num_dcn_layers):
+                xin, Cin = self._dcn(li, xin, H, Cin)
+            x, Cc = xin, Cin
+        self.x_after_block = x
+        s = self._buf(B, H, H, Cc)
+        self._add(lib.gssd_l2norm_f32, (x.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc,
+                                        float(net.L2Norm.eps)))
+        src0 = self._branch(s, H, Cc, 0, '11')
+        pooled, Hp = self._pool_only(x, H, Cc, 2, 2, 0)
+        return pooled, Hp, Cc, src0
+
+    def _branch(self, s, H, Cc, sa_i, fuse):
+        """[SA] -> 1x1 fuse conv + BN + ReLU -> a multibox source (models/...group.py:284-297)."""
+        net = self.eng.net
+        if net.use_self_attention:
+            s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False)
+        if net.use_fuseconv:
+            conv, bn = getattr(net, f'fuse_{fuse}'), getattr(net, f'bn_fuse_{fuse}')
+            s, H, Cc = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
+        return (s, H, Cc)
+
+    def _self_attn(self, lst_name, idx, x, H, Cc, need_out2):
+        """layers/self_attn.py:46-89 as five launches (K9/K10): theta|phi conv, g conv (transposed), theta^T phi,
+        row softmax, attn.g^T, and the o conv with the sigma-gated residual epilogue."""
+        eng, B = self.eng, self.B
+        sa = getattr(eng.net, lst_name)[idx]
+        a_tp, a_g, a_o = self.sa_state[(lst_name, idx)]
+        N = H * H
+        Np = ops.round_up(N, 4)
+        C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+        dev, f32 = self.dev, torch.float32
+        name = f'{lst_name}.{idx}'
+
+        def build_tp(out):
+            if out is None:
+                out = torch.empty(C4, Cc, device=dev, dtype=f32)
+            out[:C8].copy_(sa.snconv1x1_theta.weight_orig.detach().view(C8, Cc))
+            out[C8:].copy_(sa.snconv1x1_phi.weight_orig.detach().view(C8, Cc))
+            return out
+
+        def build_tpb(out):
+            if out is None:
+                out = torch.empty(C4, device=dev, dtype=f32)
+            out[:C8].copy_(sa.snconv1x1_theta.bias.detach())
+            out[C8:].copy_(sa.snconv1x1_phi.bias.detach())
+            return out
+        w_tp = eng._pack(name + '.tp.w', build_tp)
+        b_tp = eng._pack(name + '.tp.b', build_tpb)
+        w_g = sa.snconv1x1_g.weight_orig.detach().view(C2, Cc)      # already K-major rows
+        w_o = sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)
+        tp = self._buf(B, N, C4)
+        gT = self._buf(B, C2, Np)
+        S = self._buf(B, N, Np)
+        ag = self._buf(B, N, C2)
+        out = self._buf(B, H, H, Cc)
+        out2 = self._buf(B, H, H, Cc) if need_out2 else None
+        mk = ops.make_conv_desc
+        d1, _, _ = mk(x, w_tp, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4, bias=b_tp, alpha=a_tp)
+        d2, _, _ = mk(x, w_g, gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=sa.snconv1x1_g.bias.detach(),
+                      alpha=a_g, out_mode=_lib.OUT_TRANSPOSED, out_stride=Np, m_per_image=True,
+                      in_batch_stride=N * Cc, out_batch_stride=C2 * Np)
+        # S[b,i,j] = sum_c theta[b,i,c] * phi[b,j,c]   (no 1/sqrt(d) scaling, self_attn.py:71)
+        d3, _, _ = mk(tp, tp[0, 0, C8:], S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
+                      in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
+        # attn_g[b,i,c] = sum_j attn[b,i,j] * g[b,c,j]
+        d4, _, _ = mk(S, gT, ag, B=B, H=H, W=H, in_stride=Np, cin_g=Np, Cout=C2, m_per_image=True, in_batch_stride=N * Np,
+                      wgt_batch_stride=C2 * Np, out_batch_stride=N * C2, wgt_row_stride=Np)
+        d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
+                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2)
+        fn = lib.gssd_conv2d_nhwc_f32
+        self._add(fn, (C.byref(d1),), keep=(d1, w_tp, b_tp))
+        self._add(fn, (C.byref(d2),), keep=d2)
+        self._add(fn, (C.byref(d3),), keep=d3)
+        self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
+        self._add(fn, (C.byref(d4),), keep=d4)
+        self._add(fn, (C.byref(d5),), keep=d5)
+        self.attn_maps = getattr(self, 'attn_maps', {})
+        self.attn_maps[(lst_name, idx)] = (S, N, Np)
+        return out, out2
+
+    def _dcn(self, li, x, H, Cin):
+        """layers/dcn_v2_custom.py:79-89: offset/mask conv -> modulated bilinear im2col -> 1x1 GEMM."""
+        eng, B = self.eng, self.B
+        m = eng.net.dcn_list[li]
+        dg, Cout = m.deformable_groups, m.out_channels
+        w_om = self._packed_conv(f'dcn_list.{li}.om', m.conv_offset_mask)
+
+        def build_w(out, m=m):
+            return ops.pack_weight(m.weight, out)
+        w_main = eng._pack(f'dcn_list.{li}.w', build_w)
+        om = self._buf(B, H, H, 27 * dg)
+        cols = self._buf(B * H * H, 9 * Cin)
+        out = self._buf(B, H, H, Cout)
+        d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1,
+                                      bias=m.conv_offset_mask.bias.detach())
+        d2, _, _ = ops.make_conv_desc(cols, w_main, out, B=B, H=H, W=H, in_stride=9 * Cin, cin_g=9 * Cin, Cout=Cout,
+                                      bias=m.bias.detach())
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d1),), keep=d1)
+        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, 27 * dg))
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d2),), keep=d2)
+        self.offsets = getattr(self, 'offsets', [])
+        self.offsets.append((om, H, dg))
+        return out, Cout
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, x):
+        B, dev = self.B, self.dev
+        x = x.contiguous().float()
+        loc = torch.empty(B, self.P, 4, device=dev, dtype=torch.float32)
+        conf = torch.empty(B, self.P, self.nc, device=dev, dtype=torch.float32)
+        for d in self.head_descs:
+            d.out, d.out_b = loc.data_ptr(), conf.data_ptr()
+        self.steps[self._pack_step].args[0] = x.data_ptr()
+        if self.training:
+            self.stats.zero_()
+        stream = torch.cuda.current_stream().cuda_stream
+        for st in self.steps:
+            rc = st.fn(*st.args, stream)
+            if rc != 0:
+                _lib.check(rc)
+        if self.training and self.nbt:
+            torch._foreach_add_(self.nbt, 1)
+        self._x_keepalive = x
+        return loc, conf

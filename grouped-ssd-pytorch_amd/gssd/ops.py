@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI: each takes torch CUDA(ROCm) tensors, hands raw device
+pointers + the current HIP stream to libgssd_hip.so and returns torch tensors.  PyTorch is only the
+allocator / stream owner here; every computation happens in the HIP kernels.  No CPU fallback:
+a non-CUDA tensor raises."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SnItem, check, lib
+
+BK = 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GssdError('the GSSD HIP path needs tensors on the MI355X (got a CPU tensor); '
+                                 'there is no CPU fallback')
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# packing
+# ------------------------------------------------------------------------------------------------
+def pack_input(x_nchw, groups, cpg_out):
+    _need_cuda(x_nchw)
+    x = x_nchw.contiguous().float()
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, groups * cpg_out, device=x.device, dtype=torch.float32)
+    check(lib.gssd_pack_input_nhwc(_p(x), _p(y), B, Cc, H, W, groups, cpg_out, _stream()))
+    return y
+
+
+def unpack_nhwc(x_nhwc, C_=None):
+    _need_cuda(x_nhwc)
+    B, H, W, S = x_nhwc.shape
+    C_ = C_ or S
+    y = torch.empty(B, C_, H, W, device=x_nhwc.device, dtype=torch.float32)
+    check(lib.gssd_unpack_nhwc_to_nchw(_p(x_nhwc), _p(y), B, C_, H, W, S, _stream()))
+    return y
+
+
+def packed_k(cin_g, kh, kw):
+    cin_pad = round_up(cin_g, 4)
+    return cin_pad, kh * kw * cin_pad
+
+
+def pack_weight(w_oihw, out=None, row_offset=0):
+    """OIHW -> [Cout][K] K-major rows (k = tap*cin_g_pad + c).  ``out``/``row_offset`` let several
+    weights share one packed matrix (loc+conf heads)."""
+    _need_cuda(w_oihw)
+    w = w_oihw.detach().contiguous().float()
+    Cout, cin_g, KH, KW = w.shape
+    cin_pad, K = packed_k(cin_g, KH, KW)
+    if out is None:
+        out = torch.empty(Cout, K, device=w.device, dtype=torch.float32)
+    assert out.shape[1] == K
+    dst = out[row_offset:row_offset + Cout]
+    check(lib.gssd_pack_conv_weight(_p(w), _p(dst), Cout, cin_g, KH, KW, cin_pad, K, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# conv
+# ------------------------------------------------------------------------------------------------
+def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, k=1, stride=1, pad=0, dil=1,
+                   bias=None, in_ch_off=0, out_stride=None, out_ch_off=0, out_mode=_lib.OUT_NHWC, relu=False,
+                   stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
+                   m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
+                   outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None):
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    K = k * k * cin_g
+    d = ConvDesc()
+    d.in_, d.wgt, d.bias, d.out, d.out_b = _p(inp), _p(wgt), _p(bias), _p(out), _p(out_b)
+    d.alpha, d.gate, d.resid, d.out2, d.stats = _p(alpha), _p(gate), _p(resid), _p(out2), _p(stats)
+    d.B, d.H, d.W, d.in_stride, d.in_ch_off, d.Ho, d.Wo = B, H, W, in_stride, in_ch_off, Ho, Wo
+    d.Cout, d.groups, d.cin_g, d.KH, d.KW, d.stride, d.pad, d.dil = Cout, groups, cin_g, k, k, stride, pad, dil
+    d.K = K
+    d.wgt_row_stride = wgt_row_stride if wgt_row_stride is not None else K
+    d.out_stride = out_stride if out_stride is not None else Cout
+    d.out_ch_off, d.out_mode, d.relu, d.m_per_image, d.split_n = out_ch_off, out_mode, int(relu), int(m_per_image), split_n
+    d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride
+    d.out_batch_stride, d.outb_batch_stride, d.out_off, d.outb_off = out_batch_stride, outb_batch_stride, out_off, outb_off
+    return d, Ho, Wo
+
+
+def run_conv(desc):
+    check(lib.gssd_conv2d_nhwc_f32(C.byref(desc), _stream()))
+
+
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None):
+    """Convenience one-shot conv for tests: x NHWC [B,H,W,Cin], weight OIHW; returns NHWC."""
+    _need_cuda(x, w_oihw)
+    B, H, W, Cin = x.shape
+    Cout, cin_g, k, _ = w_oihw.shape
+    assert cin_g % 4 == 0 and Cin == cin_g * groups
+    wp = pack_weight(w_oihw)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    d, _, _ = make_conv_desc(x, wp, out, B=B, H=H, W=W, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
+                             stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats)
+    run_conv(d)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------------------------
+def bn_relu_pool(raw, out, stats, count, gamma, beta, rmean, rvar, training, relu=True, pool=None, momentum=0.1,
+                 eps=1e-5):
+    """raw/out NHWC.  pool = (k, s, p) or None."""
+    B, H, W, Cc = raw.shape
+    _, Ho, Wo, _ = out.shape
+    pk, ps, pp = pool if pool else (0, 1, 0)
+    check(lib.gssd_bn_relu_pool_f32(_p(raw), _p(out), B, H, W, Cc, Ho, Wo, pk, ps, pp, _p(stats), float(count),
+                                    _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps, int(training), int(relu),
+                                    _stream()))
+    return out
+
+
+def pool_out_size(n, k, s, p, ceil):
+    if ceil:
+        o = -(-(n + 2 * p - k) // s) + 1
+        if (o - 1) * s >= n + p:
+            o -= 1
+        return o
+    return (n + 2 * p - k) // s + 1
+
+
+def l2norm(x, weight, eps=1e-10, out=None):
+    _need_cuda(x, weight)
+    Cc = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    check(lib.gssd_l2norm_f32(_p(x), _p(weight), _p(out), x.numel() // Cc, Cc, eps, _stream()))
+    return out
+
+
+def softmax_rows_(x, n):
+    rows = x.numel() // x.shape[-1]
+    check(lib.gssd_softmax_rows_f32(_p(x), rows, n, x.shape[-1], _stream()))
+    return x
+
+
+def slice_and_cat(a, b, groups, out=None):
+    _need_cuda(a, b)
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    out = torch.empty(*a.shape[:-1], Ca + Cb, device=a.device, dtype=torch.float32) if out is None else out
+    check(lib.gssd_slice_and_cat_f32(_p(a), _p(b), _p(out), a.numel() // Ca, Ca, Cb, groups, _stream()))
+    return out
+
+
+def sn_items_tensor(items, device):
+    """items: list of (w, u, v, inv_sigma_slice).  Returns a uint8 device tensor holding gssd_sn_item[]."""
+    arr = (SnItem * len(items))()
+    for i, (w, u, v, s) in enumerate(items):
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        arr[i].w, arr[i].u, arr[i].v, arr[i].inv_sigma, arr[i].rows, arr[i].cols = _p(w), _p(u), _p(v), _p(s), rows, cols
+    raw = bytes(arr)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def spectral_norm(items_dev, n, do_power_iteration, eps=1e-12):
+    check(lib.gssd_spectral_norm_f32(_p(items_dev), n, int(do_power_iteration), eps, _stream()))
+
+
+def dcn_im2col(x, om, cols, dg):
+    B, H, W, Cc = x.shape
+    check(lib.gssd_dcn_im2col_f32(_p(x), _p(om), _p(cols), B, H, W, Cc, dg, om.shape[-1], _stream()))
+    return cols
+
+
+def softmax_lastdim(x):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    check(lib.gssd_softmax_lastdim_f32(_p(x), _p(y), x.numel() // x.shape[-1], x.shape[-1], _stream()))
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# loss / detect
+# ------------------------------------------------------------------------------------------------
+def pack_targets(targets, device):
+    """Python list of [n_i, 5] tensors -> (flat [sum n_i, 5] float32, offsets [B+1] int32) on ``device``.
+    Shapes are host metadata, so nothing synchronises: GPU-resident targets are concatenated on the device
+    (the reference does B D2H copies instead, multibox_loss.py:67-75)."""
+    ns = [int(t.shape[0]) for t in targets]
+    if max(ns) > 64:
+        raise _lib.GssdError('more than 64 ground-truth boxes in one image')
+    off = [0]
+    for n in ns:
+        off.append(off[-1] + n)
+    if all(t.is_cuda for t in targets):
+        flat = torch.cat([t.detach().reshape(-1, 5) for t in targets], 0).to(device=device, dtype=torch.float32)
+    else:
+        flat = torch.cat([t.detach().to('cpu', torch.float32).reshape(-1, 5) for t in targets], 0).to(device)
+    if flat.shape[0] == 0:
+        flat = torch.zeros(1, 5, device=device)
+    return flat.contiguous(), torch.tensor(off, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def match_batch(tg, gt_off, priors, threshold=0.5, variance=(0.1, 0.2)):
+    _need_cuda(tg, gt_off, priors)
+    B = gt_off.shape[0] - 1
+    P = priors.shape[0]
+    loc_t = torch.empty(B, P, 4, device=tg.device, dtype=torch.float32)
+    conf_t = torch.empty(B, P, device=tg.device, dtype=torch.int64)
+    check(lib.gssd_match_batch(_p(tg), _p(gt_off), _p(priors), B, P, threshold, variance[0], variance[1], _p(loc_t),
+                               _p(conf_t), _stream()))
+    return loc_t, conf_t
+
+
+def multibox_loss_forward(loc, conf, priors, tg, n_gt, threshold=0.5, negpos_ratio=3, variance=(0.1, 0.2),
+                          want_scores=False):
+    """Returns dict(losses[2], loc_t, conf_t, sel, n_total, loss_c_all?)."""
+    _need_cuda(loc, conf, priors)
+    loc = loc.contiguous()
+    conf = conf.contiguous()
+    B, P, _ = loc.shape
+    Cc = conf.shape[-1]
+    priors = priors[:P].contiguous()
+    loc_t, conf_t = match_batch(tg, n_gt, priors, threshold, variance)
+    dev = loc.device
+    xmax = torch.empty(1, device=dev, dtype=torch.float32)
+    check(lib.gssd_reduce_max_f32(_p(conf), conf.numel(), _p(xmax), _stream()))
+    sel = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    partial = torch.empty(B, 4, device=dev, dtype=torch.float64)
+    lca = torch.empty(B, P, device=dev, dtype=torch.float32) if want_scores else None
+    check(lib.gssd_hnm_loss(_p(loc), _p(conf), _p(loc_t), _p(conf_t), _p(xmax), B, P, Cc, int(negpos_ratio), _p(sel),
+                            _p(partial), _p(lca), _stream()))
+    losses = torch.empty(2, device=dev, dtype=torch.float32)
+    n_total = torch.empty(1, device=dev, dtype=torch.float64)
+    check(lib.gssd_loss_finalize(_p(partial), B, _p(losses), _p(n_total), _stream()))
+    return dict(losses=losses, loc_t=loc_t, conf_t=conf_t, sel=sel, n_total=n_total, loss_c_all=lca, partial=partial,
+                loc=loc, conf=conf)
+
+
+def multibox_loss_backward(ctx, grad_l, grad_c):
+    loc, conf = ctx['loc'], ctx['conf']
+    B, P, _ = loc.shape
+    Cc = conf.shape[-1]
+    dloc = torch.empty_like(loc)
+    dconf = torch.empty_like(conf)
+    gl = grad_l.reshape(1).float().contiguous() if grad_l is not None else None
+    gc = grad_c.reshape(1).float().contiguous() if grad_c is not None else None
+    check(lib.gssd_loss_backward(_p(loc), _p(conf), _p(ctx['loc_t']), _p(ctx['conf_t']), _p(ctx['sel']),
+                                 _p(ctx['n_total']), _p(gl), _p(gc), B, P, Cc, _p(dloc), _p(dconf), _stream()))
+    if grad_l is None:
+        dloc.zero_()
+    if grad_c is None:
+        dconf.zero_()
+    return dloc, dconf
+
+
+def detect(loc, conf, priors, num_classes, top_k=200, conf_thresh=0.01, nms_thresh=0.45, variance=(0.1, 0.2),
+           conf_is_logits=False, want_keep=False, loc_is_boxes=False):
+    _need_cuda(loc, conf, priors)
+    if nms_thresh <= 0:
+        raise ValueError('nms_threshold must be non negative.')     # detection_pytorch_ver_1point5.py:39-40
+    loc = loc.contiguous().float()
+    conf = conf.contiguous().float()
+    priors = priors.contiguous().float()
+    B, P, _ = loc.shape
+    out = torch.empty(B, num_classes, top_k, 5, device=loc.device, dtype=torch.float32)
+    keep = torch.empty(B, num_classes, top_k, device=loc.device, dtype=torch.int32) if want_keep else None
+    cnt = torch.empty(B, num_classes, device=loc.device, dtype=torch.int32) if want_keep else None
+    check(lib.gssd_detect(_p(loc), _p(conf), _p(priors), B, P, num_classes, top_k, conf_thresh, nms_thresh,
+                          variance[0], variance[1], int(conf_is_logits), int(loc_is_boxes), _p(out), _p(keep), _p(cnt),
+                          _stream()))
+    return (out, keep, cnt) if want_keep else out
+
+
+def detect_boxes(boxes, scores, overlap, top_k):
+    """Greedy NMS over raw (x1,y1,x2,y2) boxes with positive scores: (rows[top_k,5], keep[top_k] int32, count)."""
+    _need_cuda(boxes, scores)
+    n = boxes.shape[0]
+    conf = torch.stack([torch.zeros_like(scores), scores], 1).unsqueeze(0).contiguous()
+    out, keep, cnt = detect(boxes.unsqueeze(0), conf, boxes, 2, top_k=top_k, conf_thresh=0.0, nms_thresh=overlap,
+                            want_keep=True, loc_is_boxes=True)
+    return out[0, 1], keep[0, 1], cnt[0, 1]

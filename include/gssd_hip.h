@@ -1,0 +1,204 @@
+/*
+ * gssd_hip.h -- C ABI of libgssd_hip.so: the MI355X (gfx950) kernels behind the GSSD / GSSD++
+ * detection hot path of L0SG/grouped-ssd-pytorch.
+ *
+ * The reference has no native code and no FFI of its own: its "kernel layer" is
+ * whatever ATen/cuDNN op each Python line dispatches, plus the un-vendored `dcn_v2` CUDA
+ * extension.  Each entry point below replaces one such implicit kernel family; the comment
+ * on it cites the reference call site it stands in for (paths relative to
+ * /root/reference/ssd_liverdet/).  The Python host code binds these with ctypes
+ * (grouped-ssd-pytorch_amd/gssd/_lib.py); INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats; no torch / HIP C++ types in any signature.
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), allocates
+ *     nothing, and returns 0 on success or a negative GSSD_E* code (gssd_last_error() gives text).
+ *   - activations are NHWC fp32 ("pixel-major"): element (b, y, x, c) at ((b*H + y)*W + x)*stride + c.
+ *     Channels are phase-major, so conv group g owns the contiguous slab [g*C/G, (g+1)*C/G).
+ *   - re-entrant per stream: no global scratch; all workspaces are caller-provided.
+ */
+#ifndef GSSD_HIP_H
+#define GSSD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSSD_OK 0
+#define GSSD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define GSSD_ELAUNCH (-2)  /* hipLaunch / runtime error */
+
+typedef void* gssd_stream_t; /* hipStream_t */
+
+int gssd_abi_version(void);
+const char* gssd_last_error(void);
+/* name of the GPU architecture the library was built for ("gfx950") */
+const char* gssd_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout packing
+ * ------------------------------------------------------------------------------------------ */
+
+/* NCHW image batch -> NHWC with each group's channels padded from cpg_in to cpg_out (zeros).
+ * Replaces: the implicit NCHW tensor handed to vgg[0] (train_lesion_multiphase_v2.py:198,
+ * models/ssd_multiphase_custom_group.py:258-259). */
+int gssd_pack_input_nhwc(const float* x_nchw, float* y_nhwc, int B, int C, int H, int W, int groups,
+                         int cpg_out, gssd_stream_t stream);
+
+/* NHWC -> NCHW (for handing activations back to torch callers, e.g. visualize=True outputs). */
+int gssd_unpack_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int B, int C, int H, int W, int x_stride,
+                             gssd_stream_t stream);
+
+/* Conv weight OIHW [Cout][cin_g][KH][KW] -> K-major rows [Cout][Kpad], k = (kh*KW + kw)*cin_g_pad + c,
+ * zero padded. */
+int gssd_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int cin_g, int KH, int KW,
+                          int cin_g_pad, int Kpad, gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32)
+ * ------------------------------------------------------------------------------------------
+ * out[m, n] = epilogue( sum_k A[m, k] * Wp[n, k] ),  m = output pixel, n = output channel,
+ * k = (tap, input channel of the group).  One kernel family serves
+ *   K1/K2  grouped 3x3 / dilated 3x3 / grouped 1x1 trunk convs (models/...group.py:444,451-452)
+ *   K5     extras (:463-490)            K7  1x1 fuse convs (:77-139)
+ *   K8     loc/conf heads + permute + cat (:375-380, out_mode = GSSD_OUT_HEADS)
+ *   K9     Self_Attn theta/phi/g/o 1x1 convs (layers/self_attn.py:62-82)
+ *   K10    the two attention bmm's (layers/self_attn.py:71,80) via per-image operands
+ *   K13    DCN offset/mask conv (layers/dcn_v2_custom.py:80)   K14  DCN main contraction
+ */
+#define GSSD_OUT_NHWC 0
+#define GSSD_OUT_TRANSPOSED 1 /* per image [n][m] with row stride out_stride (needs m_per_image) */
+#define GSSD_OUT_HEADS 2      /* n < split_n -> out (loc), else -> out_b (conf), SSD prior order */
+
+typedef struct gssd_conv_desc {
+    const float* in;    /* NHWC activations */
+    const float* wgt;   /* packed rows [Cout][wgt_row_stride], K-major */
+    const float* bias;  /* [Cout] or NULL */
+    float* out;
+    float* out_b;       /* GSSD_OUT_HEADS second buffer, else NULL */
+    const float* alpha; /* per-output-channel scale [Cout] applied to the accumulator (1/sigma of spectral norm) or NULL */
+    const float* gate;  /* device scalar: out = resid + gate*(acc*alpha + bias) (Self_Attn sigma) or NULL */
+    const float* resid; /* NHWC, same geometry as out, or NULL */
+    float* out2;        /* receives gate*(acc*alpha+bias) when gate != NULL and out2 != NULL */
+    double* stats;      /* [2*Cout]: per-channel sum / sum of squares of the pre-activation output
+                           accumulated with fp64 atomics (BatchNorm batch statistics), or NULL */
+    int B, H, W;        /* input geometry */
+    int in_stride;      /* floats between consecutive input pixels */
+    int in_ch_off;      /* first input channel used */
+    int Ho, Wo;
+    int Cout, groups;
+    int cin_g;          /* input channels per group (multiple of 4) */
+    int KH, KW, stride, pad, dil;
+    int K;              /* KH*KW*cin_g */
+    int wgt_row_stride; /* floats between packed weight rows (>= K, multiple of 4) */
+    int out_stride;     /* floats between output pixels (NHWC) or between channel rows (TRANSPOSED) */
+    int out_ch_off;
+    int out_mode;
+    int relu;
+    int m_per_image;    /* 1: grid.z = image, tiles do not cross images, *_batch_stride apply */
+    int split_n;        /* GSSD_OUT_HEADS: channels [0, split_n) are loc, the rest conf */
+    int64_t in_batch_stride, wgt_batch_stride, out_batch_stride, outb_batch_stride;
+    int64_t out_off, outb_off; /* GSSD_OUT_HEADS: float offset of this source inside one image's rows */
+} gssd_conv_desc;
+
+int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (train / eval) + ReLU + max-pool, one pass
+ * ------------------------------------------------------------------------------------------
+ * Replaces nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d (models/...group.py:439-441,446,450,455-456;
+ * extras :477,484 with the ReLU of :354-355; fuse BNs :292,319,369).  training != 0: batch mean and
+ * biased variance come from `stats` (filled by the conv) over `count` elements per channel, and
+ * running_mean / running_var are updated in place (momentum, unbiased variance);
+ * training == 0: running statistics are used.  pool_k == 0 means no pooling.  gamma == NULL means
+ * identity affine (plain ReLU / max-pool pass, e.g. pool4 after the DCN block).
+ */
+int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H, int W, int C, int Ho, int Wo, int pool_k,
+                          int pool_s, int pool_p, const double* stats, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          int training, int relu, gssd_stream_t stream);
+
+/* x / (sqrt(sum_c x^2) + eps) * w_c per pixel.  Replaces layers/modules/l2norm.py:19-23. */
+int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pixels, int C, float eps,
+                    gssd_stream_t stream);
+
+/* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
+ * Replaces nn.Softmax(dim=-1) on the attention logits (layers/self_attn.py:72). */
+int gssd_softmax_rows_f32(float* x, int64_t rows, int n, int row_stride, gssd_stream_t stream);
+
+/* Per-phase channel interleave [x_p | a_p] (models/...group.py:185-192). */
+int gssd_slice_and_cat_f32(const float* a, const float* b, float* out, int64_t pixels, int Ca, int Cb,
+                           int groups, gssd_stream_t stream);
+
+/* Spectral norm (layers/spectral_norm.py:74-89): for each of n matrices W_i [rows_i][cols_i]
+ * (row-major), optionally run one power iteration updating u_i, v_i in place, then write
+ * 1 / (u^T W v) into inv_sigma[0 .. rows_i) (one copy per output channel: it is the `alpha` vector
+ * of the conv that uses W_i).  The descriptor array lives in device memory. */
+typedef struct gssd_sn_item {
+    const float* w;
+    float* u;
+    float* v;
+    float* inv_sigma;
+    int rows, cols;
+} gssd_sn_item;
+int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int do_power_iteration, float eps,
+                           gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DCNv2 sampling (K12 + K14 gather side)
+ * ------------------------------------------------------------------------------------------
+ * Builds the modulated, bilinearly sampled column matrix cols[b*H*W + p][tap*C + c] for a 3x3 / stride 1 /
+ * pad 1 / dil 1 deformable conv; offset/mask come from the raw conv_offset_mask output `om`
+ * ([pixels][om_stride], channels [0, 2*dg*9) = offsets in (o1|o2) chunk order, [2*dg*9, 3*dg*9) = mask logits;
+ * layers/dcn_v2_custom.py:80-83).  The contraction with the weight is then a 1x1 gssd_conv2d over cols.
+ */
+int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols, int B, int H, int W, int C, int dg,
+                        int om_stride, gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Batched match(): one workgroup per image.  targets [sum n_i][5] (xmin,ymin,xmax,ymax,label) is the
+ * concatenation of the per-image ground-truth lists, gt_off [B+1] their row offsets (n_i <= 64).
+ * Writes loc_t [B][P][4] and conf_t [B][P] (int64, like the reference's LongTensor). */
+int gssd_match_batch(const float* targets, const int* gt_off, const float* priors, int B, int P,
+                     float threshold, float var0, float var1, float* loc_t, int64_t* conf_t, gssd_stream_t stream);
+
+/* Global max of a float array (log_sum_exp's x_max, box_utils.py:167). `out` = 1 float. */
+int gssd_reduce_max_f32(const float* x, int64_t n, float* out, gssd_stream_t stream);
+
+/* Hard-negative mining + the two loss sums.  sel [B][P] uint8: 0 unused, 1 positive, 2 mined negative.
+ * partial [B][4] doubles (loss_l sum, loss_c sum, n_pos, spare); losses [2] floats = (loss_l/N, loss_c/N)
+ * after gssd_loss_finalize.  loss_c_all [B][P] (optional, may be NULL) receives the mining scores. */
+int gssd_hnm_loss(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t, const float* xmax,
+                  int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial, float* loss_c_all,
+                  gssd_stream_t stream);
+int gssd_loss_finalize(const double* partial, int B, float* losses, double* n_total, gssd_stream_t stream);
+/* d(loss_l + loss_c)/d(loc, conf) scaled by grad_l, grad_c (device scalars) / N. */
+int gssd_loss_backward(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t,
+                       const uint8_t* sel, const double* n_total, const float* grad_l, const float* grad_c, int B,
+                       int P, int C, float* dloc, float* dconf, gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detect (layers/functions/detection_pytorch_ver_1point5.py:32-89, box_utils.py:139-157,174-238)
+ * ------------------------------------------------------------------------------------------
+ * One workgroup per (image, class >= 1): threshold, top_k selection, decode, greedy NMS.
+ * conf_is_logits != 0 fuses the class softmax (models/...group.py:388); loc_is_boxes != 0 skips decode
+ * (rows of `loc` are already x1,y1,x2,y2 -- the box_utils.nms() entry).  out [B][C][top_k][5] is fully
+ * written (zero rows included).  keep_idx (optional) [B][C][top_k] int32 prior indices, -1 padded;
+ * keep_cnt (optional) [B][C]. */
+int gssd_detect(const float* loc, const float* conf, const float* priors, int B, int P, int C, int top_k,
+                float conf_thresh, float nms_thresh, float var0, float var1, int conf_is_logits, int loc_is_boxes,
+                float* out, int* keep_idx, int* keep_cnt, gssd_stream_t stream);
+
+/* 2-class (C-class) softmax over the last axis, double exp + one rounding (models/...group.py:388). */
+int gssd_softmax_lastdim_f32(const float* x, float* y, int64_t rows, int C, gssd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSSD_HIP_H */

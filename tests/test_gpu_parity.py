@@ -1,0 +1,458 @@
+"""GPU parity tests: every HIP kernel family and the end-to-end nets against the CPU oracle and the
+reference-generated golden fixtures, called through the C ABI (ctypes -> libgssd_hip.so).
+
+Tolerances (BASELINE.json north_star): integer / index outputs bit-exact; fp32 activations and
+losses <= 1e-4 relative (max-abs-diff / max-abs-ref per tensor).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gssd_oracle as O          # noqa: E402
+from gssd import synth                       # noqa: E402
+
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gssd import ops as _ops
+    return _ops
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# conv family
+# --------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, Cin, Cout, k, s, p, d, groups
+    (2, 37, 16, 64, 3, 1, 1, 1, 4),      # conv1_1-like: 4 ch / group (3 real + 1 pad)
+    (2, 30, 64, 64, 3, 1, 1, 1, 4),      # cout_g = 16 tile
+    (2, 21, 128, 128, 3, 1, 1, 1, 4),    # cout_g = 32
+    (2, 19, 256, 256, 3, 1, 1, 1, 4),    # cout_g = 64
+    (2, 19, 512, 512, 3, 1, 1, 1, 4),    # cout_g = 128
+    (2, 19, 512, 1024, 3, 1, 6, 6, 4),   # conv6: dilation 6
+    (3, 19, 1024, 1024, 1, 1, 0, 1, 4),  # conv7: grouped 1x1
+    (2, 19, 256, 512, 3, 2, 1, 1, 4),    # extras stride 2
+    (2, 5, 128, 256, 3, 1, 0, 1, 4),     # extras valid 3x3 (5 -> 3)
+    (5, 3, 128, 256, 3, 1, 0, 1, 4),     # 3 -> 1
+    (2, 10, 512, 512, 1, 1, 0, 1, 1),    # dense 1x1 fuse
+    (2, 38, 512, 108, 3, 1, 1, 1, 1),    # DCN offset conv shape (Cout not a tile multiple)
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_igemm(dev, ops, case):
+    B, H, Cin, Cout, k, s, p, d, g = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = torch.from_numpy(rng.normal(size=(B, Cin, H, H)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, k, k)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    ref = torch.nn.functional.conv2d(x, w, b, s, p, d, g)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    y = ops.conv2d_nhwc(nhwc(x).to(dev), w.to(dev), b.to(dev), s, p, d, g, stats=stats)
+    assert rel(nchw(y), ref) < TOL
+    # fused batch statistics (what BatchNorm consumes)
+    n = ref.numel() / Cout
+    assert rel(stats[:Cout] / n, ref.double().mean(dim=(0, 2, 3))) < 1e-5
+    assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < 1e-5
+
+
+def test_conv_heads_layout(dev, ops):
+    """loc|conf heads write straight into the concatenated [B,P,4] / [B,P,C] buffers in SSD prior order
+    (models/ssd_multiphase_custom_group.py:375-380)."""
+    from gssd import _lib
+    import ctypes
+    rng = np.random.default_rng(3)
+    B, H, Cin, A, nc = 2, 5, 64, 6, 2
+    x = torch.from_numpy(rng.normal(size=(B, Cin, H, H)).astype(np.float32))
+    wl = torch.from_numpy(rng.normal(0, 0.1, size=(A * 4, Cin, 3, 3)).astype(np.float32))
+    wc = torch.from_numpy(rng.normal(0, 0.1, size=(A * nc, Cin, 3, 3)).astype(np.float32))
+    bl = torch.from_numpy(rng.normal(size=(A * 4,)).astype(np.float32))
+    bc = torch.from_numpy(rng.normal(size=(A * nc,)).astype(np.float32))
+    P, off = 400, 100                      # pretend this source starts at prior 100 of 400
+    wp = torch.empty(A * 4 + A * nc, 9 * Cin, device=dev)
+    ops.pack_weight(wl.to(dev), wp, 0)
+    ops.pack_weight(wc.to(dev), wp, A * 4)
+    bias = torch.cat([bl, bc]).to(dev)
+    loc = torch.full((B, P, 4), -7.0, device=dev)
+    conf = torch.full((B, P, nc), -7.0, device=dev)
+    d, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, loc, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=A * (4 + nc),
+                                 k=3, pad=1, bias=bias, out_mode=_lib.OUT_HEADS, out_b=conf, split_n=A * 4,
+                                 out_batch_stride=P * 4, outb_batch_stride=P * nc, out_off=off * 4, outb_off=off * nc)
+    ops.run_conv(d)
+    rl = torch.nn.functional.conv2d(x, wl, bl, padding=1).permute(0, 2, 3, 1).reshape(B, -1, 4)
+    rc = torch.nn.functional.conv2d(x, wc, bc, padding=1).permute(0, 2, 3, 1).reshape(B, -1, nc)
+    n = H * H * A
+    assert rel(loc[:, off:off + n], rl) < TOL and rel(conf[:, off:off + n], rc) < TOL
+    assert (loc[:, :off] == -7).all() and (loc[:, off + n:] == -7).all() and (conf[:, off + n:] == -7).all()
+
+
+# --------------------------------------------------------------------------------------------------
+# BN + ReLU + pool, L2Norm, softmax, slice_and_cat, spectral norm
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('H,pool', [(30, None), (30, (2, 2, 0, False)), (75, (2, 2, 0, True)), (19, (3, 1, 1, False))])
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_relu_pool(dev, ops, H, pool, training):
+    rng = np.random.default_rng(H)
+    B, Cc = 3, 64
+    x = torch.from_numpy(rng.normal(0.3, 1.5, size=(B, Cc, H, H)).astype(np.float32))
+    gm = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cc).astype(np.float32))     # negative gammas: max after affine
+    bt = torch.from_numpy(rng.normal(size=Cc).astype(np.float32))
+    rm = torch.from_numpy(rng.normal(size=Cc).astype(np.float32))
+    rv = torch.from_numpy(rng.uniform(0.5, 2, size=Cc).astype(np.float32))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = torch.relu(torch.nn.functional.batch_norm(x, rm_ref, rv_ref, gm, bt, training, 0.1, 1e-5))
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, pool[0], pool[1], pool[2], ceil_mode=pool[3])
+    xd = nhwc(x).to(dev)
+    stats = torch.stack([x.double().sum(dim=(0, 2, 3)), (x.double() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(dev)
+    Ho = ref.shape[2]
+    out = torch.empty(B, Ho, Ho, Cc, device=dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    ops.bn_relu_pool(xd, out, stats, B * H * H, gm.to(dev), bt.to(dev), rmd, rvd, training, True,
+                     pool[:3] if pool else None)
+    assert rel(nchw(out), ref) < TOL
+    assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5
+
+
+def test_l2norm_softmax_slicecat(dev, ops, golden):
+    g = golden('ops')
+    y = ops.l2norm(nhwc(torch.from_numpy(g['l2_x'])).to(dev), torch.from_numpy(g['l2_w']).to(dev))
+    assert rel(nchw(y), g['l2_y']) < 1e-5                      # reference fixture
+    rng = np.random.default_rng(0)
+    for n in (1, 9, 25, 361, 1444):
+        npad = (n + 3) // 4 * 4
+        x = torch.from_numpy(rng.normal(0, 3, size=(7, npad)).astype(np.float32))
+        ref = torch.softmax(x[:, :n], -1)
+        xd = x.to(dev)
+        ops.softmax_rows_(xd, n)
+        assert rel(xd[:, :n], ref) < 1e-5 and (xd[:, n:] == 0).all()
+    a = torch.from_numpy(rng.normal(size=(2, 512, 6, 6)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(2, 512, 6, 6)).astype(np.float32))
+    ref = O.slice_and_cat(a, b, 4)
+    out = ops.slice_and_cat(nhwc(a).to(dev), nhwc(b).to(dev), 4)
+    assert torch.equal(nchw(out).cpu(), ref)
+
+
+@pytest.mark.parametrize('do_iter', [True, False])
+def test_spectral_norm(dev, ops, do_iter):
+    rng = np.random.default_rng(5)
+    items, refs = [], []
+    for (r, c) in ((64, 512), (256, 512), (512, 256), (128, 1024), (512, 1024), (32, 256)):
+        w = torch.from_numpy(rng.normal(0, 0.05, size=(r, c, 1, 1)).astype(np.float32))
+        u = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=r).astype(np.float32)), dim=0)
+        v = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=c).astype(np.float32)), dim=0)
+        wsn, un, vn = O.spectral_weight(w, u, v, do_iter)
+        refs.append((float((w.flatten()[0] / wsn.flatten()[0])), un, vn))
+        items.append((w.to(dev), u.to(dev), v.to(dev), torch.zeros(r, device=dev)))
+    tab = ops.sn_items_tensor(items, dev)
+    ops.spectral_norm(tab, len(items), do_iter)
+    for (w, u, v, s), (sigma, un, vn) in zip(items, refs):
+        assert rel(1.0 / s, np.full(s.shape[0], sigma)) < 1e-5
+        assert rel(u, un) < 1e-5 and rel(v, vn) < 1e-5
+
+
+def test_dcn_im2col_and_identities(dev, ops):
+    """DCN sampling vs the oracle restatement (parity unpinned upstream) + the zero-offset identity the
+    reference's zero-initialised conv_offset_mask guarantees (layers/dcn_v2_custom.py:75-77)."""
+    rng = np.random.default_rng(8)
+    B, Cc, H, dg, Cout = 2, 64, 9, 4, 32
+    x = torch.from_numpy(rng.normal(size=(B, Cc, H, H)).astype(np.float32))
+    om = torch.from_numpy(rng.normal(0, 1.5, size=(B, 27 * dg, H, H)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cc, 3, 3)).astype(np.float32))
+    bias = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    ref = O.dcn_v2_conv(x, torch.cat((o1, o2), 1), torch.sigmoid(m), w, bias, 1, 1, 1, dg)
+    xd, omd = nhwc(x).to(dev), nhwc(om).to(dev)
+    cols = torch.empty(B * H * H, 9 * Cc, device=dev)
+    ops.dcn_im2col(xd, omd, cols, dg)
+    y = ops.conv2d_nhwc(cols.view(B, H, H, 9 * Cc), w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc, 1, 1).contiguous().to(dev),
+                        bias.to(dev))
+    assert rel(nchw(y), ref) < TOL
+    omd.zero_()
+    ops.dcn_im2col(xd, omd, cols, dg)
+    y0 = ops.conv2d_nhwc(cols.view(B, H, H, 9 * Cc), w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cc, 1, 1).contiguous().to(dev),
+                         bias.to(dev))
+    ident = 0.5 * torch.nn.functional.conv2d(x, w, None, 1, 1) + bias.view(1, -1, 1, 1)
+    assert rel(nchw(y0), ident) < TOL
+
+
+# --------------------------------------------------------------------------------------------------
+# matching / loss / detect: index work is bit-exact
+# --------------------------------------------------------------------------------------------------
+def test_match_bit_exact(dev, ops, golden):
+    g = golden('match')
+    pri = torch.from_numpy(O.prior_box()).to(dev)
+    n = int(g['n'])
+    targets = [torch.from_numpy(g[f't{i}']) for i in range(n)]
+    tg, ngt = ops.pack_targets(targets, dev)
+    loc_t, conf_t = ops.match_batch(tg, ngt, pri)
+    for i in range(n):
+        ct = conf_t[i].cpu().numpy()
+        assert np.array_equal(ct.astype(np.int8), g[f'conf{i}']), f'case {i}'          # vs the reference
+        lo, co, _ = O.match(0.5, g[f't{i}'][:, :-1], O.prior_box(), (0.1, 0.2), g[f't{i}'][:, -1])
+        assert np.array_equal(ct, co)                                                # vs the oracle
+        pos = ct > 0
+        ref = g[f'locpos{i}']
+        fin = np.isfinite(ref)
+        got = loc_t[i].cpu().numpy()[pos]
+        assert np.allclose(got[fin], ref[fin], rtol=2e-6, atol=2e-6)
+
+
+def test_box_utils_api(dev, golden):
+    from layers import box_utils
+    g = golden('match')
+    pri = torch.from_numpy(O.prior_box()).to(dev)
+    t = torch.from_numpy(g['t1']).to(dev)
+    loc_t = torch.zeros(2, 8732, 4, device=dev)
+    conf_t = torch.zeros(2, 8732, dtype=torch.long, device=dev)
+    box_utils.match(0.5, t[:, :-1], pri, [0.1, 0.2], t[:, -1], loc_t, conf_t, 1)
+    assert np.array_equal(conf_t[1].cpu().numpy().astype(np.int8), g['conf1']) and (conf_t[0] == 0).all()
+    # nms() on raw boxes
+    rng = np.random.default_rng(2)
+    c = rng.uniform(0.2, 0.8, size=(300, 2))
+    wh = rng.uniform(0.05, 0.3, size=(300, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    scores = rng.uniform(0.02, 1, size=300).astype(np.float32)
+    keep_ref = O.nms(boxes, scores, 0.45, 200)
+    keep, cnt = box_utils.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.45, 200)
+    assert cnt == keep_ref.shape[0] and np.array_equal(keep[:cnt].cpu().numpy(), keep_ref)
+
+
+def test_multibox_loss(dev, ops, golden):
+    from layers.modules import MultiBoxLoss
+    g = golden('loss')
+    m = golden('match')
+    pri_np = O.prior_box()
+    pri = torch.from_numpy(pri_np).to(dev)
+    P = pri_np.shape[0]
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    ll, lc = crit((torch.zeros(2, P, 4, device=dev), torch.zeros(2, P, 2, device=dev), pri),
+                  [torch.from_numpy(m['t0']), torch.from_numpy(m['t1'])])
+    assert abs(ll.item() - g['zero_loss'][0]) < 1e-5 and abs(lc.item() - g['zero_loss'][1]) < 1e-5
+    for ci in range(3):
+        rng = np.random.default_rng(int(g[f'seed{ci}']))
+        loc = rng.normal(0, 1.0, size=(4, P, 4)).astype(np.float32)
+        conf = rng.normal(0, 2.0, size=(4, P, 2)).astype(np.float32)
+        tg = [torch.from_numpy(g[f'tg{ci}_{b}']) for b in range(4)]
+        loc_d = torch.from_numpy(loc).to(dev).requires_grad_()
+        conf_d = torch.from_numpy(conf).to(dev).requires_grad_()
+        ll, lc = crit((loc_d, conf_d, pri), tg)
+        assert rel(ll, g[f'loss{ci}'][0]) < TOL and rel(lc, g[f'loss{ci}'][1]) < TOL
+        (ll + lc).backward()
+        idx = np.random.default_rng(3).choice(4 * P * 4, size=512, replace=False)
+        assert np.allclose(loc_d.grad.cpu().numpy().reshape(-1)[idx], g[f'gloc_sample{ci}'], rtol=1e-4, atol=1e-7)
+        idx = np.random.default_rng(3).choice(4 * P * 2, size=512, replace=False)
+        assert np.allclose(conf_d.grad.cpu().numpy().reshape(-1)[idx], g[f'gconf_sample{ci}'], rtol=1e-4, atol=1e-7)
+        # masks: positives bit-exact; mined negatives identical except where two scores tie to the last ulp
+        tgp, ngt = ops.pack_targets(tg, dev)
+        st = ops.multibox_loss_forward(loc_d.detach(), conf_d.detach(), pri, tgp, ngt, want_scores=True)
+        sel = st['sel'].cpu().numpy()
+        assert np.array_equal(np.packbits((sel & 1).astype(bool)), g[f'pos{ci}'])
+        neg_ref = np.unpackbits(g[f'neg{ci}'])[:4 * P].reshape(4, P).astype(bool)
+        neg = (sel & 2).astype(bool)
+        assert neg.sum() == neg_ref.sum() and (neg != neg_ref).sum() <= 2
+        # the selection logic itself is exact: oracle ranking of the kernel's own scores gives the same set
+        lca = st['loss_c_all'].cpu().numpy()
+        order = np.argsort(-lca, axis=1, kind='stable')
+        rank = np.argsort(order, axis=1, kind='stable')
+        npos = (sel & 1).sum(1, keepdims=True)
+        assert np.array_equal(neg, rank < np.minimum(3 * npos, P - 1))
+
+
+def test_detect_bit_exact(dev, ops, golden):
+    from layers.functions import Detect
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from make_golden import closed_form_detect_inputs
+    g = golden('detect')
+    pri_np = O.prior_box()
+    pri = torch.from_numpy(pri_np).to(dev)
+    loc, _ = closed_form_detect_inputs(pri_np.shape[0], 2)
+    conf_sm = g['conf_sm']
+    out, keep, cnt = ops.detect(torch.from_numpy(loc).to(dev), torch.from_numpy(conf_sm).to(dev), pri, 2, want_keep=True)
+    ref_out, ref_keep = O.detect(2, 0, 200, 0.01, 0.45, loc, conf_sm, pri_np, return_keep=True)
+    for b in range(2):
+        k = keep[b, 1, :int(cnt[b, 1])].cpu().numpy()
+        assert np.array_equal(k, g[f'keep{b}'])                 # vs the reference (exact ties included)
+        assert np.array_equal(k, ref_keep[(b, 1)])              # vs the oracle
+    assert np.array_equal(out.cpu().numpy(), ref_out)           # bit-exact vs the oracle (same exp recipe)
+    assert np.allclose(out.cpu().numpy(), g['out'], rtol=0, atol=2e-6)
+    # the autograd.Function API of the reference
+    out2 = Detect.apply(2, 0, 200, 0.01, 0.45, torch.from_numpy(loc).to(dev), torch.from_numpy(conf_sm).to(dev), pri)
+    assert torch.equal(out2, out)
+    with pytest.raises(ValueError):
+        Detect.apply(2, 0, 200, 0.01, 0.0, torch.from_numpy(loc).to(dev), torch.from_numpy(conf_sm).to(dev), pri)
+    # random logits, > 200 candidates
+    rng = np.random.default_rng(5)
+    loc_r = rng.normal(0, 0.5, size=(2, pri_np.shape[0], 4)).astype(np.float32)
+    sm_r = g['conf_sm_rand']
+    out_r = ops.detect(torch.from_numpy(loc_r).to(dev), torch.from_numpy(sm_r).to(dev), pri, 2).cpu().numpy()
+    assert np.array_equal(out_r, O.detect(2, 0, 200, 0.01, 0.45, loc_r, sm_r, pri_np))
+    assert np.allclose(out_r, g['out_rand'], rtol=0, atol=3e-6)
+    # edge: nothing above threshold -> all zeros
+    z = ops.detect(torch.from_numpy(loc_r).to(dev), torch.zeros(2, pri_np.shape[0], 2, device=dev), pri, 2)
+    assert (z == 0).all()
+
+
+# --------------------------------------------------------------------------------------------------
+# end to end
+# --------------------------------------------------------------------------------------------------
+NETS = {
+    'gssd': (dict(), (True, 4, 4, 1, True, False, False, 0, 1, False, False, 1)),
+    'gssd_sa': (dict(use_self_attention=True, use_self_attention_base=True),
+                (True, 4, 4, 1, True, True, True, 0, 1, False, False, 1)),
+    'gssdpp': (dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                    dcn_cat_sab=True), (True, 4, 4, 1, True, True, True, 1, 4, True, False, 1)),
+}
+
+
+def canon_rows(det):
+    out = det.copy()
+    for b in range(det.shape[0]):
+        for c in range(det.shape[1]):
+            r = det[b, c]
+            key = np.lexsort((np.round(r[:, 2], 4), np.round(r[:, 1], 4), -np.round(r[:, 0], 5)))
+            out[b, c] = r[key]
+    return out
+
+
+@pytest.mark.parametrize('name', list(NETS))
+def test_end_to_end(dev, golden, name):
+    from models.ssd_multiphase_custom_group import build_ssd
+    from layers.modules import MultiBoxLoss
+    flags, args = NETS[name]
+    g = golden('e2e')
+    net = build_ssd('train', 300, 2, *args)
+    keys = sorted(net.state_dict().keys())
+    assert keys == [str(k) for k in g[f'{name}.keys']]                              # checkpoint key parity
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert [str(shapes[k]) for k in keys] == [str(s) for s in g[f'{name}.shapes']]
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = synth.synth_images(2, seed=5)
+    tg = synth.synth_targets(2, seed=5)
+    with torch.no_grad():
+        loc, conf, pri = net(x.to(dev))
+        ll, lc = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)((loc, conf, pri), tg)
+    assert loc.shape == (2, 8732, 4) and conf.shape == (2, 8732, 2) and pri.shape == (8732, 4)
+    # (1) vs the reference's sampled outputs
+    l, c = loc.cpu().numpy().reshape(-1), conf.cpu().numpy().reshape(-1)
+    assert np.abs(l[g[f'{name}.loc_idx']] - g[f'{name}.loc_val']).max() / g[f'{name}.loc_absmax'] < TOL
+    assert np.abs(c[g[f'{name}.conf_idx']] - g[f'{name}.conf_val']).max() / g[f'{name}.conf_absmax'] < TOL
+    assert rel(ll, g[f'{name}.loss'][0]) < TOL and rel(lc, g[f'{name}.loss'][1]) < TOL
+    # (2) full tensors vs the oracle
+    with torch.no_grad():
+        lo, co, upd = O.gssd_forward(sd, x, **flags)
+    assert rel(loc, lo) < TOL and rel(conf, co) < TOL
+    # (3) state the training forward mutates
+    after = net.state_dict()
+    for k, v in upd.items():
+        assert rel(after[k], v) < TOL, k
+    for k in ('vgg.1.running_mean', 'vgg.1.running_var', 'bn_fuse_11.running_mean', 'extras.15.running_var'):
+        assert rel(after[k], g[f'{name}.after.{k}']) < TOL, k
+    assert int(after['vgg.1.num_batches_tracked']) == 1
+    # (4) test phase twin: strict load, eval-mode BN, fused softmax + Detect
+    net_t = build_ssd('test', 300, 2, *args)
+    net_t.load_state_dict(after)
+    net_t = net_t.to(dev).eval()
+    with torch.no_grad():
+        det = net_t(x.to(dev)).cpu().numpy()
+    assert det.shape == (2, 2, 200, 5)
+    ref = g[f'{name}.det']
+    assert np.array_equal(det[..., 0] > 0, ref[..., 0] > 0)
+    assert np.allclose(canon_rows(det), canon_rows(ref), rtol=0, atol=5e-5)
+
+
+def test_visualize_outputs(dev):
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssdpp']
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = synth.synth_images(2, seed=5)
+    with torch.no_grad():
+        out, offs, attnb, attn = net(x.to(dev), visualize=True)
+        taps = {}
+        O.gssd_forward(sd, x, training=False, taps=taps, **flags)
+    assert len(offs) == 1 and offs[0].shape == (2, 72, 38, 38)
+    assert rel(offs[0], taps['dcn0.offset']) < TOL
+    assert [a.shape[1] for a in attnb] == [1444, 361, 100, 25, 9, 1] and len(attn) == 6
+    assert all(abs(a.sum(-1) - 1).max() < 1e-4 for a in attnb + attn)
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] size (B=32): size-independent properties instead of a 12 s CPU forward."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    from layers.modules import MultiBoxLoss
+    flags, args = NETS['gssd']
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth.synth_state_dict(shapes, seed=1111))
+    net = net.to(dev)
+    x = synth.synth_images(32, seed=11).to(dev)
+    tg = synth.synth_targets(32, seed=11)
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    with torch.no_grad():
+        net.train()
+        loc, conf, pri = net(x)
+        ll, lc = crit((loc, conf, pri), tg)
+    assert torch.isfinite(loc).all() and torch.isfinite(conf).all()
+    # loss kernels at full size vs the oracle fed the same predictions
+    rl, rc = O.multibox_loss(loc.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), [t.numpy() for t in tg])
+    assert rel(ll, rl) < TOL and rel(lc, rc) < TOL
+    # eval mode: images are independent -> image i of the batch-32 run == the same image in a batch of 2
+    with torch.no_grad():
+        net.eval()
+        l32, c32, _ = net(x)
+        l2, c2, _ = net(x[5:7])
+    assert rel(l32[5:7], l2) < 1e-5 and rel(c32[5:7], c2) < 1e-5
+    # Detect on the full batch: descending scores, survivors pairwise IoU <= 0.45, matches the oracle
+    from gssd import ops
+    det, keep, cnt = ops.detect(l32, c32, pri, 2, conf_is_logits=True, want_keep=True)
+    det = det.cpu().numpy()
+    sc = det[:, 1, :, 0]
+    assert (np.diff(sc, axis=1) <= 0).all() and (det[:, 0] == 0).all()
+    b = 3
+    n = int(cnt[b, 1])
+    bx = det[b, 1, :n, 1:]
+    iou = O.jaccard(bx, bx)
+    assert (iou[np.triu_indices(n, 1)] <= 0.45 + 1e-6).all()
+    ref = O.detect(2, 0, 200, 0.01, 0.45, l32[b:b + 1].cpu().numpy(), O.softmax_scores(c32[b:b + 1].cpu().numpy()),
+                   pri.cpu().numpy())
+    assert np.array_equal(det[b:b + 1], ref)
+
+
+def test_cpu_input_fails_loudly():
+    from models.ssd_multiphase_custom_group import build_ssd
+    from gssd._lib import GssdError
+    net = build_ssd('train', 300, 2, True, 4, 4, 1, True, False, False, 0, 1, False, False, 1)
+    with pytest.raises(GssdError):
+        net(torch.zeros(2, 12, 300, 300))

@@ -1,0 +1,101 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/gssd_hip.h
+declares (no compute calls: there is no GPU here), and the host logic (PriorBox, module tree / state-dict
+keys, pooling arithmetic, target packing) matches the reference-generated fixtures."""
+import copy
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_match_header():
+    from gssd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'gssd_hip.h')).read()
+    declared = set(re.findall(r'\b(gssd_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'gssd_conv_desc', 'gssd_sn_item', 'gssd_stream_t'}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert _lib.lib.gssd_abi_version() == 1 and _lib.lib.gssd_build_arch() == b'gfx950'
+    # struct layout agrees with the header's field order / C packing rules
+    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 23 * 4 + 4 + 6 * 8
+    assert ctypes.sizeof(_lib.SnItem) == 4 * 8 + 2 * 4
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad descriptors before touching the device."""
+    from gssd import _lib
+    d = _lib.ConvDesc()
+    assert _lib.lib.gssd_conv2d_nhwc_f32(ctypes.byref(d), None) == -1
+    assert b'invalid argument' in _lib.lib.gssd_last_error()
+    assert _lib.lib.gssd_detect(None, None, None, 1, 8732, 2, 200, 0.01, 0.45, 0.1, 0.2, 0, 0, None, None, None, None) == -1
+
+
+def test_priorbox_bit_exact(golden):
+    from layers.functions import PriorBox
+    from data import v2, v2_512
+    g = golden('priors')
+    p = PriorBox(v2).forward()
+    assert p.dtype == torch.float32 and np.array_equal(p.numpy(), g['v2'])
+    p5 = PriorBox(v2_512).forward().numpy()
+    assert p5.shape == (24564, 4) and np.array_equal(p5[g['v2_512_sample_idx']], g['v2_512_sample'])
+
+
+@pytest.mark.parametrize('name,args', [
+    ('gssd', (True, 4, 4, 1, True, False, False, 0, 1, False, False, 1)),
+    ('gssd_sa', (True, 4, 4, 1, True, True, True, 0, 1, False, False, 1)),
+    ('gssdpp', (True, 4, 4, 1, True, True, True, 1, 4, True, False, 1)),
+])
+def test_module_tree_matches_reference(golden, name, args):
+    from models.ssd_multiphase_custom_group import build_ssd, weights_init
+    g = golden('e2e')
+    net = build_ssd('train', 300, 2, *args)
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in g[f'{name}.keys']]
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd.keys())] == [str(s) for s in g[f'{name}.shapes']]
+    # the surface the driver touches (train_lesion_multiphase_v2.py:587-615)
+    net.extras.apply(weights_init)
+    net.loc.apply(weights_init)
+    net.conf.apply(weights_init)
+    twin = copy.deepcopy(net)
+    assert twin._engine is not net._engine and twin._engine.net is twin
+    test_net = build_ssd('test', 300, 2, *args)
+    test_net.load_state_dict(net.state_dict())                 # strict, train -> test phase
+    if name == 'gssdpp':
+        assert any(n.startswith('dcn_list') for n, _ in net.named_parameters())
+    assert net.priors.shape == (8732, 4)
+
+
+def test_build_ssd_rejects_like_reference(capsys):
+    from models.ssd_multiphase_custom_group import build_ssd
+    assert build_ssd('val', 300, 2, True) is None
+    assert build_ssd('train', 512, 2, True) is None
+    assert 'only SSD300' in capsys.readouterr().out
+    with pytest.raises(AssertionError):
+        build_ssd('train', 300, 2, True, 4, 4, 1, True, False, False, 1, 4, True, False, 1)   # cat_sab needs sab
+
+
+def test_pool_and_pack_helpers():
+    from gssd import ops
+    for n, k, s, p, ceil in [(300, 2, 2, 0, False), (75, 2, 2, 0, True), (19, 3, 1, 1, False), (38, 2, 2, 0, False),
+                             (5, 2, 2, 0, True), (7, 3, 2, 1, True)]:
+        ref = torch.nn.functional.max_pool2d(torch.zeros(1, 1, n, n), k, s, p, ceil_mode=ceil).shape[-1]
+        assert ops.pool_out_size(n, k, s, p, ceil) == ref
+    tg = [torch.rand(2, 5), torch.rand(0, 5), torch.rand(3, 5)]
+    flat, off = ops.pack_targets(tg, 'cpu')
+    assert off.tolist() == [0, 2, 2, 5] and torch.equal(flat[2:], tg[2])
+    assert ops.packed_k(3, 3, 3) == (4, 36)
+
+
+def test_synth_is_deterministic():
+    from gssd import synth
+    a, b = synth.synth_images(2, seed=4), synth.synth_images(2, seed=4)
+    assert torch.equal(a, b) and float(a.min()) == 0.0 and float(a.max()) == 1.0
+    t = synth.synth_targets(4, seed=1)
+    assert all(x.shape[1] == 5 and 1 <= x.shape[0] <= 3 for x in t)
