@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of forward + MultiBoxLoss (train-mode BatchNorm, no backward) of the GSSD detector on
+MI355X, the metric BASELINE.json names, on its configs[1] workload (GSSD, groups 4, 4-phase CT, batch 32/GPU).
+
+One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); the path shards by image with no
+data-path collective, so N GPUs = N independent batch-32 shards ("scaling": "weak") and the
+only communication is the timing barrier.  Inputs (resized 300x300 slices, targets, weights) are resident in
+HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+  roofline     : the dominant kernel (the conv_igemm tile instance with the most time).  achieved = algorithmic
+                 FLOPs per launch / average launch duration, measured live with HIP events recorded on the
+                 launch stream around every conv launch of the timed region.  fp32 runs are bound by the fp32
+                 matrix/vector peak (157.3 TFLOP/s), not HBM.
+  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, all host cores) timed on a
+                 bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'grouped-ssd-pytorch_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                                              # noqa: E402
+import torch.distributed as dist                                          # noqa: E402
+
+CONFIGS = {
+    # name: (build_ssd positional args after (phase, size, num_classes), oracle flags, GFLOP/img, MB/img train-mode)
+    'gssd': ((True, 4, 4, 1, True, False, False, 0, 1, False, False, 1), dict(), 17.47, 374.0),
+    'gssdpp': ((True, 4, 4, 1, True, True, True, 1, 4, True, False, 1),
+               dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                    dcn_cat_sab=True), 39.4, 402.0),
+}
+PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg_name, sample_b, seed):
+    """Oracle forward + loss on the host cores (never the product path)."""
+    from oracle import gssd_oracle as O
+    from gssd import synth
+    from models.ssd_multiphase_custom_group import build_ssd
+    args, flags, _, _ = CONFIGS[cfg_name]
+    net = build_ssd('train', 300, 2, *args)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pri = O.prior_box()
+
+    def one(b, s):
+        x = synth.synth_images(b, seed=s)
+        tg = [t.numpy() for t in synth.synth_targets(b, seed=s)]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            loc, conf, _ = O.gssd_forward(sd, x, **flags)
+        O.multibox_loss(loc.numpy(), conf.numpy(), pri, tg)
+        return time.perf_counter() - t0
+    one(2, seed)                      # warm-up (thread pool, oneDNN primitives)
+    dt = one(sample_b, seed + 1)
+    return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port',
+                sample=f'1 forward+MultiBoxLoss pass over {sample_b} synthetic images ({cfg_name}, fp32, train-mode BN, '
+                       f'torch-CPU {cores} threads) after a 2-image warm-up; {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='gssd', choices=list(CONFIGS))
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--cpu-sample', type=int, default=16, help='images in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if a.gpus > 1 and world == 1:
+        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from gssd import synth
+    from layers.modules import MultiBoxLoss
+    from models.ssd_multiphase_custom_group import build_ssd
+    args, flags, gflop_img, mb_img = CONFIGS[a.config]
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    B = a.batch
+    x = synth.synth_images(B, seed=100 + rank).to(dev)                    # rank r owns its own 32 images
+    tg = [t.to(dev) for t in synth.synth_targets(B, seed=100 + rank)]
+
+    def step():
+        with torch.no_grad():
+            out = net(x)
+            return crit(out, tg)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        ll, lc = step()
+    events = None if a.no_events else []
+    net.__dict__['_events'] = events
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ll, lc = step()
+    sync()
+    dt = time.perf_counter() - t0
+    net.__dict__['_events'] = None
+    loss = (float(ll), float(lc))
+    if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
+        raise SystemExit(f'non-finite loss {loss}')
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    roof = None
+    kernels = {}
+    if events:
+        agg = {}
+        for (name, flops, byts), e0, e1 in events:
+            ms = e0.elapsed_time(e1)
+            r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += ms
+            r[2] += flops
+            r[3] += byts
+        for name, (n, ms, fl, by) in agg.items():
+            kernels[name] = dict(launches_per_step=n // a.steps, avg_us=round(1e3 * ms / n, 2),
+                                 ms_per_step=round(ms / a.steps, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
+                                 alg_gbs=round(by / (ms * 1e-3) / 1e9, 1))
+        dom = max(agg, key=lambda k: agg[k][1])
+        n, ms, fl, by = agg[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(a.config, {}).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roof = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=dom,
+                    avg_launch_us=round(1e3 * ms / n, 2), alg_flop_per_launch=round(fl / n),
+                    alg_bytes_per_launch=round(by / n),
+                    note='fp32 exact MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)')
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        cpu = cpu_baseline(a.config, a.cpu_sample, 100)
+
+    if rank == 0:
+        total = world * B * a.steps
+        value = total / dt
+        line = {
+            'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': round(value, 2), 'unit': 'img/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.config}: build_ssd(groups 4, BN, fuse) forward + MultiBoxLoss, train-mode BN, '
+                                   f'[B,12,300,300] slices (4-phase 512x512 CT resized outside the timed region)',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
+                       'alg_gflop_per_img': gflop_img, 'alg_mb_per_img': mb_img},
+            'whole_path': {'tflops': round(value * gflop_img / 1e3, 2),
+                           'frac_f32_peak': round(value * gflop_img / 1e3 / (PEAK_F32_TFLOPS * world), 4),
+                           'alg_gbs': round(value * mb_img / 1e3, 1),
+                           'frac_hbm_peak': round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)},
+            'loss': [round(loss[0], 5), round(loss[1], 5)],
+            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
         const float dy = omp[d * 18 + 2 * tap];
         const float dx = omp[d * 18 + 2 * tap + 1];
         const float ml = omp[dg * 18 + d * 9 + tap];
-        const float m = 1.f / (1.f + __expf(-ml));            // torch.sigmoid (dcn_v2_custom.py:83)
+        const float m = 1.f / (1.f + expf(-ml));            // torch.sigmoid (dcn_v2_custom.py:83)
         const float py = (float)(h - 1 + tap / 3) + dy;
         const float px = (float)(w - 1 + tap % 3) + dx;
         float* dst = cols + (bp * 9 + tap) * C + d * cpg;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
         m = wave_max(m);
         float s = 0.f;
         for (int c = lane; c < n; c += 64) {
-            const float e = __expf(row[c] - m);
+            const float e = expf(row[c] - m);
             row[c] = e;
             s += e;
         }

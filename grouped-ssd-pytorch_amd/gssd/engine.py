@@ -29,10 +29,22 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
 
 class _Step:
-    __slots__ = ('fn', 'args', 'keep')
+    __slots__ = ('fn', 'args', 'keep', 'tag')
 
-    def __init__(self, fn, args, keep=None):
-        self.fn, self.args, self.keep = fn, args, keep
+    def __init__(self, fn, args, keep=None, tag=None):
+        self.fn, self.args, self.keep, self.tag = fn, args, keep, tag
+
+
+def conv_tag(d, real_cin_g=None):
+    """(kernel instance, algorithmic FLOPs, algorithmic bytes) of one gssd_conv2d launch; the instance name
+    mirrors the tile selection in csrc/conv_igemm.hip so it can be matched against rocprofv3's kernel names."""
+    cout_g = d.Cout // d.groups
+    inst = '128x128' if cout_g > 64 else '128x64' if cout_g > 32 else '128x32' if cout_g > 16 else '128x16'
+    M = d.B * d.Ho * d.Wo
+    cin_g = real_cin_g if real_cin_g is not None else d.cin_g
+    flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
+    byts = 4.0 * (d.B * d.H * d.W * cin_g * d.groups + M * d.Cout + d.Cout * d.KH * d.KW * cin_g)
+    return ('conv_igemm<' + inst + '>', flops, byts)
 
 
 class GssdEngine:
@@ -54,7 +66,7 @@ class GssdEngine:
         self._versions = None
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, x, training, want_attn=False):
+    def forward(self, x, training, events=None):
         net = self.net
         if not x.is_cuda:
             raise _lib.GssdError('GSSD HIP engine: input must live on the MI355X (cuda/ROCm tensor); there is no '
@@ -77,7 +89,7 @@ class GssdEngine:
             for job in self._pack_jobs:
                 job()
             self._versions = vers
-        return plan.run(x)
+        return plan.run(x, events)
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, name, build):
@@ -241,8 +253,11 @@ class _Plan:
         assert off == self.P, off
 
     # ------------------------------------------------------------------------------------------------
-    def _add(self, fn, args, keep=None):
-        self.steps.append(_Step(fn, args, keep))
+    def _add(self, fn, args, keep=None, tag=None):
+        if tag is None and fn is lib.gssd_conv2d_nhwc_f32:
+            d = keep[0] if isinstance(keep, tuple) else keep
+            tag = conv_tag(d, 3 if (d.cin_g == 4 and d.groups == 4 and d.H == 300) else None)
+        self.steps.append(_Step(fn, args, keep, tag))
 
     def _buf(self, *shape):
         t = torch.empty(*shape, device=self.dev, dtype=torch.float32)
@@ -411,7 +426,9 @@ class _Plan:
         return out, Cout
 
     # ------------------------------------------------------------------------------------------------
-    def run(self, x):
+    def run(self, x, events=None):
+        """``events``: optional list; when given, every conv launch is bracketed by a pair of HIP events recorded
+        on the launch stream and (tag, start, end) is appended (bench.py's live roofline measurement)."""
         B, dev = self.B, self.dev
         x = x.contiguous().float()
         loc = torch.empty(B, self.P, 4, device=dev, dtype=torch.float32)
@@ -422,10 +439,23 @@ class _Plan:
         if self.training:
             self.stats.zero_()
         stream = torch.cuda.current_stream().cuda_stream
-        for st in self.steps:
-            rc = st.fn(*st.args, stream)
-            if rc != 0:
-                _lib.check(rc)
+        if events is None:
+            for st in self.steps:
+                rc = st.fn(*st.args, stream)
+                if rc != 0:
+                    _lib.check(rc)
+        else:
+            for st in self.steps:
+                if st.tag is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = st.fn(*st.args, stream)
+                    e1.record()
+                    events.append((st.tag, e0, e1))
+                else:
+                    rc = st.fn(*st.args, stream)
+                if rc != 0:
+                    _lib.check(rc)
         if self.training and self.nbt:
             torch._foreach_add_(self.nbt, 1)
         self._x_keepalive = x

@@ -42,6 +42,9 @@ def import_reference():
     # our own drop-in packages share the names models/layers/data: make sure the reference wins here
     for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'layers', 'data', 'utils')]:
         del sys.modules[k]
+    # the reference's `models` is a namespace package (no __init__.py) and would lose to ours: drop our path
+    pkg = os.path.join(ROOT, 'grouped-ssd-pytorch_amd')
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p) != pkg]
     sys.path.insert(0, REF)
     import layers                                            # noqa: F401
     from layers import box_utils
@@ -81,6 +84,9 @@ def random_targets(rng, n):
     wh = rng.uniform(0.02, 0.4, size=(n, 2))
     box = np.concatenate([cxy - wh / 2, cxy + wh / 2], 1).clip(0, 1)
     return np.concatenate([box, np.zeros((n, 1))], 1).astype(np.float32)
+
+
+EB = 4   # batch of the end-to-end fixtures: >= 4 keeps the 1x1-map train-mode BatchNorm well conditioned
 
 
 def main():
@@ -226,8 +232,8 @@ def main():
         'gssd_sa': dict(args=(True, 4, 4, 1, True, True, True, 0, 1, False, False, 1)),
         'gssdpp': dict(args=(True, 4, 4, 1, True, True, True, 1, 4, True, False, 1)),
     }
-    x = synth.synth_images(2, seed=5)
-    tg = synth.synth_targets(2, seed=5)
+    x = synth.synth_images(EB, seed=5)
+    tg = synth.synth_targets(EB, seed=5)
     ed = {}
     for name, spec in nets.items():
         net = R.mg.build_ssd('train', 300, 2, *spec['args'])
@@ -262,7 +268,7 @@ def main():
             det = net_t(x)
         ed[f'{name}.det'] = det.numpy()
         print(name, 'params', sum(p.numel() for p in net.parameters()), 'loss', ed[f'{name}.loss'],
-              'det kept', [(det[b, 1, :, 0] > 0).sum().item() for b in range(2)])
+              'det kept', [(det[b, 1, :, 0] > 0).sum().item() for b in range(EB)])
     # vanilla SSD300 (BASELINE.json configs[0])
     net = R.mv.build_ssd('train', 300, 2)
     shapes = {k: v.shape for k, v in net.state_dict().items()}
@@ -270,7 +276,7 @@ def main():
     net.load_state_dict(sd)
     xv = synth.synth_images(2, seed=6, channels=3)
     loc, conf, pr = net(xv)
-    ll, lc = crit((loc, conf, pr), tg)
+    ll, lc = crit((loc, conf, pr), tg[:2])
     (ll + lc).backward()
     gfin = all(torch.isfinite(p.grad).all().item() for p in net.parameters() if p.grad is not None)
     ed['ssd.keys'] = np.array(sorted(shapes.keys()))

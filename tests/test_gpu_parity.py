@@ -173,7 +173,7 @@ def test_spectral_norm(dev, ops, do_iter):
     tab = ops.sn_items_tensor(items, dev)
     ops.spectral_norm(tab, len(items), do_iter)
     for (w, u, v, s), (sigma, un, vn) in zip(items, refs):
-        assert rel(1.0 / s, np.full(s.shape[0], sigma)) < 1e-5
+        assert rel(1.0 / s, np.full(s.shape[0], sigma)) < (1e-5 if do_iter else 1e-4)   # random u,v: u.Wv cancels
         assert rel(u, un) < 1e-5 and rel(v, vn) < 1e-5
 
 
@@ -355,12 +355,12 @@ def test_end_to_end(dev, golden, name):
     sd = synth.synth_state_dict(shapes, seed=1111)
     net.load_state_dict(sd)
     net = net.to(dev).train()
-    x = synth.synth_images(2, seed=5)
-    tg = synth.synth_targets(2, seed=5)
+    x = synth.synth_images(4, seed=5)
+    tg = synth.synth_targets(4, seed=5)
     with torch.no_grad():
         loc, conf, pri = net(x.to(dev))
         ll, lc = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)((loc, conf, pri), tg)
-    assert loc.shape == (2, 8732, 4) and conf.shape == (2, 8732, 2) and pri.shape == (8732, 4)
+    assert loc.shape == (4, 8732, 4) and conf.shape == (4, 8732, 2) and pri.shape == (8732, 4)
     # (1) vs the reference's sampled outputs
     l, c = loc.cpu().numpy().reshape(-1), conf.cpu().numpy().reshape(-1)
     assert np.abs(l[g[f'{name}.loc_idx']] - g[f'{name}.loc_val']).max() / g[f'{name}.loc_absmax'] < TOL
@@ -383,7 +383,7 @@ def test_end_to_end(dev, golden, name):
     net_t = net_t.to(dev).eval()
     with torch.no_grad():
         det = net_t(x.to(dev)).cpu().numpy()
-    assert det.shape == (2, 2, 200, 5)
+    assert det.shape == (4, 2, 200, 5)
     ref = g[f'{name}.det']
     assert np.array_equal(det[..., 0] > 0, ref[..., 0] > 0)
     assert np.allclose(canon_rows(det), canon_rows(ref), rtol=0, atol=5e-5)
@@ -396,12 +396,12 @@ def test_visualize_outputs(dev):
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     sd = synth.synth_state_dict(shapes, seed=1111)
     net.load_state_dict(sd)
-    net = net.to(dev).eval()
+    net = net.to(dev).train()
     x = synth.synth_images(2, seed=5)
     with torch.no_grad():
         out, offs, attnb, attn = net(x.to(dev), visualize=True)
         taps = {}
-        O.gssd_forward(sd, x, training=False, taps=taps, **flags)
+        O.gssd_forward(sd, x, training=True, taps=taps, **flags)
     assert len(offs) == 1 and offs[0].shape == (2, 72, 38, 38)
     assert rel(offs[0], taps['dcn0.offset']) < TOL
     assert [a.shape[1] for a in attnb] == [1444, 361, 100, 25, 9, 1] and len(attn) == 6
