@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ('B', c_i), ('H', c_i), ('W', c_i), ('in_stride', c_i), ('in_ch_off', c_i), ('Ho', c_i), ('Wo', c_i),
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
-        ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i),
+        ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i), ('split_k', c_i),
         ('in_batch_stride', c_i64), ('wgt_batch_stride', c_i64), ('out_batch_stride', c_i64),
         ('outb_batch_stride', c_i64), ('out_off', c_i64), ('outb_off', c_i64),
     ]
@@ -55,8 +55,8 @@ SIGNATURES = {
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),
     'gssd_dcn_im2col_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
-    'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_fp]),
-    'gssd_hnm_loss': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_i, c_fp]),
+    'gssd_hnm_loss': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     'gssd_loss_finalize': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp]),
     'gssd_loss_backward': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     'gssd_detect': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),

@@ -5,16 +5,18 @@
 //   n : output channel inside conv group g
 //   k : (tap, input channel of the group) flattened, k = tap*cin_g + c
 //
-// Both operands are K-contiguous in memory (NHWC activations; K-major packed weights), so both
-// tiles are staged with 16-byte loads into LDS as [row][BK+4] and read back as one ds_read_b128
-// per 16x16 fragment and 16 k values: lane (r = lane&15, kq = lane>>4) holds k = 16*ks + 4*kq + s
-// for MFMA step s -- A and B use the same k permutation, so the sum is unchanged.
-// The +4 float row pad keeps the 16 rows of a fragment on distinct 16-byte LDS slots.
+// Both operands are K-contiguous in memory (NHWC activations; K-major packed weights).  Tiles are staged
+// straight from global memory into LDS with 16-byte LDS-DMA loads (global_load_lds_dwordx4: no VGPR
+// round trip, no ds_write): a wave instruction lands 64 lanes x 16 B = 8 tile rows x 128 B (BK = 32
+// floats) contiguously.  Because the DMA image is lane-linear, the bank swizzle is applied on the SOURCE
+// side: LDS slot q' of row r holds logical k-quad q' ^ (r & 7), and fragment reads XOR the same way
+// (one ds_read_b128 per 16x16 fragment per 16 k; lane (r = lane&15, kq = lane>>4) holds
+// k = 16*ks + 4*kq + s for MFMA step s -- A and B use the same k permutation, so the sum is unchanged).
+// Out-of-image taps and tile tails read a 16-byte zero page instead of branching.
 //
-// A 256-thread workgroup (4 waves) owns a BM x BN output tile; global loads of K-chunk i+1 are
-// issued into registers before the MFMAs of chunk i and written to the other LDS buffer after
-// them (one barrier per chunk).  fp32 MFMA is exact fp32 FMA at the vector rate, so results
-// match an fp32 reference to accumulation-order rounding.
+// A 256-thread workgroup (4 waves) owns a BM x BN output tile; the DMA of K-chunk i+1 is issued before the
+// MFMAs of chunk i into the other LDS stage (one barrier per chunk).  fp32 MFMA is exact fp32 FMA at the
+// vector rate, so results match an fp32 reference to accumulation-order rounding.
 //
 // Replaces the implicit cuDNN/ATen kernels behind nn.Conv2d / torch.bmm on the reference path;
 // see include/gssd_hip.h for the call-site map.
@@ -24,19 +26,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
+constexpr int BK = 32;          // floats per tile row = 128 B = 8 DMA lanes
+
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p, const int M,
                                                          const int tiles_per_group) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int AR = BM / 32;                     // A float4 loads per thread per chunk
-    constexpr int BR = (BN * 8 + 255) / 256;        // B float4 loads per thread per chunk
-    constexpr int STAGE = (BM + BN) * LDK;
+    constexpr int AR = BM / 32;                     // A DMA instructions per wave per chunk (8 rows each)
+    constexpr int BPIECES = BN / 8;                 // B 1-KiB pieces per chunk
+    constexpr int BR = (BPIECES + 3) / 4;           // B DMA instructions per wave per chunk
+    constexpr int STAGE = (BM + BN) * BK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, kq = lane >> 4;
     const int g = blockIdx.y / tiles_per_group;
@@ -44,6 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     const int cout_g = p.Cout / p.groups;
     const int m0 = blockIdx.x * BM;
     const int img = p.m_per_image ? blockIdx.z : 0;
+    const int kz = p.m_per_image ? 0 : blockIdx.z;   // split-K slice (split_k > 1 only without m_per_image)
     const int HoWo = p.Ho * p.Wo;
     const int K = p.K;
     const int taps = p.KH * p.KW;
@@ -51,51 +62,64 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     const float* __restrict__ in = p.in + (size_t)img * p.in_batch_stride + p.in_ch_off + g * p.cin_g;
     const float* __restrict__ wgt =
         p.wgt + (size_t)img * p.wgt_batch_stride + (size_t)(g * cout_g) * p.wgt_row_stride;
+    const float* zero = g_zero_page;
 
-    // ---- per-thread A rows -------------------------------------------------------------
-    const int aq = tid & 7, ar = tid >> 3;
-    int a_iy0[AR], a_ix0[AR], a_base[AR];
-    bool a_ok[AR];
+    // ---- DMA lane roles: lane L lands at (row_in = L>>3, slot = L&7) of its 8-row piece and must fetch the
+    //      logical k-quad slot ^ row_in (source-side swizzle) ----------------------------------------------------
+    const int row_in = lane >> 3;
+    const int lq = (lane & 7) ^ row_in;              // logical quad (k = 4*lq within the chunk)
+    int a_iy0[AR], a_ix0[AR], a_off[AR];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + ar + 32 * i;
-        a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
+    for (int j = 0; j < AR; ++j) {
+        const int m = m0 + (j * 4 + wave) * 8 + row_in;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
         int b = 0, pix = mm;
         if (!p.m_per_image) {
             b = mm / HoWo;
             pix = mm - b * HoWo;
         }
         const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
-        a_iy0[i] = oy * p.stride - p.pad;
-        a_ix0[i] = ox * p.stride - p.pad;
-        a_base[i] = b * p.H * p.W;
+        a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 20);      // invalid rows fail every bounds test
+        a_ix0[j] = ox * p.stride - p.pad;
+        a_off[j] = ((b * p.H + oy * p.stride - p.pad) * p.W + a_ix0[j]) * p.in_stride;
     }
-    int a_tap = (4 * aq) / p.cin_g;
-    int a_c = (4 * aq) - a_tap * p.cin_g;
+    int b_off[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int row = (j * 4 + wave) * 8 + row_in;
+        b_ok[j] = (j * 4 + wave) < BPIECES && (n0g + row) < cout_g;
+        b_off[j] = (n0g + row) * p.wgt_row_stride + 4 * lq;
+    }
+    const int nchunks_all = (K + BK - 1) / BK;
+    const int cps = (nchunks_all + p.split_k - 1) / p.split_k;      // chunks per split-K slice
+    const int ch_begin = kz * cps;
+    const int ch_end = min(nchunks_all, ch_begin + cps);
+    int a_tap = (ch_begin * BK + 4 * lq) / p.cin_g;
+    int a_c = (ch_begin * BK + 4 * lq) - a_tap * p.cin_g;
 
-    f32x4 areg[AR], breg[BR];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto gload = [&](int chunk) {
+    auto issue = [&](int chunk, int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + BM * BK;
         const int ty = a_tap / p.KW, tx = a_tap - ty * p.KW;
         const int dy = ty * p.dil, dx = tx * p.dil;
         const bool tap_ok = a_tap < taps;
+        const int toff = (dy * p.W + dx) * p.in_stride + a_c;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const size_t off = (size_t)(a_base[i] + iy * p.W + ix) * p.in_stride + a_c;
-            areg[i] = ok ? *reinterpret_cast<const f32x4*>(in + off) : zero4;
+        for (int j = 0; j < AR; ++j) {
+            const bool ok = tap_ok && (unsigned)(a_iy0[j] + dy) < (unsigned)p.H && (unsigned)(a_ix0[j] + dx) < (unsigned)p.W;
+            const float* src = ok ? in + (a_off[j] + toff) : zero;
+            dma16(src, As + (j * 4 + wave) * 8 * BK);
         }
         const int k0 = chunk * BK;
+        const bool kok = k0 + 4 * lq < K;
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            const int idx = tid + j * 256;
-            const int row = idx >> 3, q = idx & 7;
-            const bool ok = (idx < BN * 8) && (n0g + row < cout_g) && (k0 + 4 * q < K);
-            breg[j] = ok ? *reinterpret_cast<const f32x4*>(wgt + (size_t)(n0g + row) * p.wgt_row_stride + k0 + 4 * q)
-                         : zero4;
+            if ((j * 4 + wave) < BPIECES) {           // wave-uniform
+                const float* src = (b_ok[j] && kok) ? wgt + (b_off[j] + k0) : zero;
+                dma16(src, Bs + (j * 4 + wave) * 8 * BK);
+            }
         }
         a_c += BK;
         while (a_c >= p.cin_g) {
@@ -103,40 +127,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
             ++a_tap;
         }
     };
-    auto lds_store = [&](int buf) {
-        float* As = smem + buf * STAGE;
-        float* Bs = As + BM * LDK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (ar + 32 * i) * LDK + 4 * aq) = areg[i];
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int idx = tid + j * 256;
-            if (idx < BN * 8) *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * LDK + 4 * (idx & 7)) = breg[j];
-        }
-    };
 
     f32x4 acc[MT][NT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
 
-    const int nchunks = (K + BK - 1) / BK;
-    gload(0);
-    lds_store(0);
+    // fragment read offsets (floats) inside a stage: row (base + r), physical slot (4*ks + kq) ^ (r & 7)
+    const int fo0 = r * BK + ((kq ^ (r & 7)) << 2);
+    const int fo1 = r * BK + (((4 + kq) ^ (r & 7)) << 2);
+
+    if (ch_begin < ch_end) issue(ch_begin, 0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) gload(ch + 1);
-        const float* As = smem + buf * STAGE + (wm * WTM + r) * LDK + kq * 4;
-        const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WTN + r) * LDK + kq * 4;
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int buf = (ch - ch_begin) & 1;
+        if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        const float* As = smem + buf * STAGE + wm * WTM * BK;
+        const float* Bs = smem + buf * STAGE + BM * BK + wn * WTN * BK;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
             f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * LDK + ks * 16);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * BK + fo);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * LDK + ks * 16);
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * BK + fo);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -145,7 +162,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (ch + 1 < nchunks) lds_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
         const int ng = n0g + wn * WTN + j * 16 + r;
         const bool n_ok = ng < cout_g;
         const int n = g * cout_g + ng;
-        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        const float bias = (p.bias && n_ok && kz == 0) ? p.bias[n] : 0.f;
         const float alpha = (p.alpha && n_ok) ? p.alpha[n] : 1.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -194,11 +210,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
                     float t = v[e];
                     if (p.out_mode == GSSD_OUT_HEADS) {
                         const int b = m / HoWo, pix = m - b * HoWo;
-                        if (n < p.split_n)
-                            p.out[(size_t)b * p.out_batch_stride + p.out_off + (size_t)pix * p.split_n + n] = t;
-                        else
-                            p.out_b[(size_t)b * p.outb_batch_stride + p.outb_off +
-                                    (size_t)pix * (p.Cout - p.split_n) + (n - p.split_n)] = t;
+                        float* dst = (n < p.split_n)
+                                         ? p.out + ((size_t)b * p.out_batch_stride + p.out_off + (size_t)pix * p.split_n + n)
+                                         : p.out_b + ((size_t)b * p.outb_batch_stride + p.outb_off +
+                                                      (size_t)pix * (p.Cout - p.split_n) + (n - p.split_n));
+                        if (p.split_k > 1) unsafeAtomicAdd(dst, t);   // caller zero-fills the buffers
+                        else *dst = t;
                     } else {
                         const size_t o = (size_t)img * p.out_batch_stride + (size_t)m * p.out_stride + p.out_ch_off + n;
                         if (p.gate) {
@@ -209,7 +226,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
                             t += p.resid[o];
                         }
                         if (p.relu) t = fmaxf(t, 0.f);
-                        p.out[o] = t;
+                        if (p.split_k > 1) unsafeAtomicAdd(p.out + o, t);
+                        else p.out[o] = t;
                     }
                 }
             }
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     static bool attr_set = false;
-    constexpr size_t smem = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
+    constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(float);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -262,7 +280,7 @@ int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     }
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;
-    dim3 grid((M + BM - 1) / BM, d.groups * tiles, images);
+    dim3 grid((M + BM - 1) / BM, d.groups * tiles, d.m_per_image ? images : d.split_k);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, d, M, tiles);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -287,13 +305,19 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     }
     if (d.out_mode == GSSD_OUT_HEADS) GSSD_CHECK_ARG(d.out_b && d.split_n > 0 && d.split_n < d.Cout && !d.m_per_image);
     if (d.m_per_image) GSSD_CHECK_ARG(d.in_batch_stride % 4 == 0 && d.wgt_batch_stride % 4 == 0);
+    GSSD_CHECK_ARG(d.split_k >= 1 && d.split_k <= 64);
+    // split-K accumulates with fp32 atomics into a zero-filled output: linear epilogues only
+    if (d.split_k > 1) GSSD_CHECK_ARG(!d.m_per_image && !d.stats && !d.relu && !d.gate && !d.resid && d.out_mode != GSSD_OUT_TRANSPOSED);
     // the conv arithmetic must reproduce Ho/Wo
     GSSD_CHECK_ARG((d.H + 2 * d.pad - d.dil * (d.KH - 1) - 1) / d.stride + 1 == d.Ho);
     GSSD_CHECK_ARG((d.W + 2 * d.pad - d.dil * (d.KW - 1) - 1) / d.stride + 1 == d.Wo);
 
     const int images = d.m_per_image ? d.B : 1;
     const long long Mll = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
-    GSSD_CHECK_ARG(Mll < (1ll << 31) && (long long)d.B * d.H * d.W < (1ll << 31));
+    GSSD_CHECK_ARG(Mll < (1ll << 31));
+    // 32-bit element offsets inside the kernel (one image set / one weight matrix per launch)
+    GSSD_CHECK_ARG((long long)(d.m_per_image ? 1 : d.B) * d.H * d.W * d.in_stride < (1ll << 31));
+    GSSD_CHECK_ARG((long long)(d.Cout / d.groups + 256) * d.wgt_row_stride < (1ll << 31));
     const int M = (int)Mll;
     const int cout_g = d.Cout / d.groups;
     hipStream_t s = as_stream(stream);

@@ -293,13 +293,20 @@ __global__ void softmax_lastdim_kernel(const float* __restrict__ x, float* __res
 }
 
 __global__ __launch_bounds__(256) void reduce_max_kernel(const float* __restrict__ x, long long n, float* out) {
+    // one partial maximum per block; consumers take the max over gridDim.x partials
     __shared__ float red[4];
     float m = -INFINITY;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, x[i]);
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, x[i]);
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 }  // namespace
@@ -398,9 +405,9 @@ extern "C" int gssd_softmax_lastdim_f32(const float* x, float* y, int64_t rows, 
     return GSSD_OK;
 }
 
-extern "C" int gssd_reduce_max_f32(const float* x, int64_t n, float* out, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(x && out && n > 0);
-    hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, (long long)n, out);
+extern "C" int gssd_reduce_max_f32(const float* x, int64_t n, float* out, int out_n, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && out && n > 0 && out_n > 0 && out_n <= 1024 && ((uintptr_t)x % 16) == 0);
+    hipLaunchKernelGGL(reduce_max_kernel, dim3(out_n), dim3(256), 0, as_stream(stream), x, (long long)n, out);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -163,7 +163,7 @@ __device__ unsigned radix_select_desc(const float* vals, int n, int k, unsigned*
 __global__ __launch_bounds__(LT) void hnm_loss_kernel(const float* __restrict__ loc, const float* __restrict__ conf,
                                                       const float* __restrict__ loc_t,
                                                       const int64_t* __restrict__ conf_t,
-                                                      const float* __restrict__ xmax_p, int P, int C, int negpos_ratio,
+                                                      const float* __restrict__ xmax_p, int xmax_n, int P, int C, int negpos_ratio,
                                                       uint8_t* __restrict__ sel, double* __restrict__ partial,
                                                       float* __restrict__ lca_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(LT) void hnm_loss_kernel(const float* __restrict__ 
     __shared__ int s_tie_base;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float xmax = *xmax_p;
+    float xmax = xmax_p[0];
+    for (int i = 1; i < xmax_n; ++i) xmax = fmaxf(xmax, xmax_p[i]);
     const float* cb = conf + (size_t)b * P * C;
     const int64_t* tb = conf_t + (size_t)b * P;
 
@@ -348,9 +349,9 @@ extern "C" int gssd_match_batch(const float* targets, const int* gt_off, const f
 }
 
 extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t,
-                             const float* xmax, int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial,
-                             float* loss_c_all, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(loc && conf && loc_t && conf_t && xmax && sel && partial);
+                             const float* xmax, int xmax_n, int B, int P, int C, int negpos_ratio, uint8_t* sel,
+                             double* partial, float* loss_c_all, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(loc && conf && loc_t && conf_t && xmax && xmax_n > 0 && sel && partial);
     GSSD_CHECK_ARG(B > 0 && P > 0 && P <= 36000 && C >= 2 && negpos_ratio >= 0);
     GSSD_CHECK_ARG(((uintptr_t)loc % 16) == 0 && ((uintptr_t)loc_t % 16) == 0);
     static bool attr_set = false;
@@ -360,8 +361,8 @@ extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* l
                             150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(hnm_loss_kernel, dim3(B), dim3(LT), smem, as_stream(stream), loc, conf, loc_t, conf_t, xmax, P, C,
-                       negpos_ratio, sel, partial, loss_c_all);
+    hipLaunchKernelGGL(hnm_loss_kernel, dim3(B), dim3(LT), smem, as_stream(stream), loc, conf, loc_t, conf_t, xmax, xmax_n, P,
+                       C, negpos_ratio, sel, partial, loss_c_all);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

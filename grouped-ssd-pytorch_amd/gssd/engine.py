@@ -77,7 +77,8 @@ class GssdEngine:
         B = x.shape[0]
         if tuple(x.shape[1:]) != (12, 300, 300):
             raise _lib.GssdError(f'expected input [B,12,300,300], got {tuple(x.shape)}')
-        key = (B, bool(training), x.device.index, p0.data_ptr())
+        bn_cfg = tuple((m.momentum, m.eps) for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        key = (B, bool(training), x.device.index, p0.data_ptr(), hash(bn_cfg))
         plan = self._plans.get(key)
         if plan is None:
             if self._plans and next(iter(self._plans))[3] != p0.data_ptr():
@@ -246,7 +247,8 @@ class _Plan:
             d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
                                          pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
                                          out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
-                                         out_off=off * 4, outb_off=off * self.nc)
+                                         out_off=off * 4, outb_off=off * self.nc,
+                                         split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
             self.head_descs.append(d)
             self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
             off += Hs * Hs * A
@@ -431,8 +433,9 @@ class _Plan:
         on the launch stream and (tag, start, end) is appended (bench.py's live roofline measurement)."""
         B, dev = self.B, self.dev
         x = x.contiguous().float()
-        loc = torch.empty(B, self.P, 4, device=dev, dtype=torch.float32)
-        conf = torch.empty(B, self.P, self.nc, device=dev, dtype=torch.float32)
+        # zero-filled: the heads accumulate split-K slices with atomics
+        loc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
+        conf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
         for d in self.head_descs:
             d.out, d.out_b = loc.data_ptr(), conf.data_ptr()
         self.steps[self._pack_step].args[0] = x.data_ptr()

@@ -79,7 +79,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    bias=None, in_ch_off=0, out_stride=None, out_ch_off=0, out_mode=_lib.OUT_NHWC, relu=False,
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
-                   outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None):
+                   outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -92,9 +92,19 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.wgt_row_stride = wgt_row_stride if wgt_row_stride is not None else K
     d.out_stride = out_stride if out_stride is not None else Cout
     d.out_ch_off, d.out_mode, d.relu, d.m_per_image, d.split_n = out_ch_off, out_mode, int(relu), int(m_per_image), split_n
+    d.split_k = split_k
     d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride
     d.out_batch_stride, d.outb_batch_stride, d.out_off, d.outb_off = out_batch_stride, outb_batch_stride, out_off, outb_off
     return d, Ho, Wo
+
+
+def auto_split_k(M, Cout, groups, K, target_blocks=1024, max_split=48):
+    """Split-K factor for small-grid / long-K launches (mirrors the tile choice of csrc/conv_igemm.hip)."""
+    cout_g = Cout // groups
+    bn = 128 if cout_g > 64 else 64 if cout_g > 32 else 32 if cout_g > 16 else 16
+    blocks = -(-M // 128) * groups * (-(-cout_g // bn))
+    chunks = -(-K // BK)
+    return int(max(1, min(max_split, chunks // 4, target_blocks // blocks)))
 
 
 def run_conv(desc):
@@ -236,12 +246,13 @@ def multibox_loss_forward(loc, conf, priors, tg, n_gt, threshold=0.5, negpos_rat
     priors = priors[:P].contiguous()
     loc_t, conf_t = match_batch(tg, n_gt, priors, threshold, variance)
     dev = loc.device
-    xmax = torch.empty(1, device=dev, dtype=torch.float32)
-    check(lib.gssd_reduce_max_f32(_p(conf), conf.numel(), _p(xmax), _stream()))
+    NX = 128
+    xmax = torch.empty(NX, device=dev, dtype=torch.float32)
+    check(lib.gssd_reduce_max_f32(_p(conf), conf.numel(), _p(xmax), NX, _stream()))
     sel = torch.empty(B, P, device=dev, dtype=torch.uint8)
     partial = torch.empty(B, 4, device=dev, dtype=torch.float64)
     lca = torch.empty(B, P, device=dev, dtype=torch.float32) if want_scores else None
-    check(lib.gssd_hnm_loss(_p(loc), _p(conf), _p(loc_t), _p(conf_t), _p(xmax), B, P, Cc, int(negpos_ratio), _p(sel),
+    check(lib.gssd_hnm_loss(_p(loc), _p(conf), _p(loc_t), _p(conf_t), _p(xmax), NX, B, P, Cc, int(negpos_ratio), _p(sel),
                             _p(partial), _p(lca), _stream()))
     losses = torch.empty(2, device=dev, dtype=torch.float32)
     n_total = torch.empty(1, device=dev, dtype=torch.float64)

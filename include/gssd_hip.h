@@ -100,6 +100,8 @@ typedef struct gssd_conv_desc {
     int relu;
     int m_per_image;    /* 1: grid.z = image, tiles do not cross images, *_batch_stride apply */
     int split_n;        /* GSSD_OUT_HEADS: channels [0, split_n) are loc, the rest conf */
+    int split_k;        /* >= 1; > 1 slices K over grid.z and accumulates with fp32 atomics into a zero-filled
+                           output (small-M / long-K launches such as the heads); plain epilogues only */
     int64_t in_batch_stride, wgt_batch_stride, out_batch_stride, outb_batch_stride;
     int64_t out_off, outb_off; /* GSSD_OUT_HEADS: float offset of this source inside one image's rows */
 } gssd_conv_desc;
@@ -168,14 +170,15 @@ int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols, int B, int
 int gssd_match_batch(const float* targets, const int* gt_off, const float* priors, int B, int P,
                      float threshold, float var0, float var1, float* loc_t, int64_t* conf_t, gssd_stream_t stream);
 
-/* Global max of a float array (log_sum_exp's x_max, box_utils.py:167). `out` = 1 float. */
-int gssd_reduce_max_f32(const float* x, int64_t n, float* out, gssd_stream_t stream);
+/* Global max of a float array (log_sum_exp's x_max, box_utils.py:167) as out_n partial maxima
+ * (one per workgroup); the consumer takes the max over them. */
+int gssd_reduce_max_f32(const float* x, int64_t n, float* out, int out_n, gssd_stream_t stream);
 
 /* Hard-negative mining + the two loss sums.  sel [B][P] uint8: 0 unused, 1 positive, 2 mined negative.
  * partial [B][4] doubles (loss_l sum, loss_c sum, n_pos, spare); losses [2] floats = (loss_l/N, loss_c/N)
  * after gssd_loss_finalize.  loss_c_all [B][P] (optional, may be NULL) receives the mining scores. */
 int gssd_hnm_loss(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t, const float* xmax,
-                  int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial, float* loss_c_all,
+                  int xmax_n, int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial, float* loss_c_all,
                   gssd_stream_t stream);
 int gssd_loss_finalize(const double* partial, int B, float* losses, double* n_total, gssd_stream_t stream);
 /* d(loss_l + loss_c)/d(loc, conf) scaled by grad_l, grad_c (device scalars) / N. */

@@ -414,9 +414,12 @@ def extras_layers(batch_norm=True, groups=4, in_ch=1024):
     return layers
 
 
+BN_MOMENTUM = [0.1]     # nn.BatchNorm2d default; tests set 1.0 to make running stats == batch stats
+
+
 def _bn(x, sd, prefix, training, updates):
     rm, rv = sd[prefix + '.running_mean'].clone(), sd[prefix + '.running_var'].clone()
-    y = F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], training, 0.1, 1e-5)
+    y = F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], training, BN_MOMENTUM[0], 1e-5)
     if training and updates is not None:
         updates[prefix + '.running_mean'], updates[prefix + '.running_var'] = rm, rv
     return y

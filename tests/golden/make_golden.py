@@ -244,7 +244,7 @@ def main():
         with torch.no_grad():
             loc, conf, pr = net(x)
             ll, lc = crit((loc, conf, pr), tg)
-        after = net.state_dict()
+        after = {k: v.clone() for k, v in net.state_dict().items()}
         ed[f'{name}.keys'] = np.array(sorted(shapes.keys()))
         ed[f'{name}.shapes'] = np.array([str(tuple(shapes[k])) for k in sorted(shapes.keys())])
         ed[f'{name}.loc_sha'] = np.frombuffer(bytes.fromhex(sha(loc.numpy())), dtype=np.uint8)
@@ -260,7 +260,15 @@ def main():
         if name != 'gssd':
             k = 'self_attn_list.0.snconv1x1_theta.weight_u'
             ed[f'{name}.after.{k}'] = after[k].numpy().copy()
-        # test-phase twin shares the state dict (strict load) and runs Detect
+        # test-phase twin shares the state dict (strict load) and runs Detect.  The synthetic running statistics
+        # do not describe these activations (eval-mode BN would blow the scale up layer by layer), so first run one
+        # more training forward with momentum 1.0: running stats := this batch's statistics.
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.momentum = 1.0
+        with torch.no_grad():
+            net(x)
+        after = net.state_dict()
         net_t = R.mg.build_ssd('test', 300, 2, *spec['args'])
         net_t.load_state_dict(after)
         net_t.eval()

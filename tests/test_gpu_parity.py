@@ -331,14 +331,25 @@ NETS = {
 }
 
 
-def canon_rows(det):
-    out = det.copy()
-    for b in range(det.shape[0]):
-        for c in range(det.shape[1]):
-            r = det[b, c]
-            key = np.lexsort((np.round(r[:, 2], 4), np.round(r[:, 1], 4), -np.round(r[:, 0], 5)))
-            out[b, c] = r[key]
-    return out
+def same_detections(det, ref, atol):
+    """Rows agree as a set: scores saturate so exact fp32 ties exist, and the reference's visiting order among
+    ties is an accident of torch's unstable sort.  Every reference row must have its own partner within atol."""
+    if np.allclose(det, ref, rtol=0, atol=atol):
+        return True
+    for b in range(ref.shape[0]):
+        for c in range(ref.shape[1]):
+            d, r = det[b, c], ref[b, c]
+            if (d[:, 0] > 0).sum() != (r[:, 0] > 0).sum():
+                return False
+            used = np.zeros(d.shape[0], bool)
+            for row in r[r[:, 0] > 0]:
+                err = np.abs(d - row).max(1)
+                err[used] = np.inf
+                j = int(err.argmin())
+                if err[j] > atol:
+                    return False
+                used[j] = True
+    return True
 
 
 @pytest.mark.parametrize('name', list(NETS))
@@ -377,16 +388,22 @@ def test_end_to_end(dev, golden, name):
     for k in ('vgg.1.running_mean', 'vgg.1.running_var', 'bn_fuse_11.running_mean', 'extras.15.running_var'):
         assert rel(after[k], g[f'{name}.after.{k}']) < TOL, k
     assert int(after['vgg.1.num_batches_tracked']) == 1
-    # (4) test phase twin: strict load, eval-mode BN, fused softmax + Detect
+    # (4) test phase twin: strict load, eval-mode BN, fused softmax + Detect.  As in make_golden.py, one more
+    # training forward with BN momentum 1.0 first makes the running statistics describe these activations.
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():
+        net(x.to(dev))
     net_t = build_ssd('test', 300, 2, *args)
-    net_t.load_state_dict(after)
+    net_t.load_state_dict(net.state_dict())
     net_t = net_t.to(dev).eval()
     with torch.no_grad():
         det = net_t(x.to(dev)).cpu().numpy()
     assert det.shape == (4, 2, 200, 5)
     ref = g[f'{name}.det']
     assert np.array_equal(det[..., 0] > 0, ref[..., 0] > 0)
-    assert np.allclose(canon_rows(det), canon_rows(ref), rtol=0, atol=5e-5)
+    assert same_detections(det, ref, 5e-5)
 
 
 def test_visualize_outputs(dev):

@@ -175,35 +175,45 @@ def test_end_to_end_vs_reference(golden, name, flags):
     if name != 'gssd':
         k = 'self_attn_list.0.snconv1x1_theta.weight_u'
         assert rel(upd[k].numpy(), g[f'{name}.after.{k}']) < 1e-5
-    # test phase twin: eval-mode forward with the post-step state, then Detect
+    # test phase twin: one more training forward with BN momentum 1.0 (running stats := batch stats, see
+    # make_golden.py), then the eval-mode forward + Detect
     sd2 = dict(sd)
     sd2.update(upd)
-    # the reference's state after the train forward carries ALL running stats; rebuild them
+    O.BN_MOMENTUM[0] = 1.0
+    try:
+        with torch.no_grad():
+            _, _, upd2 = O.gssd_forward(sd2, x, **flags)
+    finally:
+        O.BN_MOMENTUM[0] = 0.1
+    sd2.update(upd2)
     with torch.no_grad():
-        loc_e, conf_e, _ = O.gssd_forward(sd2_full(sd, x, flags), x, training=False, **flags)
+        loc_e, conf_e, _ = O.gssd_forward(sd2, x, training=False, **flags)
     det = O.detect(2, 0, 200, 0.01, 0.45, loc_e.numpy(), O.softmax_scores(conf_e.numpy()), O.prior_box())
     assert np.array_equal(det[..., 0] > 0, g[f'{name}.det'][..., 0] > 0)
-    # scores saturate near 1.0 -> exact fp32 ties, whose visiting order in the reference is an accident of
-    # torch's unstable sort: compare the rows as a set (canonical order), values to 2e-5
-    assert np.allclose(canon_rows(det), canon_rows(g[f'{name}.det']), rtol=0, atol=2e-5)
+    # exact fp32 score ties are visited in an order that is an accident of torch's unstable sort: compare the rows
+    # as a set (canonical order), values to 2e-5
+    assert same_detections(det, g[f'{name}.det'], 2e-5)
 
 
-def canon_rows(det):
-    out = det.copy()
-    for b in range(det.shape[0]):
-        for c in range(det.shape[1]):
-            r = det[b, c]
-            key = np.lexsort((np.round(r[:, 2], 4), np.round(r[:, 1], 4), -np.round(r[:, 0], 5)))
-            out[b, c] = r[key]
-    return out
-
-
-def sd2_full(sd, x, flags):
-    with torch.no_grad():
-        _, _, upd = O.gssd_forward(sd, x, **flags)
-    out = dict(sd)
-    out.update(upd)
-    return out
+def same_detections(det, ref, atol):
+    """Rows agree as a set: scores saturate so exact fp32 ties exist, and the reference's visiting order among
+    ties is an accident of torch's unstable sort.  Every reference row must have its own partner within atol."""
+    if np.allclose(det, ref, rtol=0, atol=atol):
+        return True
+    for b in range(ref.shape[0]):
+        for c in range(ref.shape[1]):
+            d, r = det[b, c], ref[b, c]
+            if (d[:, 0] > 0).sum() != (r[:, 0] > 0).sum():
+                return False
+            used = np.zeros(d.shape[0], bool)
+            for row in r[r[:, 0] > 0]:
+                err = np.abs(d - row).max(1)
+                err[used] = np.inf
+                j = int(err.argmin())
+                if err[j] > atol:
+                    return False
+                used[j] = True
+    return True
 
 
 def test_vanilla_ssd_config0(golden):
