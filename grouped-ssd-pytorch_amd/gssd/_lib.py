@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
     """struct gssd_conv_desc (include/gssd_hip.h)."""
     _fields_ = [
         ('in_', c_fp), ('wgt', c_fp), ('bias', c_fp), ('out', c_fp), ('out_b', c_fp), ('alpha', c_fp),
-        ('gate', c_fp), ('resid', c_fp), ('out2', c_fp), ('stats', c_fp),
+        ('gate', c_fp), ('resid', c_fp), ('out2', c_fp), ('in_scale', c_fp), ('in_shift', c_fp), ('in_pad', c_fp),
+        ('stats', c_fp),
         ('B', c_i), ('H', c_i), ('W', c_i), ('in_stride', c_i), ('in_ch_off', c_i), ('Ho', c_i), ('Wo', c_i),
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
@@ -49,6 +50,7 @@ SIGNATURES = {
     'gssd_conv2d_nhwc_f32': (c_i, [C.POINTER(ConvDesc), c_fp]),
     'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
+    'gssd_bn_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),

@@ -47,3 +47,6 @@ __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// conv_thin.hip: returns 1 when the descriptor is not one of the thin grouped 3x3 shapes, else a GSSD_* code
+int gssd_try_conv_thin(const gssd_conv_desc& d, hipStream_t stream);

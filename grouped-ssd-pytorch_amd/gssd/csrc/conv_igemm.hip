@@ -306,6 +306,7 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     if (d.out_mode == GSSD_OUT_HEADS) GSSD_CHECK_ARG(d.out_b && d.split_n > 0 && d.split_n < d.Cout && !d.m_per_image);
     if (d.m_per_image) GSSD_CHECK_ARG(d.in_batch_stride % 4 == 0 && d.wgt_batch_stride % 4 == 0);
     GSSD_CHECK_ARG(d.split_k >= 1 && d.split_k <= 64);
+    GSSD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr) && (d.in_scale == nullptr) == (d.in_pad == nullptr));
     // split-K accumulates with fp32 atomics into a zero-filled output: linear epilogues only
     if (d.split_k > 1) GSSD_CHECK_ARG(!d.m_per_image && !d.stats && !d.relu && !d.gate && !d.resid && d.out_mode != GSSD_OUT_TRANSPOSED);
     // the conv arithmetic must reproduce Ho/Wo
@@ -321,6 +322,12 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     const int M = (int)Mll;
     const int cout_g = d.Cout / d.groups;
     hipStream_t s = as_stream(stream);
+    {
+        const int rc = gssd_try_conv_thin(d, s);      // conv1_1 / conv1_2 / conv2_1: patch-staged kernel
+        if (rc != 1) return rc;
+    }
+    // on-the-fly producer BN+ReLU is implemented by the patch-staged thin kernel only (so far)
+    GSSD_CHECK_ARG(d.in_scale == nullptr && d.in_shift == nullptr);
     if (cout_g > 64) return launch_cfg<128, 128, 2, 2>(d, M, images, s);
     if (cout_g > 32) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
     if (cout_g > 16) return launch_cfg<128, 32, 4, 1>(d, M, images, s);

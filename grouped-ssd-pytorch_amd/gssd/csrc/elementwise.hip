@@ -141,6 +141,33 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(
     }
 }
 
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, int training, int C, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ pad) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = stats[c] / count;
+        var = stats[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    double sc = (double)gamma[c] / sqrt(var + (double)eps);
+    const float sh = (float)((double)beta[c] - mean * sc);
+    float scf = (float)sc;
+    if (scf == 0.f) scf = 1e-30f;                 // keeps the pad value mapped below zero
+    scale[c] = scf;
+    shift[c] = sh;
+    pad[c] = scf > 0.f ? -3.0e38f : 3.0e38f;      // max(pad*scale + shift, 0) == 0: zero padding after BN+ReLU
+}
+
 // ---------------------------------------------------------------------------------------------
 // L2Norm: one wave per pixel, channels strided over lanes as float4.
 // ---------------------------------------------------------------------------------------------
@@ -356,6 +383,17 @@ extern "C" int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H,
     hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(blocks), dim3(EW_THREADS), 2 * C * sizeof(float), as_stream(stream),
                        raw, out, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, stats, count, gamma, beta, running_mean,
                        running_var, momentum, eps, training, relu);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_finalize_f32(const double* stats, double count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, int training,
+                                    int C, float* scale, float* shift, float* pad, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && pad && C > 0);
+    GSSD_CHECK_ARG(!training || (stats != nullptr && count > 0));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, training, C, scale, shift, pad);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

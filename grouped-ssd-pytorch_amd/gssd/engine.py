@@ -40,11 +40,15 @@ def conv_tag(d, real_cin_g=None):
     mirrors the tile selection in csrc/conv_igemm.hip so it can be matched against rocprofv3's kernel names."""
     cout_g = d.Cout // d.groups
     inst = '128x128' if cout_g > 64 else '128x64' if cout_g > 32 else '128x32' if cout_g > 16 else '128x16'
+    name = 'conv_igemm<' + inst + '>'
+    if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
+            and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
+        name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
     M = d.B * d.Ho * d.Wo
     cin_g = real_cin_g if real_cin_g is not None else d.cin_g
     flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
     byts = 4.0 * (d.B * d.H * d.W * cin_g * d.groups + M * d.Cout + d.Cout * d.KH * d.KW * cin_g)
-    return ('conv_igemm<' + inst + '>', flops, byts)
+    return (name, flops, byts)
 
 
 class GssdEngine:
@@ -173,6 +177,7 @@ class _Plan:
         cfg = list(VGG_CFG)
         i = 0
         x43 = None
+        xf = None
         while i < len(cfg):
             v = cfg[i]
             assert v not in ('M', 'C')
@@ -185,7 +190,11 @@ class _Plan:
                 pool = (2, 2, 0, nxt == 'C')
             if last:
                 pool = (3, 1, 1, False)               # pool5
-            cur, H, Cc = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, pool=pool)
+            # conv1_1's BatchNorm + ReLU is applied on the fly inside conv1_2 (thin kernel): its 737 MB output makes one
+            # HBM round trip less.  Elsewhere BN + ReLU (+ pool) is a separate pass.
+            defer = (vi == 0 and pool is None)
+            cur, H, Cc, xf = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, pool=pool, in_xf=xf,
+                                           defer_bn=defer)
             vi += 3
             if nxt in ('M', 'C'):
                 vi += 1
@@ -197,7 +206,7 @@ class _Plan:
         vi += 1   # pool5 module
         for _ in range(2):                                  # conv6, conv7
             conv, bn = net.vgg[vi], net.vgg[vi + 1]
-            cur, H, Cc = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True)
+            cur, H, Cc, _ = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True)
             vi += 3
         sources = [src0]
         sab_i, sa_i = 1, 1
@@ -212,7 +221,7 @@ class _Plan:
         fi = 2
         for k in range(0, n_ex, 2):
             conv, bn = net.extras[k], net.extras[k + 1]
-            cur, H, Cc = self._conv_bn(f'extras.{k}', conv, bn, cur, H, Cc, ge, relu=True)
+            cur, H, Cc, _ = self._conv_bn(f'extras.{k}', conv, bn, cur, H, Cc, ge, relu=True)
             if (k + 1) % 4 == 3:
                 if net.use_self_attention_base:
                     cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)
@@ -273,8 +282,10 @@ class _Plan:
             return ops.pack_weight(conv.weight, out)
         return eng._pack(name + '.w', build)
 
-    def _conv_bn(self, name, conv, bn, x, H, Cin, groups, relu=True, pool=None):
-        """conv (raw output + fp64 batch sums) -> BN + ReLU (+ max-pool)."""
+    def _conv_bn(self, name, conv, bn, x, H, Cin, groups, relu=True, pool=None, in_xf=None, defer_bn=False):
+        """conv (raw output + fp64 batch sums) -> BN + ReLU (+ max-pool).  ``in_xf`` = (scale, shift, pad) of a producer
+        whose BN + ReLU this conv applies on the fly; ``defer_bn`` leaves this layer's own BN + ReLU to its consumer and
+        returns (raw, H, C, (scale, shift, pad))."""
         B = self.B
         k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         Cout = conv.out_channels
@@ -285,8 +296,18 @@ class _Plan:
         st = self.eng_stat(bn)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(),
-                                     stats=st if self.training else None)
+                                     stats=st if self.training else None,
+                                     in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
+                                     in_pad=in_xf[2] if in_xf else None)
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        if defer_bn:
+            assert pool is None and relu
+            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._buf(Cout)
+            self._add(lib.gssd_bn_finalize_f32,
+                      (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
+            return raw, Ho, Cout, (sc, sh, pd)
         if pool:
             pk, ps, pp, ceil = pool
             Hp = ops.pool_out_size(Ho, pk, ps, pp, ceil)
@@ -297,7 +318,7 @@ class _Plan:
                   (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
                    bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                    float(bn.momentum), float(bn.eps), int(self.training), int(relu)))
-        return act, Hp, Cout
+        return act, Hp, Cout, None
 
     def eng_stat(self, bn):
         return self.stat_of[id(bn)]
@@ -341,7 +362,7 @@ class _Plan:
             s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False)
         if net.use_fuseconv:
             conv, bn = getattr(net, f'fuse_{fuse}'), getattr(net, f'bn_fuse_{fuse}')
-            s, H, Cc = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
+            s, H, Cc, _ = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
         return (s, H, Cc)
 
     def _self_attn(self, lst_name, idx, x, H, Cc, need_out2):

@@ -79,7 +79,8 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    bias=None, in_ch_off=0, out_stride=None, out_ch_off=0, out_mode=_lib.OUT_NHWC, relu=False,
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
-                   outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1):
+                   outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
+                   in_shift=None, in_pad=None):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -93,6 +94,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.out_stride = out_stride if out_stride is not None else Cout
     d.out_ch_off, d.out_mode, d.relu, d.m_per_image, d.split_n = out_ch_off, out_mode, int(relu), int(m_per_image), split_n
     d.split_k = split_k
+    d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride
     d.out_batch_stride, d.outb_batch_stride, d.out_off, d.outb_off = out_batch_stride, outb_batch_stride, out_off, outb_off
     return d, Ho, Wo
@@ -140,6 +142,11 @@ def bn_relu_pool(raw, out, stats, count, gamma, beta, rmean, rvar, training, rel
                                     _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps, int(training), int(relu),
                                     _stream()))
     return out
+
+
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, training, scale, shift, pad, momentum=0.1, eps=1e-5):
+    check(lib.gssd_bn_finalize_f32(_p(stats), float(count), _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                                   int(training), gamma.numel(), _p(scale), _p(shift), _p(pad), _stream()))
 
 
 def pool_out_size(n, k, s, p, ceil):

@@ -83,6 +83,9 @@ typedef struct gssd_conv_desc {
     const float* gate;  /* device scalar: out = resid + gate*(acc*alpha + bias) (Self_Attn sigma) or NULL */
     const float* resid; /* NHWC, same geometry as out, or NULL */
     float* out2;        /* receives gate*(acc*alpha+bias) when gate != NULL and out2 != NULL */
+    const float* in_scale; /* fused producer BatchNorm+ReLU: the input is read as max(x*in_scale[c] + in_shift[c], 0) */
+    const float* in_shift; /* (per input channel, from gssd_bn_finalize_f32); NULL = plain input.  Zero padding applies */
+    const float* in_pad;   /* AFTER the transform: out-of-image taps read in_pad[c], a value the transform maps to 0 */
     double* stats;      /* [2*Cout]: per-channel sum / sum of squares of the pre-activation output
                            accumulated with fp64 atomics (BatchNorm batch statistics), or NULL */
     int B, H, W;        /* input geometry */
@@ -122,6 +125,13 @@ int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H, int W, int
                           int pool_s, int pool_p, const double* stats, double count, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                           int training, int relu, gssd_stream_t stream);
+
+/* BatchNorm statistics -> per-channel affine, for consumers that apply BN+ReLU on the fly (gssd_conv_desc.in_scale):
+ * scale = gamma / sqrt(var + eps), shift = beta - mean*scale, pad = -/+3e38 (mapped to <= 0 by the transform);
+ * training != 0 uses the fp64 batch sums and updates running_mean / running_var like nn.BatchNorm2d. */
+int gssd_bn_finalize_f32(const double* stats, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int training, int C,
+                         float* scale, float* shift, float* pad, gssd_stream_t stream);
 
 /* x / (sqrt(sum_c x^2) + eps) * w_c per pixel.  Replaces layers/modules/l2norm.py:19-23. */
 int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pixels, int C, float eps,

@@ -62,6 +62,10 @@ CONV_CASES = [
     (5, 3, 128, 256, 3, 1, 0, 1, 4),     # 3 -> 1
     (2, 10, 512, 512, 1, 1, 0, 1, 1),    # dense 1x1 fuse
     (2, 38, 512, 108, 3, 1, 1, 1, 1),    # DCN offset conv shape (Cout not a tile multiple)
+    (2, 83, 16, 64, 3, 1, 1, 1, 4),      # thin patch-staged kernel <4,16>, ragged 8x16 tiles
+    (2, 80, 64, 64, 3, 1, 1, 1, 4),      # thin <16,16>
+    (3, 75, 64, 128, 3, 1, 1, 1, 4),     # thin <16,32>, exact 5x25 tiles
+    (1, 150, 64, 128, 3, 1, 1, 1, 4),
 ]
 
 
@@ -80,6 +84,35 @@ def test_conv_igemm(dev, ops, case):
     n = ref.numel() / Cout
     assert rel(stats[:Cout] / n, ref.double().mean(dim=(0, 2, 3))) < 1e-5
     assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('Cin,Cout,H', [(64, 64, 80), (64, 128, 75), (16, 64, 77)])
+def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H):
+    """A consumer conv applying its producer's BatchNorm + ReLU on the fly (conv1_1 -> conv1_2 in the engine): equals
+    conv2d(relu(bn(x))) with zero padding applied AFTER the transform."""
+    rng = np.random.default_rng(Cin + H)
+    B, g = 2, 4
+    x = torch.from_numpy(rng.normal(0.2, 1.0, size=(B, Cin, H, H)).astype(np.float32))
+    gm = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
+    bt = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    rm, rv = torch.zeros(Cin), torch.ones(Cin)
+    ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.batch_norm(x, rm.clone(), rv.clone(), gm, bt, True, 0.1,
+                                                                              1e-5)), w, b, 1, 1, 1, g)
+    stats = torch.stack([x.double().sum(dim=(0, 2, 3)), (x.double() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(dev)
+    sc, sh, pd = (torch.empty(Cin, device=dev) for _ in range(3))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    ops.bn_finalize(stats, B * H * H, gm.to(dev), bt.to(dev), rmd, rvd, True, sc, sh, pd)
+    wp = ops.pack_weight(w.to(dev))
+    out = torch.empty(B, H, H, Cout, device=dev)
+    d, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g,
+                                 k=3, pad=1, bias=b.to(dev), in_scale=sc, in_shift=sh, in_pad=pd)
+    ops.run_conv(d)
+    assert rel(nchw(out), ref) < TOL
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    torch.nn.functional.batch_norm(x, rm_ref, rv_ref, gm, bt, True, 0.1, 1e-5)
+    assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5
 
 
 def test_conv_heads_layout(dev, ops):
