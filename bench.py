@@ -27,7 +27,6 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 import torch                                                              # noqa: E402
-import torch.distributed as dist                                          # noqa: E402
 
 CONFIGS = {
     # name: (build_ssd positional args after (phase, size, num_classes), oracle flags, GFLOP/img, MB/img train-mode)
@@ -78,9 +77,8 @@ def main():
     ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     a = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from gssd import dist as gd
+    world, rank, local = gd.env_world()
     if a.gpus != world and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if a.gpus > 1 and world == 1:
@@ -88,9 +86,7 @@ def main():
                          '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+    gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)
 
     from gssd import synth
     from layers.modules import MultiBoxLoss
@@ -101,8 +97,8 @@ def main():
     net = net.to(dev).train()
     crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
     B = a.batch
-    x = synth.synth_images(B, seed=100 + rank).to(dev)                    # rank r owns its own 32 images
-    tg = [t.to(dev) for t in synth.synth_targets(B, seed=100 + rank)]
+    x = synth.synth_images(B, seed=gd.shard_seed(100, rank)).to(dev)      # rank r owns its own 32 images
+    tg = [t.to(dev) for t in synth.synth_targets(B, seed=gd.shard_seed(100, rank))]
 
     def step():
         with torch.no_grad():
@@ -110,10 +106,7 @@ def main():
             return crit(out, tg)
 
     def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        gd.barrier(dev)
 
     for _ in range(a.warmup):
         ll, lc = step()
@@ -129,10 +122,7 @@ def main():
     loss = (float(ll), float(lc))
     if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
         raise SystemExit(f'non-finite loss {loss}')
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = gd.max_over_ranks(dt, dev)
 
     roof = None
     kernels = {}
@@ -170,8 +160,7 @@ def main():
         cpu = cpu_baseline(a.config, a.cpu_sample, 100)
 
     if rank == 0:
-        total = world * B * a.steps
-        value = total / dt
+        value = gd.aggregate_rate(world, B, a.steps, dt)
         line = {
             'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': round(value, 2), 'unit': 'img/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 3),
@@ -188,8 +177,7 @@ def main():
             'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    gd.finish()
 
 
 if __name__ == '__main__':

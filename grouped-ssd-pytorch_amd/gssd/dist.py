@@ -1,0 +1,51 @@
+"""One-process-per-GPU harness of the sharded path: rank r owns images [r*B, (r+1)*B) of the global
+batch; the forward + loss path has NO data-path collective, so the only communication is the timing barrier and the
+max-over-ranks of the elapsed time.  Backend 'nccl' (= RCCL over xGMI) on GPUs, 'gloo' in the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init(backend, device=None):
+    world, rank, _ = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        kw = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return world, rank
+
+
+def shard_seed(base_seed, rank):
+    """Each rank draws its own shard of the global synthetic batch."""
+    return base_seed + rank
+
+
+def barrier(device=None):
+    if device is not None and device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+        if device is not None and device.type == 'cuda':
+            torch.cuda.synchronize(device)
+
+
+def max_over_ranks(seconds, device=None):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else 'cpu')
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_rate(world, per_rank_units, steps, seconds):
+    """Whole-job throughput: units all ranks processed / max-over-ranks time."""
+    return world * per_rank_units * steps / seconds
+
+
+def finish():
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,51 @@
+"""N > 1 path on CPU: two processes over gloo exercise the sharding / barrier / max-over-ranks harness bench.py uses
+with RCCL on the GPUs (the forward + loss path itself has no collective)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from gssd import dist as gd, synth
+    w, r = gd.init('gloo')
+    assert (w, r) == (world, rank)
+    x = synth.synth_images(2, seed=gd.shard_seed(100, rank))          # each rank owns different images
+    tg = synth.synth_targets(2, seed=gd.shard_seed(100, rank))
+    gd.barrier()
+    t = gd.max_over_ranks(1.0 + rank)                                  # slowest rank defines the step time
+    rate = gd.aggregate_rate(w, 32, 10, t)
+    out.put((rank, float(x.sum()), len(tg), t, rate))
+    gd.barrier()
+    gd.finish()
+
+
+def test_two_rank_harness():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] != res[1][1]                     # different shards
+    assert res[0][3] == res[1][3] == 2.0              # max over ranks
+    assert res[0][4] == res[1][4] == 2 * 32 * 10 / 2.0
