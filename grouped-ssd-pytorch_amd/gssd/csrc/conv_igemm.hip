@@ -63,6 +63,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     const float* __restrict__ wgt =
         p.wgt + (size_t)img * p.wgt_batch_stride + (size_t)(g * cout_g) * p.wgt_row_stride;
     const float* zero = g_zero_page;
+    // fused producer BatchNorm + ReLU: fragments are read as max(x*scale[c] + shift[c], 0); out-of-image taps DMA the
+    // per-channel pad value (mapped to 0 by the transform) instead of the zero page
+    const bool xf = p.in_scale != nullptr;
+    float* xtab = smem + 2 * STAGE;                  // [2][cin_g]: scale | shift of this group's input channels
+    if (xf) {
+        for (int c = tid; c < p.cin_g; c += 256) {
+            xtab[c] = p.in_scale[p.in_ch_off + g * p.cin_g + c];
+            xtab[p.cin_g + c] = p.in_shift[p.in_ch_off + g * p.cin_g + c];
+        }
+    }
+    const float* padp = xf ? p.in_pad + p.in_ch_off + g * p.cin_g : nullptr;
 
     // ---- DMA lane roles: lane L lands at (row_in = L>>3, slot = L&7) of its 8-row piece and must fetch the
     //      logical k-quad slot ^ row_in (source-side swizzle) ----------------------------------------------------
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const bool ok = tap_ok && (unsigned)(a_iy0[j] + dy) < (unsigned)p.H && (unsigned)(a_ix0[j] + dx) < (unsigned)p.W;
-            const float* src = ok ? in + (a_off[j] + toff) : zero;
+            const float* src = ok ? in + (a_off[j] + toff) : (xf ? padp + a_c : zero);
             dma16(src, As + (j * 4 + wave) * 8 * BK);
         }
         const int k0 = chunk * BK;
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     const int fo0 = r * BK + ((kq ^ (r & 7)) << 2);
     const int fo1 = r * BK + (((4 + kq) ^ (r & 7)) << 2);
 
+    int f_c0 = (ch_begin * BK + 4 * kq) % p.cin_g, f_c1 = (ch_begin * BK + 16 + 4 * kq) % p.cin_g;   // fragment channels
     if (ch_begin < ch_end) issue(ch_begin, 0);
     __syncthreads();
     for (int ch = ch_begin; ch < ch_end; ++ch) {
@@ -154,6 +166,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
             for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * BK + fo);
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * BK + fo);
+            if (xf) {
+                const int fc = ks ? f_c1 : f_c0;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(xtab + fc);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(xtab + p.cin_g + fc);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    f32x4 v = af[i] * sc + sh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    af[i] = v;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -161,6 +185,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (xf) {
+            f_c0 += BK;
+            while (f_c0 >= p.cin_g) f_c0 -= p.cin_g;
+            f_c1 += BK;
+            while (f_c1 >= p.cin_g) f_c1 -= p.cin_g;
         }
         __syncthreads();
     }
@@ -268,12 +298,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     static bool attr_set = false;
-    constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    constexpr size_t smem_base = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    const size_t smem = smem_base + (d.in_scale ? 2 * (size_t)d.cin_g * sizeof(float) : 0);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) {
-            gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", smem);
+                                (int)(smem_base + 4096)) != hipSuccess) {
+            gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", smem_base + 4096);
             return GSSD_ELAUNCH;
         }
         attr_set = true;
@@ -326,9 +357,17 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const int rc = gssd_try_conv_thin(d, s);      // conv1_1 / conv1_2 / conv2_1: patch-staged kernel
         if (rc != 1) return rc;
     }
-    // on-the-fly producer BN+ReLU is implemented by the patch-staged thin kernel only (so far)
-    GSSD_CHECK_ARG(d.in_scale == nullptr && d.in_shift == nullptr);
-    if (cout_g > 64) return launch_cfg<128, 128, 2, 2>(d, M, images, s);
+    if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 512 && !d.m_per_image);
+    if (cout_g > 64) {
+        // 128x128 tiles run 2 workgroups per CU (LDS), 128x64 tiles 3: pick the one whose last round of workgroups is
+        // fuller (wave quantisation decides small 19x19 / 38x38 layers); the wide tile wins ties (less B re-read).
+        const long long mt = (M + 127) / 128, z = d.m_per_image ? images : d.split_k;
+        const long long b128 = mt * d.groups * ((cout_g + 127) / 128) * z, b64 = mt * d.groups * ((cout_g + 63) / 64) * z;
+        const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
+        const double e64 = 0.94 * (double)b64 / (double)(((b64 + 767) / 768) * 768);
+        if (e64 > e128) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
+        return launch_cfg<128, 128, 2, 2>(d, M, images, s);
+    }
     if (cout_g > 32) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
     if (cout_g > 16) return launch_cfg<128, 32, 4, 1>(d, M, images, s);
     return launch_cfg<128, 16, 4, 1>(d, M, images, s);

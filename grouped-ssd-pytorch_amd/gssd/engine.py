@@ -40,6 +40,15 @@ def conv_tag(d, real_cin_g=None):
     mirrors the tile selection in csrc/conv_igemm.hip so it can be matched against rocprofv3's kernel names."""
     cout_g = d.Cout // d.groups
     inst = '128x128' if cout_g > 64 else '128x64' if cout_g > 32 else '128x32' if cout_g > 16 else '128x16'
+    if cout_g > 64:       # same wave-quantisation rule as gssd_conv2d_nhwc_f32
+        mt = -(-(d.Ho * d.Wo * (1 if d.m_per_image else d.B)) // 128)
+        z = d.B if d.m_per_image else d.split_k
+        b128 = mt * d.groups * (-(-cout_g // 128)) * z
+        b64 = mt * d.groups * (-(-cout_g // 64)) * z
+        e128 = b128 / (-(-b128 // 512) * 512)
+        e64 = 0.94 * b64 / (-(-b64 // 768) * 768)
+        if e64 > e128:
+            inst = '128x64'
     name = 'conv_igemm<' + inst + '>'
     if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
@@ -190,9 +199,10 @@ class _Plan:
                 pool = (2, 2, 0, nxt == 'C')
             if last:
                 pool = (3, 1, 1, False)               # pool5
-            # conv1_1's BatchNorm + ReLU is applied on the fly inside conv1_2 (thin kernel): its 737 MB output makes one
-            # HBM round trip less.  Elsewhere BN + ReLU (+ pool) is a separate pass.
-            defer = (vi == 0 and pool is None)
+            # A conv whose only consumer is the next conv (no pool, not a multibox source) leaves its BatchNorm + ReLU to
+            # that consumer, which applies scale/shift/ReLU on the fragments it reads: one HBM round trip less per layer
+            # (737 MB for conv1_1).  Pooled layers and sources keep the separate BN + ReLU (+ pool) pass.
+            defer = (pool is None and not is_conv4_3)
             cur, H, Cc, xf = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, pool=pool, in_xf=xf,
                                            defer_bn=defer)
             vi += 3
@@ -204,9 +214,10 @@ class _Plan:
                 x43 = cur
                 cur, H, Cc, src0 = self._after_conv4_3(cur, H, Cc)
         vi += 1   # pool5 module
-        for _ in range(2):                                  # conv6, conv7
+        xf = None
+        for li in range(2):                                 # conv6 (BN deferred into conv7), conv7
             conv, bn = net.vgg[vi], net.vgg[vi + 1]
-            cur, H, Cc, _ = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True)
+            cur, H, Cc, xf = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, in_xf=xf, defer_bn=(li == 0))
             vi += 3
         sources = [src0]
         sab_i, sa_i = 1, 1
@@ -219,9 +230,11 @@ class _Plan:
         ge = net.groups_extra
         n_ex = len(net.extras)
         fi = 2
+        xf = None
         for k in range(0, n_ex, 2):
             conv, bn = net.extras[k], net.extras[k + 1]
-            cur, H, Cc, _ = self._conv_bn(f'extras.{k}', conv, bn, cur, H, Cc, ge, relu=True)
+            cur, H, Cc, xf = self._conv_bn(f'extras.{k}', conv, bn, cur, H, Cc, ge, relu=True, in_xf=xf,
+                                           defer_bn=((k + 1) % 4 != 3))
             if (k + 1) % 4 == 3:
                 if net.use_self_attention_base:
                     cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)

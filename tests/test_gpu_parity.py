@@ -86,8 +86,10 @@ def test_conv_igemm(dev, ops, case):
     assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize('Cin,Cout,H', [(64, 64, 80), (64, 128, 75), (16, 64, 77)])
-def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H):
+@pytest.mark.parametrize('Cin,Cout,H,k,st,pd', [(64, 64, 80, 3, 1, 1), (64, 128, 75, 3, 1, 1), (16, 64, 77, 3, 1, 1),
+                                               (128, 128, 40, 3, 1, 1), (512, 512, 19, 3, 1, 1), (1024, 1024, 19, 1, 1, 0),
+                                               (256, 512, 19, 3, 2, 1), (64, 256, 21, 3, 1, 1)])
+def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H, k, st, pd):
     """A consumer conv applying its producer's BatchNorm + ReLU on the fly (conv1_1 -> conv1_2 in the engine): equals
     conv2d(relu(bn(x))) with zero padding applied AFTER the transform."""
     rng = np.random.default_rng(Cin + H)
@@ -95,19 +97,20 @@ def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H):
     x = torch.from_numpy(rng.normal(0.2, 1.0, size=(B, Cin, H, H)).astype(np.float32))
     gm = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
     bt = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
-    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, k, k)).astype(np.float32))
     b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
     rm, rv = torch.zeros(Cin), torch.ones(Cin)
     ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.batch_norm(x, rm.clone(), rv.clone(), gm, bt, True, 0.1,
-                                                                              1e-5)), w, b, 1, 1, 1, g)
+                                                                              1e-5)), w, b, st, pd, 1, g)
     stats = torch.stack([x.double().sum(dim=(0, 2, 3)), (x.double() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(dev)
-    sc, sh, pd = (torch.empty(Cin, device=dev) for _ in range(3))
+    sc, sh, pdv = (torch.empty(Cin, device=dev) for _ in range(3))
     rmd, rvd = rm.to(dev), rv.to(dev)
-    ops.bn_finalize(stats, B * H * H, gm.to(dev), bt.to(dev), rmd, rvd, True, sc, sh, pd)
+    ops.bn_finalize(stats, B * H * H, gm.to(dev), bt.to(dev), rmd, rvd, True, sc, sh, pdv)
     wp = ops.pack_weight(w.to(dev))
-    out = torch.empty(B, H, H, Cout, device=dev)
+    Ho = ref.shape[2]
+    out = torch.empty(B, Ho, Ho, Cout, device=dev)
     d, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g,
-                                 k=3, pad=1, bias=b.to(dev), in_scale=sc, in_shift=sh, in_pad=pd)
+                                 k=k, stride=st, pad=pd, bias=b.to(dev), in_scale=sc, in_shift=sh, in_pad=pdv)
     ops.run_conv(d)
     assert rel(nchw(out), ref) < TOL
     rm_ref, rv_ref = rm.clone(), rv.clone()
