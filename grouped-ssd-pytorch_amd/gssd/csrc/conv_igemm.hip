@@ -20,6 +20,7 @@
 //
 // Replaces the implicit cuDNN/ATen kernels behind nn.Conv2d / torch.bmm on the reference path;
 // see include/gssd_hip.h for the call-site map.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,13 +37,14 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p, const int M,
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_conv_desc p, const int M,
                                                          const int tiles_per_group) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int AR = BM / 32;                     // A DMA instructions per wave per chunk (8 rows each)
+    constexpr int NW = WM * WN, NTHR = NW * 64;     // waves / threads per workgroup
+    constexpr int AR = BM / (8 * NW);               // A DMA instructions per wave per chunk (8 rows each)
     constexpr int BPIECES = BN / 8;                 // B 1-KiB pieces per chunk
-    constexpr int BR = (BPIECES + 3) / 4;           // B DMA instructions per wave per chunk
+    constexpr int BR = (BPIECES + NW - 1) / NW;     // B DMA instructions per wave per chunk
     constexpr int STAGE = (BM + BN) * BK;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     const bool xf = p.in_scale != nullptr;
     float* xtab = smem + 2 * STAGE;                  // [2][cin_g]: scale | shift of this group's input channels
     if (xf) {
-        for (int c = tid; c < p.cin_g; c += 256) {
+        for (int c = tid; c < p.cin_g; c += NTHR) {
             xtab[c] = p.in_scale[p.in_ch_off + g * p.cin_g + c];
             xtab[p.cin_g + c] = p.in_shift[p.in_ch_off + g * p.cin_g + c];
         }
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     int a_iy0[AR], a_ix0[AR], a_off[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        const int m = m0 + (j * 4 + wave) * 8 + row_in;
+        const int m = m0 + (j * NW + wave) * 8 + row_in;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         int b = 0, pix = mm;
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
     bool b_ok[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int row = (j * 4 + wave) * 8 + row_in;
-        b_ok[j] = (j * 4 + wave) < BPIECES && (n0g + row) < cout_g;
+        const int row = (j * NW + wave) * 8 + row_in;
+        b_ok[j] = (j * NW + wave) < BPIECES && (n0g + row) < cout_g;
         b_off[j] = (n0g + row) * p.wgt_row_stride + 4 * lq;
     }
     const int nchunks_all = (K + BK - 1) / BK;
@@ -121,15 +123,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
         for (int j = 0; j < AR; ++j) {
             const bool ok = tap_ok && (unsigned)(a_iy0[j] + dy) < (unsigned)p.H && (unsigned)(a_ix0[j] + dx) < (unsigned)p.W;
             const float* src = ok ? in + (a_off[j] + toff) : (xf ? padp + a_c : zero);
-            dma16(src, As + (j * 4 + wave) * 8 * BK);
+            dma16(src, As + (j * NW + wave) * 8 * BK);
         }
         const int k0 = chunk * BK;
         const bool kok = k0 + 4 * lq < K;
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            if ((j * 4 + wave) < BPIECES) {           // wave-uniform
+            if ((j * NW + wave) < BPIECES) {          // wave-uniform
                 const float* src = (b_ok[j] && kok) ? wgt + (b_off[j] + k0) : zero;
-                dma16(src, Bs + (j * 4 + wave) * 8 * BK);
+                dma16(src, Bs + (j * NW + wave) * 8 * BK);
             }
         }
         a_c += BK;
@@ -158,24 +160,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
         if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
         const float* As = smem + buf * STAGE + wm * WTM * BK;
         const float* Bs = smem + buf * STAGE + BM * BK + wn * WTN * BK;
+        // both 16-k fragment sets are requested up front: the second set's LDS latency hides behind the first set's MFMAs
+        f32x4 af[2][MT], bf[2][NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? fo1 : fo0;
-            f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * BK + fo);
+            for (int i = 0; i < MT; ++i) af[ks][i] = *reinterpret_cast<const f32x4*>(As + i * 16 * BK + fo);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * BK + fo);
+            for (int j = 0; j < NT; ++j) bf[ks][j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * BK + fo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             if (xf) {
                 const int fc = ks ? f_c1 : f_c0;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(xtab + fc);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(xtab + p.cin_g + fc);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    f32x4 v = af[i] * sc + sh;
+                    f32x4 v = af[ks][i] * sc + sh;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    af[i] = v;
+                    af[ks][i] = v;
                 }
             }
 #pragma unroll
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const gssd_conv_desc p,
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
         }
         if (xf) {
             f_c0 += BK;
@@ -312,7 +319,8 @@ int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;
     dim3 grid((M + BM - 1) / BM, d.groups * tiles, d.m_per_image ? images : d.split_k);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, d, M, tiles);
+    static_assert(BM % (8 * WM * WN) == 0, "A rows must split evenly over the waves");
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, d, M, tiles);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -365,6 +373,9 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const long long b128 = mt * d.groups * ((cout_g + 127) / 128) * z, b64 = mt * d.groups * ((cout_g + 63) / 64) * z;
         const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
         const double e64 = 0.94 * (double)b64 / (double)(((b64 + 767) / 768) * 768);
+        if (const char* e = getenv("GSSD_TILE256")) {
+            if (e[0] == '1' && cout_g % 128 == 0) return launch_cfg<256, 128, 4, 2>(d, M, images, s);
+        }
         if (e64 > e128) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
         return launch_cfg<128, 128, 2, 2>(d, M, images, s);
     }

@@ -17,6 +17,7 @@
 //     tiles and flushed with one fp64 atomic per channel per workgroup.
 // fp32 MFMA (v_mfma_f32_16x16x4_f32) = exact fp32 FMA, so results match the generic kernel / fp32 reference
 // to accumulation-order rounding.  Reference call sites: models/ssd_multiphase_custom_group.py:444.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,9 +42,12 @@ struct ThinParams {
     const float* in_pad;
     int B, H, W;
     int TH, TW, tiles_y, tiles_x;
+    unsigned inv_pw, inv_tw;   // ceil(65536 / (TW+2)), ceil(65536 / TW)
+    int acc_off;               // float offset of the fp64 batch-sum accumulators inside dynamic LDS
 };
 
-template <int CIN_G, int COUT_G>
+// FIXED: the 8 x 16 tile is a compile-time constant (all pixel <-> tile arithmetic folds; fragment offsets need 3 registers)
+template <int CIN_G, int COUT_G, bool FIXED, bool XF>
 __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(const ThinParams p) {
     constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
     constexpr int QPR = CIN / 4;                  // 16-byte quads per pixel row
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = conv group
     const int r = lane & 15, kq = lane >> 4;
-    const int TH = p.TH, TW = p.TW, PW = TW + 2, PH = TH + 2;
+    const int TH = FIXED ? 8 : p.TH, TW = FIXED ? 16 : p.TW, PW = TW + 2, PH = TH + 2;
     const int npix = TH * TW, npatch = PH * PW;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int ntiles = p.B * tiles_per_img;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
             }
         }
     // fused producer BatchNorm + ReLU: this lane always reads the same input channels (quad g*CIN_G/4 + ks*4 + kq)
-    const bool xf = p.in_scale != nullptr;
+    constexpr bool xf = XF;                    // fused producer BatchNorm + ReLU (compile-time: no selects in the loop)
     f32x4 isc[KS], ish[KS];
     float isc1 = 1.f, ish1 = 0.f;
     if (xf) {
@@ -93,24 +97,37 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
             }
         }
     }
-    const float* zero = xf ? nullptr : g_zero_page_thin;
+    const float* zero = g_zero_page_thin;
     float bias[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bias[j] = p.bias ? p.bias[g * COUT_G + j * 16 + r] : 0.f;
 
-    // per m-tile: patch row of this lane's pixel (tap (0,0) corner)
-    int prow0[MTILES];
+    // Fragment-read offsets (floats): the 16-byte quads of a patch pixel are XOR-swizzled with its patch COLUMN, so a
+    // tap only adds a row term (dy*PW*CIN) and selects one of three precomputed column terms (dx = 0, 1, 2).
+    const int lqd0 = (CIN_G == 4) ? g : g * (CIN_G / 4) + kq;          // logical quad this lane reads (ks = 0)
+    constexpr int FT = FIXED ? 1 : MTILES;        // FIXED: m-tile i is tile row i, so foff[i] = foff[0] + i*PW*CIN
+    int foff[FT][3];
 #pragma unroll
-    for (int i = 0; i < MTILES; ++i) {
+    for (int i = 0; i < FT; ++i) {
         int px = i * 16 + r;
-        if (px >= npix) px = 0;                     // dummy lanes read a valid row; results are discarded
+        if (px >= npix) px = 0;                     // dummy lanes read a valid pixel; results are discarded
         const int ty = px / TW, tx = px - ty * TW;
-        prow0[i] = ty * PW + tx;
-    }
-
-    double dsum[4], dsq[4];       // batch sums of this thread's 4 output channels (fp32 within a tile, fp64 across)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dsum[e] = dsq[e] = 0.0;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int col = tx + dx;
+            foff[i][dx] = (ty * PW + col) * CIN + ((lqd0 ^ (col & (QPR - 1))) << 2) + ((CIN_G == 4) ? kq : 0);
+        }
+    }
+    constexpr int C4 = COUT / 4;
+    constexpr int NST = 128 * C4 / 256;
+    const int ninstr = (npatch + PPI - 1) / PPI;
+    // x / PW and x / TW for x < 4096 by multiply-shift (host-computed reciprocals, exact in that range)
+    const unsigned inv_pw = FIXED ? (65536u + 17u) / 18u : p.inv_pw, inv_tw = FIXED ? 4096u : p.inv_tw;
+
+    // batch sums: fp32 within a tile, then fp64 accumulators in LDS (beyond the patch / staging area) for the whole
+    // lifetime of the workgroup; flushed with one fp64 global atomic per channel at the end
+    double* lacc = reinterpret_cast<double*>(smem + p.acc_off);     // [2][COUT]
+    for (int c = tid; c < 2 * COUT; c += 256) lacc[c] = 0.0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img;
@@ -119,17 +136,14 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
         const int y0 = tyi * TH, x0 = txi * TW;
 
         // ---- stage the (TH+2) x (TW+2) patch: pixel rows of CIN floats, quads XOR-swizzled by the patch row -----
-        const int ninstr = (npatch + PPI - 1) / PPI;
         for (int i = g; i < ninstr; i += 4) {
             const int pp = i * PPI + lane / QPR;
-            const int slot = lane % QPR;
-            const int lq = slot ^ (pp & (QPR - 1));
-            const int py = pp / PW, pxx = pp - py * PW;
+            const int py = (int)(((unsigned)pp * inv_pw) >> 16), pxx = pp - py * PW;
+            const int lq = (lane % QPR) ^ (pxx & (QPR - 1));
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
             const bool ok = pp < npatch && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* src = ok ? p.in + ((size_t)(b * p.H + iy) * p.W + ix) * CIN + lq * 4
-                                  : (xf ? p.in_pad + lq * 4 : zero);
-            dma16(src, smem + (size_t)i * PPI * CIN);
+            const float* src = ok ? p.in + ((b * p.H + iy) * p.W + ix) * CIN + lq * 4 : (xf ? p.in_pad + lq * 4 : zero);
+            dma16(src, smem + i * PPI * CIN);
         }
         __syncthreads();
 
@@ -141,9 +155,12 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // software-pipelined by one (m-tile pair, tap) step; sched_barrier keeps the compiler from hoisting all 72
         // fragment reads (256 VGPRs) to the top
-        auto ld4 = [&](int pr, int ks) -> f32x4 {
-            const int lqd = g * (CIN_G / 4) + ks * 4 + kq;
-            f32x4 v = *reinterpret_cast<const f32x4*>(smem + pr * CIN + ((lqd ^ (pr & (QPR - 1))) << 2));
+        auto FO = [&](int i, int dx) -> int { return FIXED ? foff[0][dx] + i * (18 * CIN) : foff[FIXED ? 0 : i][dx]; };
+        auto ld4 = [&](int off, int ks) -> f32x4 {
+            static_assert(KS == 1, "ks > 0 needs its own column terms");
+            return *reinterpret_cast<const f32x4*>(smem + off);
+        };
+        auto tf4 = [&](f32x4 v, int ks) -> f32x4 {      // producer BN + ReLU on a fragment
             if (xf) {
                 v = v * isc[ks] + ish[ks];
 #pragma unroll
@@ -151,21 +168,20 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
             }
             return v;
         };
-        auto ld1 = [&](int pr) -> float {
-            float v = smem[pr * CIN + ((g ^ (pr & (QPR - 1))) << 2) + kq];
-            if (xf) v = fmaxf(v * isc1 + ish1, 0.f);
-            return v;
+        auto tf1 = [&](float v) -> float { return xf ? fmaxf(v * isc1 + ish1, 0.f) : v; };
+        auto ld1 = [&](int off) -> float {
+            return smem[off];
         };
         f32x4 a0[KS], a1[KS], n0[KS], n1[KS];
         float s0 = 0.f, s1 = 0.f, m0 = 0.f, m1 = 0.f;
         if constexpr (CIN_G == 4) {
-            s0 = ld1(prow0[0]);
-            s1 = ld1(prow0[1]);
+            s0 = tf1(ld1(FO(0, 0)));
+            s1 = tf1(ld1(FO(1, 0)));
         } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                a0[ks] = ld4(prow0[0], ks);
-                a1[ks] = ld4(prow0[1], ks);
+                a0[ks] = tf4(ld4(FO(0, 0), ks), ks);
+                a1[ks] = tf4(ld4(FO(1, 0), ks), ks);
             }
         }
 #pragma unroll
@@ -174,26 +190,27 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
             for (int t = 0; t < 9; ++t) {
                 const int tn = (t + 1) % 9, ipn = (t == 8) ? ip + 2 : ip;
                 if (ipn < MTILES) {
-                    const int toff = (tn / 3) * PW + (tn % 3);
+                    const int roff = (tn / 3) * PW * CIN;
                     if constexpr (CIN_G == 4) {
-                        m0 = ld1(prow0[ipn] + toff);
-                        m1 = ld1(prow0[ipn + 1] + toff);
+                        m0 = ld1(FO(ipn, tn % 3) + roff);
+                        m1 = ld1(FO(ipn + 1, tn % 3) + roff);
                     } else {
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
-                            n0[ks] = ld4(prow0[ipn] + toff, ks);
-                            n1[ks] = ld4(prow0[ipn + 1] + toff, ks);
+                            n0[ks] = ld4(FO(ipn, tn % 3) + roff, ks);
+                            n1[ks] = ld4(FO(ipn + 1, tn % 3) + roff, ks);
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);     // next step's fragment reads stay ahead of this step's MFMAs
                 if constexpr (CIN_G == 4) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         acc[ip][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, wf1[t][j], acc[ip][j], 0, 0, 0);
                         acc[ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, wf1[t][j], acc[ip + 1][j], 0, 0, 0);
                     }
-                    s0 = m0;
-                    s1 = m1;
+                    s0 = tf1(m0);        // the load was issued before this step's MFMAs: its latency is covered
+                    s1 = tf1(m1);
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
@@ -207,8 +224,8 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
                             }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        a0[ks] = n0[ks];
-                        a1[ks] = n1[ks];
+                        a0[ks] = tf4(n0[ks], ks);    // issued before this step's MFMAs: latency covered
+                        a1[ks] = tf4(n1[ks], ks);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -225,52 +242,49 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
                 for (int e = 0; e < 4; ++e)
                     smem[(i * 16 + kq * 4 + e) * OLD + g * COUT_G + j * 16 + r] = acc[i][j][e] + bias[j];
         __syncthreads();
-        constexpr int C4 = COUT / 4;          // 256 % C4 == 0: a thread always owns the same 4 channels
+        // 256 % C4 == 0: a thread always owns the same 4 channels
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
-        for (int idx = tid; idx < npix * C4; idx += 256) {
-            const int px = idx / C4, c4 = idx % C4;
-            const int ty = px / TW, tx = px - ty * TW;
+        const int c4 = tid % C4;
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int px = (tid + 256 * it) / C4;
+            const int ty = (int)(((unsigned)px * inv_tw) >> 16), tx = px - ty * TW;
             const int y = y0 + ty, x = x0 + tx;
-            if (y < p.H && x < p.W) {
+            if (px < npix && y < p.H && x < p.W) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(smem + px * OLD + c4 * 4);
                 *reinterpret_cast<f32x4*>(p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + c4 * 4) = v;
                 s4 += v;
                 q4 += v * v;
             }
         }
+        if (p.stats) {
+            // lanes l, l+C4, l+2*C4, ... of a wave own the same channel quad
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            dsum[e] += (double)s4[e];
-            dsq[e] += (double)q4[e];
+            for (int o = 32; o >= C4; o >>= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s4[e] += __shfl_xor(s4[e], o, 64);
+                    q4[e] += __shfl_xor(q4[e], o, 64);
+                }
+            if (lane < C4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsafeAtomicAdd(lacc + lane * 4 + e, (double)s4[e]);
+                    unsafeAtomicAdd(lacc + COUT + lane * 4 + e, (double)q4[e]);
+                }
+            }
         }
         __syncthreads();
     }
 
-    if (p.stats) {
-        // threads with the same (tid % C4) own the same 4 channels: combine through LDS, one fp64 atomic per channel
-        constexpr int C4 = COUT / 4;
-        double* red = reinterpret_cast<double*>(smem);      // [256][8]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[tid * 8 + e] = dsum[e];
-            red[tid * 8 + 4 + e] = dsq[e];
-        }
-        __syncthreads();
-        if (tid < COUT) {
-            const int c4 = tid >> 2, e = tid & 3;
-            double s = 0.0, q = 0.0;
-            for (int t = c4; t < 256; t += C4) {
-                s += red[t * 8 + e];
-                q += red[t * 8 + 4 + e];
-            }
-            unsafeAtomicAdd(p.stats + tid, s);
-            unsafeAtomicAdd(p.stats + COUT + tid, q);
-        }
+    if (p.stats && tid < COUT) {
+        unsafeAtomicAdd(p.stats + tid, lacc[tid]);
+        unsafeAtomicAdd(p.stats + COUT + tid, lacc[COUT + tid]);
     }
 }
 
-template <int CIN_G, int COUT_G>
-int launch_thin(const gssd_conv_desc& d, hipStream_t stream) {
+template <int CIN_G, int COUT_G, bool FIXED, bool XF>
+int launch_thin_impl(const gssd_conv_desc& d, hipStream_t stream) {
     constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
     ThinParams p;
     p.in = d.in;
@@ -285,21 +299,25 @@ int launch_thin(const gssd_conv_desc& d, hipStream_t stream) {
     p.H = d.H;
     p.W = d.W;
     // tile shape: 5 x 25 divides 150 and 75 exactly; 8 x 16 otherwise
-    if (d.W % 25 == 0 && d.H % 5 == 0) {
+    if (!FIXED) {
         p.TH = 5;
         p.TW = 25;
     } else {
         p.TH = 8;
         p.TW = 16;
     }
+    p.inv_pw = (65536u + (unsigned)(p.TW + 2) - 1) / (unsigned)(p.TW + 2);
+    p.inv_tw = (65536u + (unsigned)p.TW - 1) / (unsigned)p.TW;
     p.tiles_y = (d.H + p.TH - 1) / p.TH;
     p.tiles_x = (d.W + p.TW - 1) / p.TW;
     const int npatch = (p.TH + 2) * (p.TW + 2);
     constexpr int PPI = 64 / (CIN / 4);
     const size_t patch_bytes = (size_t)((npatch + PPI - 1) / PPI) * PPI * CIN * sizeof(float);
     const size_t out_bytes = (size_t)128 * (COUT + 4) * sizeof(float);
-    const size_t smem = patch_bytes > out_bytes ? patch_bytes : out_bytes;
-    auto kern = conv_thin_kernel<CIN_G, COUT_G>;
+    const size_t work = patch_bytes > out_bytes ? patch_bytes : out_bytes;
+    p.acc_off = (int)(work / sizeof(float));
+    const size_t smem = work + 2 * COUT * sizeof(double);
+    auto kern = conv_thin_kernel<CIN_G, COUT_G, FIXED, XF>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -316,6 +334,16 @@ int launch_thin(const gssd_conv_desc& d, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
+}
+
+template <int CIN_G, int COUT_G>
+int launch_thin(const gssd_conv_desc& d, hipStream_t stream) {
+    // 5 x 25 tiles divide 150 and 75 exactly; otherwise the compile-time 8 x 16 tile (97.4 % of 300 x 300)
+    if (d.W % 25 == 0 && d.H % 5 == 0 && d.W != 300 && getenv("GSSD_THIN_5X25"))    // runtime-tile variant: opt-in
+        return d.in_scale ? launch_thin_impl<CIN_G, COUT_G, false, true>(d, stream)
+                          : launch_thin_impl<CIN_G, COUT_G, false, false>(d, stream);
+    return d.in_scale ? launch_thin_impl<CIN_G, COUT_G, true, true>(d, stream)
+                      : launch_thin_impl<CIN_G, COUT_G, true, false>(d, stream);
 }
 
 }  // namespace

@@ -10,6 +10,6 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
-    if 'conv_igemm' not in k and 'patch' not in k: continue
+    if 'conv_' not in k: continue
     print(k, {c: round(sum(v[len(v)//2:]) / len(v[len(v)//2:])) for c, v in d.items()}, 'n=', len(next(iter(d.values()))))
 PY
