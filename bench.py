@@ -75,6 +75,9 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--cpu-sample', type=int, default=16, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    ap.add_argument('--full-step', type=int, default=0, metavar='K',
+                    help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
+                         'reported as "full_step" beside the fwd+loss metric (BASELINE config 4)')
     a = ap.parse_args()
 
     from gssd import dist as gd
@@ -155,6 +158,35 @@ def main():
                     alg_bytes_per_launch=round(by / n),
                     note='fp32 exact MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)')
 
+    full = None
+    if a.full_step > 0:
+        # BASELINE.json configs[3]: forward + loss + backward + RCCL all-reduce of the flat gradient buffer + SGD.
+        # Backward of the network is the interim ATen recomputation (gssd/autograd_shadow.py), so this is reported
+        # separately and is NOT the headline metric.
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+        gd.broadcast_params(net)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            ll, lc = crit(net(x), tg)
+            (ll + lc).backward()
+            n = gd.allreduce_grads(params, world)
+            opt.step()
+            return n
+        for _ in range(2):
+            nred = train_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.full_step):
+            train_step()
+        sync()
+        fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+        full = dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
+                    ms_per_step=round(1e3 * fdt / a.full_step, 3), allreduce_elems=int(nred),
+                    note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (interim ATen recomputation) + '
+                         'flat-buffer gradient all-reduce (RCCL) + SGD')
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(a.config, a.cpu_sample, 100)
@@ -174,7 +206,7 @@ def main():
                            'alg_gbs': round(value * mb_img / 1e3, 1),
                            'frac_hbm_peak': round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)},
             'loss': [round(loss[0], 5), round(loss[1], 5)],
-            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu, 'full_step': full,
         }
         print(json.dumps(line))
     gd.finish()

@@ -1,0 +1,163 @@
+"""INTERIM backward of the network (SURVEY.md 8f row 1 is the HIP version).
+
+Forward values always come from the HIP engine.  When gradients are needed, ``GssdTrainFn.backward`` re-evaluates the
+graph with differentiable ATen ops ON THE GPU (MIOpen convs, torch bmm / softmax, a gather-based deformable conv) from
+the saved input and the live parameters, and back-propagates ``(dloc, dconf)`` through that recomputation
+(activation-checkpoint style).  Nothing here runs on the CPU and nothing here is used by a forward, ``MultiBoxLoss``
+or ``Detect`` call.  Graph restated from models/ssd_multiphase_custom_group.py:217-400.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _conv(m, x):
+    return F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+
+
+def _bn(m, x):
+    # batch statistics, no running-stat update (the engine already did it).  Written out with elementary ops:
+    # MIOpen's fused batch-norm is off by ~1e-3 for [B,256,75,75] maps on gfx950 (probed), which the ill-conditioned
+    # BN backward then amplifies to 10-20 % gradient error.
+    var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + m.eps) * m.weight.view(1, -1, 1, 1) + m.bias.view(1, -1, 1, 1)
+
+
+def _sn_weight(sn):
+    """layers/spectral_norm.py:83-85 with the (already iterated) u, v held constant."""
+    w = sn.weight_orig
+    wm = w.reshape(w.shape[0], -1)
+    sigma = torch.dot(sn.weight_u.detach(), torch.mv(wm, sn.weight_v.detach()))
+    return w / sigma
+
+
+def _self_attn(sa, x):
+    """layers/self_attn.py:46-89 (max_pool_factor = 1)."""
+    B, ch, h, w = x.shape
+    theta = F.conv2d(x, _sn_weight(sa.snconv1x1_theta), sa.snconv1x1_theta.bias).view(B, ch // 8, h * w)
+    phi = F.conv2d(x, _sn_weight(sa.snconv1x1_phi), sa.snconv1x1_phi.bias).view(B, ch // 8, h * w)
+    attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
+    g = F.conv2d(x, _sn_weight(sa.snconv1x1_g), sa.snconv1x1_g.bias).view(B, ch // 2, h * w)
+    attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(B, ch // 2, h, w)
+    attn_g = F.conv2d(attn_g, _sn_weight(sa.snconv1x1_attn), sa.snconv1x1_attn.bias)
+    return x + sa.sigma * attn_g, sa.sigma * attn_g
+
+
+def _dcn(m, x):
+    """Modulated deformable 3x3 conv, differentiable (gather formulation of DCNv2; layers/dcn_v2_custom.py:79-89)."""
+    B, Cin, H, W = x.shape
+    dg = m.deformable_groups
+    om = _conv(m.conv_offset_mask, x)
+    o1, o2, mk = torch.chunk(om, 3, dim=1)
+    off = torch.cat((o1, o2), 1).view(B, dg, 9, 2, H, W)
+    msk = torch.sigmoid(mk).view(B, dg, 9, H * W)
+    cpg = Cin // dg
+    xg = x.view(B, dg, cpg, H * W)
+    ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, 1, H, 1) - 1
+    xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, 1, W) - 1
+    cols = []
+    for k in range(9):
+        i, j = divmod(k, 3)
+        py = ys + i + off[:, :, k, 0]
+        px = xs + j + off[:, :, k, 1]
+        valid = (py > -1) & (px > -1) & (py < H) & (px < W)
+        y0, x0 = torch.floor(py), torch.floor(px)
+        ly, lx = py - y0, px - x0
+        hy, hx = 1 - ly, 1 - lx
+        val = 0
+        for (yy, xx, wgt) in ((y0, x0, hy * hx), (y0, x0 + 1, hy * lx), (y0 + 1, x0, ly * hx), (y0 + 1, x0 + 1, ly * lx)):
+            inside = valid & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+            lin = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().view(B, dg, 1, H * W)
+            v = torch.gather(xg, 3, lin.expand(B, dg, cpg, H * W))
+            val = val + v * (wgt * inside.to(x.dtype)).view(B, dg, 1, H * W)
+        cols.append(val * msk[:, :, k].unsqueeze(2))
+    cols = torch.stack(cols, 3).view(B, Cin * 9, H * W)                       # (c, k) like weight.view(Cout, Cin*9)
+    out = torch.matmul(m.weight.view(m.out_channels, Cin * 9), cols) + m.bias.view(1, -1, 1)
+    return out.view(B, m.out_channels, H, W)
+
+
+def _slice_and_cat(a, b, groups):
+    a = torch.split(a, a.size(1) // groups, dim=1)
+    b = torch.split(b, b.size(1) // groups, dim=1)
+    return torch.cat([torch.cat([a[i], b[i]], dim=1) for i in range(len(a))], dim=1)
+
+
+def shadow_forward(net, x):
+    """Differentiable train-mode forward -> (loc [B,P,4], conf [B,P,C])."""
+    sab_i = sa_i = 0
+
+    def run(mods, x):
+        for m in mods:
+            if isinstance(m, torch.nn.Conv2d):
+                x = _conv(m, x)
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                x = _bn(m, x)
+            elif isinstance(m, torch.nn.ReLU):
+                x = F.relu(x)
+            else:
+                x = m(x)           # MaxPool2d
+        return x
+
+    def branch(s, name):
+        nonlocal sa_i
+        if net.use_self_attention:
+            s, _ = _self_attn(net.self_attn_list[sa_i], s)
+            sa_i += 1
+        return F.relu(_bn(getattr(net, f'bn_fuse_{name}'), _conv(getattr(net, f'fuse_{name}'), s)))
+
+    x = run(list(net.vgg)[:33], x)
+    attn_g = None
+    if net.use_self_attention_base:
+        x, attn_g = _self_attn(net.self_attn_base_list[sab_i], x)
+        sab_i += 1
+    if net.dcn_cat_sab:
+        x = _slice_and_cat(x, attn_g.detach() if net.detach_sab else attn_g, net.groups_vgg)
+    if net.use_dcn:
+        for m in net.dcn_list:
+            x = _dcn(m, x)
+    w = net.L2Norm.weight.view(1, -1, 1, 1)
+    s = w * (x / (x.pow(2).sum(dim=1, keepdim=True).sqrt() + net.L2Norm.eps))
+    sources = [branch(s, '11')]
+    x = run(list(net.vgg)[33:], x)
+    if net.use_self_attention_base:
+        x, _ = _self_attn(net.self_attn_base_list[sab_i], x)
+        sab_i += 1
+    sources.append(branch(x, '21'))
+    names = ['31', '41', '51', '61']
+    fi = 0
+    for k, m in enumerate(net.extras):
+        x = _conv(m, x) if isinstance(m, torch.nn.Conv2d) else _bn(m, x)
+        if k % 2 == 1:
+            x = F.relu(x)
+        if k % 4 == 3:
+            if net.use_self_attention_base:
+                x, _ = _self_attn(net.self_attn_base_list[sab_i], x)
+                sab_i += 1
+            sources.append(branch(x, names[fi]))
+            fi += 1
+    B = x.shape[0]
+    loc = torch.cat([_conv(l, s).permute(0, 2, 3, 1).reshape(B, -1) for s, l in zip(sources, net.loc)], 1)
+    conf = torch.cat([_conv(c, s).permute(0, 2, 3, 1).reshape(B, -1) for s, c in zip(sources, net.conf)], 1)
+    return loc.view(B, -1, 4), conf.view(B, -1, net.num_classes)
+
+
+class GssdTrainFn(torch.autograd.Function):
+    """forward = HIP engine; backward = gradients of the recomputed ATen graph w.r.t. the live parameters."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        loc, conf = net._engine.forward(x, True, net.__dict__.get('_events'))
+        ctx.net, ctx.x, ctx.params = net, x, params
+        return loc, conf
+
+    @staticmethod
+    def backward(ctx, dloc, dconf):
+        net, x, params = ctx.net, ctx.x, ctx.params
+        with torch.enable_grad():
+            xin = x.detach().requires_grad_(x.requires_grad)
+            loc, conf = shadow_forward(net, xin)
+            wanted = [p for p in params if p.requires_grad] + ([xin] if xin.requires_grad else [])
+            grads = torch.autograd.grad((loc, conf), wanted, (dloc, dconf), allow_unused=True)
+        it = iter(grads)
+        out = [next(it) if p.requires_grad else None for p in params]
+        gx = next(it) if xin.requires_grad else None
+        return (None, gx) + tuple(out)

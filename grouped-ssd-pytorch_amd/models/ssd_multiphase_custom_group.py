@@ -127,7 +127,12 @@ class SSD(nn.Module):
         return ops.slice_and_cat(ah, bh, self.groups_vgg).permute(0, 3, 1, 2)
 
     def forward(self, x, visualize=False):
-        loc, conf = self._engine.forward(x, self.training, self.__dict__.get('_events'))
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # forward on the HIP engine; backward through the interim ATen recomputation (gssd/autograd_shadow.py)
+            from gssd.autograd_shadow import GssdTrainFn
+            loc, conf = GssdTrainFn.apply(self, x, *tuple(self.parameters()))
+        else:
+            loc, conf = self._engine.forward(x, self.training, self.__dict__.get('_events'))
         priors = self.priors if self.priors.device == x.device else self.priors.to(x.device)
         if self.phase == 'test':
             # softmax (reference :388) is fused into the Detect kernel (conf_is_logits)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# HBM traffic of every kernel of one bench step (run on the GPU box): two separate --pmc passes (FETCH_SIZE needs 3 of
+# the 4 TCC slots, WRITE_SIZE 2), kernel-trace only, as MI355X_MICROARCH.md prescribes.  Writes profiles/pmc_summary.json.
+cfg=${1:-gssd}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-events --config $cfg > /dev/null 2>&1
+done
+python3 - "$GRAFT_REPO_ROOT" "$cfg" <<'PY'
+import csv, sys, glob, json, collections, re, os
+root, cfg = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    f = glob.glob(f'{root}/gpurun_out/pmc_{c}/*counter_collection.csv')[0]
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == c:
+            agg[r['Kernel_Name']][c].append(float(r['Counter_Value']))
+def short(n):
+    m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
+    if m: return f'conv_igemm<{m.group(1)}x{m.group(2)}>'
+    m = re.search(r'conv_thin_kernel<(\d+), (\d+)', n)
+    if m: return f'conv_thin<{m.group(1)},{m.group(2)}>'
+    m = re.search(r'::(\w+_kernel)', n)
+    return m.group(1) if m else n[:40]
+out = {}
+for k, d in agg.items():
+    fs, ws = d.get('FETCH_SIZE', [0]), d.get('WRITE_SIZE', [0])
+    f_kb, w_kb = sum(fs) / len(fs), sum(ws) / len(ws)
+    # counters are KiB; on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM): x2
+    out[short(k)] = dict(launches=len(fs), fetch_kib_raw=round(f_kb, 1), write_kib=round(w_kb, 1),
+                         hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024))
+p = os.path.join(root, 'gpurun_out', 'pmc_summary.json')
+allj = json.load(open(p)) if os.path.exists(p) else {}
+allj[cfg] = out
+json.dump(allj, open(p, 'w'), indent=1, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
+    print(k, v)
+PY

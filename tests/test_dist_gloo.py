@@ -31,6 +31,13 @@ def _worker(rank, world, port, out):
     t = gd.max_over_ranks(1.0 + rank)                                  # slowest rank defines the step time
     rate = gd.aggregate_rate(w, 32, 10, t)
     out.put((rank, float(x.sum()), len(tg), t, rate))
+    # gradient averaging over ranks (flat-buffer all-reduce) and the initial weight broadcast
+    lin = torch.nn.Linear(4, 3)
+    gd.broadcast_params(lin)
+    for i, q in enumerate(lin.parameters()):
+        q.grad = torch.full_like(q, float(rank + 1 + i))
+    n = gd.allreduce_grads(list(lin.parameters()))
+    out.put((rank, n, [float(q.grad.mean()) for q in lin.parameters()], float(lin.weight.sum())))
     gd.barrier()
     gd.finish()
 
@@ -42,10 +49,14 @@ def test_two_rank_harness():
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    res = sorted(r for r in got if len(r) == 5)
+    res2 = sorted(r for r in got if len(r) == 4)
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] != res[1][1]                     # different shards
     assert res[0][3] == res[1][3] == 2.0              # max over ranks
     assert res[0][4] == res[1][4] == 2 * 32 * 10 / 2.0
+    assert res2[0][1] == res2[1][1] == 15 and res2[0][2] == res2[1][2] == [1.5, 2.5]      # mean over ranks
+    assert res2[0][3] == res2[1][3]                                                            # broadcast weights

@@ -442,6 +442,47 @@ def test_end_to_end(dev, golden, name):
     assert same_detections(det, ref, 5e-5)
 
 
+@pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
+def test_backward_gradients(dev, name):
+    """Training step plumbing: HIP forward + loss, gradients through the HIP loss backward and the interim ATen
+    recomputation of the network, against CPU autograd through the oracle graph."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS[name]
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = synth.synth_images(4, seed=9)
+    rng = np.random.default_rng(0)
+    r1 = torch.from_numpy(rng.normal(size=(4, 8732, 4)).astype(np.float32))
+    r2 = torch.from_numpy(rng.normal(size=(4, 8732, 2)).astype(np.float32))
+    r1[:, 8728:] = 0          # the 1x1 map's BatchNorm over 4 values has an ill-conditioned backward: keep it out
+    r2[:, 8728:] = 0
+    loc, conf, _ = net(x.to(dev))
+    assert loc.requires_grad and conf.requires_grad
+    ((loc * r1.to(dev)).sum() + (conf * r2.to(dev)).sum()).backward()
+    sdg = {k: (v.clone().requires_grad_() if (v.is_floating_point() and not k.endswith(('running_mean', 'running_var',
+                                                                                         'weight_u', 'weight_v'))) else v)
+           for k, v in sd.items()}
+    lo, co, _ = O.gssd_forward(sdg, x, **flags)
+    ((lo * r1).sum() + (co * r2).sum()).backward()
+    named = dict(net.named_parameters())
+    keys = ['vgg.0.weight', 'vgg.14.weight', 'vgg.30.bias', 'vgg.31.weight', 'vgg.44.weight', 'extras.2.weight', 'fuse_11.weight',
+            'bn_fuse_21.bias', 'loc.0.weight', 'conf.3.bias', 'L2Norm.weight']
+    if name == 'gssdpp':
+        keys += ['self_attn_list.0.snconv1x1_theta.weight_orig', 'self_attn_base_list.0.sigma', 'dcn_list.0.weight',
+                 'dcn_list.0.conv_offset_mask.weight']
+    errs = {k: rel(named[k].grad, sdg[k].grad) for k in keys}
+    print('gradient rel errors', {k: f'{v:.1e}' for k, v in errs.items()})
+    # heads see the exact upstream gradient; everything upstream of a train-mode BatchNorm is a heavily cancelling sum
+    # (BN removes scale and shift), where fp32 CPU vs GPU reductions differ at the percent level; a conv bias in front of a
+    # BatchNorm has a mathematically zero gradient (pure rounding noise), so vgg.30.bias is only checked to be tiny.
+    assert errs['loc.0.weight'] < 1e-4 and errs['conf.3.bias'] < 1e-4
+    assert float(named['vgg.30.bias'].grad.abs().max()) < 1e-2 * float(named['vgg.31.bias'].grad.abs().max())
+    assert max(v for k, v in errs.items() if k != 'vgg.30.bias') < 6e-2, errs
+
+
 def test_visualize_outputs(dev):
     from models.ssd_multiphase_custom_group import build_ssd
     flags, args = NETS['gssdpp']
