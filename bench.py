@@ -47,8 +47,7 @@ def cpu_baseline(cfg_name, sample_b, seed):
     args, flags, _, _ = CONFIGS[cfg_name]
     net = build_ssd('train', 300, 2, *args)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     pri = O.prior_box()
 
     def one(b, s):
@@ -59,11 +58,22 @@ def cpu_baseline(cfg_name, sample_b, seed):
             loc, conf, _ = O.gssd_forward(sd, x, **flags)
         O.multibox_loss(loc.numpy(), conf.numpy(), pri, tg)
         return time.perf_counter() - t0
-    one(2, seed)                      # warm-up (thread pool, oneDNN primitives)
+    # pick the intra-op thread count that is fastest for this graph on this host (all cores oversubscribes oneDNN's
+    # grouped convs on big boxes): 2-image probes double as the warm-up
+    best = None
+    for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        torch.set_num_threads(nt)
+        one(2, seed)
+        t = one(2, seed)
+        if best is None or t < best[0]:
+            best = (t, nt)
+    cores = best[1]
+    torch.set_num_threads(cores)
     dt = one(sample_b, seed + 1)
     return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port',
                 sample=f'1 forward+MultiBoxLoss pass over {sample_b} synthetic images ({cfg_name}, fp32, train-mode BN, '
-                       f'torch-CPU {cores} threads) after a 2-image warm-up; {dt:.1f} s')
+                       f'torch-CPU, {cores} of {ncpu} hardware threads = the fastest of a 2-image probe over thread counts); '
+                       f'{dt:.1f} s')
 
 
 def main():
@@ -73,7 +83,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='gssd', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='images in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--full-step', type=int, default=0, metavar='K',
                     help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
