@@ -88,8 +88,9 @@ class GssdEngine:
         if p0.device != x.device:
             raise _lib.GssdError(f'model is on {p0.device}, input on {x.device}')
         B = x.shape[0]
-        if tuple(x.shape[1:]) != (12, 300, 300):
-            raise _lib.GssdError(f'expected input [B,12,300,300], got {tuple(x.shape)}')
+        cin = 3 if getattr(net, 'vanilla', False) else 12
+        if tuple(x.shape[1:]) != (cin, 300, 300):
+            raise _lib.GssdError(f'expected input [B,{cin},300,300], got {tuple(x.shape)}')
         bn_cfg = tuple((m.momentum, m.eps) for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
         key = (B, bool(training), x.device.index, p0.data_ptr(), hash(bn_cfg))
         plan = self._plans.get(key)
@@ -115,6 +116,8 @@ class GssdEngine:
         return self._packed[name]
 
     def _build(self, B, training, dev):
+        if getattr(self.net, 'vanilla', False):
+            return _PlanVanilla(self, B, training, dev)
         return _Plan(self, B, training, dev)
 
 
@@ -497,3 +500,97 @@ class _Plan:
             torch._foreach_add_(self.nbt, 1)
         self._x_keepalive = x
         return loc, conf
+
+
+class _PlanVanilla(_Plan):
+    """models/ssd.py:48-108: dense VGG-SSD300 without BatchNorm (BASELINE.json configs[0]).  conv + ReLU is one launch
+    (ReLU in the conv epilogue); pools are the identity-affine pool pass."""
+
+    def __init__(self, eng, B, training, dev):   # noqa: super().__init__ builds the grouped graph; not called on purpose
+        self.eng, self.B, self.training, self.dev = eng, B, training, dev
+        net = eng.net
+        self.steps, self.bufs, self.head_descs = [], [], []
+        self.P, self.nc = 8732, net.num_classes
+        self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
+        self.nbt = []
+        x4 = self._buf(B, 300, 300, 4)
+        self._pack_step = 0
+        self._add(lib.gssd_pack_input_nhwc, [0, x4.data_ptr(), B, 3, 300, 300, 1, 4])
+        cur, H, Cc = x4, 300, 4
+        sources = []
+        mods = list(net.vgg)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, torch.nn.Conv2d):
+                cur, H, Cc = self._conv_relu(f'vgg.{i}', m, cur, H, Cc)
+                i += 2                                   # conv + ReLU
+                if i - 2 == 21:                          # conv4_3 (+ReLU at 22): L2Norm source (ssd.py:73-77)
+                    s = self._buf(B, H, H, Cc)
+                    self._add(lib.gssd_l2norm_f32, (cur.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc,
+                                                    float(net.L2Norm.eps)))
+                    sources.append((s, H, Cc))
+            else:                                        # MaxPool2d
+                k, st, pd = m.kernel_size, m.stride, m.padding
+                Hp = ops.pool_out_size(H, k, st, pd, m.ceil_mode)
+                out = self._buf(B, Hp, Hp, Cc)
+                self._add(lib.gssd_bn_relu_pool_f32, (cur.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, st, pd, 0, 1.0, 0, 0,
+                                                      0, 0, 0.1, 1e-5, 0, 0))
+                cur, H = out, Hp
+                i += 1
+        sources.append((cur, H, Cc))                     # conv7
+        for k, m in enumerate(net.extras):
+            cur, H, Cc = self._conv_relu(f'extras.{k}', m, cur, H, Cc)
+            if k % 2 == 1:
+                sources.append((cur, H, Cc))
+        self.sources = sources
+        off = 0
+        f32 = torch.float32
+        for i, (s, Hs, Cs) in enumerate(sources):
+            A = MBOX[i]
+            nloc, nconf = A * 4, A * self.nc
+            lw, cw = net.loc[i], net.conf[i]
+            _, K = ops.packed_k(Cs, 3, 3)
+
+            def build_w(out, lw=lw, cw=cw, nloc=nloc, nconf=nconf, K=K):
+                if out is None:
+                    out = torch.empty(nloc + nconf, K, device=dev, dtype=f32)
+                ops.pack_weight(lw.weight, out, 0)
+                ops.pack_weight(cw.weight, out, nloc)
+                return out
+
+            def build_b(out, lw=lw, cw=cw, nloc=nloc):
+                if out is None:
+                    out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
+                out[:nloc].copy_(lw.bias.detach())
+                out[nloc:].copy_(cw.bias.detach())
+                return out
+            wp = eng._pack(f'heads.{i}.w', build_w)
+            bp = eng._pack(f'heads.{i}.b', build_b)
+            d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
+                                         pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
+                                         out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
+                                         out_off=off * 4, outb_off=off * self.nc,
+                                         split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
+            self.head_descs.append(d)
+            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+            off += Hs * Hs * A
+        assert off == self.P, off
+
+    def _conv_relu(self, name, conv, x, H, Cin):
+        B = self.B
+        k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+        Cout = conv.out_channels
+
+        def build(out, conv=conv, Cin=Cin):
+            w = conv.weight
+            if w.shape[1] != Cin:                        # conv1_1: 3 input channels stored in 4 (zero pad)
+                w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, Cin - w.shape[1]))
+            return ops.pack_weight(w, out)
+        wp = self.eng._pack(name + '.w', build)
+        Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
+        out = self._buf(B, Ho, Ho, Cout)
+        d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=Cout, k=k, stride=s, pad=p,
+                                     dil=dl, bias=conv.bias.detach(), relu=True)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        return out, Ho, Cout

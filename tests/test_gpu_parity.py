@@ -483,6 +483,31 @@ def test_backward_gradients(dev, name):
     assert max(v for k, v in errs.items() if k != 'vgg.30.bias') < 6e-2, errs
 
 
+def test_vanilla_ssd_config0(dev, golden):
+    """BASELINE.json configs[0] / SURVEY row a16: vanilla VGG-SSD300 (3-channel, dense, no BN), batch 2, forward +
+    MultiBoxLoss, against the reference's sampled outputs and the oracle."""
+    from models.ssd import build_ssd
+    from layers.modules import MultiBoxLoss
+    g = golden('e2e')
+    net = build_ssd('train', 300, 2)
+    keys = sorted(net.state_dict().keys())
+    assert keys == [str(k) for k in g['ssd.keys']]
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = synth.synth_images(2, seed=6, channels=3)
+    tg = synth.synth_targets(4, seed=5)[:2]
+    with torch.no_grad():
+        loc, conf, pri = net(x.to(dev))
+        ll, lc = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)((loc, conf, pri), tg)
+        lo, co = O.vanilla_ssd_forward(sd, x)
+    l, c = loc.cpu().numpy().reshape(-1), conf.cpu().numpy().reshape(-1)
+    assert rel(l[g['ssd.loc_idx']], g['ssd.loc_val']) < TOL and rel(c[g['ssd.conf_idx']], g['ssd.conf_val']) < TOL
+    assert rel(loc, lo) < TOL and rel(conf, co) < TOL
+    assert rel(ll, g['ssd.loss'][0]) < TOL and rel(lc, g['ssd.loss'][1]) < TOL
+
+
 def test_visualize_outputs(dev):
     from models.ssd_multiphase_custom_group import build_ssd
     flags, args = NETS['gssdpp']

@@ -72,6 +72,16 @@ def test_module_tree_matches_reference(golden, name, args):
     assert net.priors.shape == (8732, 4)
 
 
+def test_vanilla_module_tree(golden):
+    from models.ssd import build_ssd
+    g = golden('e2e')
+    net = build_ssd('train', 300, 2)
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in g['ssd.keys']]
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd.keys())] == [str(s) for s in g['ssd.shapes']]
+    assert build_ssd('train', 512, 2) is None and build_ssd('x', 300, 2) is None
+
+
 def test_build_ssd_rejects_like_reference(capsys):
     from models.ssd_multiphase_custom_group import build_ssd
     assert build_ssd('val', 300, 2, True) is None
