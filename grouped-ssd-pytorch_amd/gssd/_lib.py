@@ -48,6 +48,9 @@ SIGNATURES = {
     'gssd_unpack_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_nhwc_f32': (c_i, [C.POINTER(ConvDesc), c_fp]),
+    'gssd_conv2d_wgrad_f32': (c_i, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp]),
+    'gssd_unpack_conv_weight_grad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_pack_conv_weight_dgrad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
     'gssd_bn_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),

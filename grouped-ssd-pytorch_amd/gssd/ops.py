@@ -129,6 +129,29 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=Fal
     return out
 
 
+def conv_wgrad(desc, dy, Cout, cin_g_real, k, cin_g_pad=None, out=None, accumulate=False):
+    """OIHW weight gradient of the conv described by ``desc`` for the dense NHWC output gradient ``dy``."""
+    cin_g_pad = cin_g_pad or desc.cin_g
+    K = k * k * cin_g_pad
+    dwp = torch.zeros(Cout, K, device=dy.device, dtype=torch.float32)
+    check(lib.gssd_conv2d_wgrad_f32(C.byref(desc), _p(dy), _p(dwp), _stream()))
+    if out is None:
+        out = torch.empty(Cout, cin_g_real, k, k, device=dy.device, dtype=torch.float32)
+    check(lib.gssd_unpack_conv_weight_grad(_p(dwp), _p(out), Cout, cin_g_real, k, k, cin_g_pad, K, int(accumulate), _stream()))
+    return out
+
+
+def pack_weight_dgrad(w_oihw, groups, out=None):
+    """OIHW -> [Cin_total][taps*cout_g] rows for the data-gradient conv (flipped taps, co <-> ci)."""
+    w = w_oihw.detach().contiguous().float()
+    Cout, cin_g, KH, KW = w.shape
+    Kd = KH * KW * (Cout // groups)
+    if out is None:
+        out = torch.empty(groups * cin_g, Kd, device=w.device, dtype=torch.float32)
+    check(lib.gssd_pack_conv_weight_dgrad(_p(w), _p(out), Cout, groups, cin_g, KH, KW, _stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # elementwise
 # ------------------------------------------------------------------------------------------------

@@ -112,6 +112,22 @@ typedef struct gssd_conv_desc {
 int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Convolution backward (replaces the cuDNN dgrad / wgrad kernels behind loss.backward(),
+ * train_lesion_multiphase_v2.py:247-248)
+ * ------------------------------------------------------------------------------------------
+ * Weight gradient: dw_packed[n][k] += sum_m dy[m][n] * im2col(in)[m][k] for the forward described by `d`
+ * (d->in / geometry / in_scale.. are used; d->wgt, d->out are ignored).  dy is the dense NHWC gradient
+ * [B*Ho*Wo][Cout]; dw_packed [Cout][K] must be zero-filled (split-K partials are added with fp32 atomics).
+ * gssd_unpack_conv_weight_grad turns it into the OIHW gradient (accumulate != 0: +=).
+ * Data gradient: a stride-1 conv's dgrad is a forward gssd_conv2d_nhwc_f32 over dy with the weights packed by
+ * gssd_pack_conv_weight_dgrad (rows = input channels, k' = flipped tap * cout_g + co) and pad' = dil*(k-1) - pad. */
+int gssd_conv2d_wgrad_f32(const gssd_conv_desc* d, const float* dy, float* dw_packed, gssd_stream_t stream);
+int gssd_unpack_conv_weight_grad(const float* w_packed, float* w_oihw, int Cout, int cin_g, int KH, int KW,
+                                 int cin_g_pad, int Kpad, int accumulate, gssd_stream_t stream);
+int gssd_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int groups, int cin_g, int KH, int KW,
+                                gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * BatchNorm (train / eval) + ReLU + max-pool, one pass
  * ------------------------------------------------------------------------------------------
  * Replaces nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d (models/...group.py:439-441,446,450,455-456;

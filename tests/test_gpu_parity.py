@@ -118,6 +118,47 @@ def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H, k, st, pd):
     assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5
 
 
+BWD_CASES = [
+    # B, H, Cin, Cout, k, s, p, d, groups
+    (2, 30, 64, 64, 3, 1, 1, 1, 4),      # cout_g 16 (scalar dY path)
+    (2, 21, 64, 128, 3, 1, 1, 1, 4),     # cout_g 32
+    (2, 19, 128, 256, 3, 1, 1, 1, 4),    # cout_g 64 (b128 path, 64 x 256 tile)
+    (2, 19, 512, 512, 3, 1, 1, 1, 4),    # cout_g 128
+    (2, 19, 512, 1024, 3, 1, 6, 6, 4),   # dilation 6
+    (2, 19, 1024, 1024, 1, 1, 0, 1, 4),  # grouped 1x1
+    (2, 19, 256, 512, 3, 2, 1, 1, 4),    # stride 2 (wgrad only)
+    (2, 10, 512, 512, 1, 1, 0, 1, 1),    # dense 1x1
+    (2, 10, 512, 36, 3, 1, 1, 1, 1),     # head
+    (3, 33, 16, 64, 3, 1, 1, 1, 4),      # conv1_1: 4 (3 real) input channels per group
+]
+
+
+@pytest.mark.parametrize('case', BWD_CASES)
+def test_conv_backward(dev, ops, case):
+    """wgrad kernel and dgrad-as-forward-conv against CPU autograd."""
+    B, H, Cin, Cout, k, s, p, d, g = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = torch.from_numpy(rng.normal(size=(B, Cin, H, H)).astype(np.float32)).requires_grad_()
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, k, k)).astype(np.float32)).requires_grad_()
+    y = torch.nn.functional.conv2d(x, w, None, s, p, d, g)
+    dy = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    xd, dyd = nhwc(x.detach()).to(dev), nhwc(dy).to(dev)
+    desc, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g, k=k,
+                                    stride=s, pad=p, dil=d)
+    dw = ops.conv_wgrad(desc, dyd, Cout, Cin // g, k)
+    assert rel(dw, w.grad) < TOL
+    if s == 1:
+        wd = ops.pack_weight_dgrad(w.detach().to(dev), g)
+        Ho = y.shape[2]
+        dx = torch.empty(B, H, H, Cin, device=dev)
+        pd = d * (k - 1) - p
+        dd, _, _ = ops.make_conv_desc(dyd, wd, dx, B=B, H=Ho, W=Ho, in_stride=Cout, cin_g=Cout // g, Cout=Cin, groups=g, k=k,
+                                      pad=pd, dil=d)
+        ops.run_conv(dd)
+        assert rel(nchw(dx), x.grad) < TOL
+
+
 def test_conv_heads_layout(dev, ops):
     """loc|conf heads write straight into the concatenated [B,P,4] / [B,P,C] buffers in SSD prior order
     (models/ssd_multiphase_custom_group.py:375-380)."""
