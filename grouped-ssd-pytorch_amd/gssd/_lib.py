@@ -54,6 +54,14 @@ SIGNATURES = {
     'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
     'gssd_bn_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_bn_bwd_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_bn_bwd_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_bn_bwd_apply_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_fp]),
+    'gssd_colsum_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp, c_fp]),
+    'gssd_cast_f64_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
+    'gssd_l2norm_bwd_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
+    'gssd_heads_gather_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_upsample_insert_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),

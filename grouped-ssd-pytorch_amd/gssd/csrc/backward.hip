@@ -1,0 +1,357 @@
+// Backward of the HBM-bound passes of the GSSD trunk on gfx950: BatchNorm(train) + ReLU + max-pool, L2Norm, the heads'
+// gradient gather, the stride-2 zero-insertion and per-channel column sums.  NHWC float4 everywhere; per-channel
+// reductions are fp32 per thread -> LDS -> one fp64 atomic per channel per workgroup.
+// Replaces autograd's native_batch_norm_backward / threshold_backward / max_pool2d_with_indices_backward chain behind
+// loss.backward() (train_lesion_multiphase_v2.py:247-248).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// -----------------------------------------------------------------------------------------------------------------
+// Pass 1: window-centric.  One thread per (pooled output position, channel quad).  z = raw*scale + shift, a = relu(z);
+// the window's first maximum of a receives d_out; ReLU's mask (z > 0) is applied; dz is written for every window
+// element (non-overlapping pools) or atomically accumulated (overlapping, dz pre-zeroed).  Per-channel sums
+// s1 = sum dz, s2 = sum dz*raw feed the BatchNorm parameter gradients.
+// -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ dz, double* __restrict__ sums, int B, int H,
+                                                            int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] s1 | [C] s2
+    const int C4 = C >> 2;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+    __syncthreads();
+    const long long total = (long long)B * Ho * Wo * C4;
+    // a thread keeps the same channel quad across its grid-stride iterations when the stride is a multiple of C4
+    const long long stride = ((long long)gridDim.x * blockDim.x / C4) * C4;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int c4 = (int)(i0 % C4);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale && i0 < stride) {
+        sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
+        sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+    }
+    if (i0 < stride)
+        for (long long i = i0; i < total; i += stride) {
+            long long t = i / C4;
+            const int xo = (int)(t % Wo);
+            t /= Wo;
+            const int yo = (int)(t % Ho);
+            const int b = (int)(t / Ho);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dout + i * 4);
+            if (pk == 0) {
+                const size_t o = (((size_t)b * H + yo) * W + xo) * C + 4 * c4;
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + o);
+                const f32x4 z = rv * sc + sh;
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
+                *reinterpret_cast<f32x4*>(dz + o) = d;
+                a1 += d;
+                a2 += d * rv;
+            } else {
+                const int y0 = yo * ps - pp, x0 = xo * ps - pp;
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bi[4] = {-1, -1, -1, -1};
+                f32x4 braw = {0.f, 0.f, 0.f, 0.f};
+                for (int dy = 0; dy < pk; ++dy) {
+                    const int yy = y0 + dy;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int dx = 0; dx < pk; ++dx) {
+                        const int xx = x0 + dx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + (((size_t)b * H + yy) * W + xx) * C + 4 * c4);
+                        f32x4 a = rv * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (relu) a[e] = fmaxf(a[e], 0.f);
+                            if (a[e] > best[e]) {       // first maximum wins, like max_pool2d
+                                best[e] = a[e];
+                                bi[e] = dy * pk + dx;
+                                braw[e] = rv[e];
+                            }
+                        }
+                    }
+                }
+                const bool overlap = ps < pk;
+                for (int dy = 0; dy < pk; ++dy) {
+                    const int yy = y0 + dy;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int dx = 0; dx < pk; ++dx) {
+                        const int xx = x0 + dx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        f32x4 d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = (bi[e] == dy * pk + dx && (!relu || best[e] > 0.f)) ? g[e] : 0.f;
+                        float* o = dz + (((size_t)b * H + yy) * W + xx) * C + 4 * c4;
+                        if (!overlap) {
+                            *reinterpret_cast<f32x4*>(o) = d;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (d[e] != 0.f) unsafeAtomicAdd(o + e, d[e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = (bi[e] >= 0 && (!relu || best[e] > 0.f)) ? g[e] : 0.f;
+                    a1[e] += d;
+                    a2[e] += d * braw[e];
+                }
+            }
+        }
+    if (sums) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sm[4 * c4 + e], a1[e]);
+            atomicAdd(&sm[C + 4 * c4 + e], a2[e]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) unsafeAtomicAdd(sums + c, (double)sm[c]);
+    }
+}
+
+// per-channel constants of draw = A*dz + Bc*raw + Cc and the BatchNorm parameter gradients
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double count, const double* __restrict__ bsums,
+                                       const float* __restrict__ gamma, float eps, int C, float* __restrict__ coefA,
+                                       float* __restrict__ coefB, float* __restrict__ coefC, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = fstats[c] / count;
+    double var = fstats[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const double s1 = bsums[c], s2 = bsums[C + c];
+    const double dg = inv * (s2 - mean * s1);        // sum dz * xhat
+    const double g = (double)gamma[c];
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)s1;
+    coefA[c] = (float)(g * inv);
+    coefB[c] = (float)(-g * inv * inv * dg / count);
+    coefC[c] = (float)(-g * inv * s1 / count + g * inv * inv * mean * dg / count);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
+                                                           const float* __restrict__ coefA, const float* __restrict__ coefB,
+                                                           const float* __restrict__ coefC, long long pixels, int C,
+                                                           double* __restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C4 = C >> 2;
+    if (colsum) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+        __syncthreads();
+    }
+    const long long total = pixels * C4;
+    const long long stride = ((long long)gridDim.x * blockDim.x / C4) * C4;
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int c4 = (int)(i0 % C4);
+    if (i0 < stride) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(coefA + 4 * c4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(coefB + 4 * c4);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(coefC + 4 * c4);
+        for (long long i = i0; i < total; i += stride) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + i * 4);
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + i * 4);
+            const f32x4 o = a * d + bb * rv + cc;
+            *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+            acc += o;
+        }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&sm[4 * c4 + e], acc[e]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) unsafeAtomicAdd(colsum + c, (double)sm[c]);
+    }
+}
+
+// column sums of a dense [rows][C] matrix (conv bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int C, int stride,
+                                                     double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+    __syncthreads();
+    const long long total = rows * C;
+    const long long gstride = ((long long)gridDim.x * blockDim.x / C) * C;
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i0 < gstride) {
+        const int c = (int)(i0 % C);
+        float a = 0.f;
+        for (long long i = i0; i < total; i += gstride) a += x[(i / C) * stride + c];
+        atomicAdd(&sm[c], a);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) unsafeAtomicAdd(out + c, (double)sm[c]);
+}
+
+__global__ void cast_f64_f32_kernel(const double* __restrict__ x, float* __restrict__ y, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = accumulate ? y[i] + (float)x[i] : (float)x[i];
+}
+
+// L2Norm backward: one wave per pixel
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ dy, float* __restrict__ dx,
+                                                         const float* __restrict__ dx_add, double* __restrict__ dw,
+                                                         long long pixels, int C, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [C] dw partial
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int C4 = C >> 2;
+    for (long long p = wave0; p < pixels; p += nwaves) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(x + p * C);
+        const f32x4* gp = reinterpret_cast<const f32x4*>(dy + p * C);
+        float ss = 0.f, dot = 0.f;
+        for (int c = lane; c < C4; c += 64) {
+            const f32x4 v = xp[c], g = gp[c], ww = reinterpret_cast<const f32x4*>(w)[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += v[e] * v[e];
+                dot += ww[e] * g[e] * v[e];
+            }
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float rr = sqrtf(ss), n = rr + eps;
+        const float k1 = 1.f / n, k2 = (rr > 0.f) ? dot / (n * n * rr) : 0.f;
+        for (int c = lane; c < C4; c += 64) {
+            const f32x4 v = xp[c], g = gp[c], ww = reinterpret_cast<const f32x4*>(w)[c];
+            f32x4 o = ww * g * k1 - v * k2;
+            if (dx_add) o += reinterpret_cast<const f32x4*>(dx_add + p * C)[c];
+            reinterpret_cast<f32x4*>(dx + p * C)[c] = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&sm[4 * c + e], g[e] * v[e] * k1);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) unsafeAtomicAdd(dw + c, (double)sm[c]);
+}
+
+// heads: dloc [B,P,4] / dconf [B,P,nc] -> dense NHWC [B, HW, A*(4+nc)] of one source
+__global__ void heads_gather_kernel(const float* __restrict__ dloc, const float* __restrict__ dconf, float* __restrict__ out,
+                                    int B, int HW, int A, int nc, int P, int prior_off) {
+    const int Cc = A * (4 + nc);
+    const long long total = (long long)B * HW * Cc;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cc);
+        const long long bp = i / Cc;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        float v;
+        if (n < A * 4) v = dloc[((size_t)b * P + prior_off) * 4 + (size_t)pix * A * 4 + n];
+        else v = dconf[((size_t)b * P + prior_off) * nc + (size_t)pix * A * nc + (n - A * 4)];
+        out[i] = v;
+    }
+}
+
+// stride-s zero insertion: U[b, s*i, s*j, c] = dy[b, i, j, c], zero elsewhere (dgrad of a strided conv)
+__global__ void upsample_insert_kernel(const float* __restrict__ dy, float* __restrict__ u, int B, int Ho, int Wo, int H,
+                                       int W, int C, int s) {
+    const int C4 = C >> 2;
+    const long long total = (long long)B * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y % s == 0 && x % s == 0 && y / s < Ho && x / s < Wo)
+            v = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + y / s) * Wo + x / s) * C + 4 * c4);
+        *reinterpret_cast<f32x4*>(u + i * 4) = v;
+    }
+}
+
+inline int nblocks(long long items, int cap = 2048) {
+    long long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const float* scale, const float* shift, float* dz,
+                                      double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
+                                      int pool_p, int relu, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dout && raw && dz && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblocks(total)), dim3(256), 2 * C * sizeof(float), as_stream(stream), dout,
+                       raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, const double* bwd_sums, const float* gamma,
+                                        float eps, int C, float* coef_a, float* coef_b, float* coef_c, float* dgamma,
+                                        float* dbeta, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(fwd_stats && bwd_sums && gamma && coef_a && coef_b && coef_c && dgamma && dbeta && C > 0 && count > 0);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), fwd_stats, count,
+                       bwd_sums, gamma, eps, C, coef_a, coef_b, coef_c, dgamma, dbeta);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b,
+                                     const float* coef_c, int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dz && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(pixels * (C / 4))), dim3(256), C * sizeof(float), as_stream(stream),
+                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_colsum_f32(const float* x, int64_t rows, int C, int row_stride, double* out, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && out && rows > 0 && C > 0 && C <= 4096 && row_stride >= C);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblocks(rows * C, 512)), dim3(256), C * sizeof(float), as_stream(stream), x,
+                       (long long)rows, C, row_stride, out);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_cast_f64_f32(const double* x, float* y, int n, int accumulate, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, y, n, accumulate);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_l2norm_bwd_f32(const float* x, const float* weight, const float* dy, float* dx, const float* dx_add,
+                                   double* dweight, int64_t pixels, int C, float eps, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && weight && dy && dx && dweight && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks(pixels * 64, 1024)), dim3(256), C * sizeof(float), as_stream(stream), x,
+                       weight, dy, dx, dx_add, dweight, (long long)pixels, C, eps);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_heads_gather_f32(const float* dloc, const float* dconf, float* out, int B, int HW, int A, int nc, int P,
+                                     int prior_off, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dloc && dconf && out && B > 0 && HW > 0 && A > 0 && nc > 0 && prior_off >= 0 && prior_off + HW * A <= P);
+    hipLaunchKernelGGL(heads_gather_kernel, dim3(nblocks((long long)B * HW * A * (4 + nc))), dim3(256), 0, as_stream(stream),
+                       dloc, dconf, out, B, HW, A, nc, P, prior_off);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_upsample_insert_f32(const float* dy, float* u, int B, int Ho, int Wo, int H, int W, int C, int s,
+                                        gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dy && u && B > 0 && Ho > 0 && Wo > 0 && H >= (Ho - 1) * s + 1 && W >= (Wo - 1) * s + 1 && C % 4 == 0 && s > 0);
+    hipLaunchKernelGGL(upsample_insert_kernel, dim3(nblocks((long long)B * H * W * (C / 4))), dim3(256), 0, as_stream(stream),
+                       dy, u, B, Ho, Wo, H, W, C, s);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

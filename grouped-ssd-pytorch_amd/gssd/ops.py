@@ -334,3 +334,32 @@ def detect_boxes(boxes, scores, overlap, top_k):
     out, keep, cnt = detect(boxes.unsqueeze(0), conf, boxes, 2, top_k=top_k, conf_thresh=0.0, nms_thresh=overlap,
                             want_keep=True, loc_is_boxes=True)
     return out[0, 1], keep[0, 1], cnt[0, 1]
+
+
+# ------------------------------------------------------------------------------------------------
+# backward helpers (tests and the engine's backward plan use the same entry points)
+# ------------------------------------------------------------------------------------------------
+def bn_backward(dout, raw, fwd_stats, count, gamma, scale, shift, pool=None, relu=True, eps=1e-5, want_colsum=False):
+    """d(conv output) of conv -> BN(train) -> ReLU -> (pool).  Returns (draw NHWC, dgamma, dbeta, colsum or None)."""
+    B, H, W, Cc = raw.shape
+    _, Ho, Wo, _ = dout.shape
+    pk, ps, pp = pool if pool else (0, 1, 0)
+    dev = raw.device
+    dz = torch.zeros_like(raw) if (pool and ps < pk) else torch.empty_like(raw)
+    sums = torch.zeros(2 * Cc, device=dev, dtype=torch.float64)
+    check(lib.gssd_bn_bwd_reduce_f32(_p(dout), _p(raw), _p(scale), _p(shift), _p(dz), _p(sums), B, H, W, Cc, Ho, Wo, pk, ps, pp,
+                                     int(relu), _stream()))
+    ca, cb, cc, dg, db = (torch.empty(Cc, device=dev) for _ in range(5))
+    check(lib.gssd_bn_bwd_finalize_f32(_p(fwd_stats), float(count), _p(sums), _p(gamma), eps, Cc, _p(ca), _p(cb), _p(cc), _p(dg),
+                                       _p(db), _stream()))
+    cs = torch.zeros(Cc, device=dev, dtype=torch.float64) if want_colsum else None
+    check(lib.gssd_bn_bwd_apply_f32(_p(dz), _p(raw), _p(ca), _p(cb), _p(cc), B * H * W, Cc, _p(cs), _stream()))
+    return dz, dg, db, cs
+
+
+def l2norm_backward(x, weight, dy, dx_add=None, eps=1e-10):
+    Cc = x.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.zeros(Cc, device=x.device, dtype=torch.float64)
+    check(lib.gssd_l2norm_bwd_f32(_p(x), _p(weight), _p(dy), _p(dx), _p(dx_add), _p(dw), x.numel() // Cc, Cc, eps, _stream()))
+    return dx, dw

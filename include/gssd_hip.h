@@ -149,6 +149,34 @@ int gssd_bn_finalize_f32(const double* stats, double count, const float* gamma, 
                          float* running_mean, float* running_var, float momentum, float eps, int training, int C,
                          float* scale, float* shift, float* pad, gssd_stream_t stream);
 
+/* BatchNorm(train) + ReLU + max-pool backward, three launches (replaces autograd's native_batch_norm_backward /
+ * threshold_backward / max_pool2d_with_indices_backward):
+ *   reduce  : dz = d(out) routed through the pool's first-max and the ReLU mask of z = raw*scale + shift (scale == NULL:
+ *             z = raw, i.e. a plain pool / ReLU backward); sums[2C] += (sum dz, sum dz*raw) (fp64, may be NULL).
+ *             For overlapping pools (stride < kernel) dz must be zero-filled by the caller.
+ *   finalize: per-channel constants of d(raw) = A*dz + B*raw + C from the forward batch sums, plus dgamma, dbeta.
+ *   apply   : dz <- A*dz + B*raw + C in place; optional column sums of the result (the conv bias gradient). */
+int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const float* scale, const float* shift, float* dz,
+                           double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p,
+                           int relu, gssd_stream_t stream);
+int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, const double* bwd_sums, const float* gamma, float eps,
+                             int C, float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta,
+                             gssd_stream_t stream);
+int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b, const float* coef_c,
+                          int64_t pixels, int C, double* colsum, gssd_stream_t stream);
+/* out[c] += sum_rows x[row*row_stride + c] (fp64): conv bias gradients. */
+int gssd_colsum_f32(const float* x, int64_t rows, int C, int row_stride, double* out, gssd_stream_t stream);
+int gssd_cast_f64_f32(const double* x, float* y, int n, int accumulate, gssd_stream_t stream);
+/* L2Norm backward (layers/modules/l2norm.py:19-23): dx (+ dx_add if not NULL), dweight[C] += (fp64). */
+int gssd_l2norm_bwd_f32(const float* x, const float* weight, const float* dy, float* dx, const float* dx_add,
+                        double* dweight, int64_t pixels, int C, float eps, gssd_stream_t stream);
+/* Gradient of one multibox source's merged (loc|conf) head output, gathered from d(loc)[B,P,4] / d(conf)[B,P,nc]. */
+int gssd_heads_gather_f32(const float* dloc, const float* dconf, float* out, int B, int HW, int A, int nc, int P,
+                          int prior_off, gssd_stream_t stream);
+/* u[b, s*i, s*j, :] = dy[b, i, j, :], zero elsewhere: turns a strided conv's dgrad into a stride-1 conv. */
+int gssd_upsample_insert_f32(const float* dy, float* u, int B, int Ho, int Wo, int H, int W, int C, int s,
+                             gssd_stream_t stream);
+
 /* x / (sqrt(sum_c x^2) + eps) * w_c per pixel.  Replaces layers/modules/l2norm.py:19-23. */
 int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pixels, int C, float eps,
                     gssd_stream_t stream);

@@ -159,6 +159,67 @@ def test_conv_backward(dev, ops, case):
         assert rel(nchw(dx), x.grad) < TOL
 
 
+@pytest.mark.parametrize('H,pool', [(30, None), (30, (2, 2, 0, False)), (75, (2, 2, 0, True)), (19, (3, 1, 1, False))])
+def test_bn_relu_pool_backward(dev, ops, H, pool):
+    rng = np.random.default_rng(H + 1)
+    B, Cc = 3, 64
+    x = torch.from_numpy(rng.normal(0.3, 1.5, size=(B, Cc, H, H)).astype(np.float32)).requires_grad_()
+    gm = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cc).astype(np.float32)).requires_grad_()
+    bt = torch.from_numpy(rng.normal(size=Cc).astype(np.float32)).requires_grad_()
+    y = torch.relu(torch.nn.functional.batch_norm(x, None, None, gm, bt, True, 0.0, 1e-5))
+    if pool:
+        y = torch.nn.functional.max_pool2d(y, pool[0], pool[1], pool[2], ceil_mode=pool[3])
+    dy = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    xd = nhwc(x.detach()).to(dev)
+    stats = torch.stack([x.detach().double().sum(dim=(0, 2, 3)), (x.detach().double() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(dev)
+    sc, sh, pd = (torch.empty(Cc, device=dev) for _ in range(3))
+    ops.bn_finalize(stats, B * H * H, gm.detach().to(dev), bt.detach().to(dev), torch.zeros(Cc, device=dev),
+                    torch.ones(Cc, device=dev), True, sc, sh, pd)
+    draw, dg, db, cs = ops.bn_backward(nhwc(dy).to(dev), xd, stats, B * H * H, gm.detach().to(dev), sc, sh,
+                                       pool[:3] if pool else None, True, want_colsum=True)
+    assert rel(nchw(draw), x.grad) < 2e-4
+    assert rel(dg, gm.grad) < 1e-4 and rel(db, bt.grad) < 1e-4
+    assert float(cs.abs().max()) < 1e-2 * float(x.grad.abs().sum(dim=(0, 2, 3)).max())      # sum of d(raw) vanishes
+
+
+def test_l2norm_gather_upsample_backward(dev, ops):
+    from gssd._lib import lib, check
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.normal(size=(2, 64, 9, 9)).astype(np.float32)).requires_grad_()
+    w = torch.from_numpy(rng.uniform(15, 25, size=64).astype(np.float32)).requires_grad_()
+    y = O.l2norm(x, w)
+    dy = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    dx, dw = ops.l2norm_backward(nhwc(x.detach()).to(dev), w.detach().to(dev), nhwc(dy).to(dev))
+    assert rel(nchw(dx), x.grad) < 1e-5 and rel(dw, w.grad) < 1e-5
+    # heads gather
+    B, P, A, HW, off, nc = 2, 300, 6, 25, 100, 2
+    dloc = torch.from_numpy(rng.normal(size=(B, P, 4)).astype(np.float32))
+    dconf = torch.from_numpy(rng.normal(size=(B, P, nc)).astype(np.float32))
+    out = torch.empty(B, HW, A * (4 + nc), device=dev)
+    dl, dc = dloc.to(dev), dconf.to(dev)          # keep the device tensors alive across the raw-pointer call
+    check(lib.gssd_heads_gather_f32(dl.data_ptr(), dc.data_ptr(), out.data_ptr(), B, HW, A, nc, P, off, None))
+    ref = torch.cat([dloc[:, off:off + HW * A].reshape(B, HW, A * 4), dconf[:, off:off + HW * A].reshape(B, HW, A * nc)], 2)
+    assert torch.equal(out.cpu(), ref)
+    # stride-2 conv dgrad = zero insertion + stride-1 conv with flipped weights
+    for H in (19, 10):
+        xs = torch.from_numpy(rng.normal(size=(2, 64, H, H)).astype(np.float32)).requires_grad_()
+        ws = torch.from_numpy(rng.normal(0, 0.1, size=(128, 16, 3, 3)).astype(np.float32))
+        ys = torch.nn.functional.conv2d(xs, ws, None, 2, 1, 1, 4)
+        dys = torch.from_numpy(rng.normal(size=tuple(ys.shape)).astype(np.float32))
+        ys.backward(dys)
+        Ho = ys.shape[2]
+        u = torch.empty(2, H, H, 128, device=dev)
+        dyd = nhwc(dys).to(dev)
+        check(lib.gssd_upsample_insert_f32(dyd.data_ptr(), u.data_ptr(), 2, Ho, Ho, H, H, 128, 2, None))
+        wd = ops.pack_weight_dgrad(ws.to(dev), 4)
+        dxs = torch.empty(2, H, H, 64, device=dev)
+        dd, _, _ = ops.make_conv_desc(u, wd, dxs, B=2, H=H, W=H, in_stride=128, cin_g=32, Cout=64, groups=4, k=3, pad=1)
+        ops.run_conv(dd)
+        assert rel(nchw(dxs), xs.grad) < TOL
+
+
 def test_conv_heads_layout(dev, ops):
     """loc|conf heads write straight into the concatenated [B,P,4] / [B,P,C] buffers in SSD prior order
     (models/ssd_multiphase_custom_group.py:375-380)."""
