@@ -152,6 +152,9 @@ class GssdTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloc, dconf):
         net, x, params = ctx.net, ctx.x, ctx.params
+        if net._engine.has_hip_backward() and not x.requires_grad and not net.__dict__.get('_force_aten_backward'):
+            grads = net._engine.backward(dloc, dconf)            # hand-written HIP backward (gssd/backward.py)
+            return (None, None) + tuple(g if p.requires_grad else None for g, p in zip(grads, params))
         with torch.enable_grad():
             xin = x.detach().requires_grad_(x.requires_grad)
             loc, conf = shadow_forward(net, xin)

@@ -1,0 +1,222 @@
+"""HIP backward of the GSSD graph (grouped VGG trunk, extras, fuse convs, L2Norm, heads): SURVEY.md 8f row 1.
+
+Built from the forward plan's records (``engine._Plan.rec``) and walked in reverse.  Per conv + BN + ReLU (+ pool) layer:
+
+    d(out)  --bn_bwd_reduce-->  dz (pool's first-max routing, ReLU mask)  +  per-channel (sum dz, sum dz*raw)
+            --bn_bwd_finalize-> dgamma, dbeta, coefficients of d(raw) = A*dz + B*raw + C
+            --bn_bwd_apply----> d(raw) in place (+ column sums = conv bias gradient)
+            --conv wgrad------> packed dW (split-K atomics) --unpack--> weight.grad (OIHW)
+            --conv dgrad------> d(input): the forward conv kernel over d(raw) with flipped / transposed weights
+                                (stride 2: zero insertion first); a second contribution is added through ``resid``
+
+The consumer-side fused BN + ReLU of the forward (deferred BatchNorm) needs no activation buffer here either: wgrad
+re-applies the transform to the raw input, and the producer's BN backward recomputes its ReLU mask from raw.
+Self-attention and DCN blocks are not covered yet (GSSD++ uses the interim ATen recomputation).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import lib
+
+
+class BackwardPlan:
+    def __init__(self, plan):
+        self.plan = plan
+        self.B, self.dev = plan.B, plan.dev
+        self.steps = []
+        self.keep = []
+        self.grads = {}          # id(param) -> fp32 grad tensor
+        self.zero_list = []      # tensors to zero before every run
+        self.gbuf = {}           # data_ptr of a forward tensor -> gradient buffer w.r.t. it
+        self.dloc = torch.empty(self.B, plan.P, 4, device=self.dev)
+        self.dconf = torch.empty(self.B, plan.P, plan.nc, device=self.dev)
+        net = plan.eng.net
+        first_in = plan.rec[0][1]['x_in'].data_ptr()
+        for kind, r in reversed(plan.rec):
+            if kind == 'head':
+                self._head(r)
+            elif kind == 'convbn':
+                self._convbn(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
+            elif kind == 'pool':
+                self._pool(r)
+            elif kind == 'l2norm':
+                self._l2norm(r)
+            else:
+                raise _lib.GssdError(f'no HIP backward for {kind}')
+        self.param_order = [p for p in net.parameters()]
+
+    # ------------------------------------------------------------------------------------------------
+    def _add(self, fn, args, keep=None):
+        self.steps.append((fn, args))
+        if keep is not None:
+            self.keep.append(keep)
+
+    def _buf(self, *shape, dtype=torch.float32, zero_each_run=False):
+        t = torch.empty(*shape, device=self.dev, dtype=dtype)
+        self.keep.append(t)
+        if zero_each_run:
+            self.zero_list.append(t)
+        return t
+
+    def _pgrad(self, p):
+        g = self.grads.get(id(p))
+        if g is None:
+            g = torch.zeros_like(p, dtype=torch.float32)
+            self.grads[id(p)] = g
+            self.keep.append(g)
+        return g
+
+    def _grad_of(self, t):
+        return self.gbuf.get(t.data_ptr())
+
+    # gradient contribution of a conv to its input: dX (+)= conv(dY, flipped weights)
+    def _dgrad(self, r, dy, x_in, conv, groups, Cin, H, Ho, Cout, k, stride, pad, dil):
+        B = self.B
+        wd = self._buf(Cin, k * k * (Cout // groups))
+        self._add(lib.gssd_pack_conv_weight_dgrad, (conv_weight_ptr(conv, Cin // groups), wd.data_ptr(), Cout, groups,
+                                                    Cin // groups, k, k), keep=conv)
+        src, Hs = dy, Ho
+        if stride != 1:
+            u = self._buf(B, H, H, Cout)
+            self._add(lib.gssd_upsample_insert_f32, (dy.data_ptr(), u.data_ptr(), B, Ho, Ho, H, H, Cout, stride))
+            src, Hs = u, H
+            pd = k - 1 - pad
+        else:
+            pd = dil * (k - 1) - pad
+        existing = self._grad_of(x_in)
+        g = existing if existing is not None else self._buf(B, H, H, Cin)
+        d, Hout, _ = ops.make_conv_desc(src, wd, g, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin,
+                                        groups=groups, k=k, pad=pd, dil=dil, resid=existing)
+        assert Hout == H, (Hout, H)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self.gbuf[x_in.data_ptr()] = g
+
+    def _wgrad(self, fdesc, dy, conv, cin_g_real, cin_g_pad, k, Cout, row0=0, param=None):
+        """packed dW (zeroed each run) -> OIHW grad of ``param`` (rows [row0, row0 + param.shape[0]) of the packed matrix)."""
+        K = k * k * cin_g_pad
+        dwp = self._buf(Cout, K, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(fdesc), dy.data_ptr(), dwp.data_ptr()), keep=fdesc)
+        return dwp, K
+
+    def _unpack(self, dwp, K, row0, param, cin_g_real, cin_g_pad, k):
+        g = self._pgrad(param)
+        n = param.shape[0]
+        self._add(lib.gssd_unpack_conv_weight_grad, (dwp[row0:row0 + n].data_ptr(), g.data_ptr(), n, cin_g_real, k, k, cin_g_pad,
+                                                     K, 0))
+
+    def _bias_from_colsum(self, cs64, param, off=0):
+        g = self._pgrad(param)
+        self._add(lib.gssd_cast_f64_f32, (cs64[off:off + param.numel()].data_ptr(), g.data_ptr(), param.numel(), 0))
+
+    # ------------------------------------------------------------------------------------------------
+    def _head(self, r):
+        B, H, Cs, A, nc = self.B, r['H'], r['C'], r['A'], self.plan.nc
+        Cout = A * (4 + nc)
+        dyh = self._buf(B, H, H, Cout)
+        self._add(lib.gssd_heads_gather_f32, (self.dloc.data_ptr(), self.dconf.data_ptr(), dyh.data_ptr(), B, H * H, A, nc,
+                                              self.plan.P, r['off']))
+        fdesc, _, _ = ops.make_conv_desc(r['src'], None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=Cout, k=3, pad=1)
+        dwp, K = self._wgrad(fdesc, dyh, None, Cs, Cs, 3, Cout)
+        self._unpack(dwp, K, 0, r['loc'].weight, Cs, Cs, 3)
+        self._unpack(dwp, K, A * 4, r['conf'].weight, Cs, Cs, 3)
+        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dyh.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))
+        self._bias_from_colsum(cs, r['loc'].bias, 0)
+        self._bias_from_colsum(cs, r['conf'].bias, A * 4)
+        # d(source): the merged head weight [Cout][9*Cs] viewed as one conv
+        wd = self._buf(Cs, 9 * Cout)
+        hw = self.plan.eng._packed[f"heads.{r['i']}.w"]          # packed forward rows [Cout][9*Cs] (k = tap*Cs + c)
+        self._add(_pack_dgrad_from_packed, (hw, wd, Cout, Cs))
+        existing = self._grad_of(r['src'])
+        g = existing if existing is not None else self._buf(B, H, H, Cs)
+        d, _, _ = ops.make_conv_desc(dyh, wd, g, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Cs, k=3, pad=1, resid=existing)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self.gbuf[r['src'].data_ptr()] = g
+
+    def _convbn(self, r, need_dgrad=True):
+        B, H, Ho, Hp, Cin, Cout, groups = self.B, r['H'], r['Ho'], r['Hp'], r['Cin'], r['Cout'], r['groups']
+        conv, bn, raw = r['conv'], r['bn'], r['raw']
+        dout = self._grad_of(r['out'])
+        if dout is None:
+            raise _lib.GssdError(f"no gradient reaches {r['name']}")
+        # scale / shift of this layer's BatchNorm (deferred layers already hold them from the forward)
+        if r['xf'] is not None:
+            sc, sh = r['xf'][0], r['xf'][1]
+        else:
+            sc, sh, pd_ = self._buf(Cout), self._buf(Cout), self._buf(Cout)
+            self._add(lib.gssd_bn_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(),
+                                                 bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                 float(bn.momentum), float(bn.eps), 2, Cout, sc.data_ptr(), sh.data_ptr(),
+                                                 pd_.data_ptr()))
+        pool = r['pool']
+        pk, ps, pp = (pool[0], pool[1], pool[2]) if pool else (0, 1, 0)
+        dz = self._buf(B, Ho, Ho, Cout, zero_each_run=bool(pool and ps < pk))
+        sums = self._buf(2 * Cout, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr(),
+                                               sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
+        ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
+        self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
+                                                 float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                                 self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr()))
+        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                              B * Ho * Ho, Cout, cs.data_ptr()))
+        self._bias_from_colsum(cs, conv.bias)
+        # weight gradient (the forward descriptor carries the input geometry and the fused input transform)
+        cin_g_pad = Cin // groups
+        cin_g_real = conv.weight.shape[1]
+        dwp, K = self._wgrad(r['desc'], dz, conv, cin_g_real, cin_g_pad, r['k'], Cout)
+        self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
+        if need_dgrad:
+            self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
+
+    def _pool(self, r):
+        B, H, Cc, Hp = self.B, r['H'], r['C'], r['Hp']
+        dout = self._grad_of(r['out'])
+        existing = self._grad_of(r['x_in'])
+        assert existing is None, 'pool backward must be the first contribution to its input'
+        g = self._buf(B, H, H, Cc, zero_each_run=(r['s'] < r['k']))
+        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), r['x_in'].data_ptr(), 0, 0, g.data_ptr(), 0, B, H, H, Cc, Hp, Hp,
+                                               r['k'], r['s'], r['p'], 0))
+        self.gbuf[r['x_in'].data_ptr()] = g
+
+    def _l2norm(self, r):
+        B, H, Cc, mod = self.B, r['H'], r['C'], r['mod']
+        dy = self._grad_of(r['out'])
+        existing = self._grad_of(r['x_in'])
+        g = existing if existing is not None else self._buf(B, H, H, Cc)
+        dw = self._buf(Cc, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_l2norm_bwd_f32, (r['x_in'].data_ptr(), mod.weight.data_ptr(), dy.data_ptr(), g.data_ptr(),
+                                            existing.data_ptr() if existing is not None else 0, dw.data_ptr(), B * H * H, Cc,
+                                            float(mod.eps)))
+        self._bias_from_colsum(dw, mod.weight)
+        self.gbuf[r['x_in'].data_ptr()] = g
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, dloc, dconf):
+        self.dloc.copy_(dloc)
+        self.dconf.copy_(dconf)
+        if self.zero_list:
+            torch._foreach_zero_(self.zero_list)
+        stream = torch.cuda.current_stream().cuda_stream
+        for fn, args in self.steps:
+            if fn is _pack_dgrad_from_packed:
+                fn(*args)
+                continue
+            rc = fn(*args, stream)
+            if rc != 0:
+                _lib.check(rc)
+        return [self.grads.get(id(p)) for p in self.param_order]
+
+
+def conv_weight_ptr(conv, cin_g_expected):
+    """OIHW weight pointer for the dgrad packer (conv1_1 never needs a dgrad, so no channel padding arises)."""
+    assert conv.weight.shape[1] == cin_g_expected
+    return conv.weight.data_ptr()
+
+
+def _pack_dgrad_from_packed(hw, wd, Cout, Cs):
+    """Merged head weights [Cout][9][Cs] (forward packing) -> dgrad rows [Cs][9 flipped][Cout] (tiny: plain tensor ops)."""
+    wd.copy_(hw.view(Cout, 9, Cs).flip(1).permute(2, 1, 0).reshape(Cs, 9 * Cout))

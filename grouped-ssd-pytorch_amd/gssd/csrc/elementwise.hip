@@ -152,9 +152,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
         mean = stats[c] / count;
         var = stats[C + c] / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        if (training == 1) {      // training == 2: batch statistics again (backward) without a second running update
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        }
     } else {
         mean = (double)running_mean[c];
         var = (double)running_var[c];

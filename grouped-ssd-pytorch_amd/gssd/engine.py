@@ -104,6 +104,7 @@ class GssdEngine:
             for job in self._pack_jobs:
                 job()
             self._versions = vers
+        self._last_plan = plan
         return plan.run(x, events)
 
     # ------------------------------------------------------------------------------------------
@@ -114,6 +115,19 @@ class GssdEngine:
             self._packed[name] = t
             self._pack_jobs.append(lambda: build(self._packed[name]))
         return self._packed[name]
+
+    def backward(self, dloc, dconf):
+        """HIP backward of the last training forward (GSSD graph without SA / DCN): list of gradients in
+        ``net.parameters()`` order."""
+        plan = self._last_plan
+        if getattr(plan, '_bwd', None) is None:
+            from .backward import BackwardPlan
+            plan._bwd = BackwardPlan(plan)
+        return plan._bwd.run(dloc.contiguous(), dconf.contiguous())
+
+    def has_hip_backward(self):
+        net = self.net
+        return not (getattr(net, 'vanilla', False) or net.use_self_attention or net.use_self_attention_base or net.use_dcn)
 
     def _build(self, B, training, dev):
         if getattr(self.net, 'vanilla', False):
@@ -128,6 +142,7 @@ class _Plan:
         self.steps = []
         self.bufs = []
         self.head_descs = []
+        self.rec = []          # forward graph records, consumed by gssd/backward.py
         self.P = 8732
         self.nc = net.num_classes
         g = net.groups_vgg
@@ -276,6 +291,7 @@ class _Plan:
                                          split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
             self.head_descs.append(d)
             self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+            self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
             off += Hs * Hs * A
         assert off == self.P, off
 
@@ -316,6 +332,9 @@ class _Plan:
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None)
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        rec = dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho, Cout=Cout,
+                   desc=d, stats=st, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
+        self.rec.append(('convbn', rec))
         if defer_bn:
             assert pool is None and relu
             sc, sh, pd = self._buf(Cout), self._buf(Cout), self._buf(Cout)
@@ -323,6 +342,7 @@ class _Plan:
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                        int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
+            rec.update(out=raw, Hp=Ho, xf=(sc, sh, pd))
             return raw, Ho, Cout, (sc, sh, pd)
         if pool:
             pk, ps, pp, ceil = pool
@@ -334,6 +354,7 @@ class _Plan:
                   (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
                    bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                    float(bn.momentum), float(bn.eps), int(self.training), int(relu)))
+        rec.update(out=act, Hp=Hp, xf=None)
         return act, Hp, Cout, None
 
     def eng_stat(self, bn):
@@ -345,6 +366,7 @@ class _Plan:
         out = self._buf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_f32, (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0,
                                               0.1, 1e-5, 0, 0))
+        self.rec.append(('pool', dict(x_in=x, out=out, H=H, C=Cc, k=k, s=s, p=p, Hp=Hp)))
         return out, Hp
 
     def _after_conv4_3(self, x, H, Cc):
@@ -367,6 +389,7 @@ class _Plan:
         s = self._buf(B, H, H, Cc)
         self._add(lib.gssd_l2norm_f32, (x.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc,
                                         float(net.L2Norm.eps)))
+        self.rec.append(('l2norm', dict(x_in=x, out=s, H=H, C=Cc, mod=net.L2Norm)))
         src0 = self._branch(s, H, Cc, 0, '11')
         pooled, Hp = self._pool_only(x, H, Cc, 2, 2, 0)
         return pooled, Hp, Cc, src0

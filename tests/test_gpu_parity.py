@@ -575,39 +575,30 @@ def test_backward_gradients(dev, name):
     if name == 'gssdpp':
         keys += ['self_attn_list.0.snconv1x1_theta.weight_orig', 'self_attn_base_list.0.sigma', 'dcn_list.0.weight',
                  'dcn_list.0.conv_offset_mask.weight']
-    errs = {k: rel(named[k].grad, sdg[k].grad) for k in keys}
-    print('gradient rel errors', {k: f'{v:.1e}' for k, v in errs.items()})
-    # heads see the exact upstream gradient; everything upstream of a train-mode BatchNorm is a heavily cancelling sum
-    # (BN removes scale and shift), where fp32 CPU vs GPU reductions differ at the percent level; a conv bias in front of a
-    # BatchNorm has a mathematically zero gradient (pure rounding noise), so vgg.30.bias is only checked to be tiny.
+    def l2rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm())
+    errs = {k: l2rel(named[k].grad, sdg[k].grad) for k in keys if k != 'vgg.30.bias'}
+    print('gradient L2-relative errors vs CPU autograd', {k: f'{v:.1e}' for k, v in errs.items()})
+    # Metric: relative L2 error per tensor.  ReLU masks and max-pool arg-maxes are discontinuous: a forward difference of
+    # 1e-7 flips a handful of them between two implementations, and one flip moves single weight-gradient entries by
+    # ~1/sqrt(pixels) ~ 1 % (seen equally in CPU-fp32 vs CPU-fp64, scripts/dbg_grad64.py), so max-abs is not meaningful
+    # here.  A conv bias in front of a train-mode BatchNorm has a mathematically zero gradient (pure rounding noise).
     assert errs['loc.0.weight'] < 1e-4 and errs['conf.3.bias'] < 1e-4
     assert float(named['vgg.30.bias'].grad.abs().max()) < 1e-2 * float(named['vgg.31.bias'].grad.abs().max())
-    assert max(v for k, v in errs.items() if k != 'vgg.30.bias') < 6e-2, errs
-
-
-def test_vanilla_ssd_config0(dev, golden):
-    """BASELINE.json configs[0] / SURVEY row a16: vanilla VGG-SSD300 (3-channel, dense, no BN), batch 2, forward +
-    MultiBoxLoss, against the reference's sampled outputs and the oracle."""
-    from models.ssd import build_ssd
-    from layers.modules import MultiBoxLoss
-    g = golden('e2e')
-    net = build_ssd('train', 300, 2)
-    keys = sorted(net.state_dict().keys())
-    assert keys == [str(k) for k in g['ssd.keys']]
-    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = synth.synth_state_dict(shapes, seed=1111)
-    net.load_state_dict(sd)
-    net = net.to(dev).train()
-    x = synth.synth_images(2, seed=6, channels=3)
-    tg = synth.synth_targets(4, seed=5)[:2]
-    with torch.no_grad():
-        loc, conf, pri = net(x.to(dev))
-        ll, lc = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)((loc, conf, pri), tg)
-        lo, co = O.vanilla_ssd_forward(sd, x)
-    l, c = loc.cpu().numpy().reshape(-1), conf.cpu().numpy().reshape(-1)
-    assert rel(l[g['ssd.loc_idx']], g['ssd.loc_val']) < TOL and rel(c[g['ssd.conf_idx']], g['ssd.conf_val']) < TOL
-    assert rel(loc, lo) < TOL and rel(conf, co) < TOL
-    assert rel(ll, g['ssd.loss'][0]) < TOL and rel(lc, g['ssd.loss'][1]) < TOL
+    assert max(errs.values()) < 2e-2, errs
+    if name == 'gssd':
+        # the hand-written HIP backward (default for GSSD) against the ATen recomputation on the same device
+        hip = {k: named[k].grad.clone() for k in keys}
+        for p in net.parameters():
+            p.grad = None
+        net.__dict__['_force_aten_backward'] = True
+        loc, conf, _ = net(x.to(dev))
+        ((loc * r1.to(dev)).sum() + (conf * r2.to(dev)).sum()).backward()
+        net.__dict__['_force_aten_backward'] = False
+        e2 = {k: l2rel(hip[k], named[k].grad) for k in keys if k != 'vgg.30.bias'}
+        print('HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in e2.items()})
+        assert max(e2.values()) < 2e-2, e2
 
 
 def test_visualize_outputs(dev):
