@@ -152,27 +152,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         if (ch + 1 < nchunks) issue(m_begin + (ch + 1) * BP, buf ^ 1);
         const float* A = smem + buf * STAGE;                 // [BP][BMW]
         const float* Bm = A + BP * BMW;                      // [BP][BNW]
+        // software-pipelined by one k-step: step s+1's operands are requested before step s's MFMAs
+        auto ldb = [&](int s) -> f32x4 { return *reinterpret_cast<const f32x4*>(Bm + (4 * s + kq) * BNW + wn * 64 + 4 * r); };
+        auto lda4 = [&](int s) -> f32x4 { return *reinterpret_cast<const f32x4*>(A + (4 * s + kq) * BMW + wm * 64 + 4 * r); };
+        auto lda1 = [&](int s) -> float { return A[(4 * s + kq) * BMW + wm * 16 + r]; };
+        f32x4 bv = ldb(0), av4 = {0.f, 0.f, 0.f, 0.f}, bn_ = bv, an4 = av4;
+        float av1 = 0.f, an1 = 0.f;
+        if constexpr (MT == 4) av4 = lda4(0);
+        else av1 = lda1(0);
 #pragma unroll
         for (int s = 0; s < BP / 4; ++s) {
-            const int prow = 4 * s + kq;
-            f32x4 bv = *reinterpret_cast<const f32x4*>(Bm + prow * BNW + wn * 64 + 4 * r);
+            if (s + 1 < BP / 4) {
+                bn_ = ldb(s + 1);
+                if constexpr (MT == 4) an4 = lda4(s + 1);
+                else an1 = lda1(s + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (xf) {
                 bv = bv * sc + sh;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[e] = fmaxf(bv[e], 0.f);
             }
             if constexpr (MT == 4) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(A + prow * BMW + wm * 64 + 4 * r);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[i], bv[j], acc[i][j], 0, 0, 0);
             } else {
-                const float av = A[prow * BMW + wm * 16 + r];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[0][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv[j], acc[0][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            bv = bn_;
+            av4 = an4;
+            av1 = an1;
         }
         __syncthreads();
     }
@@ -198,9 +212,10 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.m_tiles = (cout_g + BMW - 1) / BMW;
     p.n_tiles = (p.K + BNW - 1) / BNW;
     const long long tiles = (long long)p.groups * p.m_tiles * p.n_tiles;
-    // split the pixel range so that ~2048 workgroups exist, each with >= 8 chunks
-    long long slices = (2048 + tiles - 1) / tiles;
-    const long long max_slices = (p.M + 8 * BP - 1) / (8 * BP);
+    // split the pixel range so that ~3 workgroups per CU exist, each with >= 16 chunks: every slice adds one full
+    // [Cout][K] round of fp32 atomics, which would dominate the traffic of the small-map layers otherwise
+    long long slices = (768 + tiles - 1) / tiles;
+    const long long max_slices = (p.M + 16 * BP - 1) / (16 * BP);
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     p.pix_per_slice = (int)(((p.M + slices - 1) / slices + BP - 1) / BP * BP);
@@ -261,6 +276,10 @@ extern "C" int gssd_conv2d_wgrad_f32(const gssd_conv_desc* dp, const float* dy, 
     GSSD_CHECK_ARG(d.K == d.KH * d.KW * d.cin_g && d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0);
     GSSD_CHECK_ARG((d.Cout / d.groups) % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)d.in % 16) == 0);
     GSSD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr) && (d.in_scale == nullptr) == (d.in_pad == nullptr));
+    {
+        const int rc = gssd_try_conv_thin_wgrad(d, dy, dw_packed, as_stream(stream));    // conv1_1 / conv1_2: patch-staged
+        if (rc != 1) return rc;
+    }
     WgradParams p;
     p.in = d.in;
     p.dy = dy;

@@ -130,6 +130,8 @@ BWD_CASES = [
     (2, 10, 512, 512, 1, 1, 0, 1, 1),    # dense 1x1
     (2, 10, 512, 36, 3, 1, 1, 1, 1),     # head
     (3, 33, 16, 64, 3, 1, 1, 1, 4),      # conv1_1: 4 (3 real) input channels per group
+    (2, 83, 16, 64, 3, 1, 1, 1, 4),      # thin patch-staged wgrad <4>, ragged tiles
+    (2, 80, 64, 64, 3, 1, 1, 1, 4),      # thin wgrad <16>
 ]
 
 
