@@ -603,6 +603,41 @@ def test_backward_gradients(dev, name):
         assert max(e2.values()) < 2e-2, e2
 
 
+def test_training_steps_reduce_loss(dev):
+    """The driver's step sequence (train_lesion_multiphase_v2.py:242-253) on a fixed synthetic batch: forward, MultiBoxLoss,
+    backward (HIP), SGD(momentum 0.9, wd 5e-4).  The loss must fall, and the weights must track the same steps taken with
+    the ATen backward."""
+    import copy
+    from models.ssd_multiphase_custom_group import build_ssd
+    from layers.modules import MultiBoxLoss
+    flags, args = NETS['gssd']
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    twin = copy.deepcopy(net)
+    twin.__dict__['_force_aten_backward'] = True
+    x = synth.synth_images(8, seed=21).to(dev)
+    tg = [t.to(dev) for t in synth.synth_targets(8, seed=21)]
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    hist = {}
+    for tag, m in (('hip', net), ('aten', twin)):
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        losses = []
+        for _ in range(6):
+            opt.zero_grad()
+            ll, lc = crit(m(x), tg)
+            (ll + lc).backward()
+            opt.step()
+            losses.append(float(ll + lc))
+        hist[tag] = losses
+    print('loss trajectories', hist)
+    assert all(np.isfinite(hist['hip'])) and hist['hip'][-1] < hist['hip'][0]
+    assert abs(hist['hip'][-1] - hist['aten'][-1]) < 0.05 * abs(hist['aten'][0])
+    w1, w2 = dict(net.named_parameters()), dict(twin.named_parameters())
+    for k in ('vgg.0.weight', 'vgg.24.weight', 'fuse_21.weight', 'loc.2.weight'):
+        assert rel(w1[k], w2[k]) < 2e-2, k
+
+
 def test_visualize_outputs(dev):
     from models.ssd_multiphase_custom_group import build_ssd
     flags, args = NETS['gssdpp']
