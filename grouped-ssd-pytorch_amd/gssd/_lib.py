@@ -7,6 +7,11 @@ not export every symbol of the header, importing this module raises.
 import ctypes as C
 import os
 
+# torch must load ITS HIP runtime (libamdhip64 bundled under torch/lib) before libgssd_hip.so is opened: if the
+# system copy under /opt/rocm is pulled in first the process ends up with two runtimes and kernels launched from this
+# library fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libgssd_hip.so')
 
