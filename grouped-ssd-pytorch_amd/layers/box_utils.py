@@ -8,47 +8,58 @@ import torch
 from gssd import ops
 
 
-def point_form(boxes):      # box_utils.py:4-13
-    return torch.cat((boxes[:, :2] - boxes[:, 2:] / 2, boxes[:, :2] + boxes[:, 2:] / 2), 1)
+def _cxcywh(t):
+    return t[..., 0], t[..., 1], t[..., 2], t[..., 3]
 
 
-def center_size(boxes):     # box_utils.py:16-25
-    return torch.cat(((boxes[:, 2:] + boxes[:, :2]) / 2, boxes[:, 2:] - boxes[:, :2]), 1)
+def point_form(boxes):
+    """(cx, cy, w, h) -> (xmin, ymin, xmax, ymax)   [reference box_utils.py:4-13]"""
+    cx, cy, w, h = _cxcywh(boxes)
+    hw, hh = w / 2, h / 2
+    return torch.stack((cx - hw, cy - hh, cx + hw, cy + hh), dim=-1)
 
 
-def intersect(box_a, box_b):  # box_utils.py:28-46
-    A, B = box_a.size(0), box_b.size(0)
-    max_xy = torch.min(box_a[:, 2:].unsqueeze(1).expand(A, B, 2), box_b[:, 2:].unsqueeze(0).expand(A, B, 2))
-    min_xy = torch.max(box_a[:, :2].unsqueeze(1).expand(A, B, 2), box_b[:, :2].unsqueeze(0).expand(A, B, 2))
-    inter = torch.clamp((max_xy - min_xy), min=0)
-    return inter[:, :, 0] * inter[:, :, 1]
+def center_size(boxes):
+    """(xmin, ymin, xmax, ymax) -> (cx, cy, w, h)   [reference box_utils.py:16-25]"""
+    x1, y1, x2, y2 = _cxcywh(boxes)
+    return torch.stack(((x2 + x1) / 2, (y2 + y1) / 2, x2 - x1, y2 - y1), dim=-1)
 
 
-def jaccard(box_a, box_b):    # box_utils.py:49-67
+def intersect(box_a, box_b):
+    """Pairwise intersection areas [A, B]   [reference box_utils.py:28-46]"""
+    lo = torch.maximum(box_a[:, None, :2], box_b[None, :, :2])
+    hi = torch.minimum(box_a[:, None, 2:], box_b[None, :, 2:])
+    wh = (hi - lo).clamp_min(0)
+    return wh[..., 0] * wh[..., 1]
+
+
+def jaccard(box_a, box_b):
+    """Pairwise IoU [A, B]   [reference box_utils.py:49-67]"""
     inter = intersect(box_a, box_b)
-    area_a = ((box_a[:, 2] - box_a[:, 0]) * (box_a[:, 3] - box_a[:, 1])).unsqueeze(1).expand_as(inter)
-    area_b = ((box_b[:, 2] - box_b[:, 0]) * (box_b[:, 3] - box_b[:, 1])).unsqueeze(0).expand_as(inter)
-    return inter / (area_a + area_b - inter)
+    area = lambda t: (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])       # noqa: E731
+    return inter / (area(box_a)[:, None] + area(box_b)[None, :] - inter)
 
 
-def encode(matched, priors, variances):   # box_utils.py:114-135
-    g_cxcy = (matched[:, :2] + matched[:, 2:]) / 2 - priors[:, :2]
-    g_cxcy = g_cxcy / (variances[0] * priors[:, 2:])
-    g_wh = torch.log((matched[:, 2:] - matched[:, :2]) / priors[:, 2:]) / variances[1]
-    return torch.cat([g_cxcy, g_wh], 1)
+def encode(matched, priors, variances):
+    """Regression targets of matched ground truth w.r.t. priors   [reference box_utils.py:114-135]"""
+    p_c, p_wh = priors[:, :2], priors[:, 2:]
+    centre = ((matched[:, :2] + matched[:, 2:]) / 2 - p_c) / (variances[0] * p_wh)
+    size = torch.log((matched[:, 2:] - matched[:, :2]) / p_wh) / variances[1]
+    return torch.cat((centre, size), dim=1)
 
 
-def decode(loc, priors, variances):       # box_utils.py:139-157
-    boxes = torch.cat((priors[:, :2] + loc[:, :2] * variances[0] * priors[:, 2:],
-                       priors[:, 2:] * torch.exp(loc[:, 2:] * variances[1])), 1)
-    boxes[:, :2] -= boxes[:, 2:] / 2
-    boxes[:, 2:] += boxes[:, :2]
-    return boxes
+def decode(loc, priors, variances):
+    """Boxes (x1, y1, x2, y2) from regression outputs   [reference box_utils.py:139-157]"""
+    centre = priors[:, :2] + loc[:, :2] * variances[0] * priors[:, 2:]
+    size = priors[:, 2:] * torch.exp(loc[:, 2:] * variances[1])
+    top_left = centre - size / 2
+    return torch.cat((top_left, size + top_left), dim=1)
 
 
-def log_sum_exp(x):                       # box_utils.py:160-168
-    x_max = x.data.max()
-    return torch.log(torch.sum(torch.exp(x - x_max), 1, keepdim=True)) + x_max
+def log_sum_exp(x):
+    """log sum_c exp(x) with the GLOBAL maximum as shift   [reference box_utils.py:160-168]"""
+    shift = x.detach().max()
+    return (x - shift).exp().sum(dim=1, keepdim=True).log() + shift
 
 
 def match(threshold, truths, priors, variances, labels, loc_t, conf_t, idx):
