@@ -11,7 +11,8 @@ Built from the forward plan's records (``engine._Plan.rec``) and walked in rever
 
 The consumer-side fused BN + ReLU of the forward (deferred BatchNorm) needs no activation buffer here either: wgrad
 re-applies the transform to the raw input, and the producer's BN backward recomputes its ReLU mask from raw.
-Self-attention and DCN blocks are not covered yet (GSSD++ uses the interim ATen recomputation).
+The deformable conv is HIP too (dcn.hip: col2im with atomics).  Self-attention blocks have no hand-written backward
+kernels yet: inside this plan they run block-local ATen autograd (token-major matmul / softmax); everything else is HIP.
 """
 import ctypes as C
 
@@ -43,6 +44,12 @@ class BackwardPlan:
                 self._pool(r)
             elif kind == 'l2norm':
                 self._l2norm(r)
+            elif kind == 'sa':
+                self._sa(r)
+            elif kind == 'slice_cat':
+                self._slice_cat(r)
+            elif kind == 'dcn':
+                self._dcn(r)
             else:
                 raise _lib.GssdError(f'no HIP backward for {kind}')
         self.param_order = [p for p in net.parameters()]
@@ -194,6 +201,106 @@ class BackwardPlan:
         self._bias_from_colsum(dw, mod.weight)
         self.gbuf[r['x_in'].data_ptr()] = g
 
+    # ---- GSSD++ blocks ---------------------------------------------------------------------------------------------------------
+    def _reserve(self, t, shape):
+        """Gradient buffer of forward tensor ``t`` (created on first use); returns (buffer, existed_before)."""
+        buf = self.gbuf.get(t.data_ptr())
+        if buf is not None:
+            return buf, True
+        buf = self._buf(*shape)
+        self.gbuf[t.data_ptr()] = buf
+        return buf, False
+
+    def _sa(self, r):
+        """Self_Attn (layers/self_attn.py:46-89), interim: the block is re-evaluated token-major ([B, N, C] views of the
+        NHWC buffers, plain matmuls) under ATen autograd and back-propagated locally."""
+        from .autograd_shadow import _sn_weight
+        sa, x, out, out2 = r['mod'], r['x_in'], r['out'], r['out2']
+        g_out = self._grad_of(out)
+        g_out2 = self._grad_of(out2) if out2 is not None else None
+        params = [q for q in sa.parameters()]
+        gx, existed = self._reserve(x, x.shape)
+        pg = [self._pgrad(q) for q in params]
+        B, N, Cc = self.B, r['H'] * r['H'], r['C']
+
+        def block(xt):
+            def lin(sn, t):
+                w = _sn_weight(sn)
+                return torch.matmul(t, w.view(w.shape[0], -1).t()) + sn.bias
+            theta, phi, g = lin(sa.snconv1x1_theta, xt), lin(sa.snconv1x1_phi, xt), lin(sa.snconv1x1_g, xt)
+            attn = torch.softmax(torch.bmm(theta, phi.transpose(1, 2)), dim=-1)
+            o = sa.sigma * lin(sa.snconv1x1_attn, torch.bmm(attn, g))
+            return xt + o, o
+
+        def step():
+            with torch.enable_grad():
+                xt = x.view(B, N, Cc).detach().requires_grad_()
+                o1, o2 = block(xt)
+                outs, gos = [o1], [g_out.view(B, N, Cc)]
+                if g_out2 is not None:
+                    outs.append(o2)
+                    gos.append(g_out2.view(B, N, Cc))
+                grads = torch.autograd.grad(outs, [xt] + params, gos, allow_unused=True)
+            dxn = grads[0].view(gx.shape)
+            gx.add_(dxn) if existed else gx.copy_(dxn)
+            for g, d in zip(pg, grads[1:]):
+                g.copy_(d) if d is not None else g.zero_()
+        self.steps.append((step, None))
+
+    def _slice_cat(self, r):
+        a, b, out, groups, Ca, Cb = r['a'], r['b'], r['out'], r['groups'], r['Ca'], r['Cb']
+        g_out = self._grad_of(out)
+        ga, a_existed = self._reserve(a, a.shape)
+        gb, b_existed = (None, False) if r['detach_b'] else self._reserve(b, b.shape)
+        ca, cb = Ca // groups, Cb // groups
+
+        def step():
+            v = g_out.view(*g_out.shape[:-1], groups, ca + cb)
+            da = v[..., :ca].reshape(a.shape)
+            ga.add_(da) if a_existed else ga.copy_(da)
+            if gb is not None:
+                db = v[..., ca:].reshape(b.shape)
+                gb.add_(db) if b_existed else gb.copy_(db)
+        self.steps.append((step, None))
+
+    def _dcn(self, r):
+        """Modulated deformable conv (layers/dcn_v2_custom.py:79-89): the 1x1 GEMM over the sampled columns, the sampling
+        itself (gssd_dcn_col2im_f32) and the offset/mask conv, all HIP."""
+        B, H, Cin, Cout, dg, m = self.B, r['H'], r['Cin'], r['Cout'], r['dg'], r['mod']
+        x, om, cols = r['x_in'], r['om'], r['cols']
+        dy = self._grad_of(r['out'])
+        Kc = 9 * Cin
+        # main weight / bias
+        dwp = self._buf(Cout, Kc, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(r['d_main']), dy.data_ptr(), dwp.data_ptr()), keep=r['d_main'])
+        self._unpack(dwp, Kc, 0, m.weight, Cin, Cin, 3)
+        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))
+        self._bias_from_colsum(cs, m.bias)
+        # d(cols) = dY . W   (1x1 conv with the transposed packed weight)
+        wt = self._buf(Kc, Cout)
+        self.steps.append((lambda w=r['w_main'], wt=wt: wt.copy_(w.t()), None))
+        dcols = self._buf(B * H * H, Kc)
+        dd, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(dd),), keep=dd)
+        # sampling backward: d(x) by atomics, d(offset / mask logits) per pixel
+        gx = self._grad_of(x)
+        if gx is None:
+            gx = self._buf(B, H, H, Cin, zero_each_run=True)
+            self.gbuf[x.data_ptr()] = gx
+        dom = self._buf(B, H, H, 27 * dg)
+        self._add(lib.gssd_dcn_col2im_f32, (x.data_ptr(), om.data_ptr(), dcols.data_ptr(), gx.data_ptr(), dom.data_ptr(), B, H, H,
+                                            Cin, dg, 27 * dg))
+        # offset / mask conv
+        cm = m.conv_offset_mask
+        dwo = self._buf(27 * dg, Kc, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(r['d_om']), dom.data_ptr(), dwo.data_ptr()), keep=r['d_om'])
+        self._unpack(dwo, Kc, 0, cm.weight, Cin, Cin, 3)
+        cs2 = self._buf(27 * dg, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dom.data_ptr(), B * H * H, 27 * dg, 27 * dg, cs2.data_ptr()))
+        self._bias_from_colsum(cs2, cm.bias)
+        self._dgrad(r, dom, x, cm, 1, Cin, H, H, 27 * dg, 3, 1, 1, 1)
+
     # ------------------------------------------------------------------------------------------------
     def run(self, dloc, dconf):
         self.dloc.copy_(dloc)
@@ -202,6 +309,9 @@ class BackwardPlan:
             torch._foreach_zero_(self.zero_list)
         stream = torch.cuda.current_stream().cuda_stream
         for fn, args in self.steps:
+            if args is None:                     # block-local ATen autograd callback
+                fn()
+                continue
             if fn is _pack_dgrad_from_packed:
                 fn(*args)
                 continue

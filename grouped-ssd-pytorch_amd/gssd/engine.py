@@ -127,7 +127,7 @@ class GssdEngine:
 
     def has_hip_backward(self):
         net = self.net
-        return not (getattr(net, 'vanilla', False) or net.use_self_attention or net.use_self_attention_base or net.use_dcn)
+        return not getattr(net, 'vanilla', False)
 
     def _build(self, B, training, dev):
         if getattr(self.net, 'vanilla', False):
@@ -381,6 +381,8 @@ class _Plan:
                 xc = self._buf(B, H, H, 2 * Cc)
                 self._add(lib.gssd_slice_and_cat_f32, (x.data_ptr(), attn_g.data_ptr(), xc.data_ptr(), B * H * H, Cc, Cc,
                                                        net.groups_vgg))
+                self.rec.append(('slice_cat', dict(a=x, b=attn_g, out=xc, H=H, Ca=Cc, Cb=Cc, groups=net.groups_vgg,
+                                                   detach_b=bool(net.detach_sab))))
                 xin, Cin = xc, 2 * Cc
             for li in range(net.num_dcn_layers):
                 xin, Cin = self._dcn(li, xin, H, Cin)
@@ -461,6 +463,7 @@ class _Plan:
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, N, Np)
+        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc)))
         return out, out2
 
     def _dcn(self, li, x, H, Cin):
@@ -485,6 +488,8 @@ class _Plan:
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d2),), keep=d2)
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
+        self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, cols=cols, d_om=d1, d_main=d2,
+                                     w_main=w_main, dg=dg)))
         return out, Cout
 
     # ------------------------------------------------------------------------------------------------

@@ -224,6 +224,13 @@ def dcn_im2col(x, om, cols, dg):
     return cols
 
 
+def dcn_col2im(x, om, dcols, dx, dom, dg):
+    """Backward of :func:`dcn_im2col`: ADDS d(x) into ``dx``; writes d(om) (offsets + mask logits)."""
+    B, H, W, Cc = x.shape
+    check(lib.gssd_dcn_col2im_f32(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, H, W, Cc, dg, om.shape[-1], _stream()))
+    return dx, dom
+
+
 def softmax_lastdim(x):
     _need_cuda(x)
     x = x.contiguous().float()

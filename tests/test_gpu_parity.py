@@ -342,6 +342,27 @@ def test_dcn_im2col_and_identities(dev, ops):
     assert rel(nchw(y0), ident) < TOL
 
 
+def test_dcn_col2im_backward(dev, ops):
+    """Sampling backward (d x by atomics, d offset, d mask logit) vs autograd through the oracle's DCN restatement."""
+    rng = np.random.default_rng(18)
+    B, Cc, H, dg = 2, 64, 9, 4
+    x = torch.from_numpy(rng.normal(size=(B, Cc, H, H)).astype(np.float32)).requires_grad_()
+    om = torch.from_numpy(rng.normal(0, 1.5, size=(B, 27 * dg, H, H)).astype(np.float32)).requires_grad_()
+    # identity "weight": the conv output IS the column matrix (channel c*9 + tap), so d(out) = d(cols)
+    w = torch.eye(Cc * 9).view(Cc * 9, Cc, 3, 3)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    cols_ref = O.dcn_v2_conv(x, torch.cat((o1, o2), 1), torch.sigmoid(m), w, torch.zeros(Cc * 9), 1, 1, 1, dg)
+    gcols = torch.from_numpy(rng.normal(size=(B, Cc, 9, H, H)).astype(np.float32))       # [b][c][tap][h][w]
+    cols_ref.backward(gcols.view(B, Cc * 9, H, H))
+    xd, omd = nhwc(x.detach()).to(dev), nhwc(om.detach()).to(dev)
+    dcols = gcols.permute(0, 3, 4, 2, 1).reshape(B * H * H, 9 * Cc).contiguous().to(dev)   # [pixel][tap*C + c]
+    dx = torch.zeros_like(xd)
+    dom = torch.full_like(omd, float('nan'))
+    ops.dcn_col2im(xd, omd, dcols, dx, dom, dg)
+    assert rel(nchw(dx), x.grad) < TOL
+    assert rel(nchw(dom), om.grad) < TOL
+
+
 # --------------------------------------------------------------------------------------------------
 # matching / loss / detect: index work is bit-exact
 # --------------------------------------------------------------------------------------------------
@@ -588,19 +609,23 @@ def test_backward_gradients(dev, name):
     # here.  A conv bias in front of a train-mode BatchNorm has a mathematically zero gradient (pure rounding noise).
     assert errs['loc.0.weight'] < 1e-4 and errs['conf.3.bias'] < 1e-4
     assert float(named['vgg.30.bias'].grad.abs().max()) < 1e-2 * float(named['vgg.31.bias'].grad.abs().max())
-    assert max(errs.values()) < 2e-2, errs
-    if name == 'gssd':
-        # the hand-written HIP backward (default for GSSD) against the ATen recomputation on the same device
+    # self-attention's sigma is a scalar whose gradient is one heavily cancelling sum over the whole map: looser bound
+    assert max(v for k, v in errs.items() if not k.endswith('sigma')) < 2e-2, errs
+    assert all(v < 6e-2 for k, v in errs.items() if k.endswith('sigma')), errs
+    if True:
+        # the HIP backward plan (default) against the whole-graph ATen recomputation on the same device
         hip = {k: named[k].grad.clone() for k in keys}
         for p in net.parameters():
             p.grad = None
         net.__dict__['_force_aten_backward'] = True
+        net.load_state_dict(sd)              # the training forward advanced spectral norm's u, v: same start again
         loc, conf, _ = net(x.to(dev))
         ((loc * r1.to(dev)).sum() + (conf * r2.to(dev)).sum()).backward()
         net.__dict__['_force_aten_backward'] = False
         e2 = {k: l2rel(hip[k], named[k].grad) for k in keys if k != 'vgg.30.bias'}
         print('HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in e2.items()})
-        assert max(e2.values()) < 2e-2, e2
+        assert max(v for k, v in e2.items() if not k.endswith('sigma')) < 2e-2, e2
+        assert all(v < 6e-2 for k, v in e2.items() if k.endswith('sigma')), e2
 
 
 def test_training_steps_reduce_loss(dev):
