@@ -288,7 +288,7 @@ class BackwardPlan:
         if gx is None:
             gx = self._buf(B, H, H, Cin, zero_each_run=True)
             self.gbuf[x.data_ptr()] = gx
-        dom = self._buf(B, H, H, 27 * dg)
+        dom = self._buf(B, H, H, 27 * dg, zero_each_run=True)
         self._add(lib.gssd_dcn_col2im_f32, (x.data_ptr(), om.data_ptr(), dcols.data_ptr(), gx.data_ptr(), dom.data_ptr(), B, H, H,
                                             Cin, dg, 27 * dg))
         # offset / mask conv

@@ -225,7 +225,7 @@ def dcn_im2col(x, om, cols, dg):
 
 
 def dcn_col2im(x, om, dcols, dx, dom, dg):
-    """Backward of :func:`dcn_im2col`: ADDS d(x) into ``dx``; writes d(om) (offsets + mask logits)."""
+    """Backward of :func:`dcn_im2col`: ADDS d(x) into ``dx`` and d(om) (offsets + mask logits) into ``dom``."""
     B, H, W, Cc = x.shape
     check(lib.gssd_dcn_col2im_f32(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, H, W, Cc, dg, om.shape[-1], _stream()))
     return dx, dom

@@ -216,7 +216,8 @@ int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols, int B, int
 
 /* Backward of gssd_dcn_im2col_f32 (what the reference gets from the dcn_v2 extension's backward through autograd,
  * layers/dcn_v2_custom.py:84-89): given d(cols), ADDS d(x) into `dx` (fp32 atomics; the caller zero-fills or pre-loads it)
- * and writes d(om) ([pixels][om_stride]; offsets' and mask logits' gradients, sigmoid included) for every pixel. */
+ * and ADDS d(om) ([pixels][om_stride]; offsets' and mask logits' gradients, sigmoid included) into `dom` (zero-filled by
+ * the caller).  Channels per deformable group must be a multiple of 64. */
 int gssd_dcn_col2im_f32(const float* x, const float* om, const float* dcols, float* dx, float* dom, int B, int H, int W,
                         int C, int dg, int om_stride, gssd_stream_t stream);
 

@@ -345,9 +345,9 @@ def test_dcn_im2col_and_identities(dev, ops):
 def test_dcn_col2im_backward(dev, ops):
     """Sampling backward (d x by atomics, d offset, d mask logit) vs autograd through the oracle's DCN restatement."""
     rng = np.random.default_rng(18)
-    B, Cc, H, dg = 2, 64, 9, 4
+    B, Cc, H, dg = 2, 128, 11, 2
     x = torch.from_numpy(rng.normal(size=(B, Cc, H, H)).astype(np.float32)).requires_grad_()
-    om = torch.from_numpy(rng.normal(0, 1.5, size=(B, 27 * dg, H, H)).astype(np.float32)).requires_grad_()
+    om = torch.from_numpy(rng.normal(0, 2.5, size=(B, 27 * dg, H, H)).astype(np.float32)).requires_grad_()
     # identity "weight": the conv output IS the column matrix (channel c*9 + tap), so d(out) = d(cols)
     w = torch.eye(Cc * 9).view(Cc * 9, Cc, 3, 3)
     o1, o2, m = torch.chunk(om, 3, dim=1)
@@ -357,7 +357,7 @@ def test_dcn_col2im_backward(dev, ops):
     xd, omd = nhwc(x.detach()).to(dev), nhwc(om.detach()).to(dev)
     dcols = gcols.permute(0, 3, 4, 2, 1).reshape(B * H * H, 9 * Cc).contiguous().to(dev)   # [pixel][tap*C + c]
     dx = torch.zeros_like(xd)
-    dom = torch.full_like(omd, float('nan'))
+    dom = torch.zeros_like(omd)
     ops.dcn_col2im(xd, omd, dcols, dx, dom, dg)
     assert rel(nchw(dx), x.grad) < TOL
     assert rel(nchw(dom), om.grad) < TOL
