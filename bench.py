@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--full-step', type=int, default=0, metavar='K',
                     help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
                          'reported as "full_step" beside the fwd+loss metric (BASELINE config 4)')
+    ap.add_argument('--no-input-stage', action='store_true', help='skip the separate timing of the device input stage')
     a = ap.parse_args()
 
     from gssd import dist as gd
@@ -197,6 +198,30 @@ def main():
                          + ('HIP: gssd/backward.py' if net._engine.has_hip_backward() else 'interim ATen recomputation')
                          + ') + flat-buffer gradient all-reduce (RCCL) + SGD')
 
+    # Device-side input stage, timed on its own: raw uint8 [B,4,512,512,3] -> [B,12,300,300] fp32.  The
+    # headline keeps the reference's split (resize in the loader, outside the timed region).
+    stage_info = None
+    if not a.no_input_stage:
+        import numpy as np
+        from gssd.input_stage import DeviceInputStage
+        one = synth.synth_study_u8(gd.shard_seed(100, rank), 4, 512)
+        raw = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(one, (B,) + one.shape))).to(dev)
+        stage = DeviceInputStage(300, (49., 49., 49.), True)
+        xs = stage(raw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            stage(raw, out=xs)
+        e1.record()
+        torch.cuda.synchronize()
+        sms = e0.elapsed_time(e1) / 10
+        sby = raw.numel() + xs.numel() * 4
+        stage_info = dict(ms_per_batch=round(sms, 4), alg_bytes=sby, alg_gbs=round(sby / sms / 1e6, 1),
+                          frac_hbm_peak=round(sby / sms / 1e6 / PEAK_HBM_GBS, 4), dtype='u8',
+                          note='Pillow-exact 8-bit bicubic 512->300 + mean + min-max + [B,12,300,300] pack; 3 launches')
+        del raw, xs
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(a.config, a.cpu_sample, 100)
@@ -216,7 +241,7 @@ def main():
                            'alg_gbs': round(value * mb_img / 1e3, 1),
                            'frac_hbm_peak': round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)},
             'loss': [round(loss[0], 5), round(loss[1], 5)],
-            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu, 'full_step': full,
+            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu, 'full_step': full, 'input_stage': stage_info,
         }
         print(json.dumps(line))
     gd.finish()

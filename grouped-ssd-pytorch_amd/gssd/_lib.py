@@ -72,6 +72,11 @@ SIGNATURES = {
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),
     'gssd_dcn_im2col_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_resample_ksize': (c_i, [c_i, c_i, c_i]),
+    'gssd_resample_coeffs': (c_i, [c_i, c_i, c_i, c_fp, c_fp]),
+    'gssd_resize_u8_horizontal': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_resize_u8_vertical': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    'gssd_input_finish_f32': (c_i, [c_fp, c_fp, c_f, c_f, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_col2im_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_i, c_fp]),

@@ -74,7 +74,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 // sum over the 64 lanes, result wave-uniform: quad xor 1, xor 2, half-row mirror, row mirror (DPP), then the four rows
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_mov<0xB1>(v);
     v += dpp_mov<0x4E>(v);
     v += dpp_mov<0x141>(v);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void dcn_col2im_kernel(const float* __restrict_
                 if (kk[q] & 4) unsafeAtomicAdd(gp + (size_t)W * C, gm * (ly[q] * hx));
                 if (kk[q] & 8) unsafeAtomicAdd(gp + (size_t)W * C + C, gm * (ly[q] * lx[q]));
             }
-            const float t_m = wave_sum(s_m), t_y = wave_sum(s_y), t_x = wave_sum(s_x);
+            const float t_m = wave_sum_dpp(s_m), t_y = wave_sum_dpp(s_y), t_x = wave_sum_dpp(s_x);
             if (lane == 0) {
                 float* domp = dom + bp[q] * om_stride;
                 unsafeAtomicAdd(domp + d * 18 + 2 * tap, t_y * m[q]);

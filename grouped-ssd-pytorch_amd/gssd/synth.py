@@ -34,6 +34,23 @@ def synth_images(batch, seed=0, size=300, channels=12):
     return torch.from_numpy(x)
 
 
+def synth_study_u8(seed, phases=4, size=512):
+    """One raw study slice as the reference's loaders hand it to ``BaseTransform``: uint8 ``[phases, S, S, 3]`` (three
+    adjacent z-slices per contrast phase).  Smooth structure + noise + a few saturated blobs (they exercise the clip of
+    the resampler)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, size), np.linspace(0, 1, size), indexing='ij')
+    out = np.empty((phases, size, size, 3), np.uint8)
+    for p in range(phases):
+        for c in range(3):
+            f = 120 + 90 * np.sin(6.28 * (rng.uniform(1, 5) * xx + rng.uniform(1, 5) * yy) + rng.uniform(0, 6.28))
+            f += rng.normal(0, 25, size=(size, size))
+            f[(xx - rng.uniform(.2, .8)) ** 2 + (yy - rng.uniform(.2, .8)) ** 2 < 0.004] = 255
+            f[(xx - rng.uniform(.2, .8)) ** 2 + (yy - rng.uniform(.2, .8)) ** 2 < 0.004] = 0
+            out[p, :, :, c] = np.clip(f, 0, 255).astype(np.uint8)
+    return out
+
+
 def synth_targets(batch, seed=0, max_boxes=3):
     """List of ``[n, 5]`` fp32 tensors: 1..max_boxes small lesion boxes per image."""
     rng = np.random.default_rng(seed + 7919)

@@ -222,6 +222,33 @@ int gssd_dcn_col2im_f32(const float* x, const float* om, const float* dcols, flo
                         int C, int dg, int om_stride, gssd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Input stage: data/__init__.py:33-54 (base_transform_fast / BaseTransform),
+ * utils/augmentations.py:506-524 (ResizeFast, Normalize), train_lesion_multiphase_v2.py:198 ([B,4,3,H,W] -> [B,12,H,W]).
+ * The resize is Pillow's `Image.resize` on uint8 (third-party; algorithm restated from src/libImaging/Resample.c).
+ * ------------------------------------------------------------------------------------------ */
+#define GSSD_FILTER_BILINEAR 2 /* PIL.Image.BILINEAR */
+#define GSSD_FILTER_BICUBIC 3  /* PIL.Image.BICUBIC: Image.resize's default since Pillow 7.0 */
+
+/* HOST functions: taps per output pixel, and the 22-bit fixed-point coefficient tables (`bounds` [out][2] = first input
+ * index, tap count; `kk` [out][ksize]) -- Resample.c precompute_coeffs + normalize_coeffs_8bpc.  The caller uploads them. */
+int gssd_resample_ksize(int in_size, int out_size, int filter);
+int gssd_resample_coeffs(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk);
+
+/* One 8-bit resampling pass over n_img interleaved images (device pointers).  horizontal: [n][H][W_in][C] ->
+ * [n][H][W_out][C]; vertical: [n][H_in][W][C] -> [n][H_out][W][C].  The vertical pass also folds each study's
+ * (imgs_per_study consecutive images) per-channel extrema into minmax[study][C][2] = (max of 255 - v, max of v); zero-fill it
+ * first, or pass NULL.  C <= 4. */
+int gssd_resize_u8_horizontal(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize,
+                              int n_img, int H, int W_in, int W_out, int C, gssd_stream_t stream);
+int gssd_resize_u8_vertical(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize, int n_img,
+                            int H_in, int H_out, int W, int C, int imgs_per_study, int32_t* minmax, gssd_stream_t stream);
+
+/* u8 [B][phases][S][S][C] -> fp32 NCHW [B][phases*C][S][S] (channel = phase*C + slice): x = v - mean[c]; with
+ * `normalize`, (x - min) / (max - min) over the study, min / max taken from `minmax` (see above). */
+int gssd_input_finish_f32(const uint8_t* img, const int32_t* minmax, float mean0, float mean1, float mean2, float* out_nchw,
+                          int B, int phases, int S, int C, int normalize, gssd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
  * ------------------------------------------------------------------------------------------ */
 

@@ -730,3 +730,34 @@ def test_cpu_input_fails_loudly():
     net = build_ssd('train', 300, 2, True, 4, 4, 1, True, False, False, 0, 1, False, False, 1)
     with pytest.raises(GssdError):
         net(torch.zeros(2, 12, 300, 300))
+
+
+# --------------------------------------------------------------------------------------------------
+# input stage: byte work, bit-exact
+# --------------------------------------------------------------------------------------------------
+def test_input_stage_bit_exact(dev, golden):
+    import hashlib
+    from gssd.input_stage import DeviceInputStage
+    from oracle import input_oracle as IO
+    from data import BaseTransform
+    g = golden('input')
+    mean = (49., 49., 49.)
+    for key_in, size, norm, key_out in (('small_in', 37, True, 'small_out_norm'), ('small_in', 37, False, 'small_out_raw'),
+                                        ('up_in', 33, True, 'up_out_norm')):
+        raw = torch.from_numpy(g[key_in]).unsqueeze(0).to(dev)
+        x = DeviceInputStage(size, mean, norm)(raw)
+        ref = IO.to_network_input(g[key_out])                                   # the reference's own output
+        assert x.shape == (1, 12, size, size)
+        assert np.array_equal(x[0].cpu().numpy(), ref), key_out
+    # drop-in BaseTransform: same call, same shape as the reference's numpy result
+    xb, _, _ = BaseTransform(37, np.array(mean), use_normalize=True)(g['small_in'])
+    assert xb.is_cuda and np.array_equal(xb.cpu().numpy(), g['small_out_norm'])
+    # the real geometry, a batch of different studies; bilinear too (vs the oracle)
+    raws = np.stack([synth.synth_study_u8(777 + i, 4, 512) for i in range(3)])
+    x = DeviceInputStage(300, mean, True)(torch.from_numpy(raws).to(dev)).cpu().numpy()
+    out0 = np.transpose(x[0].reshape(4, 3, 300, 300), (0, 2, 3, 1))
+    assert hashlib.sha256(np.ascontiguousarray(out0).tobytes()).digest() == g['big_out_sha'].tobytes()
+    for i in (1, 2):
+        assert np.array_equal(x[i], IO.to_network_input(IO.base_transform(raws[i], 300, mean, True)))
+    xl = DeviceInputStage(300, mean, True, filt='bilinear')(torch.from_numpy(raws[:1]).to(dev)).cpu().numpy()
+    assert np.array_equal(xl[0], IO.to_network_input(IO.base_transform(raws[0], 300, mean, True, filt='bilinear')))

@@ -109,3 +109,18 @@ def test_synth_is_deterministic():
     assert torch.equal(a, b) and float(a.min()) == 0.0 and float(a.max()) == 1.0
     t = synth.synth_targets(4, seed=1)
     assert all(x.shape[1] == 5 and 1 <= x.shape[0] <= 3 for x in t)
+
+
+def test_resample_coefficients_match_pillow_restatement():
+    """Host half of the input stage (no GPU): the C library's fixed-point tables equal the oracle's (pinned on Pillow)."""
+    from gssd import input_stage as IS
+    from oracle import input_oracle as IO
+    for a, b in ((512, 300), (64, 37), (20, 33), (300, 300), (513, 127)):
+        for f in ('bicubic', 'bilinear'):
+            bo, ko, ks = IO.resample_coeffs(a, b, f)
+            bh, kh = IS.resample_tables(a, b, f)
+            assert kh.shape[1] == ks and np.array_equal(bo, bh) and np.array_equal(ko, kh), (a, b, f)
+    with pytest.raises(Exception):
+        IS.resample_tables(0, 300)
+    with pytest.raises(Exception):
+        IS.DeviceInputStage(300)(torch.zeros(1, 4, 8, 8, 3, dtype=torch.uint8))      # CPU tensor: no fallback

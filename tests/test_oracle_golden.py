@@ -231,3 +231,27 @@ def test_vanilla_ssd_config0(golden):
     ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), O.prior_box(), [t.numpy() for t in synth.synth_targets(4, 5)[:2]])
     assert rel(ll, g['ssd.loss'][0]) < 1e-5 and rel(lc, g['ssd.loss'][1]) < 1e-5
     assert bool(g['ssd.grad_finite'])
+
+
+# --------------------------------------------------------------------------------------------------
+# input stage: Pillow resample restatement vs the reference's base_transform_fast / ResizeFast
+# --------------------------------------------------------------------------------------------------
+def test_input_stage_golden(golden):
+    import hashlib
+    from oracle import input_oracle as IO
+    from gssd import synth
+    g = golden('input')
+    mean = (49., 49., 49.)
+    assert np.array_equal(IO.base_transform(g['small_in'], 37, mean, True), g['small_out_norm'])
+    assert np.array_equal(IO.base_transform(g['small_in'], 37, mean, False), g['small_out_raw'])
+    assert np.array_equal(IO.base_transform(g['up_in'], 33, mean, True), g['up_out_norm'])          # up-scaling branch
+    big = synth.synth_study_u8(777, 4, 512)
+    assert hashlib.sha256(big.tobytes()).digest() == g['big_in_sha'].tobytes()
+    out = IO.base_transform(big, 300, mean, True)
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == g['big_out_sha'].tobytes()
+    assert np.array_equal(out.reshape(-1)[g['big_sample_idx']], g['big_sample'])
+    # ResizeFast: (x * 255).astype(uint8) -> resize -> / 255
+    xf = g['resizefast_in']
+    rz = np.stack([IO.pil_resize_u8((xf[i] * 255).astype(np.uint8), 37).astype(np.float32) / 255. for i in range(4)])
+    assert np.array_equal(rz, g['resizefast_out'])
+    assert IO.to_network_input(out).shape == (12, 300, 300)
