@@ -51,6 +51,34 @@ def synth_study_u8(seed, phases=4, size=512):
     return out
 
 
+def synth_detections(n_images, seed=0, size=512, top_k=200):
+    """Synthetic Detect outputs for the evaluator: ``det[N, 2, top_k, 5]`` fp32 (class-1 rows = score, x1, y1, x2, y2
+    normalised; descending score; zero rows after the last detection, like ``Detect``) and per-image ground truth
+    ``[n_i, 4]`` float64 pixel boxes.  A mix of jittered true positives, duplicates and random false positives."""
+    rng = np.random.default_rng(seed)
+    det = np.zeros((n_images, 2, top_k, 5), np.float32)
+    gts = []
+    for n in range(n_images):
+        k = int(rng.integers(0 if n % 9 == 8 else 1, 4))
+        cxy = rng.uniform(0.2, 0.8, size=(k, 2))
+        wh = rng.uniform(0.05, 0.3, size=(k, 2))
+        g = np.concatenate([cxy - wh / 2, cxy + wh / 2], 1).clip(0, 1)
+        gts.append(np.round(g * size).astype(np.float64))
+        rows = []
+        for j in range(k):
+            for _ in range(int(rng.integers(0, 4))):                  # 0-3 jittered hits per lesion
+                jit = g[j] + rng.normal(0, 0.03, 4)
+                rows.append([rng.uniform(0.2, 1.0), *jit])
+        for _ in range(int(rng.integers(0, 12))):                     # random false positives
+            c, w = rng.uniform(0.1, 0.9, 2), rng.uniform(0.03, 0.3, 2)
+            rows.append([rng.uniform(0.011, 0.7), *(c - w / 2), *(c + w / 2)])
+        if rows:
+            r = np.asarray(rows, np.float32)
+            r = r[np.argsort(-r[:, 0], kind='stable')][:top_k]
+            det[n, 1, :r.shape[0]] = r
+    return det, gts
+
+
 def synth_targets(batch, seed=0, max_boxes=3):
     """List of ``[n, 5]`` fp32 tensors: 1..max_boxes small lesion boxes per image."""
     rng = np.random.default_rng(seed + 7919)

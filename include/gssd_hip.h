@@ -289,6 +289,29 @@ int gssd_detect(const float* loc, const float* conf, const float* priors, int B,
 /* 2-class (C-class) softmax over the last axis, double exp + one rounding (models/...group.py:388). */
 int gssd_softmax_lastdim_f32(const float* x, float* y, int64_t rows, int C, gssd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AP / IoBB evaluator: test_ap_iobb.py:126-148 (make_pred's use of the Detect output), :231-328
+ * (test_net: greedy TP / FP, precision / recall), :10-41 (voc_ap)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Per image n: walk the class-1 rows det[n*img_stride + 5*d .. +5] = (score, x1, y1, x2, y2) of Detect's output in order;
+ * a row is kept iff score > 0 and score > thresh; its box is scaled by scales[n][4] (fp32 multiply) and matched in float64
+ * against gt[gt_off[n] .. gt_off[n+1]) ([.][4] pixel boxes, at most `max_gt` <= 256 per image).  Metric m < n_iou uses IoU
+ * with threshold thr[m], the next n_iobb use intersection-over-detection-box.  Outputs over M = N*top_k rows:
+ * conf_out[row] = score (or -inf for dropped rows); flag_out[m*M + row] = 1 (TP), 2 (FP) or 0 (neither: dropped row, or an
+ * image without ground truth -- the reference leaves both counters untouched there). */
+int gssd_eval_match(const float* det, long long img_stride, int N, int top_k, const float* scales, const double* gt,
+                    const int* gt_off, int max_gt, double thresh, const double* thr, int n_iou, int n_iobb, float* conf_out,
+                    uint8_t* flag_out, gssd_stream_t stream);
+
+/* Global ranking + AP.  Sorts the M confidences in descending order (stable: ties keep their row order; the reference's
+ * np.argsort is unstable there), accumulates TP / FP per metric and writes ap_out[n_metrics] (device, float64):
+ * use_07_metric != 0: the 11-point VOC07 value (bit-exact); else the area under the precision envelope.
+ * `workspace` must hold gssd_eval_workspace_bytes(M) bytes (HOST query). */
+long long gssd_eval_workspace_bytes(int M);
+int gssd_eval_ap(const float* conf, const uint8_t* flags, int M, int n_metrics, double npos, int use_07_metric, void* workspace,
+                 long long workspace_bytes, double* ap_out, gssd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

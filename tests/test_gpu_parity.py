@@ -761,3 +761,62 @@ def test_input_stage_bit_exact(dev, golden):
         assert np.array_equal(x[i], IO.to_network_input(IO.base_transform(raws[i], 300, mean, True)))
     xl = DeviceInputStage(300, mean, True, filt='bilinear')(torch.from_numpy(raws[:1]).to(dev)).cpu().numpy()
     assert np.array_equal(xl[0], IO.to_network_input(IO.base_transform(raws[0], 300, mean, True, filt='bilinear')))
+
+
+# --------------------------------------------------------------------------------------------------
+# AP / IoBB evaluator
+# --------------------------------------------------------------------------------------------------
+def test_evaluator_vs_reference_and_oracle(dev, golden):
+    from gssd.evaluator import DeviceEvaluator
+    from oracle import eval_oracle as EO
+    from test_oracle_golden import eval_case
+    g = golden('eval')
+    for case in (0, 1):
+        det, scales, gts = eval_case(g, case)
+        for use07 in (True, False):
+            ev = DeviceEvaluator(0.05, (0.1, 0.5), (0.1, 0.5), use07)
+            confs, flags = [], []
+            for s in range(0, det.shape[0], 16):                              # two batches: accumulation across add_batch
+                c, f = ev.add_batch(torch.from_numpy(det[s:s + 16]).to(dev), scales[s:s + 16], gts[s:s + 16])
+                confs.append(c.cpu().numpy())
+                flags.append(f.cpu().numpy())
+            ap, iobb = ev.result()
+            ref_ap, ref_iobb = g[f'c{case}_ap_{int(use07)}'], g[f'c{case}_iobb_{int(use07)}']
+            if use07:
+                assert np.array_equal(np.array(ap), ref_ap) and np.array_equal(np.array(iobb), ref_iobb), (case, ap, ref_ap)
+            else:                                                             # np.sum's pairwise order is not reproduced
+                assert np.allclose(ap, ref_ap, rtol=1e-13, atol=0) and np.allclose(iobb, ref_iobb, rtol=1e-13, atol=0)
+            # TP / FP flags against the oracle's greedy loop (integer work: exact)
+            _, _, dt = EO.evaluate(det, scales, gts, 0.05, (0.1, 0.5), (0.1, 0.5), use07, details=True)
+            conf = np.concatenate(confs)
+            fl = np.concatenate(flags, axis=1)
+            order = np.argsort(-conf, kind='stable')[:len(dt['conf'])]
+            assert np.array_equal(conf[order].astype(np.float64), dt['conf'])
+            assert np.array_equal(fl[:, order] == 1, dt['tp'] == 1) and np.array_equal(fl[:, order] == 2, dt['fp'] == 1)
+    # no detections at all -> zeros, like the reference's early exit
+    ev = DeviceEvaluator(0.05, (0.5,), (0.1,), True)
+    ev.add_batch(torch.zeros(2, 2, 200, 5, device=dev), np.full((2, 4), 512., np.float32), [np.zeros((1, 4)), np.zeros((0, 4))])
+    assert ev.result() == ([0.0], [0.0])
+
+
+def test_test_net_dropin(dev):
+    """``test_ap_iobb.test_net`` with the reference's calling convention on a tiny synthetic 'dataset'."""
+    import test_ap_iobb as T
+    from data import BaseTransform
+    from models.ssd_multiphase_custom_group import build_ssd
+    net = build_ssd('test', 300, 2, *NETS['gssd'][1])
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=3))
+    net = net.to(dev).eval()
+
+    class Set:
+        name = 'lesion_test_ap_synth'
+        def __len__(self): return 3
+        def pull_image(self, i): return synth.synth_study_u8(40 + i, 4, 128)
+        def pull_anno(self, i): return np.array([[20., 30., 60., 80., 0.]])
+    ap, iobb = T.test_net(net, True, Set(), BaseTransform(300, (49., 49., 49.), use_normalize=True), 300, thresh=0.05,
+                          mode='v2', use_07_metric=True, ap_list=[0.1, 0.5], iobb_list=[0.1, 0.5], batch_size=2)
+    assert len(ap) == 2 and len(iobb) == 2 and all(0. <= v <= 1. for v in ap + iobb)
+    rec, prec = np.array([0.2, 0.4, 0.4, 0.8]), np.array([1.0, 1.0, 0.66, 0.5])
+    from oracle import eval_oracle as EO
+    for m in (True, False):
+        assert abs(T.voc_ap(rec, prec, m) - EO.voc_ap(rec, prec, m)) < 1e-15

@@ -255,3 +255,26 @@ def test_input_stage_golden(golden):
     rz = np.stack([IO.pil_resize_u8((xf[i] * 255).astype(np.uint8), 37).astype(np.float32) / 255. for i in range(4)])
     assert np.array_equal(rz, g['resizefast_out'])
     assert IO.to_network_input(out).shape == (12, 300, 300)
+
+
+# --------------------------------------------------------------------------------------------------
+# AP / IoBB evaluator vs the reference's own test_net on the same synthetic detections
+# --------------------------------------------------------------------------------------------------
+def eval_case(g, case):
+    det = g[f'c{case}_det']
+    S = float(g[f'c{case}_size'])
+    off = np.concatenate([[0], np.cumsum(g[f'c{case}_gt_n'])])
+    gts = [g[f'c{case}_gt'][off[i]:off[i + 1]] for i in range(det.shape[0])]
+    scales = np.full((det.shape[0], 4), S, np.float32)
+    return det, scales, gts
+
+
+def test_evaluator_golden(golden):
+    from oracle import eval_oracle as EO
+    g = golden('eval')
+    for case in (0, 1):
+        det, scales, gts = eval_case(g, case)
+        for use07 in (True, False):
+            ap, iobb = EO.evaluate(det, scales, gts, 0.05, (0.1, 0.5), (0.1, 0.5), use07)
+            assert np.array_equal(np.array(ap), g[f'c{case}_ap_{int(use07)}']), (case, use07)
+            assert np.array_equal(np.array(iobb), g[f'c{case}_iobb_{int(use07)}']), (case, use07)
