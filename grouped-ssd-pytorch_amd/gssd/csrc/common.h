@@ -50,4 +50,6 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // conv_thin.hip: returns 1 when the descriptor is not one of the thin grouped 3x3 shapes, else a GSSD_* code
 int gssd_try_conv_thin(const gssd_conv_desc& d, hipStream_t stream);
+// conv_wino.hip: returns 1 when the descriptor is not a Winograd shape / has no transformed weights
+int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream);
 int gssd_try_conv_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);

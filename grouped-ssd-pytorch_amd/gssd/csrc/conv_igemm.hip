@@ -365,6 +365,10 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const int rc = gssd_try_conv_thin(d, s);      // conv1_1 / conv1_2 / conv2_1: patch-staged kernel
         if (rc != 1) return rc;
     }
+    {
+        const int rc = gssd_try_conv_wino(d, s);      // compute-bound 3x3 trunk layers: Winograd F(2x2,3x3)
+        if (rc != 1) return rc;
+    }
     if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 512 && !d.m_per_image);
     if (cout_g > 64) {
         // 128x128 tiles run 2 workgroups per CU (LDS), 128x64 tiles 3: pick the one whose last round of workgroups is

@@ -1,0 +1,345 @@
+// Winograd F(2x2, 3x3) for the grouped 3x3 / stride 1 / pad 1 trunk convolutions (conv2_x .. conv5_x and their data
+// gradients) on gfx950.  These layers sit far above the fp32 ridge, so the direct implicit GEMM is bound by the
+// fp32 MFMA rate; Winograd spends 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36, i.e. 2.25x fewer
+// MFMA flops for the same convolution:
+//     V = B^T d B   (4x4 input tile d, per channel)            -- in registers, straight from global memory
+//     M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[co][ci]    -- 16 independent GEMMs (xi = 0..15) on v_mfma_f32_16x16x4_f32
+//     Y = A^T M A   (2x2 outputs)                              -- in registers (all 16 xi of a (tile, co) live in one lane)
+// with U = G g G^T precomputed per launch of the weight packer (gssd_winograd_weight_f32).
+//
+// Work decomposition: a wave owns 16 consecutive tiles of the linearised (image, tile_y, tile_x) list of one group (so any
+// map size fills the chip without spatial padding waste) and NB output channels; the 4 waves of a workgroup share the
+// U slices, which are staged through LDS with the LDS-DMA path, double buffered over 16-channel chunks.  The A operand
+// never touches LDS: lane (tile r, k-quad kq) fetches the 16 B of its four channels for each of the 16 patch positions
+// directly (the next chunk's 16 loads are in flight during the current chunk's MFMAs), applies the fused producer
+// BatchNorm + ReLU if requested, and transforms in registers.  One 16-byte load therefore feeds four k-steps, like the
+// b128 trick of the wgrad kernel.  Accumulators: 16 xi x NB/16 tiles of 16x16 = 256 VGPRs for NB = 64 (one wave per SIMD;
+// the unified 512-entry register file of gfx950 is what makes this tiling possible).
+#include "common.h"
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __attribute__((aligned(16))) float g_zero_page_wino[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct WinoParams {
+    const float* in;
+    const float* U;          // [groups][16][cout_g][cin_g]
+    const float* bias;
+    float* out;
+    const float* resid;
+    const float* in_scale;
+    const float* in_shift;
+    const float* in_pad;
+    double* stats;
+    int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, out_stride, out_ch_off;
+    int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
+};
+
+template <int NB, bool XF, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
+    constexpr int NBT = NB / 16;                  // 16-wide output-channel tiles per wave
+    constexpr int STAGE = 16 * NB * 16;           // floats per U stage: [xi][n][16 ci]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.z, n0 = blockIdx.y * NB;
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const int t0 = (blockIdx.x * 4 + wv) * 16;
+
+    // ---- this lane's A tile: patch origin and validity of the 16 positions ------------------------------------------------
+    int pix0 = 0;
+    unsigned valid = 0;
+    {
+        const int t = t0 + r;
+        if (t < p.ntiles) {
+            const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
+            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            const int y = 2 * ty - 1, x = 2 * tx - 1;
+            pix0 = (b * p.H + y) * p.W + x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(y + i) < (unsigned)p.H && (unsigned)(x + j) < (unsigned)p.W) valid |= 1u << (i * 4 + j);
+        }
+    }
+    const int cbase = p.in_ch_off + g * p.cin_g + kq * 4;      // + chunk * 16
+    const float* in_lane = p.in + (long long)pix0 * p.in_stride + cbase;
+    const float* pad_lane = XF ? p.in_pad + cbase : g_zero_page_wino;
+    const float* Ug = p.U + ((size_t)g * 16 * p.cout_g + n0) * p.cin_g;       // + (xi * cout_g + n) * cin_g + ci
+
+    f32x4 acc[16][NBT];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.cin_g >> 4;
+    f32x4 raw[16];
+    auto load_raw1 = [&](int c, int q) {
+        const int i = q >> 2, j = q & 3;
+        const float* src = (valid >> q) & 1 ? in_lane + (i * p.W + j) * p.in_stride + c * 16 : pad_lane + (XF ? c * 16 : 0);
+        raw[q] = *reinterpret_cast<const f32x4*>(src);
+    };
+    // U stage: 16 * NBT pieces of 1 KB; piece (xi, nb) = 16 rows (n) x 64 B; lane -> row lane >> 2, quad lane & 3.  Wave w
+    // moves pieces w, w + 4, ...: NBT per xi-group of four, i.e. slot s (0 .. 4*NBT-1) -> piece 4*s + w.
+    auto stage_U1 = [&](int c, int buf, int s4) {
+        const int pc = 4 * s4 + wv;
+        const int xi = pc / NBT, nb = pc - xi * NBT;
+        const float* src = Ug + ((size_t)xi * p.cout_g + nb * 16 + (lane >> 2)) * p.cin_g + c * 16 + (lane & 3) * 4;
+        dma16(src, smem + buf * STAGE + pc * 256);
+    };
+
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NBT; ++s4) stage_U1(0, 0, s4);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) load_raw1(0, q);
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- input transform of chunk c (registers) -------------------------------------------------------------------------
+        f32x4 V[16];
+        {
+            f32x4 sc, sh;
+            if (XF) {
+                sc = *reinterpret_cast<const f32x4*>(p.in_scale + cbase + c * 16);
+                sh = *reinterpret_cast<const f32x4*>(p.in_shift + cbase + c * 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                 // one channel at a time keeps the transient registers at 32
+                float d[16], t[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d[q] = XF ? fmaxf(raw[q][e] * sc[e] + sh[e], 0.f) : raw[q][e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {             // B^T d
+                    t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+                    t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+                    t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+                    t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {             // (B^T d) B
+                    V[i * 4 + 0][e] = t[i * 4 + 0] - t[i * 4 + 2];
+                    V[i * 4 + 1][e] = t[i * 4 + 1] + t[i * 4 + 2];
+                    V[i * 4 + 2][e] = t[i * 4 + 2] - t[i * 4 + 1];
+                    V[i * 4 + 3][e] = t[i * 4 + 1] - t[i * 4 + 3];
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's DMA pieces of stage c have landed
+        __syncthreads();                                  // ... everyone's have; buffer (c+1)&1 is free again
+        const bool more = c + 1 < nchunks;
+        // ---- 16 GEMM slices: acc[xi][nb] += V_xi (16 tiles x 4 k) * U_xi (4 k x 16 co), four k-steps per 16-byte fragment ------
+        const float* ub = smem + (c & 1) * STAGE + r * 16 + kq * 4;
+        f32x4 bf[2][NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) bf[0][nb] = *reinterpret_cast<const f32x4*>(ub + nb * 256);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            if (xi + 1 < 16 && !(DBG & 4)) {
+#pragma unroll
+                for (int nb = 0; nb < NBT; ++nb)
+                    bf[(xi + 1) & 1][nb] = *reinterpret_cast<const f32x4*>(ub + ((xi + 1) * NBT + nb) * 256);
+            }
+            // the next chunk's traffic is issued a piece at a time between the MFMA groups: with one wave per SIMD a burst of
+            // 32 memory instructions in front of the MFMAs would stall the wave on the memory pipe's issue queue
+            if (more) {
+                if (!(DBG & 1)) load_raw1(c + 1, xi);
+                if (!(DBG & 2)) {
+#pragma unroll
+                    for (int s4 = xi * NBT / 4; s4 < (xi + 1) * NBT / 4; ++s4) stage_U1(c + 1, (c + 1) & 1, s4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NBT; ++nb)
+                    acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi][j], bf[(DBG & 4) ? 0 : (xi & 1)][nb][j], acc[xi][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- output transform + epilogue: lane holds M[tile 4*kq + e][co n0 + nb*16 + r] for all 16 xi ------------------------------
+    float ssum[NBT], ssq[NBT];
+#pragma unroll
+    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = t0 + kq * 4 + e;
+        if (t >= p.ntiles) continue;
+        const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int y = 2 * ty, x = 2 * tx;
+        const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
+        const size_t o00 = ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + g * p.cout_g + n0 + r;
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            float s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // A^T M
+                s[0][j] = acc[0 * 4 + j][nb][e] + acc[1 * 4 + j][nb][e] + acc[2 * 4 + j][nb][e];
+                s[1][j] = acc[1 * 4 + j][nb][e] - acc[2 * 4 + j][nb][e] - acc[3 * 4 + j][nb][e];
+            }
+            const float bia = p.bias ? p.bias[g * p.cout_g + n0 + nb * 16 + r] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float y0v = s[a][0] + s[a][1] + s[a][2] + bia;
+                const float y1v = s[a][1] - s[a][2] - s[a][3] + bia;
+                if (a == 1 && !y1) continue;
+                const size_t o = o00 + nb * 16 + (size_t)a * p.W * p.out_stride;
+                float v0 = y0v, v1 = y1v;
+                if (p.resid) {
+                    v0 += p.resid[o];
+                    if (x1) v1 += p.resid[o + p.out_stride];
+                }
+                p.out[o] = v0;
+                ssum[nb] += v0;
+                ssq[nb] += v0 * v0;
+                if (x1) {
+                    p.out[o + p.out_stride] = v1;
+                    ssum[nb] += v1;
+                    ssq[nb] += v1 * v1;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();                                  // all waves are done with the U stages
+        float* red = smem;                                // [4 waves][NB][2]
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            float s = ssum[nb], q = ssq[nb];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (kq == 0) {
+                red[(wv * NB + nb * 16 + r) * 2 + 0] = s;
+                red[(wv * NB + nb * 16 + r) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += (double)red[(w * NB + tid) * 2 + 0];
+                q += (double)red[(w * NB + tid) * 2 + 1];
+            }
+            const int n = g * p.cout_g + n0 + tid;
+            unsafeAtomicAdd(p.stats + n, s);
+            unsafeAtomicAdd(p.stats + p.Cout + n, q);
+        }
+    }
+}
+
+// packed K-major weights [Cout][tap * cin_g + ci] (row stride `ws`) -> U[g][xi][co][ci] = (G g G^T)_xi
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int cout_g, int cin_g, int ws) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * cin_g) return;
+    const int ci = i % cin_g, co = i / cin_g;
+    const int g = co / cout_g, cg = co - g * cout_g;
+    float k[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) k[a][b] = w[(size_t)co * ws + (a * 3 + b) * cin_g + ci];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {                         // G g
+        t[0][b] = k[0][b];
+        t[1][b] = 0.5f * (k[0][b] + k[1][b] + k[2][b]);
+        t[2][b] = 0.5f * (k[0][b] - k[1][b] + k[2][b]);
+        t[3][b] = k[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                         // (G g) G^T
+        const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) U[(((size_t)g * 16 + a * 4 + b) * cout_g + cg) * cin_g + ci] = u[b];
+    }
+}
+
+template <int NB, bool XF, int DBG = 0>
+int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
+    WinoParams p;
+    p.in = d.in;
+    p.U = d.wgt_wino;
+    p.bias = d.bias;
+    p.out = d.out;
+    p.resid = d.resid;
+    p.in_scale = d.in_scale;
+    p.in_shift = d.in_shift;
+    p.in_pad = d.in_pad;
+    p.stats = d.stats;
+    p.B = d.B;
+    p.H = d.H;
+    p.W = d.W;
+    p.in_stride = d.in_stride;
+    p.in_ch_off = d.in_ch_off;
+    p.Cout = d.Cout;
+    p.cin_g = d.cin_g;
+    p.cout_g = d.Cout / d.groups;
+    p.out_stride = d.out_stride;
+    p.out_ch_off = d.out_ch_off;
+    p.tiles_y = (d.H + 1) / 2;
+    p.tiles_x = (d.W + 1) / 2;
+    p.ntiles = d.B * p.tiles_y * p.tiles_x;
+    constexpr size_t smem = 2 * (size_t)16 * NB * 16 * sizeof(float);
+    auto kern = conv_wino_kernel<NB, XF, DBG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+            hipSuccess) {
+            gssd_set_error("hipFuncSetAttribute failed (winograd)");
+            return GSSD_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const dim3 grid((p.ntiles + 63) / 64, p.cout_g / NB, d.groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+}  // namespace
+
+// returns 1 when the descriptor is not a Winograd shape (or carries no transformed weights)
+int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
+    if (!d.wgt_wino) return 1;
+    const int cout_g = d.Cout / d.groups;
+    const bool ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.cin_g % 16 == 0 && cout_g % 32 == 0 &&
+                    d.out_mode == GSSD_OUT_NHWC && !d.alpha && !d.gate && !d.out2 && !d.relu && d.split_k <= 1 && !d.m_per_image &&
+                    d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
+                    (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
+    if (!ok) return 1;
+    if (const char* e = getenv("GSSD_DBG")) {
+        const int v = atoi(e);
+        if (cout_g % 64 == 0 && !d.in_scale) {
+            if (v == 1) return launch_wino<64, false, 1>(d, stream);
+            if (v == 2) return launch_wino<64, false, 2>(d, stream);
+            if (v == 3) return launch_wino<64, false, 3>(d, stream);
+            if (v == 4) return launch_wino<64, false, 4>(d, stream);
+            if (v == 7) return launch_wino<64, false, 7>(d, stream);
+        }
+    }
+    if (cout_g % 64 == 0) return d.in_scale ? launch_wino<64, true>(d, stream) : launch_wino<64, false>(d, stream);
+    return d.in_scale ? launch_wino<32, true>(d, stream) : launch_wino<32, false>(d, stream);
+}
+
+extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
+                                        gssd_stream_t stream) {
+    GSSD_CHECK_ARG(w_packed && U && Cout > 0 && groups > 0 && Cout % groups == 0 && cin_g > 0 && row_stride >= 9 * cin_g);
+    const int n = Cout * cin_g;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w_packed, U, Cout,
+                       Cout / groups, cin_g, row_stride);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

@@ -16,6 +16,7 @@ Dataflow restated from models/ssd_multiphase_custom_group.py:217-400 (SURVEY.md 
 Weights are re-packed (OIHW -> K-major rows) only when a parameter's version counter changed.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -27,6 +28,10 @@ EXTRAS_CFG = [256, 'S', 512, 128, 'S', 256, 128, 256, 128, 256]
 MBOX = [4, 6, 6, 6, 4, 4]
 FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
+
+# Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
+# implicit GEMM everywhere (ablation / cross-check).
+USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
 
 class _Step:
     __slots__ = ('fn', 'args', 'keep', 'tag')
@@ -53,6 +58,9 @@ def conv_tag(d, real_cin_g=None):
     if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
+    elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g) and not d.m_per_image
+          and d.split_k <= 1 and not d.relu):
+        name = f'conv_wino<{64 if cout_g % 64 == 0 else 32}>'   # gssd_try_conv_wino (csrc/conv_wino.hip)
     M = d.B * d.Ho * d.Wo
     cin_g = real_cin_g if real_cin_g is not None else d.cin_g
     flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
@@ -323,11 +331,16 @@ class _Plan:
         Cout = conv.out_channels
         cin_g = Cin // groups
         wp = self._packed_conv(name, conv)
+        U = None
+        if USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups):
+            def build_u(out, key=name + '.w', groups=groups, cin_g=cin_g):
+                return ops.winograd_weight(self.eng._packed[key], groups, cin_g, out)
+            U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
         raw = self._buf(B, Ho, Ho, Cout)
         st = self.eng_stat(bn)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
-                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(),
+                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None)

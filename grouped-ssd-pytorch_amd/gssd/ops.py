@@ -80,7 +80,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None):
+                   in_shift=None, in_pad=None, wgt_wino=None):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -95,6 +95,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.out_ch_off, d.out_mode, d.relu, d.m_per_image, d.split_n = out_ch_off, out_mode, int(relu), int(m_per_image), split_n
     d.split_k = split_k
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
+    d.wgt_wino = _p(wgt_wino)
     d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride
     d.out_batch_stride, d.outb_batch_stride, d.out_off, d.outb_off = out_batch_stride, outb_batch_stride, out_off, outb_off
     return d, Ho, Wo
@@ -113,7 +114,21 @@ def run_conv(desc):
     check(lib.gssd_conv2d_nhwc_f32(C.byref(desc), _stream()))
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None):
+def winograd_eligible(k, stride, pad, dil, cin_g, cout_g):
+    """Shapes csrc/conv_wino.hip takes (mirrors gssd_try_conv_wino)."""
+    return k == 3 and stride == 1 and pad == 1 and dil == 1 and cin_g % 16 == 0 and cout_g % 32 == 0
+
+
+def winograd_weight(w_packed, groups, cin_g, out=None):
+    """Packed K-major 3x3 weights [Cout][9*cin_g] -> U[g][16][cout_g][cin_g] (G g G^T)."""
+    Cout = w_packed.shape[0]
+    if out is None:
+        out = torch.empty(16 * Cout * cin_g, device=w_packed.device, dtype=torch.float32)
+    check(lib.gssd_winograd_weight_f32(_p(w_packed), _p(out), Cout, groups, cin_g, w_packed.stride(0), _stream()))
+    return out
+
+
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None, winograd=False, **kw):
     """Convenience one-shot conv for tests: x NHWC [B,H,W,Cin], weight OIHW; returns NHWC."""
     _need_cuda(x, w_oihw)
     B, H, W, Cin = x.shape
@@ -123,8 +138,9 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=Fal
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    U = winograd_weight(wp, groups, cin_g) if winograd else None
     d, _, _ = make_conv_desc(x, wp, out, B=B, H=H, W=W, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
-                             stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats)
+                             stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats, wgt_wino=U, **kw)
     run_conv(d)
     return out
 

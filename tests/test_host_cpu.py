@@ -24,7 +24,7 @@ def test_abi_exports_match_header():
         assert hasattr(raw, name), name
     assert _lib.lib.gssd_abi_version() == 1 and _lib.lib.gssd_build_arch() == b'gfx950'
     # struct layout agrees with the header's field order / C packing rules
-    assert ctypes.sizeof(_lib.ConvDesc) == 13 * 8 + 24 * 4 + 6 * 8
+    assert ctypes.sizeof(_lib.ConvDesc) == 14 * 8 + 24 * 4 + 6 * 8
     assert ctypes.sizeof(_lib.SnItem) == 4 * 8 + 2 * 4
 
 
