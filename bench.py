@@ -167,7 +167,10 @@ def main():
                     frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=dom,
                     avg_launch_us=round(1e3 * ms / n, 2), alg_flop_per_launch=round(fl / n),
                     alg_bytes_per_launch=round(by / n),
-                    note='fp32 exact MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)')
+                    note='fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)'
+                         + ('; achieved = ALGORITHMIC (direct-convolution) FLOPs per second: the Winograd F(2x2,3x3) kernel '
+                            'issues 2.25x fewer MFMA FLOPs than that, so its MFMA-pipe utilisation is achieved/2.25/peak'
+                            if dom.startswith('conv_wino') else ''))
 
     full = None
     if a.full_step > 0:

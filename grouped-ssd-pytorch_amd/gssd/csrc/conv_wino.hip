@@ -43,7 +43,7 @@ struct WinoParams {
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
 };
 
-template <int NB, bool XF, int DBG = 0>
+template <int NB, bool XF, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     constexpr int NBT = NB / 16;                  // 16-wide output-channel tiles per wave
     constexpr int STAGE = 16 * NB * 16;           // floats per U stage: [xi][n][16 ci]
@@ -53,13 +53,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int r = lane & 15, kq = lane >> 4;
     const int g = blockIdx.z, n0 = blockIdx.y * NB;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
-    const int t0 = (blockIdx.x * 4 + wv) * 16;
+    const int nitems = (p.ntiles + 63) >> 6;      // work item = 64 tiles (16 per wave) x NB output channels
+    int item = blockIdx.x;
+    if (item >= nitems) return;
 
-    // ---- this lane's A tile: patch origin and validity of the 16 positions ------------------------------------------------
-    int pix0 = 0;
-    unsigned valid = 0;
-    {
-        const int t = t0 + r;
+    // Loading lane l fetches quad (l & 3) of tile (l >> 2): four consecutive lanes read one 64-byte segment, so the memory
+    // pipe sees 16 requests per instruction instead of 64.  The MFMA wants lane (r, kq) to hold quad kq of tile r: a fixed
+    // lane permutation (ds_bpermute, LDS crossbar only) after the data has landed.
+    const int ld_quad = lane & 3;
+    const int perm_addr = ((r << 2) | kq) << 2;
+    const int cb_ld = p.in_ch_off + g * p.cin_g + ld_quad * 4;       // + chunk * 16   (loading lanes)
+    const int cb_mf = p.in_ch_off + g * p.cin_g + kq * 4;            //                (MFMA lanes: BN scale / shift)
+    const float* Ug = p.U + ((size_t)g * 16 * p.cout_g + n0) * p.cin_g;       // + (xi * cout_g + n) * cin_g + ci
+
+    // Per item a loading lane keeps just the byte offset of its tile's patch origin and a 16-bit validity mask; out-of-image
+    // positions are fetched from offset 0 (always mapped) and replaced by the padding value before the permutation.
+    auto decode = [&](int it, unsigned& pix_off, unsigned& valid) {
+        const int t = (it * 4 + wv) * 16 + (lane >> 2);
+        valid = 0;
+        int pix0 = 0;
         if (t < p.ntiles) {
             const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
             const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
@@ -71,27 +83,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 for (int j = 0; j < 4; ++j)
                     if ((unsigned)(y + i) < (unsigned)p.H && (unsigned)(x + j) < (unsigned)p.W) valid |= 1u << (i * 4 + j);
         }
-    }
-    const int cbase = p.in_ch_off + g * p.cin_g + kq * 4;      // + chunk * 16
-    const float* in_lane = p.in + (long long)pix0 * p.in_stride + cbase;
-    const float* pad_lane = XF ? p.in_pad + cbase : g_zero_page_wino;
-    const float* Ug = p.U + ((size_t)g * 16 * p.cout_g + n0) * p.cin_g;       // + (xi * cout_g + n) * cin_g + ci
+        pix_off = (unsigned)((pix0 * p.in_stride + cb_ld) * 4);        // may wrap for border tiles: only used where valid
+    };
 
     f32x4 acc[16][NBT];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
         for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[NBT], ssq[NBT];
+#pragma unroll
+    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = 0.f;
 
     const int nchunks = p.cin_g >> 4;
     f32x4 raw[16];
-    auto load_raw1 = [&](int c, int q) {
+    auto load_raw1 = [&](unsigned pix_off, unsigned valid, int c, int q) {
         const int i = q >> 2, j = q & 3;
-        const float* src = (valid >> q) & 1 ? in_lane + (i * p.W + j) * p.in_stride + c * 16 : pad_lane + (XF ? c * 16 : 0);
-        raw[q] = *reinterpret_cast<const f32x4*>(src);
+        const unsigned off = (valid >> q) & 1 ? pix_off + (unsigned)(((i * p.W + j) * p.in_stride + c * 16) * 4) : 0u;
+        raw[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
     };
     // U stage: 16 * NBT pieces of 1 KB; piece (xi, nb) = 16 rows (n) x 64 B; lane -> row lane >> 2, quad lane & 3.  Wave w
-    // moves pieces w, w + 4, ...: NBT per xi-group of four, i.e. slot s (0 .. 4*NBT-1) -> piece 4*s + w.
+    // moves pieces w, w + 4, ...: slot s (0 .. 4*NBT-1) -> piece 4*s + w.
     auto stage_U1 = [&](int c, int buf, int s4) {
         const int pc = 4 * s4 + wv;
         const int xi = pc / NBT, nb = pc - xi * NBT;
@@ -99,118 +111,149 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         dma16(src, smem + buf * STAGE + pc * 256);
     };
 
+    unsigned in_cur, valid_cur;
+    decode(item, in_cur, valid_cur);
 #pragma unroll
     for (int s4 = 0; s4 < 4 * NBT; ++s4) stage_U1(0, 0, s4);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) load_raw1(0, q);
-    for (int c = 0; c < nchunks; ++c) {
-        // ---- input transform of chunk c (registers) -------------------------------------------------------------------------
-        f32x4 V[16];
-        {
-            f32x4 sc, sh;
-            if (XF) {
-                sc = *reinterpret_cast<const f32x4*>(p.in_scale + cbase + c * 16);
-                sh = *reinterpret_cast<const f32x4*>(p.in_shift + cbase + c * 16);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {                 // one channel at a time keeps the transient registers at 32
-                float d[16], t[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) d[q] = XF ? fmaxf(raw[q][e] * sc[e] + sh[e], 0.f) : raw[q][e];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {             // B^T d
-                    t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-                    t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-                    t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-                    t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+    for (int q = 0; q < 16; ++q) load_raw1(in_cur, valid_cur, 0, q);
+    int buf = 0;
+
+    // The workgroup is persistent: it walks items item, item + gridDim.x, ... of its (group, output-channel block).  The
+    // stream of (item, chunk) steps is software pipelined as one sequence -- the loads of the NEXT step (next chunk, or the
+    // next item's first chunk) are issued piecewise between the MFMA groups of the current one -- so the load latency at an
+    // item boundary hides behind the last chunk's MFMAs and the epilogue's stores overlap the next item's first chunk.
+    for (;;) {
+        const int item_next = item + gridDim.x;
+        const bool have_next = PERSIST && item_next < nitems;
+        unsigned in_next = in_cur, valid_next = 0;
+        if (have_next) decode(item_next, in_next, valid_next);
+        for (int c = 0; c < nchunks; ++c) {
+            // ---- lane permutation + input transform of chunk c (registers) ---------------------------------------------------
+            f32x4 V[16];
+            {
+                f32x4 sc, sh, padq = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (XF) {
+                    sc = *reinterpret_cast<const f32x4*>(p.in_scale + cb_mf + c * 16);
+                    sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_mf + c * 16);
+                    padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + c * 16);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {             // (B^T d) B
-                    V[i * 4 + 0][e] = t[i * 4 + 0] - t[i * 4 + 2];
-                    V[i * 4 + 1][e] = t[i * 4 + 1] + t[i * 4 + 2];
-                    V[i * 4 + 2][e] = t[i * 4 + 2] - t[i * 4 + 1];
-                    V[i * 4 + 3][e] = t[i * 4 + 1] - t[i * 4 + 3];
+                for (int e = 0; e < 4; ++e) {             // one channel at a time keeps the transient registers at 32
+                    float d[16], t[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float v = __shfl((valid_cur >> q) & 1 ? raw[q][e] : padq[e], perm_addr >> 2, 64);
+                        d[q] = XF ? fmaxf(v * sc[e] + sh[e], 0.f) : v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {         // B^T d
+                        t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+                        t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+                        t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+                        t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {         // (B^T d) B
+                        V[i * 4 + 0][e] = t[i * 4 + 0] - t[i * 4 + 2];
+                        V[i * 4 + 1][e] = t[i * 4 + 1] + t[i * 4 + 2];
+                        V[i * 4 + 2][e] = t[i * 4 + 2] - t[i * 4 + 1];
+                        V[i * 4 + 3][e] = t[i * 4 + 1] - t[i * 4 + 3];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // raw[] is dead from here on: the next step's loads reuse its registers
+            __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): this wave's DMA pieces of the current stage have landed
+            __syncthreads();                              // ... everyone's have; the other buffer is free again
+            const bool last = c + 1 == nchunks;
+            const bool more = !last || have_next;
+            const unsigned ld_in = last ? in_next : in_cur;
+            const unsigned ld_valid = last ? valid_next : valid_cur;
+            const int ld_c = last ? 0 : c + 1;
+            // ---- 16 GEMM slices: acc[xi][nb] += V_xi (16 tiles x 4 k) * U_xi (4 k x 16 co), four k-steps per 16-byte fragment --
+            const float* ub = smem + buf * STAGE + r * 16 + kq * 4;
+            f32x4 bf[2][NBT];
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) bf[0][nb] = *reinterpret_cast<const f32x4*>(ub + nb * 256);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                if (xi + 1 < 16) {
+#pragma unroll
+                    for (int nb = 0; nb < NBT; ++nb)
+                        bf[(xi + 1) & 1][nb] = *reinterpret_cast<const f32x4*>(ub + ((xi + 1) * NBT + nb) * 256);
+                }
+                // the next step's traffic is issued a piece at a time between the MFMA groups: with one wave per SIMD a burst
+                // of 32 memory instructions in front of the MFMAs would stall the wave on the memory pipe's issue queue
+                if (more) {
+                    load_raw1(ld_in, ld_valid, ld_c, xi);
+#pragma unroll
+                    for (int s4 = xi * NBT / 4; s4 < (xi + 1) * NBT / 4; ++s4) stage_U1(ld_c, buf ^ 1, s4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; ++nb)
+                        acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi][j], bf[xi & 1][nb][j], acc[xi][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
+        }
+
+        // ---- output transform + epilogue: lane holds M[tile 4*kq + e][co n0 + nb*16 + r] for all 16 xi -------------------------
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = (item * 4 + wv) * 16 + kq * 4 + e;
+            if (t < p.ntiles) {
+                const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
+                const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+                const int y = 2 * ty, x = 2 * tx;
+                const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
+                const size_t o00 = ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + g * p.cout_g + n0 + r;
+#pragma unroll
+                for (int nb = 0; nb < NBT; ++nb) {
+                    float s[2][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {             // A^T M
+                        s[0][j] = acc[0 * 4 + j][nb][e] + acc[1 * 4 + j][nb][e] + acc[2 * 4 + j][nb][e];
+                        s[1][j] = acc[1 * 4 + j][nb][e] - acc[2 * 4 + j][nb][e] - acc[3 * 4 + j][nb][e];
+                    }
+                    const float bia = p.bias ? p.bias[g * p.cout_g + n0 + nb * 16 + r] : 0.f;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        if (a == 1 && !y1) continue;
+                        float v0 = s[a][0] + s[a][1] + s[a][2] + bia;
+                        float v1 = s[a][1] - s[a][2] - s[a][3] + bia;
+                        const size_t o = o00 + nb * 16 + (size_t)a * p.W * p.out_stride;
+                        if (p.resid) {
+                            v0 += p.resid[o];
+                            if (x1) v1 += p.resid[o + p.out_stride];
+                        }
+                        p.out[o] = v0;
+                        ssum[nb] += v0;
+                        ssq[nb] += v0 * v0;
+                        if (x1) {
+                            p.out[o + p.out_stride] = v1;
+                            ssum[nb] += v1;
+                            ssq[nb] += v1 * v1;
+                        }
+                    }
+                    // keep the accumulator read-out in small groups: the next item's prefetched patch is live here, so hoisting
+                    // all reads out of the AGPR file at once would not fit the 256 architectural VGPRs
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's DMA pieces of stage c have landed
-        __syncthreads();                                  // ... everyone's have; buffer (c+1)&1 is free again
-        const bool more = c + 1 < nchunks;
-        // ---- 16 GEMM slices: acc[xi][nb] += V_xi (16 tiles x 4 k) * U_xi (4 k x 16 co), four k-steps per 16-byte fragment ------
-        const float* ub = smem + (c & 1) * STAGE + r * 16 + kq * 4;
-        f32x4 bf[2][NBT];
+        if (!have_next) break;
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) bf[0][nb] = *reinterpret_cast<const f32x4*>(ub + nb * 256);
+        for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            if (xi + 1 < 16 && !(DBG & 4)) {
-#pragma unroll
-                for (int nb = 0; nb < NBT; ++nb)
-                    bf[(xi + 1) & 1][nb] = *reinterpret_cast<const f32x4*>(ub + ((xi + 1) * NBT + nb) * 256);
-            }
-            // the next chunk's traffic is issued a piece at a time between the MFMA groups: with one wave per SIMD a burst of
-            // 32 memory instructions in front of the MFMAs would stall the wave on the memory pipe's issue queue
-            if (more) {
-                if (!(DBG & 1)) load_raw1(c + 1, xi);
-                if (!(DBG & 2)) {
-#pragma unroll
-                    for (int s4 = xi * NBT / 4; s4 < (xi + 1) * NBT / 4; ++s4) stage_U1(c + 1, (c + 1) & 1, s4);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nb = 0; nb < NBT; ++nb)
-                    acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi][j], bf[(DBG & 4) ? 0 : (xi & 1)][nb][j], acc[xi][nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        item = item_next;
+        in_cur = in_next;
+        valid_cur = valid_next;
     }
 
-    // ---- output transform + epilogue: lane holds M[tile 4*kq + e][co n0 + nb*16 + r] for all 16 xi ------------------------------
-    float ssum[NBT], ssq[NBT];
-#pragma unroll
-    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int t = t0 + kq * 4 + e;
-        if (t >= p.ntiles) continue;
-        const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int y = 2 * ty, x = 2 * tx;
-        const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
-        const size_t o00 = ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + g * p.cout_g + n0 + r;
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            float s[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                 // A^T M
-                s[0][j] = acc[0 * 4 + j][nb][e] + acc[1 * 4 + j][nb][e] + acc[2 * 4 + j][nb][e];
-                s[1][j] = acc[1 * 4 + j][nb][e] - acc[2 * 4 + j][nb][e] - acc[3 * 4 + j][nb][e];
-            }
-            const float bia = p.bias ? p.bias[g * p.cout_g + n0 + nb * 16 + r] : 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float y0v = s[a][0] + s[a][1] + s[a][2] + bia;
-                const float y1v = s[a][1] - s[a][2] - s[a][3] + bia;
-                if (a == 1 && !y1) continue;
-                const size_t o = o00 + nb * 16 + (size_t)a * p.W * p.out_stride;
-                float v0 = y0v, v1 = y1v;
-                if (p.resid) {
-                    v0 += p.resid[o];
-                    if (x1) v1 += p.resid[o + p.out_stride];
-                }
-                p.out[o] = v0;
-                ssum[nb] += v0;
-                ssq[nb] += v0 * v0;
-                if (x1) {
-                    p.out[o + p.out_stride] = v1;
-                    ssum[nb] += v1;
-                    ssq[nb] += v1 * v1;
-                }
-            }
-        }
-    }
-    if (p.stats) {
+    if (p.stats) {                                        // one flush per workgroup: lanes sharing r -> LDS over waves -> fp64 atomics
         __syncthreads();                                  // all waves are done with the U stages
         float* red = smem;                                // [4 waves][NB][2]
 #pragma unroll
@@ -267,7 +310,7 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
-template <int NB, bool XF, int DBG = 0>
+template <int NB, bool XF, bool PERSIST>
 int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     WinoParams p;
     p.in = d.in;
@@ -293,7 +336,7 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.tiles_x = (d.W + 1) / 2;
     p.ntiles = d.B * p.tiles_y * p.tiles_x;
     constexpr size_t smem = 2 * (size_t)16 * NB * 16 * sizeof(float);
-    auto kern = conv_wino_kernel<NB, XF, DBG>;
+    auto kern = conv_wino_kernel<NB, XF, PERSIST>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
@@ -303,7 +346,11 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
         }
         attr_set = true;
     }
-    const dim3 grid((p.ntiles + 63) / 64, p.cout_g / NB, d.groups);
+    const int nitems = (p.ntiles + 63) / 64;
+    int gx = 256 / ((p.cout_g / NB) * d.groups);          // one workgroup per CU (128 KB of LDS / 512 VGPRs each)
+    if (gx < 1) gx = 1;
+    if (gx > nitems || !PERSIST) gx = nitems;
+    const dim3 grid(gx, p.cout_g / NB, d.groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -320,18 +367,10 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
                     d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
     if (!ok) return 1;
-    if (const char* e = getenv("GSSD_DBG")) {
-        const int v = atoi(e);
-        if (cout_g % 64 == 0 && !d.in_scale) {
-            if (v == 1) return launch_wino<64, false, 1>(d, stream);
-            if (v == 2) return launch_wino<64, false, 2>(d, stream);
-            if (v == 3) return launch_wino<64, false, 3>(d, stream);
-            if (v == 4) return launch_wino<64, false, 4>(d, stream);
-            if (v == 7) return launch_wino<64, false, 7>(d, stream);
-        }
-    }
-    if (cout_g % 64 == 0) return d.in_scale ? launch_wino<64, true>(d, stream) : launch_wino<64, false>(d, stream);
-    return d.in_scale ? launch_wino<32, true>(d, stream) : launch_wino<32, false>(d, stream);
+    // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
+    // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent
+    if (cout_g % 64 == 0) return d.in_scale ? launch_wino<64, true, false>(d, stream) : launch_wino<64, false, false>(d, stream);
+    return d.in_scale ? launch_wino<32, true, true>(d, stream) : launch_wino<32, false, true>(d, stream);
 }
 
 extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
