@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     auto stage_U1 = [&](int c, int buf, int s4) {
         const int pc = 4 * s4 + wv;
         const int xi = pc / NBT, nb = pc - xi * NBT;
-        const float* src = Ug + ((size_t)xi * p.cout_g + nb * 16 + (lane >> 2)) * p.cin_g + c * 16 + (lane & 3) * 4;
+        // quads of row n sit at position quad ^ ((n >> 2) & 1): the eight lanes a ds_read_b128 serves per cycle (rows r..r+7,
+        // 64 B apart) then cover all 64 banks instead of hitting 32 of them twice
+        const int row = lane >> 2;
+        const float* src = Ug + ((size_t)xi * p.cout_g + nb * 16 + row) * p.cin_g + c * 16 + (((lane & 3) ^ ((row >> 2) & 1)) << 2);
         dma16(src, smem + buf * STAGE + pc * 256);
     };
 
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             const unsigned ld_valid = last ? valid_next : valid_cur;
             const int ld_c = last ? 0 : c + 1;
             // ---- 16 GEMM slices: acc[xi][nb] += V_xi (16 tiles x 4 k) * U_xi (4 k x 16 co), four k-steps per 16-byte fragment --
-            const float* ub = smem + buf * STAGE + r * 16 + kq * 4;
+            const float* ub = smem + buf * STAGE + r * 16 + ((kq ^ ((r >> 2) & 1)) << 2);
             f32x4 bf[2][NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) bf[0][nb] = *reinterpret_cast<const f32x4*>(ub + nb * 256);
@@ -347,7 +350,12 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
         attr_set = true;
     }
     const int nitems = (p.ntiles + 63) / 64;
-    int gx = 256 / ((p.cout_g / NB) * d.groups);          // one workgroup per CU (128 KB of LDS / 512 VGPRs each)
+    static int per_cu = 0;                                // resident workgroups per CU (registers / LDS decide: 1 or 2)
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > 2) per_cu = 2;
+    }
+    int gx = 256 * per_cu / ((p.cout_g / NB) * d.groups);
     if (gx < 1) gx = 1;
     if (gx > nitems || !PERSIST) gx = nitems;
     const dim3 grid(gx, p.cout_g / NB, d.groups);

@@ -5,7 +5,7 @@ import torch
 from gssd import ops
 dev = torch.device('cuda:0')
 B, G = int(os.environ.get('B', 32)), 4
-shapes = [('conv2_1', 150, 16, 32), ('conv2_2', 150, 32, 32), ('conv3_1', 75, 32, 64), ('conv3_2', 75, 64, 64),
+shapes = [('conv1_2', 300, 16, 16), ('conv2_1', 150, 16, 32), ('conv2_2', 150, 32, 32), ('conv3_1', 75, 32, 64), ('conv3_2', 75, 64, 64),
           ('conv4_1', 38, 64, 128), ('conv4_2', 38, 128, 128), ('conv5_x', 19, 128, 128)]
 if os.environ.get('SHAPES'):
     shapes = [tuple([t.split(':')[0]] + [int(v) for v in t.split(':')[1:]]) for t in os.environ['SHAPES'].split(',')]
