@@ -1,0 +1,33 @@
+"""Per-launch conv times of one forward (HIP events), in plan order: which layer costs what."""
+import sys, os
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from gssd import synth
+from models.ssd_multiphase_custom_group import build_ssd
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'gssd'
+args = bench.CONFIGS[cfg][0]
+dev = torch.device('cuda:0')
+net = build_ssd('train', 300, 2, *args)
+net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+net = net.to(dev).train()
+x = synth.synth_images(32, seed=100).to(dev)
+with torch.no_grad():
+    for _ in range(3): net(x)
+    ev = []
+    net.__dict__['_events'] = ev
+    for _ in range(5): net(x)
+    net.__dict__['_events'] = None
+torch.cuda.synchronize()
+n = len(ev) // 5
+names = [r['name'] for k, r in net._engine._last_plan.rec if k == 'convbn']
+print(n, 'conv launches per step;', len(names), 'conv+BN records')
+tot = 0
+for i in range(n):
+    ms = sum(ev[i + k * n][1].elapsed_time(ev[i + k * n][2]) for k in range(5)) / 5
+    (tag, fl, by) = ev[i][0]
+    tot += ms
+    print(f'{i:3d} {tag:22s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {fl / 1e9:7.2f} GF')
+print('total conv ms', tot)
