@@ -118,6 +118,65 @@ def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H, k, st, pd):
     assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5
 
 
+WINO_CASES = [
+    # B, H, Cin, Cout, groups          (3x3 / stride 1 / pad 1)
+    (2, 38, 512, 512, 4),      # conv4_2: cout_g 128 -> two 64-channel blocks, 8 chunks, even map
+    (3, 19, 512, 512, 4),      # conv5_x: odd map (ragged last tile row / column), tile list crosses images
+    (2, 75, 128, 256, 4),      # conv3_1: cin_g 32 -> 2 chunks, odd map
+    (2, 37, 128, 128, 4),      # conv2_2 shape class: cout_g 32 -> persistent 32-channel variant, several items per workgroup
+    (5, 9, 64, 32, 1),         # dense, one group, one chunk; fewer tiles than one wave in places
+    (1, 150, 128, 128, 4),     # many items per persistent workgroup
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv_winograd(dev, ops, case):
+    """Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) against CPU conv2d: plain, with fused batch statistics, with the
+    producer's BatchNorm + ReLU applied on the fly, and as a data gradient accumulating into an existing gradient."""
+    B, H, Cin, Cout, g = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = torch.from_numpy(rng.normal(0.1, 1.0, size=(B, Cin, H, H)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    assert ops.winograd_eligible(3, 1, 1, 1, Cin // g, Cout // g)
+    ref = torch.nn.functional.conv2d(x, w, b, 1, 1, 1, g)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    xd = nhwc(x).to(dev)
+    y = ops.conv2d_nhwc(xd, w.to(dev), b.to(dev), 1, 1, 1, g, stats=stats, winograd=True)
+    assert rel(nchw(y), ref) < 2e-5
+    n = ref.numel() / Cout
+    assert rel(stats[:Cout] / n, ref.double().mean(dim=(0, 2, 3))) < 1e-5
+    assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < 1e-5
+    # the direct implicit GEMM on the same descriptor agrees to fp32 rounding
+    y2 = ops.conv2d_nhwc(xd, w.to(dev), b.to(dev), 1, 1, 1, g)
+    assert rel(y, y2) < 2e-5
+    # fused producer BatchNorm + ReLU, zero padding AFTER the transform
+    gm = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
+    bt = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+    refx = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.batch_norm(x, None, None, gm, bt, True, 0.0, 1e-5)), w, b, 1, 1,
+                                      1, g)
+    st_in = torch.stack([x.double().sum(dim=(0, 2, 3)), (x.double() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(dev)
+    sc, sh, pdv = (torch.empty(Cin, device=dev) for _ in range(3))
+    ops.bn_finalize(st_in, B * H * H, gm.to(dev), bt.to(dev), torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev), True, sc,
+                    sh, pdv)
+    yx = ops.conv2d_nhwc(xd, w.to(dev), b.to(dev), 1, 1, 1, g, winograd=True, in_scale=sc, in_shift=sh, in_pad=pdv)
+    assert rel(nchw(yx), refx) < 2e-5
+    # data gradient through the same kernel: dX = existing + conv(dY, flipped weights)
+    xg = x.clone().requires_grad_()
+    yg = torch.nn.functional.conv2d(xg, w, None, 1, 1, 1, g)
+    dy = torch.from_numpy(rng.normal(size=tuple(yg.shape)).astype(np.float32))
+    yg.backward(dy)
+    if ops.winograd_eligible(3, 1, 1, 1, Cout // g, Cin // g):
+        wd = ops.pack_weight_dgrad(w.to(dev), g)
+        ud = ops.winograd_weight(wd, g, Cout // g)
+        existing = torch.from_numpy(rng.normal(size=(B, H, H, Cin)).astype(np.float32)).to(dev)
+        dx = torch.empty(B, H, H, Cin, device=dev)
+        dd, _, _ = ops.make_conv_desc(nhwc(dy).to(dev), wd, dx, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout // g, Cout=Cin, groups=g,
+                                      k=3, pad=1, resid=existing, wgt_wino=ud)
+        ops.run_conv(dd)
+        assert rel(nchw(dx - existing), xg.grad) < 2e-5
+
+
 BWD_CASES = [
     # B, H, Cin, Cout, k, s, p, d, groups
     (2, 30, 64, 64, 3, 1, 1, 1, 4),      # cout_g 16 (scalar dY path)
