@@ -53,6 +53,7 @@ SIGNATURES = {
     'gssd_unpack_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_nhwc_f32': (c_i, [C.POINTER(ConvDesc), c_fp]),
+    'gssd_winograd_weight_elems': (C.c_longlong, [c_i, c_i, c_i]),
     'gssd_winograd_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_wgrad_f32': (c_i, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp]),
     'gssd_unpack_conv_weight_grad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),

@@ -96,8 +96,8 @@ class BackwardPlan:
         g = existing if existing is not None else self._buf(B, H, H, Cin)
         ud = None
         from .engine import USE_WINOGRAD
-        if USE_WINOGRAD and ops.winograd_eligible(k, 1, pd, dil, Cout // groups, Cin // groups):
-            ud = self._buf(16 * Cin * (Cout // groups))
+        if USE_WINOGRAD and ops.winograd_eligible(k, 1, pd, dil, Cout // groups, Cin // groups, groups):
+            ud = self._buf(int(lib.gssd_winograd_weight_elems(Cin, groups, Cout // groups)))
             self._add(lib.gssd_winograd_weight_f32, (wd.data_ptr(), ud.data_ptr(), Cin, groups, Cout // groups, wd.stride(0)))
         d, Hout, _ = ops.make_conv_desc(src, wd, g, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin,
                                         groups=groups, k=k, pad=pd, dil=dil, resid=existing, wgt_wino=ud)

@@ -31,7 +31,7 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
 
 struct WinoParams {
     const float* in;
-    const float* U;          // [groups][16][cout_g][cin_g]
+    const float* U;          // [groups][16][cout_pad][cin_g]  (rows >= cout_g are zero)
     const float* bias;
     float* out;
     const float* resid;
@@ -39,7 +39,7 @@ struct WinoParams {
     const float* in_shift;
     const float* in_pad;
     double* stats;
-    int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, out_stride, out_ch_off;
+    int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, cout_pad, out_stride, out_ch_off;
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
 };
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int perm_addr = ((r << 2) | kq) << 2;
     const int cb_ld = p.in_ch_off + g * p.cin_g + ld_quad * 4;       // + chunk * 16   (loading lanes)
     const int cb_mf = p.in_ch_off + g * p.cin_g + kq * 4;            //                (MFMA lanes: BN scale / shift)
-    const float* Ug = p.U + ((size_t)g * 16 * p.cout_g + n0) * p.cin_g;       // + (xi * cout_g + n) * cin_g + ci
+    const float* Ug = p.U + ((size_t)g * 16 * p.cout_pad + n0) * p.cin_g;     // + (xi * cout_pad + n) * cin_g + ci
 
     // Per item a loading lane keeps just the byte offset of its tile's patch origin and a 16-bit validity mask; out-of-image
     // positions are fetched from offset 0 (always mapped) and replaced by the padding value before the permutation.
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         // quads of row n sit at position quad ^ ((n >> 2) & 1): the eight lanes a ds_read_b128 serves per cycle (rows r..r+7,
         // 64 B apart) then cover all 64 banks instead of hitting 32 of them twice
         const int row = lane >> 2;
-        const float* src = Ug + ((size_t)xi * p.cout_g + nb * 16 + row) * p.cin_g + c * 16 + (((lane & 3) ^ ((row >> 2) & 1)) << 2);
+        const float* src = Ug + ((size_t)xi * p.cout_pad + nb * 16 + row) * p.cin_g + c * 16 + (((lane & 3) ^ ((row >> 2) & 1)) << 2);
         dma16(src, smem + buf * STAGE + pc * 256);
     };
 
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 const size_t o00 = ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + g * p.cout_g + n0 + r;
 #pragma unroll
                 for (int nb = 0; nb < NBT; ++nb) {
+                    if (n0 + nb * 16 + r >= p.cout_g) continue;       // padded output channels (cout_g not a multiple of NB)
                     float s[2][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {             // A^T M
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             }
         }
         __syncthreads();
-        if (tid < NB) {
+        if (tid < NB && n0 + tid < p.cout_g) {
             double s = 0.0, q = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -286,17 +287,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     }
 }
 
-// packed K-major weights [Cout][tap * cin_g + ci] (row stride `ws`) -> U[g][xi][co][ci] = (G g G^T)_xi
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int cout_g, int cin_g, int ws) {
+// packed K-major weights [Cout][tap * cin_g + ci] (row stride `ws`) -> U[g][xi][co][ci] = (G g G^T)_xi; rows cout_g..cout_pad-1
+// of every group are zero
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int groups, int cout_g, int cout_pad,
+                                   int cin_g, int ws) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Cout * cin_g) return;
-    const int ci = i % cin_g, co = i / cin_g;
-    const int g = co / cout_g, cg = co - g * cout_g;
+    if (i >= groups * cout_pad * cin_g) return;
+    const int ci = i % cin_g, cop = i / cin_g;
+    const int g = cop / cout_pad, cg = cop - g * cout_pad;
     float k[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) k[a][b] = w[(size_t)co * ws + (a * 3 + b) * cin_g + ci];
+        for (int b = 0; b < 3; ++b) k[a][b] = cg < cout_g ? w[(size_t)(g * cout_g + cg) * ws + (a * 3 + b) * cin_g + ci] : 0.f;
     float t[4][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {                         // G g
@@ -309,9 +312,18 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
     for (int a = 0; a < 4; ++a) {                         // (G g) G^T
         const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) U[(((size_t)g * 16 + a * 4 + b) * cout_g + cg) * cin_g + ci] = u[b];
+        for (int b = 0; b < 4; ++b) U[(((size_t)g * 16 + a * 4 + b) * cout_pad + cg) * cin_g + ci] = u[b];
     }
 }
+
+// output-channel block of the kernel for a layer (0 = not a Winograd shape) and the padded per-group row count of U
+inline int wino_nb(int cout_g, int groups) {
+    if (cout_g % 64 == 0) return 64;
+    if (cout_g % 32 == 0) return 32;
+    if (groups == 1 && cout_g >= 24) return cout_g > 32 ? 64 : 32;     // e.g. the DCN offset / mask conv (108 channels)
+    return 0;
+}
+inline int wino_cout_pad(int cout_g, int nb) { return (cout_g + nb - 1) / nb * nb; }
 
 template <int NB, bool XF, bool PERSIST>
 int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
@@ -333,6 +345,7 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.Cout = d.Cout;
     p.cin_g = d.cin_g;
     p.cout_g = d.Cout / d.groups;
+    p.cout_pad = wino_cout_pad(p.cout_g, NB);
     p.out_stride = d.out_stride;
     p.out_ch_off = d.out_ch_off;
     p.tiles_y = (d.H + 1) / 2;
@@ -355,10 +368,10 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 2) per_cu = 2;
     }
-    int gx = 256 * per_cu / ((p.cout_g / NB) * d.groups);
+    int gx = 256 * per_cu / ((p.cout_pad / NB) * d.groups);
     if (gx < 1) gx = 1;
     if (gx > nitems || !PERSIST) gx = nitems;
-    const dim3 grid(gx, p.cout_g / NB, d.groups);
+    const dim3 grid(gx, p.cout_pad / NB, d.groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -370,23 +383,33 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
 int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
     if (!d.wgt_wino) return 1;
     const int cout_g = d.Cout / d.groups;
-    const bool ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.cin_g % 16 == 0 && cout_g % 32 == 0 &&
+    const bool ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.cin_g % 16 == 0 && wino_nb(cout_g, d.groups) != 0 &&
                     d.out_mode == GSSD_OUT_NHWC && !d.alpha && !d.gate && !d.out2 && !d.relu && d.split_k <= 1 && !d.m_per_image &&
                     d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
     if (!ok) return 1;
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
     // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent
-    if (cout_g % 64 == 0) return d.in_scale ? launch_wino<64, true, false>(d, stream) : launch_wino<64, false, false>(d, stream);
+    if (wino_nb(cout_g, d.groups) == 64) return d.in_scale ? launch_wino<64, true, false>(d, stream) : launch_wino<64, false, false>(d, stream);
     return d.in_scale ? launch_wino<32, true, true>(d, stream) : launch_wino<32, false, true>(d, stream);
+}
+
+extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g) {
+    if (Cout <= 0 || groups <= 0 || Cout % groups || cin_g <= 0) return -1;
+    const int nb = wino_nb(Cout / groups, groups);
+    if (!nb) return -1;
+    return 16ll * groups * wino_cout_pad(Cout / groups, nb) * cin_g;
 }
 
 extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
                                         gssd_stream_t stream) {
     GSSD_CHECK_ARG(w_packed && U && Cout > 0 && groups > 0 && Cout % groups == 0 && cin_g > 0 && row_stride >= 9 * cin_g);
-    const int n = Cout * cin_g;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w_packed, U, Cout,
-                       Cout / groups, cin_g, row_stride);
+    const int cout_g = Cout / groups, nb = wino_nb(cout_g, groups);
+    GSSD_CHECK_ARG(nb != 0);
+    const int cout_pad = wino_cout_pad(cout_g, nb);
+    const int n = groups * cout_pad * cin_g;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w_packed, U, groups, cout_g,
+                       cout_pad, cin_g, row_stride);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -252,14 +252,14 @@ __device__ float block_sum(float v, float* red) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void spectral_norm_kernel(const gssd_sn_item* __restrict__ items, int do_iter,
+__global__ __launch_bounds__(1024) void spectral_norm_kernel(const gssd_sn_item* __restrict__ items, int do_iter,
                                                             float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const gssd_sn_item it = items[blockIdx.x];
     const int R = it.rows, Cc = it.cols;
     float* su = sm;            // [R]
     float* sv = sm + R;        // [Cc]
-    float* red = sv + Cc;      // [8]
+    float* red = sv + Cc;      // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     for (int i = tid; i < R; i += blockDim.x) su[i] = it.u[i];
     for (int i = tid; i < Cc; i += blockDim.x) sv[i] = it.v[i];
@@ -268,8 +268,15 @@ __global__ __launch_bounds__(256) void spectral_norm_kernel(const gssd_sn_item* 
         // v = W^T u : thread per column, rows serial (coalesced across threads)
         float nrm = 0.f;
         for (int c = tid; c < Cc; c += blockDim.x) {
-            float acc = 0.f;
-            for (int rr = 0; rr < R; ++rr) acc += it.w[(size_t)rr * Cc + c] * su[rr];
+            // eight independent partial sums keep eight loads in flight per thread (one workgroup owns the whole matrix)
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int rr = 0;
+            for (; rr + 8 <= R; rr += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a8[q] += it.w[(size_t)(rr + q) * Cc + c] * su[rr + q];
+            }
+            for (; rr < R; ++rr) a8[0] += it.w[(size_t)rr * Cc + c] * su[rr];
+            const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             sv[c] = acc;
             nrm += acc * acc;
         }
@@ -430,8 +437,8 @@ extern "C" int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int 
                                       gssd_stream_t stream) {
     GSSD_CHECK_ARG(items_dev && n > 0);
     // rows + cols <= 1536 for every Self_Attn conv of the path (512x1024 is the largest)
-    const size_t smem = (2048 + 8) * sizeof(float);
-    hipLaunchKernelGGL(spectral_norm_kernel, dim3(n), dim3(256), smem, as_stream(stream), items_dev,
+    const size_t smem = (2048 + 16) * sizeof(float);
+    hipLaunchKernelGGL(spectral_norm_kernel, dim3(n), dim3(1024), smem, as_stream(stream), items_dev,
                        do_power_iteration, eps);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -58,9 +58,9 @@ def conv_tag(d, real_cin_g=None):
     if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
-    elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g) and not d.m_per_image
+    elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g, d.groups) and not d.m_per_image
           and d.split_k <= 1 and not d.relu):
-        name = f'conv_wino<{64 if cout_g % 64 == 0 else 32}>'   # gssd_try_conv_wino (csrc/conv_wino.hip)
+        name = f'conv_wino<{64 if (cout_g % 64 == 0 or (cout_g % 32 != 0 and cout_g > 32)) else 32}>'   # gssd_try_conv_wino
     M = d.B * d.Ho * d.Wo
     cin_g = real_cin_g if real_cin_g is not None else d.cin_g
     flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
@@ -332,7 +332,7 @@ class _Plan:
         cin_g = Cin // groups
         wp = self._packed_conv(name, conv)
         U = None
-        if USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups):
+        if USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups, groups):
             def build_u(out, key=name + '.w', groups=groups, cin_g=cin_g):
                 return ops.winograd_weight(self.eng._packed[key], groups, cin_g, out)
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
@@ -492,8 +492,13 @@ class _Plan:
         om = self._buf(B, H, H, 27 * dg)
         cols = self._buf(B * H * H, 9 * Cin)
         out = self._buf(B, H, H, Cout)
+        u_om = None
+        if USE_WINOGRAD and ops.winograd_eligible(3, 1, 1, 1, Cin, 27 * dg, 1):
+            def build_u(out, key=f'dcn_list.{li}.om.w', cin=Cin):
+                return ops.winograd_weight(eng._packed[key], 1, cin, out)
+            u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1,
-                                      bias=m.conv_offset_mask.bias.detach())
+                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om)
         d2, _, _ = ops.make_conv_desc(cols, w_main, out, B=B, H=H, W=H, in_stride=9 * Cin, cin_g=9 * Cin, Cout=Cout,
                                       bias=m.bias.detach())
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d1),), keep=d1)

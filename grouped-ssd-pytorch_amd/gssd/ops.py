@@ -114,16 +114,21 @@ def run_conv(desc):
     check(lib.gssd_conv2d_nhwc_f32(C.byref(desc), _stream()))
 
 
-def winograd_eligible(k, stride, pad, dil, cin_g, cout_g):
+def winograd_eligible(k, stride, pad, dil, cin_g, cout_g, groups=4):
     """Shapes csrc/conv_wino.hip takes (mirrors gssd_try_conv_wino)."""
-    return k == 3 and stride == 1 and pad == 1 and dil == 1 and cin_g % 16 == 0 and cout_g % 32 == 0
+    if not (k == 3 and stride == 1 and pad == 1 and dil == 1 and cin_g % 16 == 0):
+        return False
+    return cout_g % 32 == 0 or (groups == 1 and cout_g >= 24)
 
 
 def winograd_weight(w_packed, groups, cin_g, out=None):
-    """Packed K-major 3x3 weights [Cout][9*cin_g] -> U[g][16][cout_g][cin_g] (G g G^T)."""
+    """Packed K-major 3x3 weights [Cout][9*cin_g] -> U[g][16][cout_pad][cin_g] (G g G^T)."""
     Cout = w_packed.shape[0]
     if out is None:
-        out = torch.empty(16 * Cout * cin_g, device=w_packed.device, dtype=torch.float32)
+        n = int(lib.gssd_winograd_weight_elems(Cout, groups, cin_g))
+        if n <= 0:
+            raise _lib.GssdError(f'not a Winograd shape: Cout {Cout}, groups {groups}, cin_g {cin_g}')
+        out = torch.empty(n, device=w_packed.device, dtype=torch.float32)
     check(lib.gssd_winograd_weight_f32(_p(w_packed), _p(out), Cout, groups, cin_g, w_packed.stride(0), _stream()))
     return out
 

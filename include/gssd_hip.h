@@ -89,7 +89,7 @@ typedef struct gssd_conv_desc {
     double* stats;      /* [2*Cout]: per-channel sum / sum of squares of the pre-activation output
                            accumulated with fp64 atomics (BatchNorm batch statistics), or NULL */
     const float* wgt_wino; /* optional Winograd F(2x2,3x3) form of `wgt` (gssd_winograd_weight_f32): 3x3 / stride 1 / pad 1
-                              convs with cin_g % 16 == 0 and cout_g % 32 == 0 then take the Winograd kernel; NULL = never */
+                              convs of a Winograd shape (see gssd_winograd_weight_f32) then take the Winograd kernel; NULL = never */
     int B, H, W;        /* input geometry */
     int in_stride;      /* floats between consecutive input pixels */
     int in_ch_off;      /* first input channel used */
@@ -113,9 +113,12 @@ typedef struct gssd_conv_desc {
 
 int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
 
-/* U[g][xi][co][ci] = (G g G^T)_xi of the packed K-major weights [Cout][tap*cin_g + ci] (row stride `row_stride`);
- * U holds 16 * Cout * cin_g floats.  The same packer serves the data gradient (weights packed by
+/* U[g][xi][co][ci] = (G g G^T)_xi of the packed K-major weights [Cout][tap*cin_g + ci] (row stride `row_stride`).
+ * Winograd shapes: cin_g % 16 == 0 and cout_g % 32 == 0, or (one group) any cout_g >= 24 -- U's rows per group are then
+ * padded with zeros to a multiple of the kernel's channel block; gssd_winograd_weight_elems (HOST) returns the float
+ * count of U, or -1 for other shapes.  The same packer serves the data gradient (weights packed by
  * gssd_pack_conv_weight_dgrad). */
+long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g);
 int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
                              gssd_stream_t stream);
 

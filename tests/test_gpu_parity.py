@@ -126,6 +126,8 @@ WINO_CASES = [
     (2, 37, 128, 128, 4),      # conv2_2 shape class: cout_g 32 -> persistent 32-channel variant, several items per workgroup
     (5, 9, 64, 32, 1),         # dense, one group, one chunk; fewer tiles than one wave in places
     (1, 150, 128, 128, 4),     # many items per persistent workgroup
+    (2, 38, 256, 108, 1),      # DCN offset / mask conv: 108 output channels padded to 128 inside U
+    (2, 13, 64, 24, 1),        # padded to one 32-channel block
 ]
 
 
@@ -138,7 +140,7 @@ def test_conv_winograd(dev, ops, case):
     x = torch.from_numpy(rng.normal(0.1, 1.0, size=(B, Cin, H, H)).astype(np.float32))
     w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
     b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
-    assert ops.winograd_eligible(3, 1, 1, 1, Cin // g, Cout // g)
+    assert ops.winograd_eligible(3, 1, 1, 1, Cin // g, Cout // g, g)
     ref = torch.nn.functional.conv2d(x, w, b, 1, 1, 1, g)
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
     xd = nhwc(x).to(dev)
@@ -166,7 +168,7 @@ def test_conv_winograd(dev, ops, case):
     yg = torch.nn.functional.conv2d(xg, w, None, 1, 1, 1, g)
     dy = torch.from_numpy(rng.normal(size=tuple(yg.shape)).astype(np.float32))
     yg.backward(dy)
-    if ops.winograd_eligible(3, 1, 1, 1, Cout // g, Cin // g):
+    if ops.winograd_eligible(3, 1, 1, 1, Cout // g, Cin // g, g):
         wd = ops.pack_weight_dgrad(w.to(dev), g)
         ud = ops.winograd_weight(wd, g, Cout // g)
         existing = torch.from_numpy(rng.normal(size=(B, H, H, Cin)).astype(np.float32)).to(dev)
