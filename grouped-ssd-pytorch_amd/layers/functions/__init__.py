@@ -1,4 +1,8 @@
-from .detection import Detect
-from .prior_box import PriorBox
+"""Inference-side operators of the drop-in package: prior generation and the decode + NMS op."""
+from . import detection as _detection
+from . import prior_box as _prior_box
 
-__all__ = ['Detect', 'PriorBox']
+Detect = _detection.Detect
+PriorBox = _prior_box.PriorBox
+
+__all__ = ('Detect', 'PriorBox')

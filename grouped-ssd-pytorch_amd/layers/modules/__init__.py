@@ -1,4 +1,8 @@
-from .l2norm import L2Norm
-from .multibox_loss import MultiBoxLoss
+"""Loss-side modules of the drop-in package (names as the training script imports them)."""
+from . import l2norm as _l2norm
+from . import multibox_loss as _multibox_loss
 
-__all__ = ['L2Norm', 'MultiBoxLoss']
+L2Norm = _l2norm.L2Norm
+MultiBoxLoss = _multibox_loss.MultiBoxLoss
+
+__all__ = ('L2Norm', 'MultiBoxLoss')
