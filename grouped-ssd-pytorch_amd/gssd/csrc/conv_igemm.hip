@@ -362,7 +362,11 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     const int cout_g = d.Cout / d.groups;
     hipStream_t s = as_stream(stream);
     {
-        const int rc = gssd_try_conv_thin(d, s);      // conv1_1 / conv1_2 / conv2_1: patch-staged kernel
+        const int rc = gssd_try_conv_thin_wino(d, s); // conv1_2 (and its dgrad): patch-staged Winograd
+        if (rc != 1) return rc;
+    }
+    {
+        const int rc = gssd_try_conv_thin(d, s);      // conv1_1 / conv2_1 (conv1_2 without Winograd weights): patch-staged kernel
         if (rc != 1) return rc;
     }
     {
@@ -377,9 +381,6 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const long long b128 = mt * d.groups * ((cout_g + 127) / 128) * z, b64 = mt * d.groups * ((cout_g + 63) / 64) * z;
         const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
         const double e64 = 0.94 * (double)b64 / (double)(((b64 + 767) / 768) * 768);
-        if (const char* e = getenv("GSSD_TILE256")) {
-            if (e[0] == '1' && cout_g % 128 == 0) return launch_cfg<256, 128, 4, 2>(d, M, images, s);
-        }
         if (e64 > e128) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
         return launch_cfg<128, 128, 2, 2>(d, M, images, s);
     }

@@ -338,10 +338,8 @@ int launch_thin_impl(const gssd_conv_desc& d, hipStream_t stream) {
 
 template <int CIN_G, int COUT_G>
 int launch_thin(const gssd_conv_desc& d, hipStream_t stream) {
-    // 5 x 25 tiles divide 150 and 75 exactly; otherwise the compile-time 8 x 16 tile (97.4 % of 300 x 300)
-    if (d.W % 25 == 0 && d.H % 5 == 0 && d.W != 300 && getenv("GSSD_THIN_5X25"))    // runtime-tile variant: opt-in
-        return d.in_scale ? launch_thin_impl<CIN_G, COUT_G, false, true>(d, stream)
-                          : launch_thin_impl<CIN_G, COUT_G, false, false>(d, stream);
+    // compile-time 8 x 16 tile (97.4 % of 300 x 300); a runtime 5 x 25 tile that divides 150 and 75 exactly spilled registers
+    // and lost (round 1), so only the FIXED instantiations are built
     return d.in_scale ? launch_thin_impl<CIN_G, COUT_G, true, true>(d, stream)
                       : launch_thin_impl<CIN_G, COUT_G, true, false>(d, stream);
 }

@@ -324,6 +324,12 @@ inline int wino_nb(int cout_g, int groups) {
     return 0;
 }
 inline int wino_cout_pad(int cout_g, int nb) { return (cout_g + nb - 1) / nb * nb; }
+// rows per group of U for a layer: the kernel block's padding, or (16-channel groups: conv_thin_wino.hip) none; 0 = no U
+inline int wino_u_rows(int cout_g, int groups) {
+    const int nb = wino_nb(cout_g, groups);
+    if (nb) return wino_cout_pad(cout_g, nb);
+    return cout_g % 16 == 0 ? cout_g : 0;
+}
 
 template <int NB, bool XF, bool PERSIST>
 int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
@@ -396,17 +402,16 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
 
 extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g) {
     if (Cout <= 0 || groups <= 0 || Cout % groups || cin_g <= 0) return -1;
-    const int nb = wino_nb(Cout / groups, groups);
-    if (!nb) return -1;
-    return 16ll * groups * wino_cout_pad(Cout / groups, nb) * cin_g;
+    const int rows = wino_u_rows(Cout / groups, groups);
+    if (!rows) return -1;
+    return 16ll * groups * rows * cin_g;
 }
 
 extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
                                         gssd_stream_t stream) {
     GSSD_CHECK_ARG(w_packed && U && Cout > 0 && groups > 0 && Cout % groups == 0 && cin_g > 0 && row_stride >= 9 * cin_g);
-    const int cout_g = Cout / groups, nb = wino_nb(cout_g, groups);
-    GSSD_CHECK_ARG(nb != 0);
-    const int cout_pad = wino_cout_pad(cout_g, nb);
+    const int cout_g = Cout / groups, cout_pad = wino_u_rows(cout_g, groups);
+    GSSD_CHECK_ARG(cout_pad != 0);
     const int n = groups * cout_pad * cin_g;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w_packed, U, groups, cout_g,
                        cout_pad, cin_g, row_stride);

@@ -58,6 +58,8 @@ def conv_tag(d, real_cin_g=None):
     if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
+        if d.wgt_wino and (d.cin_g, cout_g) == (16, 16) and not d.resid:
+            name = 'conv_thin_wino<16,16>'               # gssd_try_conv_thin_wino (csrc/conv_thin_wino.hip)
     elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g, d.groups) and not d.m_per_image
           and d.split_k <= 1 and not d.relu):
         name = f'conv_wino<{64 if (cout_g % 64 == 0 or (cout_g % 32 != 0 and cout_g > 32)) else 32}>'   # gssd_try_conv_wino

@@ -118,7 +118,7 @@ def winograd_eligible(k, stride, pad, dil, cin_g, cout_g, groups=4):
     """Shapes csrc/conv_wino.hip takes (mirrors gssd_try_conv_wino)."""
     if not (k == 3 and stride == 1 and pad == 1 and dil == 1 and cin_g % 16 == 0):
         return False
-    return cout_g % 32 == 0 or (groups == 1 and cout_g >= 24)
+    return cout_g % 32 == 0 or (groups == 1 and cout_g >= 24) or (groups == 4 and cin_g == 16 and cout_g == 16)
 
 
 def winograd_weight(w_packed, groups, cin_g, out=None):

@@ -128,6 +128,8 @@ WINO_CASES = [
     (1, 150, 128, 128, 4),     # many items per persistent workgroup
     (2, 38, 256, 108, 1),      # DCN offset / mask conv: 108 output channels padded to 128 inside U
     (2, 13, 64, 24, 1),        # padded to one 32-channel block
+    (2, 83, 64, 64, 4),        # conv1_2 class: patch-staged Winograd (conv_thin_wino.hip), ragged 8 x 16 tiles
+    (1, 160, 64, 64, 4),       # ... several tiles per persistent workgroup
 ]
 
 
