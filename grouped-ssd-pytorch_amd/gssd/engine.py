@@ -2,8 +2,8 @@
 
 ``GssdEngine`` turns the module tree built by ``build_ssd`` into a flat launch plan: a list of
 (C-ABI function, prebuilt argument tuple) pairs over preallocated NHWC buffers.  Running the plan
-is a tight loop of ctypes calls on the current HIP stream -- no tensor ops, no allocation -- so it
-can be captured into a hipGraph (``use_graph=True``).
+is a tight loop of ctypes calls on the current HIP stream -- no tensor ops, no allocation (≈2.5 ms of host time per
+GSSD step against 6.5 ms on the GPU, scripts/host_overhead.py).
 
 Dataflow restated from models/ssd_multiphase_custom_group.py:217-400:
 
