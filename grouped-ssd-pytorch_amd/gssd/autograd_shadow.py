@@ -153,8 +153,25 @@ class GssdTrainFn(torch.autograd.Function):
     def backward(ctx, dloc, dconf):
         net, x, params = ctx.net, ctx.x, ctx.params
         if net._engine.has_hip_backward() and not x.requires_grad and not net.__dict__.get('_force_aten_backward'):
+            # The plan writes every gradient into its own persistent buffers (views of one flat tensor).  They are handed out
+            # as ``param.grad`` directly -- no AccumulateGrad clone per parameter -- when the parameter has no gradient yet
+            # (optimizer.zero_grad(set_to_none=True), the default); an existing gradient is accumulated into, and one that
+            # still aliases the plan's buffer from an earlier backward is moved out of the way first.
+            bwd = getattr(net._engine._last_plan, '_bwd', None)
+            if bwd is not None:
+                lo, hi = bwd.flat.data_ptr(), bwd.flat.data_ptr() + bwd.flat.numel() * 4
+                for p in params:
+                    if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                        p.grad = p.grad.clone()
             grads = net._engine.backward(dloc, dconf)            # hand-written HIP backward (gssd/backward.py)
-            return (None, None) + tuple(g if p.requires_grad else None for g, p in zip(grads, params))
+            for p, g in zip(params, grads):
+                if g is None or not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            return (None, None) + (None,) * len(params)
         with torch.enable_grad():
             xin = x.detach().requires_grad_(x.requires_grad)
             loc, conf = shadow_forward(net, xin)

@@ -31,6 +31,14 @@ class BackwardPlan:
         self.grads = {}          # id(param) -> fp32 grad tensor
         self.zero_list = []      # tensors to zero before every run
         self.gbuf = {}           # data_ptr of a forward tensor -> gradient buffer w.r.t. it
+        # every parameter gradient is a 16-byte aligned slice of ONE flat fp32 tensor: the autograd glue hands these views out
+        # as ``param.grad`` without copying, and data-parallel training all-reduces ``self.flat`` in a single call
+        offs, n = [], 0
+        for p in plan.eng.net.parameters():
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(max(n, 4), device=self.dev, dtype=torch.float32)
+        self._slices = {id(p): self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(plan.eng.net.parameters(), offs)}
         self.dloc = torch.empty(self.B, plan.P, 4, device=self.dev)
         self.dconf = torch.empty(self.B, plan.P, plan.nc, device=self.dev)
         net = plan.eng.net
@@ -70,9 +78,8 @@ class BackwardPlan:
     def _pgrad(self, p):
         g = self.grads.get(id(p))
         if g is None:
-            g = torch.zeros_like(p, dtype=torch.float32)
+            g = self._slices[id(p)]              # parameters the plan never writes keep no entry -> gradient None
             self.grads[id(p)] = g
-            self.keep.append(g)
         return g
 
     def _grad_of(self, t):

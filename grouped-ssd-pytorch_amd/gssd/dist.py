@@ -56,6 +56,12 @@ def allreduce_grads(params, world=None):
     world = world or (dist.get_world_size() if dist.is_initialized() else 1)
     if world == 1:
         return sum(g.numel() for g in grads)
+    base = grads[0]._base
+    if base is not None and base.dim() == 1 and all(g._base is base for g in grads):
+        # the HIP backward plan keeps all gradients as slices of one flat tensor: reduce it in place, no copies
+        dist.all_reduce(base, op=dist.ReduceOp.SUM)
+        base.div_(world)
+        return base.numel()
     flat = torch._utils._flatten_dense_tensors(grads)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world)

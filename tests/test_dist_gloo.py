@@ -37,7 +37,17 @@ def _worker(rank, world, port, out):
     for i, q in enumerate(lin.parameters()):
         q.grad = torch.full_like(q, float(rank + 1 + i))
     n = gd.allreduce_grads(list(lin.parameters()))
-    out.put((rank, n, [float(q.grad.mean()) for q in lin.parameters()], float(lin.weight.sum())))
+    # gradients that are slices of one flat tensor (what the HIP backward plan hands out) are reduced in place, no copies
+    flat = torch.zeros(16)
+    lin2 = torch.nn.Linear(4, 3)
+    lin2.weight.grad = flat[0:12].view(3, 4)
+    lin2.bias.grad = flat[12:15].view(3)
+    flat[:12] = float(rank + 1)
+    flat[12:15] = float(10 * (rank + 1))
+    n2 = gd.allreduce_grads(list(lin2.parameters()))
+    same_storage = lin2.weight.grad.data_ptr() == flat.data_ptr()
+    out.put((rank, n, [float(q.grad.mean()) for q in lin.parameters()], float(lin.weight.sum()),
+             (n2, same_storage, float(lin2.weight.grad.mean()), float(lin2.bias.grad.mean()))))
     gd.barrier()
     gd.finish()
 
@@ -50,8 +60,8 @@ def test_two_rank_harness():
     for p in ps:
         p.start()
     got = [q.get(timeout=120) for _ in range(2 * world)]
-    res = sorted(r for r in got if len(r) == 5)
-    res2 = sorted(r for r in got if len(r) == 4)
+    res = sorted(r for r in got if len(r) == 5 and not isinstance(r[4], tuple))
+    res2 = sorted(r for r in got if len(r) == 5 and isinstance(r[4], tuple))
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -60,3 +70,4 @@ def test_two_rank_harness():
     assert res[0][4] == res[1][4] == 2 * 32 * 10 / 2.0
     assert res2[0][1] == res2[1][1] == 15 and res2[0][2] == res2[1][2] == [1.5, 2.5]      # mean over ranks
     assert res2[0][3] == res2[1][3]                                                            # broadcast weights
+    assert res2[0][4] == res2[1][4] == (16, True, 1.5, 15.0)                                   # flat-slice gradients, in place
