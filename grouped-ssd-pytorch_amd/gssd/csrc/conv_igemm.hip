@@ -381,7 +381,9 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const long long b128 = mt * d.groups * ((cout_g + 127) / 128) * z, b64 = mt * d.groups * ((cout_g + 63) / 64) * z;
         const double e128 = (double)b128 / (double)(((b128 + 511) / 512) * 512);
         const double e64 = 0.94 * (double)b64 / (double)(((b64 + 767) / 768) * 768);
-        if (e64 > e128) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
+        // short reductions (K <= 256: the attention output conv) are prologue / epilogue bound: three resident 128x64
+        // workgroups per CU overlap those phases better than two 128x128 ones
+        if (e64 > e128 || d.K <= 256) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
         return launch_cfg<128, 128, 2, 2>(d, M, images, s);
     }
     if (cout_g > 32) return launch_cfg<128, 64, 2, 2>(d, M, images, s);

@@ -52,7 +52,7 @@ def conv_tag(d, real_cin_g=None):
         b64 = mt * d.groups * (-(-cout_g // 64)) * z
         e128 = b128 / (-(-b128 // 512) * 512)
         e64 = 0.94 * b64 / (-(-b64 // 768) * 768)
-        if e64 > e128:
+        if e64 > e128 or d.K <= 256:
             inst = '128x64'
     name = 'conv_igemm<' + inst + '>'
     if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
