@@ -224,39 +224,71 @@ class BackwardPlan:
         return buf, False
 
     def _sa(self, r):
-        """Self_Attn (layers/self_attn.py:46-89), interim: the block is re-evaluated token-major ([B, N, C] views of the
-        NHWC buffers, plain matmuls) under ATen autograd and back-propagated locally."""
-        from .autograd_shadow import _sn_weight
+        """Self_Attn (layers/self_attn.py:46-89), interim: no hand-written kernels yet.  The block's backward is written out
+        by hand over the forward plan's own buffers (theta|phi, g^T, the softmaxed attention map, attn.g) as a dozen batched
+        ATen matmuls -- no autograd graph and no recomputation of the forward:
+            d_o = sigma dT;  d(ag) = d_o W_o;  dA = d(ag) g^T;  dS = A (dA - rowsum(A dA));  d theta = dS phi;
+            d phi = dS^T theta;  d g = A^T d(ag);  dx = d(out) + d(theta|phi) W_tp + d g W_g;  weight grads = d^T x,
+        and for every spectrally normalised conv (W_eff = W / s, s = u^T W v, u and v constants of the step)
+            dW = dW_eff / s - (sum dW_eff . W) / s^2 * u v^T."""
         sa, x, out, out2 = r['mod'], r['x_in'], r['out'], r['out2']
         g_out = self._grad_of(out)
         g_out2 = self._grad_of(out2) if out2 is not None else None
-        params = [q for q in sa.parameters()]
         gx, existed = self._reserve(x, x.shape)
-        pg = [self._pgrad(q) for q in params]
-        B, N, Cc = self.B, r['H'] * r['H'], r['C']
+        B, N, Cc = self.B, r['N'], r['C']
+        C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+        tp, gT, S, ag = r['tp'], r['gT'], r['S'], r['ag']
+        a_tp, a_g, a_o = r['inv_sigma']
+        cv = {k: getattr(sa, 'snconv1x1_' + k) for k in ('theta', 'phi', 'g', 'attn')}
+        pg = {k: (self._pgrad(m.weight_orig), self._pgrad(m.bias)) for k, m in cv.items()}
+        pg_sigma = self._pgrad(sa.sigma)
 
-        def block(xt):
-            def lin(sn, t):
-                w = _sn_weight(sn)
-                return torch.matmul(t, w.view(w.shape[0], -1).t()) + sn.bias
-            theta, phi, g = lin(sa.snconv1x1_theta, xt), lin(sa.snconv1x1_phi, xt), lin(sa.snconv1x1_g, xt)
-            attn = torch.softmax(torch.bmm(theta, phi.transpose(1, 2)), dim=-1)
-            o = sa.sigma * lin(sa.snconv1x1_attn, torch.bmm(attn, g))
-            return xt + o, o
+        def sn_grad(conv, dw_eff, inv_s, dst):
+            """dW_orig from dW_eff (both [rows, cols])."""
+            w = conv.weight_orig.detach().view(dw_eff.shape)
+            dot = (dw_eff * w).sum()
+            dst.copy_((dw_eff * inv_s - torch.outer(conv.weight_u.detach(), conv.weight_v.detach()) * (dot * inv_s * inv_s))
+                      .view(dst.shape))
 
         def step():
-            with torch.enable_grad():
-                xt = x.view(B, N, Cc).detach().requires_grad_()
-                o1, o2 = block(xt)
-                outs, gos = [o1], [g_out.view(B, N, Cc)]
-                if g_out2 is not None:
-                    outs.append(o2)
-                    gos.append(g_out2.view(B, N, Cc))
-                grads = torch.autograd.grad(outs, [xt] + params, gos, allow_unused=True)
-            dxn = grads[0].view(gx.shape)
+            X = x.view(B, N, Cc)
+            dT = g_out.view(B, N, Cc)
+            if g_out2 is not None:
+                dT = dT + g_out2.view(B, N, Cc)
+            sig = sa.sigma.detach()
+            is_t, is_p, is_g, is_o = a_tp[0], a_tp[C8], a_g[0], a_o[0]           # 1 / sigma_sn of each conv (device scalars)
+            w_o = cv['attn'].weight_orig.detach().view(Cc, C2)
+            w_g = cv['g'].weight_orig.detach().view(C2, Cc)
+            w_t = cv['theta'].weight_orig.detach().view(C8, Cc)
+            w_p = cv['phi'].weight_orig.detach().view(C8, Cc)
+            A = S[:, :, :N]
+            g_tok = gT[:, :, :N].transpose(1, 2)                                 # [B, N, C2] view
+            theta, phi = tp[:, :, :C8], tp[:, :, C8:]
+            # output conv and the gate
+            o_raw = torch.matmul(ag, w_o.t()) * is_o + cv['attn'].bias.detach()
+            pg_sigma.copy_((dT * o_raw).sum().view(pg_sigma.shape))
+            d_o = dT * sig
+            sn_grad(cv['attn'], torch.matmul(d_o.reshape(-1, Cc).t(), ag.reshape(-1, C2)), is_o, pg['attn'][0])
+            pg['attn'][1].copy_(d_o.sum((0, 1)))
+            dag = torch.matmul(d_o, w_o) * is_o                                  # [B, N, C2]
+            # attention
+            dA = torch.bmm(dag, g_tok.transpose(1, 2))                           # [B, N, N]
+            dS = A * (dA - (A * dA).sum(-1, keepdim=True))
+            d_theta = torch.bmm(dS, phi)
+            d_phi = torch.bmm(dS.transpose(1, 2), theta)
+            d_g = torch.bmm(A.transpose(1, 2), dag)                              # [B, N, C2] (token-major g)
+            # the three input convs
+            Xf = X.reshape(-1, Cc)
+            sn_grad(cv['theta'], torch.matmul(d_theta.reshape(-1, C8).t(), Xf), is_t, pg['theta'][0])
+            sn_grad(cv['phi'], torch.matmul(d_phi.reshape(-1, C8).t(), Xf), is_p, pg['phi'][0])
+            sn_grad(cv['g'], torch.matmul(d_g.reshape(-1, C2).t(), Xf), is_g, pg['g'][0])
+            pg['theta'][1].copy_(d_theta.sum((0, 1)))
+            pg['phi'][1].copy_(d_phi.sum((0, 1)))
+            pg['g'][1].copy_(d_g.sum((0, 1)))
+            # the residual branch carries d(out) only: out2 = sigma * o has no direct x term
+            dx = g_out.view(B, N, Cc) + torch.matmul(d_theta, w_t) * is_t + torch.matmul(d_phi, w_p) * is_p + torch.matmul(d_g, w_g) * is_g
+            dxn = dx.view(gx.shape)
             gx.add_(dxn) if existed else gx.copy_(dxn)
-            for g, d in zip(pg, grads[1:]):
-                g.copy_(d) if d is not None else g.zero_()
         self.steps.append((step, None))
 
     def _slice_cat(self, r):

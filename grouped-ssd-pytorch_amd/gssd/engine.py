@@ -488,7 +488,8 @@ class _Plan:
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, N, Np)
-        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc)))
+        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, S=S, ag=ag, N=N, Np=Np,
+                                    inv_sigma=(a_tp, a_g, a_o))))
         return out, out2
 
     def _dcn(self, li, x, H, Cin):
