@@ -36,14 +36,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     if (i0 < stride)
         for (long long i = i0; i < total; i += stride) {
-            long long t = i / C4;
-            const int xo = (int)(t % Wo);
-            t /= Wo;
-            const int yo = (int)(t % Ho);
-            const int b = (int)(t / Ho);
             const f32x4 g = *reinterpret_cast<const f32x4*>(dout + i * 4);
             if (pk == 0) {
-                const size_t o = (((size_t)b * H + yo) * W + xo) * C + 4 * c4;
+                const size_t o = (size_t)i * 4;           // Ho == H, Wo == W: dout and raw share one dense layout
                 const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + o);
                 const f32x4 z = rv * sc + sh;
                 f32x4 d;
@@ -53,6 +48,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 a1 += d;
                 a2 += d * rv;
             } else {
+                // pixel index fits 32 bits (checked by the launcher): 32-bit divisions instead of three 64-bit ones
+                unsigned t = (unsigned)(i / C4);
+                const int xo = (int)(t % (unsigned)Wo);
+                t /= (unsigned)Wo;
+                const int yo = (int)(t % (unsigned)Ho);
+                const int b = (int)(t / (unsigned)Ho);
                 const int y0 = yo * ps - pp, x0 = xo * ps - pp;
                 f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 int bi[4] = {-1, -1, -1, -1};
@@ -289,6 +290,7 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
+    GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblocks(total)), dim3(256), 2 * C * sizeof(float), as_stream(stream), dout,
                        raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
     GSSD_CHECK_LAUNCH();
