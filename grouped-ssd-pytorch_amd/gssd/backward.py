@@ -314,19 +314,18 @@ class BackwardPlan:
         x, om, cols = r['x_in'], r['om'], r['cols']
         dy = self._grad_of(r['out'])
         Kc = 9 * Cin
-        # main weight / bias
-        dwp = self._buf(Cout, Kc, zero_each_run=True)
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(r['d_main']), dy.data_ptr(), dwp.data_ptr()), keep=r['d_main'])
+        # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- plain GEMMs (rocBLAS)
+        dwp = self._buf(Cout, Kc)
+        self._add(lib.gssd_gemm_tn_f32, (dy.data_ptr(), cols.data_ptr(), dwp.data_ptr(), B * H * H, Cout, Kc, Cout, Kc, Kc, 0))
         self._unpack(dwp, Kc, 0, m.weight, Cin, Cin, 3)
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))
         self._bias_from_colsum(cs, m.bias)
-        # d(cols) = dY . W   (1x1 conv with the transposed packed weight)
         wt = self._buf(Kc, Cout)
         self.steps.append((lambda w=r['w_main'], wt=wt: wt.copy_(w.t()), None))
         dcols = self._buf(B * H * H, Kc)
-        dd, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(dd),), keep=dd)
+        self._add(lib.gssd_gemm_nt_f32, (dy.data_ptr(), wt.data_ptr(), dcols.data_ptr(), B * H * H, Kc, Cout, Cout, Cout, Kc, 0, 0),
+                  keep=wt)
         # sampling backward: d(x) by atomics, d(offset / mask logits) per pixel
         gx = self._grad_of(x)
         if gx is None:

@@ -516,7 +516,10 @@ class _Plan:
                                       bias=m.bias.detach())
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d1),), keep=d1)
         self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, 27 * dg))
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d2),), keep=d2)
+        # the contraction over the sampled columns is a plain [B*H*W, 9*Cin] x [9*Cin, Cout] GEMM + bias: library GEMM
+        self._add(lib.gssd_gemm_nt_f32, (cols.data_ptr(), w_main.data_ptr(), out.data_ptr(), B * H * H, Cout, 9 * Cin, 9 * Cin,
+                                        w_main.stride(0), Cout, m.bias.data_ptr(), 0), keep=(d2, w_main),
+                  tag=('gemm_rocblas', 2.0 * B * H * H * Cout * 9 * Cin, 4.0 * (B * H * H * (9 * Cin + Cout) + Cout * 9 * Cin)))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
         self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, cols=cols, d_om=d1, d_main=d2,

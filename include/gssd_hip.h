@@ -259,6 +259,16 @@ int gssd_resize_u8_vertical(const uint8_t* in, uint8_t* out, const int32_t* boun
 int gssd_input_finish_f32(const uint8_t* img, const int32_t* minmax, float mean0, float mean1, float mean2, float* out_nchw,
                           int B, int phases, int S, int C, int normalize, gssd_stream_t stream);
 
+/* Plain library GEMMs (rocBLAS) for the contractions of the path that are nothing but a GEMM -- the deformable conv's
+ * product over the sampled column matrix (layers/dcn_v2_custom.py:84-89 -> dcn_v2's gemm) forward, data gradient and weight
+ * gradient.  Row-major operands.
+ *   nt: C[M][N] = A[M][K] . B[N][K]^T (+ bias[N] on every row | + C when accumulate)
+ *   tn: C[N][K2] (+)= A[M][N]^T . B[M][K2]     (reduction over the M rows of both operands) */
+int gssd_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     const float* bias, int accumulate, gssd_stream_t stream);
+int gssd_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K2, int lda, int ldb, int ldc, int accumulate,
+                     gssd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
  * ------------------------------------------------------------------------------------------ */

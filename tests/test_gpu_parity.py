@@ -405,6 +405,27 @@ def test_dcn_im2col_and_identities(dev, ops):
     assert rel(nchw(y0), ident) < TOL
 
 
+def test_library_gemm_entry_points(dev):
+    """gssd_gemm_nt_f32 / gssd_gemm_tn_f32 (rocBLAS behind the C ABI): the DCN contraction forward, dgrad and wgrad forms."""
+    from gssd._lib import lib, check
+    rng = np.random.default_rng(21)
+    M, N, K = 300, 72, 200
+    a = torch.from_numpy(rng.normal(size=(M, K)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.normal(size=(N, K)).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(rng.normal(size=(N,)).astype(np.float32)).to(dev)
+    c = torch.empty(M, N, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.gssd_gemm_nt_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, bias.data_ptr(), 0, st))
+    ref = a.cpu().double() @ b.cpu().double().t() + bias.cpu().double()
+    assert rel(c, ref.float()) < 1e-5
+    check(lib.gssd_gemm_nt_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, None, 1, st))       # accumulate
+    assert rel(c, (2 * ref - bias.cpu().double()).float()) < 1e-5
+    dy = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32)).to(dev)
+    dw = torch.empty(N, K, device=dev)
+    check(lib.gssd_gemm_tn_f32(dy.data_ptr(), a.data_ptr(), dw.data_ptr(), M, N, K, N, K, K, 0, st))
+    assert rel(dw, (dy.cpu().double().t() @ a.cpu().double()).float()) < 1e-5
+
+
 def test_dcn_col2im_backward(dev, ops):
     """Sampling backward (d x by atomics, d offset, d mask logit) vs autograd through the oracle's DCN restatement."""
     rng = np.random.default_rng(18)
