@@ -56,21 +56,21 @@ def cpu_baseline(cfg_name, sample_b, seed):
         t0 = time.perf_counter()
         with torch.no_grad():
             loc, conf, _ = O.gssd_forward(sd, x, **flags)
-        O.multibox_loss(loc.numpy(), conf.numpy(), pri, tg)
-        return time.perf_counter() - t0
+        ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), pri, tg)[:2]
+        return time.perf_counter() - t0, (float(ll), float(lc))
     # pick the intra-op thread count that is fastest for this graph on this host (all cores oversubscribes oneDNN's
     # grouped convs on big boxes): 2-image probes double as the warm-up
     best = None
     for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         torch.set_num_threads(nt)
-        one(2, seed)
-        t = one(2, seed)
+        one(2, seed + 1)
+        t = one(2, seed + 1)[0]
         if best is None or t < best[0]:
             best = (t, nt)
     cores = best[1]
     torch.set_num_threads(cores)
-    dt = one(sample_b, seed + 1)
-    return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port',
+    dt, loss = one(sample_b, seed)          # the same images / targets / weights as rank 0's GPU batch when sample_b == batch
+    return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port', loss=[round(loss[0], 5), round(loss[1], 5)],
                 sample=f'1 forward+MultiBoxLoss pass over {sample_b} synthetic images ({cfg_name}, fp32, train-mode BN, '
                        f'torch-CPU, {cores} of {ncpu} hardware threads = the fastest of a 2-image probe over thread counts); '
                        f'{dt:.1f} s')
@@ -227,7 +227,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
-        cpu = cpu_baseline(a.config, a.cpu_sample, 100)
+        cpu = cpu_baseline(a.config, a.cpu_sample, gd.shard_seed(100, rank))
+        if a.cpu_sample == B:
+            # same inputs on both sides: the timed GPU batch against the CPU oracle, at the full batch size
+            cpu['gpu_vs_cpu_loss_rel'] = [round(abs(loss[i] - cpu['loss'][i]) / max(abs(cpu['loss'][i]), 1e-12), 7) for i in (0, 1)]
 
     if rank == 0:
         value = gd.aggregate_rate(world, B, a.steps, dt)
