@@ -51,10 +51,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int g = blockIdx.z, n0 = blockIdx.y * NB;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int nitems = (p.ntiles + 63) >> 6;      // work item = 64 tiles (16 per wave) x NB output channels
-    int item = blockIdx.x;
+    int g, n0, item;
+    if (PERSIST) {
+        g = blockIdx.z;
+        n0 = blockIdx.y * NB;
+        item = blockIdx.x;
+    } else {
+        // One item per workgroup, flat grid.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2: the
+        // output-channel blocks of one tile group get consecutive slots ON THE SAME XCD (ids 8 apart), so the second block
+        // finds the input patch in that L2 instead of fetching it from HBM again.
+        const int ncb = p.cout_pad / NB;
+        const int per_group = ((nitems + 7) >> 3) * 8 * ncb;
+        g = blockIdx.x / per_group;
+        const int id = blockIdx.x - g * per_group;
+        const int s = id >> 3;
+        item = (s / ncb) * 8 + (id & 7);
+        n0 = (s % ncb) * NB;
+    }
     if (item >= nitems) return;
 
     // Loading lane l fetches quad (l & 3) of tile (l >> 2): four consecutive lanes read one 64-byte segment, so the memory
@@ -377,7 +392,8 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     int gx = 256 * per_cu / ((p.cout_pad / NB) * d.groups);
     if (gx < 1) gx = 1;
     if (gx > nitems || !PERSIST) gx = nitems;
-    const dim3 grid(gx, p.cout_pad / NB, d.groups);
+    const dim3 grid = PERSIST ? dim3(gx, p.cout_pad / NB, d.groups)
+                              : dim3(((nitems + 7) / 8) * 8 * (p.cout_pad / NB) * d.groups, 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

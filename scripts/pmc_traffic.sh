@@ -20,6 +20,7 @@ def short(n):
     if m: return f'conv_igemm<{m.group(1)}x{m.group(2)}>'
     m = re.search(r'conv_thin_kernel<(\d+), (\d+)', n)
     if m: return f'conv_thin<{m.group(1)},{m.group(2)}>'
+    if 'conv_thin_wino_kernel' in n: return 'conv_thin_wino<16,16>'
     m = re.search(r'conv_wino_kernel<(\d+)', n)
     if m: return f'conv_wino<{m.group(1)}>'
     m = re.search(r'::(\w+_kernel)', n)
