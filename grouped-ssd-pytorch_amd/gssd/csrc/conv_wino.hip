@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         g = blockIdx.x / per_group;
         const int id = blockIdx.x - g * per_group;
         const int s = id >> 3;
-        item = (s / ncb) * 8 + (id & 7);
-        n0 = (s % ncb) * NB;
+        item = (id & 7) * ((nitems + 7) >> 3) + s / ncb;       // XCD k walks a contiguous eighth of the tile list: neighbouring
+        n0 = (s % ncb) * NB;                                    // items (overlapping patch rows) also share its L2
+        if (s / ncb >= ((nitems + 7) >> 3)) item = nitems;
     }
     if (item >= nitems) return;
 
