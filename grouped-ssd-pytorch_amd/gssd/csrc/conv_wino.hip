@@ -54,10 +54,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int nitems = (p.ntiles + 63) >> 6;      // work item = 64 tiles (16 per wave) x NB output channels
     int g, n0, item;
+    int item_end = nitems;
     if (PERSIST) {
+        // persistent workgroup b of gridDim.x walks the contiguous item range [b n / G, (b + 1) n / G): consecutive items
+        // overlap in two patch rows, which the same CU then finds in L1 / L2
         g = blockIdx.z;
         n0 = blockIdx.y * NB;
-        item = blockIdx.x;
+        item = (int)(((long long)blockIdx.x * nitems) / gridDim.x);
+        item_end = (int)(((long long)(blockIdx.x + 1) * nitems) / gridDim.x);
     } else {
         // One item per workgroup, flat grid.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2: the
         // output-channel blocks of one tile group get consecutive slots ON THE SAME XCD (ids 8 apart), so the second block
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         n0 = (s % ncb) * NB;                                    // items (overlapping patch rows) also share its L2
         if (s / ncb >= ((nitems + 7) >> 3)) item = nitems;
     }
-    if (item >= nitems) return;
+    if (item >= item_end) return;
 
     // Loading lane l fetches quad (l & 3) of tile (l >> 2): four consecutive lanes read one 64-byte segment, so the memory
     // pipe sees 16 requests per instruction instead of 64.  The MFMA wants lane (r, kq) to hold quad kq of tile r: a fixed
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     for (int q = 0; q < 16; ++q) load_raw1(in_cur, valid_cur, 0, q);
     int buf = 0;
 
-    // The workgroup is persistent: it walks items item, item + gridDim.x, ... of its (group, output-channel block).  The
+    // The workgroup is persistent: it walks the items of its range of its (group, output-channel block).  The
     // stream of (item, chunk) steps is software pipelined as one sequence -- the loads of the NEXT step (next chunk, or the
     // next item's first chunk) are issued piecewise between the MFMA groups of the current one -- so the load latency at an
     // item boundary hides behind the last chunk's MFMAs and the epilogue's stores overlap the next item's first chunk.
     for (;;) {
-        const int item_next = item + gridDim.x;
-        const bool have_next = PERSIST && item_next < nitems;
+        const int item_next = item + 1;
+        const bool have_next = PERSIST && item_next < item_end;
         unsigned in_next = in_cur, valid_next = 0;
         if (have_next) decode(item_next, in_next, valid_next);
         for (int c = 0; c < nchunks; ++c) {
