@@ -51,10 +51,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, kq = lane >> 4;
-    const int g = blockIdx.y / tiles_per_group;
-    const int n0g = (blockIdx.y % tiles_per_group) * BN;
+    // Flat XCD-aware grid: workgroup ids go round-robin over the 8 XCDs (one L2 each).  Id L -> XCD L & 7, slot L >> 3; the
+    // slots of an XCD run through all (group, N-tile) pairs of one M tile before the next M tile, so the A rows a wide
+    // layer reads once per N tile come from that L2 after the first fetch (fuse_11: 4 N tiles -> HBM fetch 384 -> ~100 MB).
+    // (per-image batched GEMMs keep the plain 2-D grid: their M extent is a handful of tiles and padding it to 8 only adds
+    // empty workgroups)
+    const int ny = p.groups * tiles_per_group;
+    int mt, by;
+    if (p.m_per_image) {
+        mt = blockIdx.x;
+        by = blockIdx.y;
+    } else {
+        const int slot = blockIdx.x >> 3;
+        mt = (slot / ny) * 8 + (blockIdx.x & 7);
+        by = slot % ny;
+    }
+    if (mt * BM >= M) return;
+    const int g = by / tiles_per_group;
+    const int n0g = (by % tiles_per_group) * BN;
     const int cout_g = p.Cout / p.groups;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = mt * BM;
     const int img = p.m_per_image ? blockIdx.z : 0;
     const int kz = p.m_per_image ? 0 : blockIdx.z;   // split-K slice (split_k > 1 only without m_per_image)
     const int HoWo = p.Ho * p.Wo;
@@ -318,7 +334,8 @@ int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     }
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;
-    dim3 grid((M + BM - 1) / BM, d.groups * tiles, d.m_per_image ? images : d.split_k);
+    const int mtiles = (M + BM - 1) / BM;
+    dim3 grid = d.m_per_image ? dim3(mtiles, d.groups * tiles, images) : dim3((mtiles + 7) / 8 * 8 * d.groups * tiles, 1, d.split_k);
     static_assert(BM % (8 * WM * WN) == 0, "A rows must split evenly over the waves");
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, d, M, tiles);
     GSSD_CHECK_LAUNCH();
