@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
     double* lacc = reinterpret_cast<double*>(smem + p.acc_off);     // [2][COUT]
     for (int c = tid; c < 2 * COUT; c += 256) lacc[c] = 0.0;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // workgroup ids go round-robin over the 8 XCDs: remap so that each XCD works on gridDim.x / 8 CONSECUTIVE tiles of every
+    // sweep (the halo columns / rows neighbouring tiles share then come from that XCD's L2)
+    const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
         const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;

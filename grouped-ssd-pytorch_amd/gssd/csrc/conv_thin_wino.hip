@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
     // batch sums: fp32 within a tile, fp64 per thread across the tiles of the workgroup (a thread always owns the same four
     // channels), one LDS / global flush at the very end
     double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // workgroup ids go round-robin over the 8 XCDs: remap so that each XCD works on gridDim.x / 8 CONSECUTIVE tiles of every
+    // sweep (the halo columns / rows neighbouring tiles share then come from that XCD's L2)
+    const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
         stage_patch(tile, 0);                                  // the other resident workgroup computes meanwhile
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
