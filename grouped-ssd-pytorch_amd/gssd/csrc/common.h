@@ -55,3 +55,5 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream);
 // conv_thin_wino.hip: conv1_2's shape class (4 x 16 -> 16 channels, large map) with Winograd weights; else returns 1
 int gssd_try_conv_thin_wino(const gssd_conv_desc& d, hipStream_t stream);
 int gssd_try_conv_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
+// conv_patch_wgrad.hip: conv2_1 .. conv3_3 shapes (patch-staged, one phase group per workgroup); else returns 1
+int gssd_try_conv_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);

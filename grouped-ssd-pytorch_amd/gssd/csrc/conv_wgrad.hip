@@ -13,6 +13,7 @@
 //
 // Replaces autograd's conv weight-gradient kernels (cuDNN wgrad behind loss.backward(),
 // train_lesion_multiphase_v2.py:247-248).
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -278,6 +279,10 @@ extern "C" int gssd_conv2d_wgrad_f32(const gssd_conv_desc* dp, const float* dy, 
     GSSD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr) && (d.in_scale == nullptr) == (d.in_pad == nullptr));
     {
         const int rc = gssd_try_conv_thin_wgrad(d, dy, dw_packed, as_stream(stream));    // conv1_1 / conv1_2: patch-staged
+        if (rc != 1) return rc;
+    }
+    {
+        const int rc = gssd_try_conv_patch_wgrad(d, dy, dw_packed, as_stream(stream));   // conv2_1 .. conv3_3: patch-staged per group
         if (rc != 1) return rc;
     }
     WgradParams p;

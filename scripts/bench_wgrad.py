@@ -5,7 +5,7 @@ import torch
 from gssd import ops
 B = 32
 LAYERS = [('conv1_1', 300, 16, 64, 3, 1, 1, 1, 4), ('conv1_2', 300, 64, 64, 3, 1, 1, 1, 4), ('conv2_1', 150, 64, 128, 3, 1, 1, 1, 4),
-          ('conv2_2', 150, 128, 128, 3, 1, 1, 1, 4), ('conv3_2', 75, 256, 256, 3, 1, 1, 1, 4), ('conv4_2', 38, 512, 512, 3, 1, 1, 1, 4),
+          ('conv2_2', 150, 128, 128, 3, 1, 1, 1, 4), ('conv3_1', 75, 128, 256, 3, 1, 1, 1, 4), ('conv3_2', 75, 256, 256, 3, 1, 1, 1, 4), ('conv4_2', 38, 512, 512, 3, 1, 1, 1, 4),
           ('conv5_1', 19, 512, 512, 3, 1, 1, 1, 4), ('conv6', 19, 512, 1024, 3, 1, 6, 6, 4), ('fuse_11', 38, 512, 512, 1, 1, 0, 1, 1),
           ('head1', 19, 1024, 36, 3, 1, 1, 1, 1)]
 dev = torch.device('cuda:0')
