@@ -168,7 +168,12 @@ int launch_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipS
         attr_set = true;
     }
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
-    int gx = 512 / d.groups;                              // two resident workgroups per CU over all groups
+    static int per_cu = 0;                                // resident workgroups per CU: 2 for the 64-channel variant, up to 4
+    if (!per_cu) {                                        // for the small ones (they hide each other's staging latency)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (per_cu > 4) per_cu = 4;
+    }
+    int gx = 256 * per_cu / d.groups;
     if (gx < 1) gx = 1;
     if (ntiles < gx) gx = (int)ntiles;
     hipLaunchKernelGGL(kern, dim3(gx, d.groups), dim3(256), smem, stream, p);
