@@ -7,12 +7,15 @@ data-path collective, so N GPUs = N independent batch-32 shards (
 only communication is the timing barrier.  Inputs (resized 300x300 slices, targets, weights) are resident in
 HBM before the timed region.  Prints ONE JSON line on rank 0.
 
-  roofline     : the dominant kernel (the conv_igemm tile instance with the most time).  achieved = algorithmic
-                 FLOPs per launch / average launch duration, measured live with HIP events recorded on the
-                 launch stream around every conv launch of the timed region.  fp32 runs are bound by the fp32
-                 matrix/vector peak (157.3 TFLOP/s), not HBM.
-  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, all host cores) timed on a
-                 bounded sample of the same workload, rank 0, N = 1 only.
+  roofline     : the dominant kernel instance (most time in two untimed survey passes that bracket every conv launch:
+                 that survey is the `kernels` breakdown).  achieved = algorithmic FLOPs per launch / average launch
+                 duration, measured live with HIP events recorded on the launch stream around every launch of that
+                 instance inside the timed region (only those: each event pair costs ~3 us of GPU idle).  fp32 runs are
+                 bound by the fp32 matrix/vector peak (157.3 TFLOP/s), not HBM.  traffic = HBM bytes per
+                 launch from profiles/pmc_summary.json (FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.sh).
+  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, fastest thread count of a probe) timed
+                 on the same 32 images as rank 0's GPU batch, rank 0, N = 1 only; gpu_vs_cpu_loss_rel = agreement of the
+                 two losses on that batch.
 """
 import argparse
 import json
@@ -122,9 +125,35 @@ def main():
     def sync():
         gd.barrier(dev)
 
+    class EventList(list):
+        only = None
+
+    def aggregate(evs):
+        agg = {}
+        for (name, flops, byts), e0, e1 in evs:
+            r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += e0.elapsed_time(e1)
+            r[2] += flops
+            r[3] += byts
+        return agg
+
     for _ in range(a.warmup):
         ll, lc = step()
-    events = None if a.no_events else []
+    # Per-launch HIP events cost ~3 us of GPU idle each.  Two untimed passes bracket EVERY conv launch (the `kernels`
+    # breakdown and the choice of the dominant instance); in the timed region only the dominant instance's launches are
+    # bracketed, live, on the launch stream -- that is where `roofline` comes from.
+    survey, events = None, None
+    if not a.no_events:
+        survey = EventList()
+        net.__dict__['_events'] = survey
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        net.__dict__['_events'] = None
+        sagg = aggregate(survey)
+        events = EventList()
+        events.only = {max(sagg, key=lambda k: sagg[k][1])}
     net.__dict__['_events'] = events
     sync()
     t0 = time.perf_counter()
@@ -141,18 +170,11 @@ def main():
     roof = None
     kernels = {}
     if events:
-        agg = {}
-        for (name, flops, byts), e0, e1 in events:
-            ms = e0.elapsed_time(e1)
-            r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            r[0] += 1
-            r[1] += ms
-            r[2] += flops
-            r[3] += byts
-        for name, (n, ms, fl, by) in agg.items():
-            kernels[name] = dict(launches_per_step=n // a.steps, avg_us=round(1e3 * ms / n, 2),
-                                 ms_per_step=round(ms / a.steps, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
-                                 alg_gbs=round(by / (ms * 1e-3) / 1e9, 1))
+        for name, (n, ms, fl, by) in sagg.items():
+            kernels[name] = dict(launches_per_step=n // 2, avg_us=round(1e3 * ms / n, 2),
+                                 ms_per_step=round(ms / 2, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
+                                 alg_gbs=round(by / (ms * 1e-3) / 1e9, 1), measured='2 untimed passes before the timed region')
+        agg = aggregate(events)
         dom = max(agg, key=lambda k: agg[k][1])
         n, ms, fl, by = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12

@@ -547,8 +547,9 @@ class _Plan:
                 if rc != 0:
                     _lib.check(rc)
         else:
+            only = getattr(events, 'only', None)       # optional set of kernel-instance names to bracket (bench.py)
             for st in self.steps:
-                if st.tag is not None:
+                if st.tag is not None and (only is None or st.tag[0] in only):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = st.fn(*st.args, stream)
