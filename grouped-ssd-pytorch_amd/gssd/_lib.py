@@ -83,6 +83,8 @@ SIGNATURES = {
     'gssd_eval_workspace_bytes': (C.c_longlong, [c_i]),
     'gssd_eval_ap': (c_i, [c_fp, c_fp, c_i, c_i, c_d, c_i, c_fp, C.c_longlong, c_fp, c_fp]),
     'gssd_gemm_nt_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
+    'gssd_gemm_nt_batched_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, C.c_longlong, C.c_longlong, C.c_longlong, c_i,
+                                        c_fp]),
     'gssd_gemm_tn_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_col2im_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),

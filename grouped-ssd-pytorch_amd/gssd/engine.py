@@ -32,6 +32,7 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
+USE_LIB_BMM = os.environ.get('GSSD_NO_LIB_BMM', '0') != '1'
 
 class _Step:
     __slots__ = ('fn', 'args', 'keep', 'tag')
@@ -482,9 +483,21 @@ class _Plan:
         fn = lib.gssd_conv2d_nhwc_f32
         self._add(fn, (C.byref(d1),), keep=(d1, w_tp, b_tp))
         self._add(fn, (C.byref(d2),), keep=d2)
-        self._add(fn, (C.byref(d3),), keep=d3)
+        if USE_LIB_BMM:
+            # the reference's two torch.bmm calls: plain batched GEMMs -> rocBLAS (conv_igemm's K = C/8 = 64 product is
+            # prologue / epilogue bound at 42 TFLOP/s)
+            self._add(lib.gssd_gemm_nt_batched_f32, (tp.data_ptr(), tp[0, 0, C8:].data_ptr(), S.data_ptr(), N, N, C8, C4, C4, Np,
+                                                    N * C4, N * C4, N * Np, B), keep=d3,
+                      tag=('bmm_rocblas', 2.0 * B * N * N * C8, 4.0 * B * (2 * N * C8 + N * N)))
+        else:
+            self._add(fn, (C.byref(d3),), keep=d3)
         self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
-        self._add(fn, (C.byref(d4),), keep=d4)
+        if USE_LIB_BMM:
+            self._add(lib.gssd_gemm_nt_batched_f32, (S.data_ptr(), gT.data_ptr(), ag.data_ptr(), N, C2, N, Np, Np, C2, N * Np,
+                                                    C2 * Np, N * C2, B), keep=d4,
+                      tag=('bmm_rocblas', 2.0 * B * N * N * C2, 4.0 * B * (N * N + 2 * N * C2)))
+        else:
+            self._add(fn, (C.byref(d4),), keep=d4)
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, N, Np)

@@ -268,6 +268,9 @@ int gssd_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int
                      const float* bias, int accumulate, gssd_stream_t stream);
 int gssd_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K2, int lda, int ldb, int ldc, int accumulate,
                      gssd_stream_t stream);
+/* batched nt: C_b = A_b . B_b^T, operands stride* floats apart (the two torch.bmm of Self_Attn, layers/self_attn.py:71,80) */
+int gssd_gemm_nt_batched_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             long long strideA, long long strideB, long long strideC, int batch, gssd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
