@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- images/s of forward + MultiBoxLoss (train-mode BatchNorm, no backward) of the GSSD detector on
-MI355X, the metric BASELINE.json names, on its configs[1] workload (GSSD, groups 4, 4-phase CT, batch 32/GPU).
+"""bench.py -- images/s of forward + MultiBoxLoss (train-mode BatchNorm, no backward) of the GSSD++ detector on MI355X:
+the metric BASELINE.json names, on its configs[2] workload (GSSD++: self-attention + self-attention-base + 1 deformable
+conv layer with 4 deformable groups, 4-phase CT, batch 32 per GPU) -- the largest single-GPU configuration and the N = 1
+point of configs[3]'s scaling curve.  configs[1] (plain GSSD) is measured the same way and reported as `secondary` (N = 1).
 
 One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); the path shards by image with no
-data-path collective, so N GPUs = N independent batch-32 shards ("scaling": "weak") and the
-only communication is the timing barrier.  Inputs (resized 300x300 slices, targets, weights) are resident in
-HBM before the timed region.  Prints ONE JSON line on rank 0.
+data-path collective, so N GPUs = N independent batch-32 shards ("scaling": "weak") and the only
+communication is the timing barrier.  Inputs (resized 300x300 slices, targets, weights) are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
 
-  roofline     : the dominant kernel instance (most time in two untimed survey passes that bracket every conv launch:
-                 that survey is the `kernels` breakdown).  achieved = algorithmic FLOPs per launch / average launch
+  value        : EXACTLY --steps timed steps between barrier + synchronize pairs, max over ranks.  `steady` repeats the
+                 measurement over 100 more steps (>= 1 s of GPU time) so the short default region can be judged.
+  roofline     : the dominant hand-written kernel instance (most time in two untimed survey passes that bracket every tagged
+                 launch: that survey is the `kernels` breakdown).  achieved = algorithmic FLOPs per launch / average launch
                  duration, measured live with HIP events recorded on the launch stream around every launch of that
                  instance inside the timed region (only those: each event pair costs ~3 us of GPU idle).  fp32 runs are
-                 bound by the fp32 matrix/vector peak (157.3 TFLOP/s), not HBM.  traffic = HBM bytes per
-                 launch from profiles/pmc_summary.json (FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.sh).
-  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, fastest thread count of a probe) timed
-                 on the same 32 images as rank 0's GPU batch, rank 0, N = 1 only; gpu_vs_cpu_loss_rel = agreement of the
-                 two losses on that batch.
+                 bound by the fp32 matrix/vector peak (157.3 TFLOP/s), not HBM; bf16 runs by HBM.
+                 traffic = HBM bytes per launch from the committed PMC passes (profiles/pmc_summary.json: FETCH_SIZE /
+                 WRITE_SIZE in separate --pmc runs of this same command, scripts/pmc_traffic.sh).
+  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, fastest thread count of a probe), 1 warm-up
+                 + 3 timed passes over the same 32 images as rank 0's GPU batch, median; rank 0, N = 1 only;
+                 gpu_vs_cpu_loss_rel = agreement of the two losses on that batch.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # before anything initialises the HIP runtime (RCCL / dmabuf IPC)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'grouped-ssd-pytorch_amd')
@@ -32,18 +40,26 @@ for p in (ROOT, PKG):
 import torch                                                              # noqa: E402
 
 CONFIGS = {
-    # name: (build_ssd positional args after (phase, size, num_classes), oracle flags, GFLOP/img, MB/img train-mode)
+    # name: (build_ssd positional args after (phase, size, num_classes), oracle flags, GFLOP/img, MB/img train-mode fp32)
     'gssd': ((True, 4, 4, 1, True, False, False, 0, 1, False, False, 1), dict(), 17.47, 374.0),
     'gssdpp': ((True, 4, 4, 1, True, True, True, 1, 4, True, False, 1),
                dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
                     dcn_cat_sab=True), 39.4, 402.0),
 }
+WORKLOAD = {
+    'gssd': 'gssd (BASELINE configs[1]): build_ssd(groups 4, BN, fuse) forward + MultiBoxLoss, train-mode BN, '
+            '[B,12,300,300] slices (4-phase 512x512 CT resized outside the timed region)',
+    'gssdpp': 'gssdpp (BASELINE configs[2], GSSD++): build_ssd(groups 4, BN, fuse, self-attention + self-attention-base, '
+              '1 DCN layer, 4 deformable groups, dcn_cat_sab) forward + MultiBoxLoss, train-mode BN, [B,12,300,300] slices '
+              '(4-phase 512x512 CT resized outside the timed region)',
+}
 PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline(cfg_name, sample_b, seed):
-    """Oracle forward + loss on the host cores (never the product path)."""
+    """Oracle forward + loss on the host cores (never the product path): 1 warm-up + 3 timed passes, median."""
     from oracle import gssd_oracle as O
     from gssd import synth
     from models.ssd_multiphase_custom_group import build_ssd
@@ -62,7 +78,7 @@ def cpu_baseline(cfg_name, sample_b, seed):
         ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), pri, tg)[:2]
         return time.perf_counter() - t0, (float(ll), float(lc))
     # pick the intra-op thread count that is fastest for this graph on this host (all cores oversubscribes oneDNN's
-    # grouped convs on big boxes): 2-image probes double as the warm-up
+    # grouped convs on big boxes) with 2-image probes
     best = None
     for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         torch.set_num_threads(nt)
@@ -72,22 +88,154 @@ def cpu_baseline(cfg_name, sample_b, seed):
             best = (t, nt)
     cores = best[1]
     torch.set_num_threads(cores)
-    dt, loss = one(sample_b, seed)          # the same images / targets / weights as rank 0's GPU batch when sample_b == batch
+    one(sample_b, seed)                       # warm-up
+    runs = [one(sample_b, seed) for _ in range(3)]
+    dts = [r[0] for r in runs]
+    dt, loss = statistics.median(dts), runs[0][1]
     return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port', loss=[round(loss[0], 5), round(loss[1], 5)],
-                sample=f'1 forward+MultiBoxLoss pass over {sample_b} synthetic images ({cfg_name}, fp32, train-mode BN, '
-                       f'torch-CPU, {cores} of {ncpu} hardware threads = the fastest of a 2-image probe over thread counts); '
-                       f'{dt:.1f} s')
+                passes_s=[round(t, 2) for t in dts],
+                sample=f'forward+MultiBoxLoss over the same {sample_b} synthetic images as the GPU batch ({cfg_name}, fp32, '
+                       f'train-mode BN, torch-CPU oracle, {cores} of {ncpu} hardware threads = the fastest of a 2-image probe '
+                       f'over thread counts): 1 warm-up + 3 timed passes, median {dt:.1f} s')
+
+
+class EventList(list):
+    only = None
+
+
+def aggregate(evs):
+    agg = {}
+    for (name, flops, byts), e0, e1 in evs:
+        r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+        r[2] += flops
+        r[3] += byts
+    return agg
+
+
+def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
+    """Build the net of one config on this rank, time --steps forward + loss steps; returns the result dict."""
+    from gssd import synth
+    from layers.modules import MultiBoxLoss
+    from models.ssd_multiphase_custom_group import build_ssd
+    args, flags, gflop_img, mb_img = CONFIGS[cfg]
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    if dtype == 'bf16':
+        net.compute_dtype = 'bf16'
+        mb_img = mb_img / 2
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    B = a.batch
+    x = synth.synth_images(B, seed=gd.shard_seed(100, rank)).to(dev)      # rank r owns its own 32 images
+    tg = [t.to(dev) for t in synth.synth_targets(B, seed=gd.shard_seed(100, rank))]
+
+    def step():
+        with torch.no_grad():
+            return crit(net(x), tg)
+
+    def sync():
+        gd.barrier(dev)
+
+    # the first step starts from the same state as the CPU baseline (a training forward advances spectral norm's u / v and
+    # the BN running statistics): its loss is the one compared against the oracle's
+    ll, lc = step()
+    first_loss = (float(ll), float(lc))
+    for _ in range(a.warmup - 1):
+        ll, lc = step()
+    # Per-launch HIP events cost ~3 us of GPU idle each.  Two untimed passes bracket EVERY tagged launch (the `kernels`
+    # breakdown and the choice of the dominant instance); in the timed region only the dominant instance's launches are
+    # bracketed, live, on the launch stream -- that is where `roofline` comes from.
+    sagg, events = None, None
+    if not a.no_events:
+        survey = EventList()
+        net.__dict__['_events'] = survey
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        net.__dict__['_events'] = None
+        sagg = aggregate(survey)
+        events = EventList()
+        hand = {k: v for k, v in sagg.items() if 'rocblas' not in k}        # roofline on a hand-written kernel
+        events.only = {max(hand, key=lambda k: hand[k][1])}
+    net.__dict__['_events'] = events
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ll, lc = step()
+    sync()
+    dt = time.perf_counter() - t0
+    net.__dict__['_events'] = None
+    loss = (float(ll), float(lc))
+    if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
+        raise SystemExit(f'non-finite loss {loss}')
+    dt = gd.max_over_ranks(dt, dev)
+    # the same measurement over 100 more steps, no events
+    sdt = 0.0
+    if a.steady > 0:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steady):
+            step()
+        sync()
+        sdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+
+    roof, kernels = None, {}
+    peak_t = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
+    if events:
+        for name, (n, ms, fl, by) in sagg.items():
+            kernels[name] = dict(launches_per_step=n // 2, avg_us=round(1e3 * ms / n, 2),
+                                 ms_per_step=round(ms / 2, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
+                                 alg_gbs=round(by / (ms * 1e-3) / 1e9, 1))
+        agg = aggregate(events)
+        dom = max(agg, key=lambda k: agg[k][1])
+        n, ms, fl, by = agg[dom]
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(cfg if dtype == 'f32' else f'{cfg}_{dtype}', {}).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        if ach_b / PEAK_HBM_GBS > ach_t / peak_t:
+            roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
+        else:
+            roof = dict(bound='mfma', achieved=round(ach_t, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / peak_t, 4))
+        roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
+                    alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
+                    note=('fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
+                          else 'bf16 MFMA, fp32 accumulate')
+                         + ('; achieved = ALGORITHMIC (direct-convolution) FLOPs per second: the Winograd F(2x2,3x3) kernel '
+                            'issues 2.25x fewer MFMA FLOPs than that, so its MFMA-pipe utilisation is achieved/2.25/peak'
+                            if dom.startswith('conv_wino') else ''))
+    value = gd.aggregate_rate(world, B, a.steps, dt)
+    res = dict(value=round(value, 2), ms_per_step=round(1e3 * dt / a.steps, 3), loss=[round(loss[0], 5), round(loss[1], 5)],
+               steady=(dict(steps=a.steady, ms_per_step=round(1e3 * sdt / a.steady, 3),
+                            value=round(gd.aggregate_rate(world, B, a.steady, sdt), 2)) if a.steady > 0 else None),
+               workload=WORKLOAD[cfg] + (', bf16 storage / bf16 MFMA / fp32 accumulate + BN statistics + loss' if dtype == 'bf16' else ''),
+               alg_gflop_per_img=gflop_img, alg_mb_per_img=mb_img,
+               whole_path=dict(tflops=round(value * gflop_img / 1e3, 2),
+                               frac_mfma_peak=round(value * gflop_img / 1e3 / (peak_t * world), 4),
+                               alg_gbs=round(value * mb_img / 1e3, 1),
+                               frac_hbm_peak=round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)),
+               first_step_loss=[round(first_loss[0], 5), round(first_loss[1], 5)], roofline=roof, kernels=kernels)
+    return res, net, crit, x, tg, first_loss
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', default='gssd', choices=list(CONFIGS))
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steady', type=int, default=100, help='extra steps timed after the --steps region (reported as `steady`)')
+    ap.add_argument('--config', default='gssdpp', choices=list(CONFIGS))
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary (plain GSSD) measurement')
     ap.add_argument('--full-step', type=int, default=0, metavar='K',
                     help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
                          'reported as "full_step" beside the fwd+loss metric (BASELINE config 4)')
@@ -106,93 +254,8 @@ def main():
     gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)
 
     from gssd import synth
-    from layers.modules import MultiBoxLoss
-    from models.ssd_multiphase_custom_group import build_ssd
-    args, flags, gflop_img, mb_img = CONFIGS[a.config]
-    net = build_ssd('train', 300, 2, *args)
-    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
-    net = net.to(dev).train()
-    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
     B = a.batch
-    x = synth.synth_images(B, seed=gd.shard_seed(100, rank)).to(dev)      # rank r owns its own 32 images
-    tg = [t.to(dev) for t in synth.synth_targets(B, seed=gd.shard_seed(100, rank))]
-
-    def step():
-        with torch.no_grad():
-            out = net(x)
-            return crit(out, tg)
-
-    def sync():
-        gd.barrier(dev)
-
-    class EventList(list):
-        only = None
-
-    def aggregate(evs):
-        agg = {}
-        for (name, flops, byts), e0, e1 in evs:
-            r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            r[0] += 1
-            r[1] += e0.elapsed_time(e1)
-            r[2] += flops
-            r[3] += byts
-        return agg
-
-    for _ in range(a.warmup):
-        ll, lc = step()
-    # Per-launch HIP events cost ~3 us of GPU idle each.  Two untimed passes bracket EVERY conv launch (the `kernels`
-    # breakdown and the choice of the dominant instance); in the timed region only the dominant instance's launches are
-    # bracketed, live, on the launch stream -- that is where `roofline` comes from.
-    survey, events = None, None
-    if not a.no_events:
-        survey = EventList()
-        net.__dict__['_events'] = survey
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        net.__dict__['_events'] = None
-        sagg = aggregate(survey)
-        events = EventList()
-        events.only = {max(sagg, key=lambda k: sagg[k][1])}
-    net.__dict__['_events'] = events
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ll, lc = step()
-    sync()
-    dt = time.perf_counter() - t0
-    net.__dict__['_events'] = None
-    loss = (float(ll), float(lc))
-    if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
-        raise SystemExit(f'non-finite loss {loss}')
-    dt = gd.max_over_ranks(dt, dev)
-
-    roof = None
-    kernels = {}
-    if events:
-        for name, (n, ms, fl, by) in sagg.items():
-            kernels[name] = dict(launches_per_step=n // 2, avg_us=round(1e3 * ms / n, 2),
-                                 ms_per_step=round(ms / 2, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
-                                 alg_gbs=round(by / (ms * 1e-3) / 1e9, 1), measured='2 untimed passes before the timed region')
-        agg = aggregate(events)
-        dom = max(agg, key=lambda k: agg[k][1])
-        n, ms, fl, by = agg[dom]
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(a.config, {}).get(dom, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        roof = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=dom,
-                    avg_launch_us=round(1e3 * ms / n, 2), alg_flop_per_launch=round(fl / n),
-                    alg_bytes_per_launch=round(by / n),
-                    note='fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)'
-                         + ('; achieved = ALGORITHMIC (direct-convolution) FLOPs per second: the Winograd F(2x2,3x3) kernel '
-                            'issues 2.25x fewer MFMA FLOPs than that, so its MFMA-pipe utilisation is achieved/2.25/peak'
-                            if dom.startswith('conv_wino') else ''))
+    res, net, crit, x, tg, loss = measure(a.config, a, dev, gd, rank, world, a.dtype)
 
     full = None
     if a.full_step > 0:
@@ -211,17 +274,16 @@ def main():
             return n
         for _ in range(2):
             nred = train_step()
-        sync()
+        gd.barrier(dev)
         t0 = time.perf_counter()
         for _ in range(a.full_step):
             train_step()
-        sync()
+        gd.barrier(dev)
         fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
         full = dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
                     ms_per_step=round(1e3 * fdt / a.full_step, 3), allreduce_elems=int(nred),
-                    note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward ('
-                         + ('HIP: gssd/backward.py' if net._engine.has_hip_backward() else 'interim ATen recomputation')
-                         + ') + flat-buffer gradient all-reduce (RCCL) + SGD')
+                    note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (HIP: gssd/backward.py) + flat-buffer '
+                         'gradient all-reduce (RCCL) + SGD')
 
     # Device-side input stage, timed on its own: raw uint8 [B,4,512,512,3] -> [B,12,300,300] fp32.  The
     # headline keeps the reference's split (resize in the loader, outside the timed region).
@@ -244,32 +306,35 @@ def main():
         sby = raw.numel() + xs.numel() * 4
         stage_info = dict(ms_per_batch=round(sms, 4), alg_bytes=sby, alg_gbs=round(sby / sms / 1e6, 1),
                           frac_hbm_peak=round(sby / sms / 1e6 / PEAK_HBM_GBS, 4), dtype='u8',
-                          note='Pillow-exact 8-bit bicubic 512->300 + mean + min-max + [B,12,300,300] pack; 3 launches')
+                          note='Pillow-exact 8-bit bicubic 512->300 + mean + min-max + [B,12,300,300] pack')
         del raw, xs
+
+    del net, crit, x, tg
+    torch.cuda.empty_cache()
+    secondary = None
+    if world == 1 and not a.no_secondary and a.config == 'gssdpp':
+        sres = measure('gssd', a, dev, gd, rank, world, a.dtype)[0]
+        secondary = dict(metric='512x512 4-phase CT img/s (fwd+loss)', unit='img/s', **sres)
+        torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(a.config, a.cpu_sample, gd.shard_seed(100, rank))
         if a.cpu_sample == B:
-            # same inputs on both sides: the timed GPU batch against the CPU oracle, at the full batch size
+            # same inputs and same starting state on both sides: the GPU's first step against the CPU oracle, at the full batch
             cpu['gpu_vs_cpu_loss_rel'] = [round(abs(loss[i] - cpu['loss'][i]) / max(abs(cpu['loss'][i]), 1e-12), 7) for i in (0, 1)]
 
     if rank == 0:
-        value = gd.aggregate_rate(world, B, a.steps, dt)
         line = {
-            'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': round(value, 2), 'unit': 'img/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{a.config}: build_ssd(groups 4, BN, fuse) forward + MultiBoxLoss, train-mode BN, '
-                                   f'[B,12,300,300] slices (4-phase 512x512 CT resized outside the timed region)',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
-                       'alg_gflop_per_img': gflop_img, 'alg_mb_per_img': mb_img},
-            'whole_path': {'tflops': round(value * gflop_img / 1e3, 2),
-                           'frac_f32_peak': round(value * gflop_img / 1e3 / (PEAK_F32_TFLOPS * world), 4),
-                           'alg_gbs': round(value * mb_img / 1e3, 1),
-                           'frac_hbm_peak': round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)},
-            'loss': [round(loss[0], 5), round(loss[1], 5)],
-            'roofline': roof, 'kernels': kernels, 'cpu_baseline': cpu, 'full_step': full, 'input_stage': stage_info,
+            'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': res['value'], 'unit': 'img/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': res['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
+                       'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
+            'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
+            'first_step_loss': res['first_step_loss'],
+            'roofline': res['roofline'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary,
+            'full_step': full, 'input_stage': stage_info,
         }
         print(json.dumps(line))
     gd.finish()

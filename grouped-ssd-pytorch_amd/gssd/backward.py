@@ -48,6 +48,8 @@ class BackwardPlan:
                 self._head(r)
             elif kind == 'convbn':
                 self._convbn(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
+            elif kind == 'convrelu':
+                self._convrelu(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
             elif kind == 'pool':
                 self._pool(r)
             elif kind == 'l2norm':
@@ -190,6 +192,25 @@ class BackwardPlan:
         self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
         if need_dgrad:
             self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
+
+    def _convrelu(self, r, need_dgrad=True):
+        """conv + ReLU of the vanilla SSD (models/ssd.py:104-118, no BatchNorm): dz = d(out) * [out > 0] (the mask of the
+        stored post-ReLU output equals the pre-activation's), bias gradient = column sums, then wgrad / dgrad."""
+        B, H, Ho, Cin, Cout, conv, out = self.B, r['H'], r['Ho'], r['Cin'], r['Cout'], r['conv'], r['out']
+        dout = self._grad_of(out)
+        if dout is None:
+            raise _lib.GssdError(f"no gradient reaches {r['name']}")
+        dz = self._buf(B, Ho, Ho, Cout)
+        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), out.data_ptr(), 0, 0, dz.data_ptr(), 0, B, Ho, Ho, Cout, Ho, Ho,
+                                               0, 1, 0, 1))
+        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dz.data_ptr(), B * Ho * Ho, Cout, Cout, cs.data_ptr()))
+        self._bias_from_colsum(cs, conv.bias)
+        cin_real = conv.weight.shape[1]
+        dwp, K = self._wgrad(r['desc'], dz, conv, cin_real, Cin, r['k'], Cout)
+        self._unpack(dwp, K, 0, conv.weight, cin_real, Cin, r['k'])
+        if need_dgrad:
+            self._dgrad(r, dz, r['x_in'], conv, 1, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
 
     def _pool(self, r):
         B, H, Cc, Hp = self.B, r['H'], r['C'], r['Hp']

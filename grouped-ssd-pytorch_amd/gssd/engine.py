@@ -78,33 +78,52 @@ class GssdEngine:
         self._packed = {}        # name -> packed weight tensor
         self._pack_jobs = []     # (callable) refreshers
         self._versions = None
+        self._ptrs = None
         self._param_list = None
+        self._ptr_list = None
         self._bn_list = None
 
     # ------------------------------------------------------------------------------------------
-    def _param_versions(self):
-        # the parameter / BatchNorm lists are walked once (nn.Module traversal costs ~0.5 ms per call on this net); a module
-        # that gains or loses parameters after the first forward must call invalidate()
+    def _state(self):
+        """(version counters of the parameters, storage pointers of every parameter AND buffer).  The launch plans hold raw
+        device pointers of all of them (BN gamma / beta / running stats, conv biases, L2Norm weight, spectral-norm u / v,
+        sigma, ...): a changed pointer (``p.data = ...``, a replaced head, ``bn.running_mean = ...``) rebuilds the plans, a
+        changed version only re-runs the weight pack jobs.  The module tree is walked once (nn.Module traversal costs
+        ~0.5 ms per call on this net); a module that gains or loses parameters after the first forward must call
+        invalidate()."""
         if self._param_list is None:
             self._param_list = list(self.net.parameters())
+            self._ptr_list = self._param_list + list(self.net.buffers())
             self._bn_list = [m for m in self.net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-        return tuple((p._version, p.data_ptr()) for p in self._param_list)
+        return tuple([p._version for p in self._param_list]), tuple([t.data_ptr() for t in self._ptr_list])
 
     def invalidate(self):
+        for plans in self._plans.values():
+            for pl in plans:
+                pl.generation += 1        # a backward still holding one of these plans must not use it
         self._plans.clear()
         self._packed.clear()
         self._pack_jobs = []
         self._versions = None
+        self._ptrs = None
         self._param_list = None
+        self._ptr_list = None
         self._bn_list = None
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, x, training, events=None):
+    MAX_PLANS_IN_FLIGHT = 4
+
+    def forward_plan(self, x, training, events=None):
+        """Run one forward; returns (loc, conf, plan).  A plan whose last grad-enabled forward still awaits its backward is busy
+        (gssd/autograd.py) and is never reused: the call takes (or builds) another instance with its own buffers."""
         net = self.net
         if not x.is_cuda:
             raise _lib.GssdError('GSSD HIP engine: input must live on the MI355X (cuda/ROCm tensor); there is no '
                                  'CPU fallback')
-        vers = self._param_versions()
+        vers, ptrs = self._state()
+        if self._ptrs is not None and ptrs != self._ptrs:
+            self.invalidate()              # some parameter / buffer storage moved (.cuda(), p.data = ..., new head ...)
+            vers, ptrs = self._state()
         p0 = self._param_list[0]
         if p0.device != x.device:
             raise _lib.GssdError(f'model is on {p0.device}, input on {x.device}')
@@ -113,20 +132,28 @@ class GssdEngine:
         if tuple(x.shape[1:]) != (cin, 300, 300):
             raise _lib.GssdError(f'expected input [B,{cin},300,300], got {tuple(x.shape)}')
         bn_cfg = tuple((m.momentum, m.eps) for m in self._bn_list)
-        key = (B, bool(training), x.device.index, p0.data_ptr(), hash(bn_cfg))
-        plan = self._plans.get(key)
+        key = (B, bool(training), x.device.index, hash(bn_cfg))
+        plans = self._plans.setdefault(key, [])
+        plan = next((pl for pl in plans if not pl.busy), None)
         if plan is None:
-            if self._plans and next(iter(self._plans))[3] != p0.data_ptr():
-                self.invalidate()          # parameters moved (e.g. .cuda()): rebuild everything
+            if len(plans) >= self.MAX_PLANS_IN_FLIGHT:
+                raise _lib.GssdError(f'{len(plans)} forwards of batch {B} are still waiting for their backward; free their '
+                                     f'outputs (or call backward) before running more')
             plan = self._build(B, bool(training), x.device)
-            self._plans[key] = plan
-            vers = self._param_versions()
+            plans.append(plan)
+            vers, ptrs = self._state()
+        self._ptrs = ptrs
         if vers != self._versions:
             for job in self._pack_jobs:
                 job()
             self._versions = vers
         self._last_plan = plan
-        return plan.run(x, events)
+        loc, conf = plan.run(x, events)
+        return loc, conf, plan
+
+    def forward(self, x, training, events=None):
+        loc, conf, _ = self.forward_plan(x, training, events)
+        return loc, conf
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, name, build):
@@ -137,26 +164,26 @@ class GssdEngine:
             self._pack_jobs.append(lambda: build(self._packed[name]))
         return self._packed[name]
 
-    def backward(self, dloc, dconf):
-        """HIP backward of the last training forward (GSSD graph without SA / DCN): list of gradients in
-        ``net.parameters()`` order."""
-        plan = self._last_plan
-        if getattr(plan, '_bwd', None) is None:
-            from .backward import BackwardPlan
-            plan._bwd = BackwardPlan(plan)
-        return plan._bwd.run(dloc.contiguous(), dconf.contiguous())
-
-    def has_hip_backward(self):
-        net = self.net
-        return not getattr(net, 'vanilla', False)
-
     def _build(self, B, training, dev):
         if getattr(self.net, 'vanilla', False):
             return _PlanVanilla(self, B, training, dev)
         return _Plan(self, B, training, dev)
 
 
-class _Plan:
+class _PlanBase:
+    """State shared by the grouped and the vanilla launch plans."""
+    generation = 0        # bumped by every run(): a backward checks it ran against the forward that produced it
+    busy = False          # a grad-enabled forward awaits its backward (gssd/autograd.py::_Lease)
+    _bwd = None
+
+    def backward_plan(self):
+        if self._bwd is None:
+            from .backward import BackwardPlan
+            self._bwd = BackwardPlan(self)
+        return self._bwd
+
+
+class _Plan(_PlanBase):
     def __init__(self, eng, B, training, dev):
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         net = eng.net
@@ -190,28 +217,8 @@ class _Plan:
             off += 2 * m.num_features
         self.nbt = [m.num_batches_tracked for m in uniq]
 
-        # ---- spectral norm -----------------------------------------------------------------------
-        self.sn_items = []
-        self.sa_state = {}
-        for lst_name in ('self_attn_base_list', 'self_attn_list'):
-            lst = getattr(net, lst_name, None)
-            if lst is None:
-                continue
-            for i, sa in enumerate(lst):
-                Cc = sa.in_channels
-                a_tp = buf(Cc // 4)
-                a_g = buf(Cc // 2)
-                a_o = buf(Cc)
-                self.sn_items += [
-                    (sa.snconv1x1_theta.weight_orig, sa.snconv1x1_theta.weight_u, sa.snconv1x1_theta.weight_v, a_tp[:Cc // 8]),
-                    (sa.snconv1x1_phi.weight_orig, sa.snconv1x1_phi.weight_u, sa.snconv1x1_phi.weight_v, a_tp[Cc // 8:]),
-                    (sa.snconv1x1_g.weight_orig, sa.snconv1x1_g.weight_u, sa.snconv1x1_g.weight_v, a_g),
-                    (sa.snconv1x1_attn.weight_orig, sa.snconv1x1_attn.weight_u, sa.snconv1x1_attn.weight_v, a_o),
-                ]
-                self.sa_state[(lst_name, i)] = (a_tp, a_g, a_o)
-        if self.sn_items:
-            self.sn_dev = ops.sn_items_tensor([(w.detach(), u, v, s) for (w, u, v, s) in self.sn_items], dev)
-            self._add(lib.gssd_spectral_norm_f32, (self.sn_dev.data_ptr(), len(self.sn_items), int(training), 1e-12))
+        self._setup_spectral_norm([(n, getattr(net, n)) for n in ('self_attn_base_list', 'self_attn_list')
+                                   if getattr(net, n, None) is not None])
 
         # ---- input pack ------------------------------------------------------------------------------
         self.x_in = None   # set per run
@@ -328,6 +335,28 @@ class _Plan:
         self.bufs.append(t)
         return t
 
+    def _setup_spectral_norm(self, lists):
+        """layers/spectral_norm.py:74-89 for every Self_Attn conv of ``lists`` = [(list name, ModuleList)]: ONE launch that
+        (training) runs the power iteration in place and writes 1/sigma per output channel (the convs' ``alpha`` vectors)."""
+        self.sn_items = []
+        self.sa_state = {}
+        for lst_name, lst in lists:
+            for i, sa in enumerate(lst):
+                Cc = sa.in_channels
+                a_tp = self._buf(Cc // 4)
+                a_g = self._buf(Cc // 2)
+                a_o = self._buf(Cc)
+                self.sn_items += [
+                    (sa.snconv1x1_theta.weight_orig, sa.snconv1x1_theta.weight_u, sa.snconv1x1_theta.weight_v, a_tp[:Cc // 8]),
+                    (sa.snconv1x1_phi.weight_orig, sa.snconv1x1_phi.weight_u, sa.snconv1x1_phi.weight_v, a_tp[Cc // 8:]),
+                    (sa.snconv1x1_g.weight_orig, sa.snconv1x1_g.weight_u, sa.snconv1x1_g.weight_v, a_g),
+                    (sa.snconv1x1_attn.weight_orig, sa.snconv1x1_attn.weight_u, sa.snconv1x1_attn.weight_v, a_o),
+                ]
+                self.sa_state[(lst_name, i)] = (a_tp, a_g, a_o)
+        if self.sn_items:
+            self.sn_dev = ops.sn_items_tensor([(w.detach(), u, v, s) for (w, u, v, s) in self.sn_items], self.dev)
+            self._add(lib.gssd_spectral_norm_f32, (self.sn_dev.data_ptr(), len(self.sn_items), int(self.training), 1e-12))
+
     def _packed_conv(self, name, conv):
         eng = self.eng
 
@@ -432,7 +461,7 @@ class _Plan:
             s, H, Cc, _ = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
         return (s, H, Cc)
 
-    def _self_attn(self, lst_name, idx, x, H, Cc, need_out2):
+    def _self_attn(self, lst_name, idx, x, H, Cc, need_out2, want_map=False):
         """layers/self_attn.py:46-89 as five launches (K9/K10): theta|phi conv, g conv (transposed), theta^T phi,
         row softmax, attn.g^T, and the o conv with the sigma-gated residual epilogue."""
         eng, B = self.eng, self.B
@@ -544,6 +573,7 @@ class _Plan:
         """``events``: optional list; when given, every conv launch is bracketed by a pair of HIP events recorded
         on the launch stream and (tag, start, end) is appended (bench.py's live roofline measurement)."""
         B, dev = self.B, self.dev
+        self.generation += 1
         x = x.contiguous().float()
         # zero-filled: the heads accumulate split-K slices with atomics
         loc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
@@ -585,7 +615,7 @@ class _PlanVanilla(_Plan):
     def __init__(self, eng, B, training, dev):   # noqa: super().__init__ builds the grouped graph; not called on purpose
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         net = eng.net
-        self.steps, self.bufs, self.head_descs = [], [], []
+        self.steps, self.bufs, self.head_descs, self.rec = [], [], [], []
         self.P, self.nc = 8732, net.num_classes
         self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
         self.nbt = []
@@ -605,6 +635,7 @@ class _PlanVanilla(_Plan):
                     s = self._buf(B, H, H, Cc)
                     self._add(lib.gssd_l2norm_f32, (cur.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc,
                                                     float(net.L2Norm.eps)))
+                    self.rec.append(('l2norm', dict(x_in=cur, out=s, H=H, C=Cc, mod=net.L2Norm)))
                     sources.append((s, H, Cc))
             else:                                        # MaxPool2d
                 k, st, pd = m.kernel_size, m.stride, m.padding
@@ -612,6 +643,7 @@ class _PlanVanilla(_Plan):
                 out = self._buf(B, Hp, Hp, Cc)
                 self._add(lib.gssd_bn_relu_pool_f32, (cur.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, st, pd, 0, 1.0, 0, 0,
                                                       0, 0, 0.1, 1e-5, 0, 0))
+                self.rec.append(('pool', dict(x_in=cur, out=out, H=H, C=Cc, k=k, s=st, p=pd, Hp=Hp)))
                 cur, H = out, Hp
                 i += 1
         sources.append((cur, H, Cc))                     # conv7
@@ -650,6 +682,7 @@ class _PlanVanilla(_Plan):
                                          split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
             self.head_descs.append(d)
             self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+            self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
             off += Hs * Hs * A
         assert off == self.P, off
 
@@ -669,4 +702,35 @@ class _PlanVanilla(_Plan):
         d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=Cout, k=k, stride=s, pad=p,
                                      dil=dl, bias=conv.bias.detach(), relu=True)
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self.rec.append(('convrelu', dict(name=name, conv=conv, x_in=x, out=out, H=H, Cin=Cin, Ho=Ho, Cout=Cout, desc=d, k=k,
+                                          stride=s, pad=p, dil=dl)))
         return out, Ho, Cout
+
+
+class SelfAttnOp(_Plan):
+    """ONE Self_Attn block (layers/self_attn.py:46-89) as its own launch plan -- the op-level entry the parity tests use:
+    x NHWC [B,H,H,C] -> (x + sigma*o, sigma*o, attention map [B,N,N]).  ``training`` runs the spectral-norm power iteration
+    first (and mutates weight_u / weight_v in place), like the reference's forward pre-hook."""
+
+    def __init__(self, sa, B, H, training, dev):   # noqa: a stand-alone block; _Plan.__init__ builds the whole network
+        holder = torch.nn.Module()
+        holder.self_attn_list = torch.nn.ModuleList([sa])
+        self.eng = GssdEngine(holder)
+        self.B, self.training, self.dev = B, bool(training), dev
+        self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []
+        Cc = sa.in_channels
+        self.H, self.C = H, Cc
+        self.x = self._buf(B, H, H, Cc)
+        self._setup_spectral_norm([('self_attn_list', holder.self_attn_list)])
+        self.out, self.out2 = self._self_attn('self_attn_list', 0, self.x, H, Cc, need_out2=True, want_map=True)
+
+    def run(self, x_nhwc):
+        self.generation += 1
+        self.x.copy_(x_nhwc)
+        stream = torch.cuda.current_stream().cuda_stream
+        for st in self.steps:
+            rc = st.fn(*st.args, stream)
+            if rc != 0:
+                _lib.check(rc)
+        S, N, Np = self.attn_maps[('self_attn_list', 0)]
+        return self.out, self.out2, S[:, :, :N]

@@ -52,7 +52,11 @@ class SSD(nn.Module):
         return out
 
     def forward(self, x):
-        loc, conf = self._engine.forward(x, self.training)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from gssd.autograd import GssdTrainFn                   # HIP forward plan + HIP backward plan
+            loc, conf = GssdTrainFn.apply(self, x, *tuple(self.parameters()))
+        else:
+            loc, conf = self._engine.forward(x, self.training)
         priors = self.priors if self.priors.device == x.device else self.priors.to(x.device)
         if self.phase == 'test':
             return self.detect.apply(self.num_classes, 0, 200, 0.01, 0.45, loc, conf, priors, True)

@@ -128,8 +128,8 @@ class SSD(nn.Module):
 
     def forward(self, x, visualize=False):
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # forward on the HIP engine; backward through the interim ATen recomputation (gssd/autograd_shadow.py)
-            from gssd.autograd_shadow import GssdTrainFn
+            # HIP forward plan + HIP backward plan (gssd/autograd.py); an eval-mode forward carries no autograd graph
+            from gssd.autograd import GssdTrainFn
             loc, conf = GssdTrainFn.apply(self, x, *tuple(self.parameters()))
         else:
             loc, conf = self._engine.forward(x, self.training, self.__dict__.get('_events'))
@@ -146,7 +146,7 @@ class SSD(nn.Module):
     def _engine_visuals(self, B):
         """all_offset / all_attnb / all_attn of the reference's visualize=True return (:397-398), as NCHW /
         [B,N,N] torch tensors."""
-        plan = next(p for k, p in self._engine._plans.items() if k[0] == B and k[1] == self.training)
+        plan = self._engine._last_plan
         offs = []
         for om, H, dg in getattr(plan, 'offsets', []):
             offs.append(ops.unpack_nhwc(om, 18 * dg))

@@ -1,12 +1,14 @@
 #!/bin/bash
 # HBM traffic of every kernel of one bench step (run on the GPU box): two separate --pmc passes (FETCH_SIZE needs 3 of
 # the 4 TCC slots, WRITE_SIZE 2), kernel-trace only, as MI355X_MICROARCH.md prescribes.  Writes profiles/pmc_summary.json.
-cfg=${1:-gssd}
+cfg=${1:-gssdpp}
+dtype=${2:-f32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-events --config $cfg > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
 done
-python3 - "$GRAFT_REPO_ROOT" "$cfg" <<'PY'
+key=$cfg; [ "$dtype" != f32 ] && key=${cfg}_$dtype
+python3 - "$GRAFT_REPO_ROOT" "$key" <<'PY'
 import csv, sys, glob, json, collections, re, os
 root, cfg = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -25,13 +27,18 @@ def short(n):
     if m: return f'conv_wino<{m.group(1)}>'
     m = re.search(r'::(\w+_kernel)', n)
     return m.group(1) if m else n[:40]
-out = {}
+# template variants of one kernel family share a short name: their launches are pooled (not overwritten)
+pool = collections.defaultdict(lambda: collections.defaultdict(list))
 for k, d in agg.items():
+    for c, v in d.items():
+        pool[short(k)][c] += v
+out = {}
+for k, d in pool.items():
     fs, ws = d.get('FETCH_SIZE', [0]), d.get('WRITE_SIZE', [0])
     f_kb, w_kb = sum(fs) / len(fs), sum(ws) / len(ws)
     # counters are KiB; on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM): x2
-    out[short(k)] = dict(launches=len(fs), fetch_kib_raw=round(f_kb, 1), write_kib=round(w_kb, 1),
-                         hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024))
+    out[k] = dict(launches=len(fs), fetch_kib_raw=round(f_kb, 1), write_kib=round(w_kb, 1),
+                  hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024))
 p = os.path.join(root, 'gpurun_out', 'pmc_summary.json')
 allj = json.load(open(p)) if os.path.exists(p) else {}
 allj[cfg] = out

@@ -1,10 +1,7 @@
-"""INTERIM backward of the network (SURVEY.md 8f row 1 is the HIP version).
-
-Forward values always come from the HIP engine.  When gradients are needed, ``GssdTrainFn.backward`` re-evaluates the
-graph with differentiable ATen ops ON THE GPU (MIOpen convs, torch bmm / softmax, a gather-based deformable conv) from
-the saved input and the live parameters, and back-propagates ``(dloc, dconf)`` through that recomputation
-(activation-checkpoint style).  Nothing here runs on the CPU and nothing here is used by a forward, ``MultiBoxLoss``
-or ``Detect`` call.  Graph restated from models/ssd_multiphase_custom_group.py:217-400.
+"""TEST INFRASTRUCTURE (not part of the product): a differentiable ATen restatement of the GSSD / GSSD++ graph on the
+device (MIOpen convs, torch bmm / softmax, a gather-based deformable conv), used by tests/test_gpu_parity.py as a
+second opinion on the HIP backward plan (gssd/backward.py) next to CPU autograd through the oracle.  Graph restated from
+models/ssd_multiphase_custom_group.py:217-400.  Nothing under grouped-ssd-pytorch_amd/ imports this file.
 """
 import torch
 import torch.nn.functional as F
@@ -140,44 +137,11 @@ def shadow_forward(net, x):
     return loc.view(B, -1, 4), conf.view(B, -1, net.num_classes)
 
 
-class GssdTrainFn(torch.autograd.Function):
-    """forward = HIP engine; backward = gradients of the recomputed ATen graph w.r.t. the live parameters."""
-
-    @staticmethod
-    def forward(ctx, net, x, *params):
-        loc, conf = net._engine.forward(x, True, net.__dict__.get('_events'))
-        ctx.net, ctx.x, ctx.params = net, x, params
-        return loc, conf
-
-    @staticmethod
-    def backward(ctx, dloc, dconf):
-        net, x, params = ctx.net, ctx.x, ctx.params
-        if net._engine.has_hip_backward() and not x.requires_grad and not net.__dict__.get('_force_aten_backward'):
-            # The plan writes every gradient into its own persistent buffers (views of one flat tensor).  They are handed out
-            # as ``param.grad`` directly -- no AccumulateGrad clone per parameter -- when the parameter has no gradient yet
-            # (optimizer.zero_grad(set_to_none=True), the default); an existing gradient is accumulated into, and one that
-            # still aliases the plan's buffer from an earlier backward is moved out of the way first.
-            bwd = getattr(net._engine._last_plan, '_bwd', None)
-            if bwd is not None:
-                lo, hi = bwd.flat.data_ptr(), bwd.flat.data_ptr() + bwd.flat.numel() * 4
-                for p in params:
-                    if p.grad is not None and lo <= p.grad.data_ptr() < hi:
-                        p.grad = p.grad.clone()
-            grads = net._engine.backward(dloc, dconf)            # hand-written HIP backward (gssd/backward.py)
-            for p, g in zip(params, grads):
-                if g is None or not p.requires_grad:
-                    continue
-                if p.grad is None:
-                    p.grad = g
-                else:
-                    p.grad.add_(g)
-            return (None, None) + (None,) * len(params)
-        with torch.enable_grad():
-            xin = x.detach().requires_grad_(x.requires_grad)
-            loc, conf = shadow_forward(net, xin)
-            wanted = [p for p in params if p.requires_grad] + ([xin] if xin.requires_grad else [])
-            grads = torch.autograd.grad((loc, conf), wanted, (dloc, dconf), allow_unused=True)
-        it = iter(grads)
-        out = [next(it) if p.requires_grad else None for p in params]
-        gx = next(it) if xin.requires_grad else None
-        return (None, gx) + tuple(out)
+def shadow_param_grads(net, x, dloc, dconf):
+    """Gradients of (loc, conf) . (dloc, dconf) w.r.t. net.parameters() through the ATen recomputation; list in
+    ``net.parameters()`` order (None where a parameter does not take part)."""
+    params = [p for p in net.parameters()]
+    with torch.enable_grad():
+        loc, conf = shadow_forward(net, x.detach())
+        grads = torch.autograd.grad((loc, conf), params, (dloc, dconf), allow_unused=True)
+    return list(grads)

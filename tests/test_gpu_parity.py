@@ -514,14 +514,18 @@ def test_multibox_loss(dev, ops, golden):
         assert np.allclose(loc_d.grad.cpu().numpy().reshape(-1)[idx], g[f'gloc_sample{ci}'], rtol=1e-4, atol=1e-7)
         idx = np.random.default_rng(3).choice(4 * P * 2, size=512, replace=False)
         assert np.allclose(conf_d.grad.cpu().numpy().reshape(-1)[idx], g[f'gconf_sample{ci}'], rtol=1e-4, atol=1e-7)
-        # masks: positives bit-exact; mined negatives identical except where two scores tie to the last ulp
+        # masks: positives bit-exact; mined negatives: exact count, identical to the reference's set except among priors
+        # whose score is within 2 ulp of the cut-off (tests/helpers.py states the contract)
         tgp, ngt = ops.pack_targets(tg, dev)
         st = ops.multibox_loss_forward(loc_d.detach(), conf_d.detach(), pri, tgp, ngt, want_scores=True)
         sel = st['sel'].cpu().numpy()
         assert np.array_equal(np.packbits((sel & 1).astype(bool)), g[f'pos{ci}'])
         neg_ref = np.unpackbits(g[f'neg{ci}'])[:4 * P].reshape(4, P).astype(bool)
         neg = (sel & 2).astype(bool)
-        assert neg.sum() == neg_ref.sum() and (neg != neg_ref).sum() <= 2
+        from helpers import assert_mined_negatives_contract
+        lca_o = O.multibox_loss(loc, conf, pri_np, [t.numpy() for t in tg], details=True)[2]['loss_c_all']
+        assert_mined_negatives_contract(neg, neg_ref, lca_o, (sel & 1).sum(1))
+        assert np.abs(st['loss_c_all'].cpu().numpy() - lca_o).max() <= 4 * np.spacing(np.float32(np.abs(lca_o).max()))
         # the selection logic itself is exact: oracle ranking of the kernel's own scores gives the same set
         lca = st['loss_c_all'].cpu().numpy()
         order = np.argsort(-lca, axis=1, kind='stable')
@@ -696,20 +700,14 @@ def test_backward_gradients(dev, name):
     # self-attention's sigma is a scalar whose gradient is one heavily cancelling sum over the whole map: looser bound
     assert max(v for k, v in errs.items() if not k.endswith('sigma')) < 2e-2, errs
     assert all(v < 6e-2 for k, v in errs.items() if k.endswith('sigma')), errs
-    if True:
-        # the HIP backward plan (default) against the whole-graph ATen recomputation on the same device
-        hip = {k: named[k].grad.clone() for k in keys}
-        for p in net.parameters():
-            p.grad = None
-        net.__dict__['_force_aten_backward'] = True
-        net.load_state_dict(sd)              # the training forward advanced spectral norm's u, v: same start again
-        loc, conf, _ = net(x.to(dev))
-        ((loc * r1.to(dev)).sum() + (conf * r2.to(dev)).sum()).backward()
-        net.__dict__['_force_aten_backward'] = False
-        e2 = {k: l2rel(hip[k], named[k].grad) for k in keys if k != 'vgg.30.bias'}
-        print('HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in e2.items()})
-        assert max(v for k, v in e2.items() if not k.endswith('sigma')) < 2e-2, e2
-        assert all(v < 6e-2 for k, v in e2.items() if k.endswith('sigma')), e2
+    # the HIP backward plan against the whole-graph ATen recomputation on the same device (tests/aten_shadow.py); the
+    # spectral-norm u / v the HIP forward used are the ones the module holds now
+    from aten_shadow import shadow_param_grads
+    sg = dict(zip([k for k, _ in net.named_parameters()], shadow_param_grads(net, x.to(dev), r1.to(dev), r2.to(dev))))
+    e2 = {k: l2rel(named[k].grad, sg[k]) for k in keys if k != 'vgg.30.bias'}
+    print('HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in e2.items()})
+    assert max(v for k, v in e2.items() if not k.endswith('sigma')) < 2e-2, e2
+    assert all(v < 6e-2 for k, v in e2.items() if k.endswith('sigma')), e2
 
 
 def test_training_steps_reduce_loss(dev):
@@ -724,7 +722,7 @@ def test_training_steps_reduce_loss(dev):
     net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
     net = net.to(dev).train()
     twin = copy.deepcopy(net)
-    twin.__dict__['_force_aten_backward'] = True
+    from aten_shadow import shadow_param_grads
     x = synth.synth_images(8, seed=21).to(dev)
     tg = [t.to(dev) for t in synth.synth_targets(8, seed=21)]
     crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
@@ -734,8 +732,18 @@ def test_training_steps_reduce_loss(dev):
         losses = []
         for _ in range(6):
             opt.zero_grad()
-            ll, lc = crit(m(x), tg)
-            (ll + lc).backward()
+            if tag == 'hip':
+                ll, lc = crit(m(x), tg)
+                (ll + lc).backward()
+            else:
+                # same HIP forward and loss; the network gradient from the ATen recomputation instead of the HIP plan
+                with torch.no_grad():
+                    loc, conf, pri = m(x)
+                loc.requires_grad_(), conf.requires_grad_()
+                ll, lc = crit((loc, conf, pri), tg)
+                (ll + lc).backward()
+                for p_, g_ in zip(m.parameters(), shadow_param_grads(m, x, loc.grad, conf.grad)):
+                    p_.grad = g_
             opt.step()
             losses.append(float(ll + lc))
         hist[tag] = losses
@@ -766,11 +774,13 @@ def test_visualize_outputs(dev):
     assert all(abs(a.sum(-1) - 1).max() < 1e-4 for a in attnb + attn)
 
 
-def test_full_size_properties(dev):
-    """BASELINE.json configs[1] size (B=32): size-independent properties instead of a 12 s CPU forward."""
+@pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
+def test_full_size_properties(dev, name):
+    """BASELINE.json configs[1] / configs[2] size (B=32, the benchmarked one): size-independent properties instead of a
+    12 s (GSSD) / 30 s (GSSD++) CPU forward."""
     from models.ssd_multiphase_custom_group import build_ssd
     from layers.modules import MultiBoxLoss
-    flags, args = NETS['gssd']
+    flags, args = NETS[name]
     net = build_ssd('train', 300, 2, *args)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     net.load_state_dict(synth.synth_state_dict(shapes, seed=1111))
@@ -806,6 +816,176 @@ def test_full_size_properties(dev):
     ref = O.detect(2, 0, 200, 0.01, 0.45, l32[b:b + 1].cpu().numpy(), O.softmax_scores(c32[b:b + 1].cpu().numpy()),
                    pri.cpu().numpy())
     assert np.array_equal(det[b:b + 1], ref)
+
+
+
+def test_self_attn_op(dev, golden):
+    """Self_Attn on its own (layers/self_attn.py:46-89) against the reference fixtures: out, sigma*o, the ATTENTION MAP, and
+    (train) the spectral-norm u / v after-state; eval mode leaves u / v untouched."""
+    from gssd.engine import SelfAttnOp
+    from gssd.modules import Self_Attn
+    g = golden('ops')
+    for mode in ('eval', 'train'):
+        sa = Self_Attn(64)
+        sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in sa.state_dict().items()}, seed=21)   # as make_golden.py
+        sa.load_state_dict(sd)
+        sa = sa.to(dev)
+        x = torch.from_numpy(g[f'sa_{mode}_x'])
+        op = SelfAttnOp(sa, 2, 6, mode == 'train', dev)
+        out, out2, attn = op.run(nhwc(x).to(dev))
+        assert rel(nchw(out), g[f'sa_{mode}_out']) < TOL
+        assert rel(nchw(out2), g[f'sa_{mode}_ag']) < TOL
+        assert attn.shape == (2, 36, 36)
+        assert rel(attn, g[f'sa_{mode}_attn']) < TOL
+        after = sa.state_dict()
+        for k in ('theta', 'phi', 'g', 'attn'):
+            for uv in ('weight_u', 'weight_v'):
+                key = f'snconv1x1_{k}.{uv}'
+                want = g[f'sa_train_after.{key}'] if mode == 'train' else sd[key].numpy()
+                assert rel(after[key], want) < TOL, (mode, key)
+        # the oracle agrees on the same inputs (map included)
+        upd = {}
+        o_out, o_ag, o_attn = O.self_attn(x, {f'p.{k}': v for k, v in sd.items()}, 'p', mode == 'train', updates=upd)
+        assert rel(nchw(out), o_out) < TOL and rel(attn, o_attn) < TOL
+
+
+def test_vanilla_ssd_config0(dev, golden):
+    """BASELINE.json configs[0] on the HIP engine: vanilla VGG-SSD300 (models/ssd.py:48-108), 1 phase, batch 2, forward +
+    MultiBoxLoss against the reference fixture and the oracle, and the backward (HIP plan) against CPU autograd through the
+    oracle graph: finite, and equal within fp32 noise."""
+    from models.ssd import build_ssd
+    from layers.modules import MultiBoxLoss
+    g = golden('e2e')
+    net = build_ssd('train', 300, 2)
+    keys = sorted(net.state_dict().keys())
+    assert keys == [str(k) for k in g['ssd.keys']]
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = synth.synth_images(2, seed=6, channels=3)
+    tg = synth.synth_targets(4, 5)[:2]
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    loc, conf, pri = net(x.to(dev))
+    assert loc.requires_grad and loc.shape == (2, 8732, 4) and conf.shape == (2, 8732, 2)
+    ll, lc = crit((loc, conf, pri), tg)
+    l, c = loc.detach().cpu().numpy().reshape(-1), conf.detach().cpu().numpy().reshape(-1)
+    assert rel(l[g['ssd.loc_idx']], g['ssd.loc_val']) < TOL and rel(c[g['ssd.conf_idx']], g['ssd.conf_val']) < TOL
+    assert rel(ll, g['ssd.loss'][0]) < TOL and rel(lc, g['ssd.loss'][1]) < TOL
+    (ll + lc).backward()
+    named = dict(net.named_parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # oracle: full tensors and CPU autograd of the same loss
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    lo, co = O.vanilla_ssd_forward(sdg, x)
+    assert rel(loc, lo) < TOL and rel(conf, co) < TOL
+    # d(loss)/d(loc, conf) from the HIP loss kernels (tested on their own in test_multibox_loss), pushed through CPU autograd
+    loc2 = loc.detach().clone().requires_grad_()
+    conf2 = conf.detach().clone().requires_grad_()
+    l2, c2 = crit((loc2, conf2, pri), tg)
+    (l2 + c2).backward()
+    torch.autograd.backward((lo, co), (loc2.grad.cpu(), conf2.grad.cpu()))
+
+    def l2rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+    errs = {k: l2rel(named[k].grad, sdg[k].grad) for k in named}
+    print('vanilla SSD gradient L2-relative errors vs CPU autograd:', {k: f'{v:.1e}' for k, v in errs.items()})
+    # ReLU masks / pool arg-maxes flip between two fp32 implementations (see test_backward_gradients): relative L2 per tensor
+    assert max(errs.values()) < 1e-2, {k: v for k, v in errs.items() if v >= 1e-2}
+
+
+def test_backward_runs_against_its_own_forward(dev):
+    """a second forward before .backward() must not hand stale activations to the HIP backward.  Two micro-batches
+    summed into one loss get a plan instance each; a plan re-run behind a pending backward's back raises."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    from gssd._lib import GssdError
+    flags, args = NETS['gssd']
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    xa, xb = synth.synth_images(2, seed=31).to(dev), synth.synth_images(2, seed=32).to(dev)
+    rng = np.random.default_rng(1)
+    ra = torch.from_numpy(rng.normal(size=(2, 8732, 4)).astype(np.float32)).to(dev)
+    ra[:, 8728:] = 0
+
+    def grads_of(xs):
+        for p in net.parameters():
+            p.grad = None
+        outs = [net(x) for x in xs]                      # all forwards first, then ONE backward
+        sum((o[0] * ra).sum() for o in outs).backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    # BN running stats / batch statistics are per forward, so (a then b in one graph) == grad(a) + grad(b)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    gab = grads_of([xa, xb])
+    net.load_state_dict(sd0)
+    ga = grads_of([xa])
+    gb = grads_of([xb])
+    for k in ('vgg.0.weight', 'vgg.24.weight', 'fuse_21.weight', 'loc.0.weight', 'extras.4.weight'):
+        assert rel(gab[k], ga[k] + gb[k]) < 1e-4, k
+    # a no-grad forward while a backward is pending must take another plan (the pending one stays intact)
+    loc, conf, _ = net(xa)
+    with torch.no_grad():
+        net(xb)
+    (loc * ra).sum().backward()
+    # retained graph + a fresh forward on the same plan: the second backward would read overwritten buffers -> raises
+    for p in net.parameters():
+        p.grad = None
+    loc, conf, _ = net(xa)
+    (loc * ra).sum().backward(retain_graph=True)
+    net(xb)[0].sum().backward()
+    with pytest.raises((GssdError, RuntimeError)):
+        (loc * ra).sum().backward()
+
+
+def test_autograd_grad_and_hooks_see_gradients(dev):
+    """torch.autograd.grad / tensor hooks / non-leaf parameters receive the HIP gradients (the no-copy p.grad
+    hand-out is only taken for a plain .backward() on hook-free leaves)."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssd']
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    x = synth.synth_images(2, seed=33).to(dev)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    loc, conf, _ = net(x)
+    loc[:, :8728].sum().backward()
+    ref = net.loc[0].weight.grad.clone()
+    assert net.loc[0].weight.grad._base is not None          # fast path: a view of the plan's flat gradient buffer
+    net.load_state_dict(sd0)
+    loc, conf, _ = net(x)
+    g, = torch.autograd.grad(loc[:, :8728].sum(), [net.loc[0].weight])
+    assert g is not None and rel(g, ref) < 1e-5
+    net.load_state_dict(sd0)
+    for p in net.parameters():
+        p.grad = None
+    seen = []
+    h = net.loc[0].weight.register_hook(lambda gr: seen.append(gr.clone()))
+    loc, conf, _ = net(x)
+    loc[:, :8728].sum().backward()
+    h.remove()
+    assert len(seen) == 1 and rel(seen[0], ref) < 1e-5 and rel(net.loc[0].weight.grad, ref) < 1e-5
+
+
+def test_plan_follows_reseated_storage(dev):
+    """parameters / buffers whose storage is replaced without going through ``_apply`` (``p.data = ...``,
+    ``bn.running_mean = ...``) rebuild the launch plan instead of leaving kernels on the old pointers."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssd']
+    net = build_ssd('train', 300, 2, *args)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = synth.synth_images(2, seed=34).to(dev)
+    with torch.no_grad():
+        l0, c0, _ = net(x)
+        bn = net.vgg[1]
+        bn.running_mean = bn.running_mean.clone() + 0.25         # new storage, new values
+        net.bn_fuse_11.bias.data = net.bn_fuse_11.bias.data.clone() + 0.5
+        l1, c1, _ = net(x)
+        sd2 = {k: v.clone() for k, v in net.state_dict().items()}
+        lo, co, _ = O.gssd_forward({k: v.cpu() for k, v in sd2.items()}, x.cpu(), training=False, **flags)
+    assert rel(l1, lo) < TOL and rel(c1, co) < TOL and rel(l1, l0) > 1e-3
 
 
 def test_cpu_input_fails_loudly():

@@ -71,9 +71,9 @@ def test_multibox_loss(golden):
         assert rel(ll, g[f'loss{ci}'][0]) < 1e-5 and rel(lc, g[f'loss{ci}'][1]) < 1e-5
         assert np.array_equal(np.packbits(d['pos']), g[f'pos{ci}'])
         neg_ref = np.unpackbits(g[f'neg{ci}'])[:4 * P].reshape(4, P).astype(bool)
-        # mining ranks are integer work: identical unless two losses tie to the last ulp at the cut
-        assert (d['neg'] != neg_ref).sum() <= 2
-        assert d['neg'].sum() == neg_ref.sum()
+        # mining ranks are integer work: identical to the reference except among scores within 2 ulp of the cut-off
+        from helpers import assert_mined_negatives_contract
+        assert_mined_negatives_contract(d['neg'], neg_ref, d['loss_c_all'], d['num_pos'])
 
 
 def test_detect_and_nms(golden):
