@@ -74,6 +74,9 @@ SIGNATURES = {
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),
     'gssd_dcn_im2col_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_dcn_packed_weight_elems': (C.c_longlong, [c_i, c_i]),
+    'gssd_dcn_pack_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    'gssd_dcn_forward_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_resample_ksize': (c_i, [c_i, c_i, c_i]),
     'gssd_resample_coeffs': (c_i, [c_i, c_i, c_i, c_fp, c_fp]),
     'gssd_resize_u8_horizontal': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),

@@ -332,9 +332,14 @@ class BackwardPlan:
         """Modulated deformable conv (layers/dcn_v2_custom.py:79-89): the 1x1 GEMM over the sampled columns, the sampling
         itself (gssd_dcn_col2im_f32) and the offset/mask conv, all HIP."""
         B, H, Cin, Cout, dg, m = self.B, r['H'], r['Cin'], r['Cout'], r['dg'], r['mod']
-        x, om, cols = r['x_in'], r['om'], r['cols']
+        x, om = r['x_in'], r['om']
         dy = self._grad_of(r['out'])
         Kc = 9 * Cin
+        # the fused forward keeps no column matrix: rebuild it here for the weight gradient
+        cols = self._buf(B * H * H, Kc)
+        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, 27 * dg))
+        w_main = self._buf(Cout, Kc)
+        self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
         # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- plain GEMMs (rocBLAS)
         dwp = self._buf(Cout, Kc)
         self._add(lib.gssd_gemm_tn_f32, (dy.data_ptr(), cols.data_ptr(), dwp.data_ptr(), B * H * H, Cout, Kc, Cout, Kc, Kc, 0))
@@ -343,7 +348,7 @@ class BackwardPlan:
         self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))
         self._bias_from_colsum(cs, m.bias)
         wt = self._buf(Kc, Cout)
-        self.steps.append((lambda w=r['w_main'], wt=wt: wt.copy_(w.t()), None))
+        self.steps.append((lambda w=w_main, wt=wt: wt.copy_(w.t()), None))
         dcols = self._buf(B * H * H, Kc)
         self._add(lib.gssd_gemm_nt_f32, (dy.data_ptr(), wt.data_ptr(), dcols.data_ptr(), B * H * H, Kc, Cout, Cout, Cout, Kc, 0, 0),
                   keep=wt)

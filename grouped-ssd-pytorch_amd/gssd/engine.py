@@ -535,17 +535,24 @@ class _Plan(_PlanBase):
         return out, out2
 
     def _dcn(self, li, x, H, Cin):
-        """layers/dcn_v2_custom.py:79-89: offset/mask conv -> modulated bilinear im2col -> 1x1 GEMM."""
+        """layers/dcn_v2_custom.py:79-89: offset/mask conv, then ONE fused kernel for the modulated bilinear sampling and the
+        9*Cin-deep contraction (csrc/dcn_fused.hip) -- no column buffer."""
         eng, B = self.eng, self.B
         m = eng.net.dcn_list[li]
         dg, Cout = m.deformable_groups, m.out_channels
         w_om = self._packed_conv(f'dcn_list.{li}.om', m.conv_offset_mask)
 
-        def build_w(out, m=m):
-            return ops.pack_weight(m.weight, out)
-        w_main = eng._pack(f'dcn_list.{li}.w', build_w)
+        def build_w(out, m=m, Cin=Cin, dg=dg):
+            if out is None:
+                n = int(lib.gssd_dcn_packed_weight_elems(m.out_channels, Cin))
+                if n <= 0:
+                    raise _lib.GssdError(f'deformable conv: unsupported shape Cin {Cin}, Cout {m.out_channels}')
+                out = torch.empty(n, device=self.dev, dtype=torch.float32)
+            _lib.check(lib.gssd_dcn_pack_weight_f32(m.weight.detach().contiguous().data_ptr(), out.data_ptr(), m.out_channels, Cin, dg,
+                                                    torch.cuda.current_stream().cuda_stream))
+            return out
+        w_main = eng._pack(f'dcn_list.{li}.wt', build_w)
         om = self._buf(B, H, H, 27 * dg)
-        cols = self._buf(B * H * H, 9 * Cin)
         out = self._buf(B, H, H, Cout)
         u_om = None
         if USE_WINOGRAD and ops.winograd_eligible(3, 1, 1, 1, Cin, 27 * dg, 1):
@@ -554,18 +561,14 @@ class _Plan(_PlanBase):
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1,
                                       bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om)
-        d2, _, _ = ops.make_conv_desc(cols, w_main, out, B=B, H=H, W=H, in_stride=9 * Cin, cin_g=9 * Cin, Cout=Cout,
-                                      bias=m.bias.detach())
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d1),), keep=d1)
-        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, 27 * dg))
-        # the contraction over the sampled columns is a plain [B*H*W, 9*Cin] x [9*Cin, Cout] GEMM + bias: library GEMM
-        self._add(lib.gssd_gemm_nt_f32, (cols.data_ptr(), w_main.data_ptr(), out.data_ptr(), B * H * H, Cout, 9 * Cin, 9 * Cin,
-                                        w_main.stride(0), Cout, m.bias.data_ptr(), 0), keep=(d2, w_main),
-                  tag=('gemm_rocblas', 2.0 * B * H * H * Cout * 9 * Cin, 4.0 * (B * H * H * (9 * Cin + Cout) + Cout * 9 * Cin)))
+        M = B * H * H
+        self._add(lib.gssd_dcn_forward_f32, (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H,
+                                             Cin, dg, 27 * dg, Cout), keep=w_main,
+                  tag=('dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin, 4.0 * (M * (Cin + Cout + 27 * dg) + Cout * 9 * Cin)))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
-        self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, cols=cols, d_om=d1, d_main=d2,
-                                     w_main=w_main, dg=dg)))
+        self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, d_om=d1, dg=dg, li=li)))
         return out, Cout
 
     # ------------------------------------------------------------------------------------------------

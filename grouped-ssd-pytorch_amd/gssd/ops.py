@@ -247,6 +247,32 @@ def dcn_im2col(x, om, cols, dg):
     return cols
 
 
+def dcn_pack_weight(w_oihw, dg, out=None):
+    """Dense OIHW [Cout][C][3][3] -> the chunk-major, LDS-image layout gssd_dcn_forward_f32 streams by LDS-DMA."""
+    _need_cuda(w_oihw)
+    w = w_oihw.detach().contiguous().float()
+    Cout, Cc = w.shape[0], w.shape[1]
+    if out is None:
+        n = int(lib.gssd_dcn_packed_weight_elems(Cout, Cc))
+        if n <= 0:
+            raise _lib.GssdError(f'deformable conv: unsupported shape C {Cc}, Cout {Cout}')
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(lib.gssd_dcn_pack_weight_f32(_p(w), _p(out), Cout, Cc, dg, _stream()))
+    return out
+
+
+def dcn_forward(x, om, w_oihw, bias, dg, w_packed=None):
+    """Fused modulated deformable 3x3 conv (layers/dcn_v2_custom.py:84-89): x NHWC [B,H,W,C], om NHWC [B,H,W,27*dg] (the raw
+    conv_offset_mask output) -> NHWC [B,H,W,Cout]."""
+    _need_cuda(x, om, w_oihw)
+    B, H, W, Cc = x.shape
+    Cout = w_oihw.shape[0]
+    wp = w_packed if w_packed is not None else dcn_pack_weight(w_oihw, dg)
+    out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+    check(lib.gssd_dcn_forward_f32(_p(x), _p(om), _p(wp), _p(bias), _p(out), B, H, W, Cc, dg, om.shape[-1], Cout, _stream()))
+    return out
+
+
 def dcn_col2im(x, om, dcols, dx, dom, dg):
     """Backward of :func:`dcn_im2col`: ADDS d(x) into ``dx`` and d(om) (offsets + mask logits) into ``dom``."""
     B, H, W, Cc = x.shape

@@ -225,6 +225,17 @@ int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int do_power_it
 int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols, int B, int H, int W, int C, int dg,
                         int om_stride, gssd_stream_t stream);
 
+/* Fused modulated deformable 3x3 conv (stride 1 / pad 1 / dil 1): sampling + contraction + bias in one kernel, no column
+ * buffer.  Replaces the whole `_DCNv2.apply(input, offset, mask, weight, bias, ...)` call of layers/dcn_v2_custom.py:84-89
+ * (dcn_v2's modulated_deformable_im2col + gemm).  x NHWC [B,H,W,C]; om as for gssd_dcn_im2col_f32; out NHWC [B,H,W,Cout].
+ * w_packed: the dense OIHW weight [Cout][C][3][3] re-laid by gssd_dcn_pack_weight_f32 into K-chunk-major tiles
+ * (gssd_dcn_packed_weight_elems floats, HOST query; -1 for unsupported shapes).  Channels per deformable group must be a
+ * multiple of 16. */
+long long gssd_dcn_packed_weight_elems(int Cout, int C);
+int gssd_dcn_pack_weight_f32(const float* w_oihw, float* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
+int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B, int H,
+                         int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream);
+
 /* Backward of gssd_dcn_im2col_f32 (what the reference gets from the dcn_v2 extension's backward through autograd,
  * layers/dcn_v2_custom.py:84-89): given d(cols), ADDS d(x) into `dx` (fp32 atomics; the caller zero-fills or pre-loads it)
  * and ADDS d(om) ([pixels][om_stride]; offsets' and mask logits' gradients, sigmoid included) into `dom` (zero-filled by

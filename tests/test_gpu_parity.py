@@ -405,6 +405,38 @@ def test_dcn_im2col_and_identities(dev, ops):
     assert rel(nchw(y0), ident) < TOL
 
 
+@pytest.mark.parametrize('B,Cc,H,dg,Cout', [(2, 64, 9, 4, 32), (3, 128, 13, 1, 300), (1, 64, 5, 2, 256), (5, 256, 11, 4, 512)])
+def test_dcn_fused_forward(dev, ops, B, Cc, H, dg, Cout):
+    """The fused deformable conv kernel (sampling + contraction, no column buffer) vs the oracle restatement of DCNv2 (parity
+    unpinned upstream), on ragged tiles (M not a multiple of 128, Cout not a multiple of 256, tiles crossing images) with
+    offsets that leave the image, plus the two identities the reference's wrapper guarantees."""
+    rng = np.random.default_rng(18)
+    x = torch.from_numpy(rng.normal(size=(B, Cc, H, H)).astype(np.float32))
+    om = torch.from_numpy(rng.normal(0, 2.5, size=(B, 27 * dg, H, H)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cc, 3, 3)).astype(np.float32))
+    bias = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    ref = O.dcn_v2_conv(x, torch.cat((o1, o2), 1), torch.sigmoid(m), w, bias, 1, 1, 1, dg)
+    xd, omd, wd, bd = nhwc(x).to(dev), nhwc(om).to(dev), w.to(dev), bias.to(dev)
+    y = ops.dcn_forward(xd, omd, wd, bd, dg)
+    assert rel(nchw(y), ref) < TOL
+    # zero offsets and mask logits (the zero-initialised conv_offset_mask, dcn_v2_custom.py:75-77): 0.5 * conv + b
+    y0 = ops.dcn_forward(xd, torch.zeros_like(omd), wd, bd, dg)
+    ident = 0.5 * torch.nn.functional.conv2d(x, w, None, 1, 1) + bias.view(1, -1, 1, 1)
+    assert rel(nchw(y0), ident) < TOL
+    # integer offsets (dy, dx) = (1, -2) on every tap with mask logit +30 (sigmoid = 1): a conv over the shifted, zero-padded input
+    omi = torch.zeros(B, 27 * dg, H, H)
+    omi[:, 0:18 * dg:2] = 1.0
+    omi[:, 1:18 * dg:2] = -2.0
+    omi[:, 18 * dg:] = 30.0
+    yi = ops.dcn_forward(xd, nhwc(omi).to(dev), wd, bd, dg)
+    xs = torch.zeros_like(x)
+    xs[:, :, :H - 1, 2:] = x[:, :, 1:, :H - 2]                  # xs[y, x] = x[y + 1, x - 2]
+    shifted = torch.nn.functional.conv2d(xs, w, None, 1, 1)
+    # taps that fall outside the ORIGINAL image after the shift are zero in DCN; compare on the interior where both agree
+    assert rel(nchw(yi)[:, :, 1:H - 2, 3:H - 1], (shifted + bias.view(1, -1, 1, 1))[:, :, 1:H - 2, 3:H - 1]) < TOL
+
+
 def test_library_gemm_entry_points(dev):
     """gssd_gemm_nt_f32 / gssd_gemm_tn_f32 (rocBLAS behind the C ABI): the DCN contraction forward, dgrad and wgrad forms."""
     from gssd._lib import lib, check
