@@ -4,46 +4,74 @@
 //
 //   out[m][n] = bias[n] + sum_{d, c, tap} W[n][c][tap] * mask(m,d,tap) * bilinear(x[b, :, :, c], (h-1+i+dy, w-1+j+dx))
 //
-// A 256-thread workgroup (4 waves, 2 x 2) owns BM = 128 output pixels x BN = 256 output channels; a wave owns 64 x 128
-// (4 x 8 MFMA tiles of v_mfma_f32_16x16x4_f32, 128 accumulator registers), two workgroups share a CU: while one gathers, the
-// other keeps the matrix pipe busy.  K runs in chunks of 16 input channels of ONE tap, ordered (deformable group, channel
-// chunk, tap): the nine taps of a chunk re-read the same ~20 KB window of x, so the gather hits L1 / L2 and x leaves HBM about once.
+// A 256-thread workgroup (4 waves, 2 x 2, ONE per CU, one wave per SIMD) owns BM = 128 output pixels x BN = 256 output channels; a
+// wave owns 64 x 128 (4 x 8 MFMA tiles of v_mfma_f32_16x16x4_f32, 128 accumulator registers).  K runs in chunks of 32 input channels
+// of ONE tap (128 B of every sampled pixel vector = one cache line per corner), ordered (deformable group, channel chunk, tap): the
+// nine taps of a chunk re-read the same window of x, so the gather hits L1 / L2 and x leaves HBM about once.
 //
 //   per (pixel, tap) of the current deformable group, once per group:  4 bilinear weights (mask folded in, invalid corners
-//       zeroed) + the clamped corner pixel index -> LDS "setup" table (22.5 KB)
-//   per chunk:  B tile (256 x 16 weights, pre-packed chunk-major and pre-swizzled: memory image == LDS image) by 16-byte
-//       LDS-DMA;  A tile: every thread loads the 4 corners of 2 (pixel, 4-channel) cells as float4 straight from x (issued
-//       BEFORE the chunk's MFMAs, consumed after them), blends, and writes one ds_write_b128 per cell
-//   fragments: one ds_read_b128 per 16 x 16 tile per chunk (lane (r, kq) holds k = 4*kq + s for MFMA step s; A and B use the same
-//       permutation); 64-byte rows, slot' = slot ^ (r & 8 ? 3 : 0) makes the b128 reads conflict free
+//       zeroed) + 4 clamped corner byte offsets -> LDS "setup" table (36 KB)
+//   per chunk:  B tile (256 x 32 weights, pre-packed chunk-major and pre-swizzled: memory image == LDS image); A tile: every
+//       thread loads the 4 corners of 4 (pixel, 4-channel) cells as float4 straight from x, blends, writes one ds_write_b128 per cell
+//   fragments: ds_read_b128 per 16 x 16 tile per 16 k (lane (r, kq) holds k = 4*kq + s for MFMA step s; A and B use the same
+//       permutation); 128-byte rows, slot' = slot ^ (r & 7) makes the b128 reads conflict free
+//
+// The main loop is ONE instruction stream of 256 "slots" per chunk: an MFMA holds the matrix pipe for 32 cycles but an issue slot for
+// 4, so every staging instruction of chunk ch+1 (table reads, 16 gather loads, 8 weight loads, 12 LDS writes, the blend, the
+// fragment reads, the chunk's single barrier) is placed behind a specific MFMA of chunk ch and issues in its shadow; a scheduling fence
+// after every slot keeps hipcc from regrouping them (left alone it chains dependent MFMAs and clusters the memory ops).
+// Measured (B = 32, 38 x 38, 1024 -> 512, dg 4; scripts/bench_dcn.py): 3.64 ms = 120 TFLOP/s (0.76 of the fp32 peak; the first
+// version -- end-of-chunk barrier, staging before / after the MFMA block, two workgroups per CU -- ran 4.26 ms).  The bare MFMA stream
+// of this tiling runs 3.13 ms (722 tiles on 256 CUs = 3 rounds for 2.82 rounds of work); of the 0.5 ms on top ~0.35 are the 16 gather
+// loads and ~0.1 the weight tile: every VGPR-returning 64-lane x 16-byte load costs ~50 cycles of MFMA issue however it is spread over
+// the slots (ablations in round 2: one per slot / one per four slots / wave-staggered slots all measure the same; an LDS read costs
+// ~4, an LDS-DMA piece less than a load -- hence the weight tile by LDS-DMA).  Next step: stage the x window of a channel chunk in
+// LDS once per 9 taps (10x fewer vector-memory instructions) and gather from LDS.
+#include <type_traits>
 #include "common.h"
+
+#ifndef DCN_B_DMA
+#define DCN_B_DMA 1
+#endif
+#ifndef LD_EVERY
+#define LD_EVERY 4
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 256, BKC = 16;          // tile, channels per K chunk
+constexpr int BM = 128, BN = 256, BKC = 32;          // tile, channels per K chunk (one tap, 128 B per pixel)
 constexpr int WTM = 64, WTN = 128, MT = WTM / 16, NT = WTN / 16;
 constexpr int A_STAGE = BM * BKC, B_STAGE = BN * BKC;            // floats
-constexpr int LDS_FLOATS = 2 * (A_STAGE + B_STAGE) + 9 * BM * 4 + 9 * BM;
+constexpr int SET_FLOATS = 9 * BM * 8;                           // per (tap, pixel): 4 weights + 4 corner byte offsets
+constexpr int LDS_FLOATS = 2 * (A_STAGE + B_STAGE) + SET_FLOATS;
 
 __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ int swz(int row) { return (row & 8) ? 3 : 0; }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// wp: [n_tiles][chunks][BN][16] (slot-swizzled rows), chunk = (d * cpg/16 + c16) * 9 + tap
-__global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// wp: [n_tiles][chunks][BN][32] (slot-swizzled rows), chunk = (d * cpg/32 + c32) * 9 + tap
+__global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg,
                                                           int om_stride, int Cout, int ntn, int mtiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;                                   // [2][BM][16]
-    float* const Bs = smem + 2 * A_STAGE;                     // [2][BN][16]
-    f32x4* const setw = reinterpret_cast<f32x4*>(smem + 2 * (A_STAGE + B_STAGE));   // [9][BM]
-    int* const setp = reinterpret_cast<int*>(smem + 2 * (A_STAGE + B_STAGE) + 9 * BM * 4);   // [9][BM]
+    float* const As = smem;                                   // [2][BM][32]
+    float* const Bs = smem + 2 * A_STAGE;                     // [2][BN][32]
+    f32x4* const setw = reinterpret_cast<f32x4*>(smem + 2 * (A_STAGE + B_STAGE));                 // [9][BM] weights
+    u32x4* const seto = reinterpret_cast<u32x4*>(smem + 2 * (A_STAGE + B_STAGE) + 9 * BM * 4);    // [9][BM] corner byte offsets
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restri
     const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;       // chunks of channels per deformable group
     const int nchunks = dg * cpc * 9;
     const float* wslab = wp + (size_t)nt * nchunks * B_STAGE;
+    const char* xbytes = reinterpret_cast<const char*>(x);
 
     f32x4 acc[MT][NT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -76,10 +105,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
 
-    // gather roles: thread -> (pixel row pl = (tid >> 2) + 64*j, 4-channel quad q = tid & 3)
-    const int gq = tid & 3, gp = tid >> 2;
-    const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 2);                    // LDS float offset of cell j = 0 (j = 1: + 64 rows)
-    const int fo = r * BKC + ((kq ^ swz(r)) << 2);                         // fragment read offset inside a 16-row block
+    // gather roles: thread -> (pixel row pl = (tid >> 3) + 32*j, 4-channel quad q = tid & 7), j = 0..3
+    const int gq = tid & 7, gp = tid >> 3;
+    const int a_wr0 = gp * BKC + ((gq ^ (gp & 7)) << 2);                   // (gp + 32 j) & 7 == gp & 7
+    // fragment read offsets (floats) inside a 16-row block: row r, physical slot (4*ks + kq) ^ (r & 7)
+    const int fo0 = r * BKC + ((kq ^ (r & 7)) << 2);
+    const int fo1 = r * BKC + (((4 + kq) ^ (r & 7)) << 2);
 
     auto setups = [&](int d) {
         // 9 taps x 128 pixels of deformable group d (1152 entries over 256 threads)
@@ -87,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restri
             const int tap = e / BM, pl = e - tap * BM;
             const int m = m0 + pl;
             f32x4 wv = zero4;
-            int pos = 0;
+            u32x4 ov = {0u, 0u, 0u, 0u};
             if (m < M) {
                 const int b = m / HW, pix = m - b * HW;
                 const int h = pix / W, w = pix - h * W;
@@ -107,105 +138,149 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restri
                     wv[1] = (y0ok && x1ok) ? hy * lx * msk : 0.f;
                     wv[2] = (y1ok && x0ok) ? ly * hx * msk : 0.f;
                     wv[3] = (y1ok && x1ok) ? ly * lx * msk : 0.f;
-                    const int ya = y0ok ? y0 : 0, xa = x0ok ? x0 : 0;                    // corner 00 clamped into the image
-                    const int yb = y1ok ? y0 + 1 : H - 1, xb = x1ok ? x0 + 1 : W - 1;    // (zero-weight corners read a valid pixel)
-                    pos = (int)((unsigned)(b * HW + ya * W + xa) | ((unsigned)(xb - xa) << 30) | ((unsigned)(yb - ya) << 31));
+                    const int ya = y0ok ? y0 : 0, xa = x0ok ? x0 : 0;                    // corners clamped into the image:
+                    const int yb = y1ok ? y0 + 1 : H - 1, xb = x1ok ? x0 + 1 : W - 1;    // zero-weight corners read a valid pixel
+                    const unsigned rowb = (unsigned)C * 4u;
+                    const unsigned base = (unsigned)(b * HW) * rowb;
+                    ov[0] = base + (unsigned)(ya * W + xa) * rowb;
+                    ov[1] = base + (unsigned)(ya * W + xb) * rowb;
+                    ov[2] = base + (unsigned)(yb * W + xa) * rowb;
+                    ov[3] = base + (unsigned)(yb * W + xb) * rowb;
                 }
             }
             setw[e] = wv;
-            setp[e] = pos;
+            seto[e] = ov;
         }
     };
 
-    // chunk -> (d, c16, tap)
-    int ch_tap = 0, ch_c = 0, ch_d = 0;          // of the NEXT chunk to stage
-    f32x4 gw[2];
-    f32x4 gv[2][4];
+    int ch_tap = 0, ch_c = 0, ch_d = 0;          // (tap, channel chunk, deformable group) of the NEXT chunk to stage
+    f32x4 gw[4];
+    u32x4 go[4];
+    f32x4 gv[4][4];
+    f32x4 blend[4];
+    unsigned cb = 0;
 
-    auto gather_issue = [&]() {
-        const int cb = ch_d * cpg + ch_c * BKC + gq * 4;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = ch_tap * BM + gp + 64 * j;
-            gw[j] = setw[e];
-            const int pos = setp[e];
-            const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
-            const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
-            const unsigned i10 = i00 + dyb * (unsigned)W;
-            gv[j][0] = *reinterpret_cast<const f32x4*>(x + (size_t)(i00 * (unsigned)C + cb));
-            gv[j][1] = *reinterpret_cast<const f32x4*>(x + (size_t)((i00 + dxb) * (unsigned)C + cb));
-            gv[j][2] = *reinterpret_cast<const f32x4*>(x + (size_t)(i10 * (unsigned)C + cb));
-            gv[j][3] = *reinterpret_cast<const f32x4*>(x + (size_t)((i10 + dxb) * (unsigned)C + cb));
-        }
-    };
-    auto gather_finish = [&](int buf) {
-        float* Ad = As + buf * A_STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 v = gv[j][0] * gw[j][0] + gv[j][1] * gw[j][1] + gv[j][2] * gw[j][2] + gv[j][3] * gw[j][3];
-            *reinterpret_cast<f32x4*>(Ad + a_wr0 + j * 64 * BKC) = v;
-        }
-    };
-    auto b_issue = [&](int chunk, int buf) {
-        const float* src = wslab + (size_t)chunk * B_STAGE + lane * 4;
-        float* dst = Bs + buf * B_STAGE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = j * 4 + wave;                        // 16 pieces of 1 KiB
-            dma16(src + piece * 256, dst + piece * 256);
-        }
-    };
-    auto advance = [&]() {
-        if (++ch_tap == 9) {
-            ch_tap = 0;
-            if (++ch_c == cpc) {
-                ch_c = 0;
-                ++ch_d;
-            }
-        }
+    auto advance = [&]() {                                         // branch-free
+        const int t = ch_tap + 1;
+        const bool wt = t == 9;
+        ch_tap = wt ? 0 : t;
+        const int c = ch_c + (wt ? 1 : 0);
+        const bool wc = c == cpc;
+        ch_c = wc ? 0 : c;
+        ch_d += wc ? 1 : 0;
     };
 
-    // ---- prologue: chunk 0 -----------------------------------------------------------------------------------------------
+    // ---- prologue: chunk 0, unscheduled ----------------------------------------------------------------------------------
     setups(0);
     __syncthreads();
-    gather_issue();
-    b_issue(0, 0);
-    gather_finish(0);
+    {
+        cb = (unsigned)(gq * 4) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = gp + 32 * j;
+            const f32x4 w4 = setw[e];
+            const u32x4 o = seto[e];
+            f32x4 v = zero4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += *reinterpret_cast<const f32x4*>(xbytes + (o[k] + cb)) * w4[k];
+            *reinterpret_cast<f32x4*>(As + a_wr0 + j * 32 * BKC) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma16(wslab + (j * 4 + wave) * 256 + lane * 4, Bs + (j * 4 + wave) * 256);
+    }
     advance();
     __syncthreads();
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        const bool more = ch + 1 < nchunks;
-        if (more) {
-            if (ch_tap == 0 && ch_c == 0) {          // next chunk opens a new deformable group: new sampling table
-                setups(ch_d);
-                __syncthreads();
+    // One chunk = 256 MFMAs per wave (8192 matrix-pipe cycles).  Slot k = MFMA k followed by at most a few staging instructions of
+    // chunk ch+1 that issue in that MFMA's 32-cycle shadow; a scheduling fence after every slot keeps hipcc from regrouping them:
+    //   0..11   the second half (k 16..31) of this chunk's fragment reads         12..15 sampling-table reads of the 4 cells
+    //   16..31  16 gather loads (4 corners x 4 cells, one per slot)               32..39 8 x 16-byte loads of the next weight tile
+    //   120..127 its 8 LDS writes      160..191 blend of the 4 cells (>= 4000 cycles after their loads) + the 4 LDS writes of the next
+    //   activation tile      192 the chunk's barrier      194..205 the first half (k 0..15) of the NEXT chunk's fragment reads
+    f32x4 af[2][MT], bf[2][NT], bstage[8];
+    const float* stage_src = nullptr;
+    float* stage_dst = nullptr;
+    float* stage_dst_w = nullptr;
+    float* a_dst = nullptr;
+    auto slot = [&](auto kc, auto stage_c, const float* Ab, const float* Bb, const float* Abn, const float* Bbn) {
+        constexpr int K = decltype(kc)::value;
+        constexpr bool stage = decltype(stage_c)::value;
+        constexpr int ks = K >> 7, s = (K >> 5) & 3, i = (K >> 3) & 3, j = K & 7;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
+        if constexpr (K < 4) af[1][K] = *reinterpret_cast<const f32x4*>(Ab + K * 16 * BKC + fo1);
+        if constexpr (K >= 4 && K < 12) bf[1][K - 4] = *reinterpret_cast<const f32x4*>(Bb + (K - 4) * 16 * BKC + fo1);
+        if constexpr (stage) {
+            if constexpr (K >= 12 && K < 16) {
+                const int e = ch_tap * BM + gp + 32 * (K - 12);
+                gw[K - 12] = setw[e];
+                go[K - 12] = seto[e];
             }
-            gather_issue();
-            b_issue(ch + 1, buf ^ 1);
+            if constexpr (K >= 16 && K < 16 + 16 * LD_EVERY && (K - 16) % LD_EVERY == 0) {
+                constexpr int n = (K - 16) / LD_EVERY, c = n >> 2, k = n & 3;
+                gv[c][k] = *reinterpret_cast<const f32x4*>(xbytes + (go[c][k] + cb));
+            }
+#if DCN_B_DMA
+            if constexpr (K >= 112 && K < 144 && (K & 3) == 0) dma16(stage_src + ((K - 112) >> 2) * 1024, stage_dst_w + ((K - 112) >> 2) * 1024);
+#else
+            if constexpr (K >= 32 && K < 40) bstage[K - 32] = *reinterpret_cast<const f32x4*>(stage_src + (K - 32) * 1024);
+            if constexpr (K >= 120 && K < 128) *reinterpret_cast<f32x4*>(stage_dst + (K - 120) * 1024) = bstage[K - 120];
+#endif
+            if constexpr (K >= 160 && K < 192) {
+                constexpr int c = (K - 160) >> 3, ph = (K - 160) & 7;
+                // scalar FMAs on purpose (compiled with -fno-slp-vectorize): a packed-f32 VALU op beside an MFMA costs ~25 cycles
+                // more than the two scalar ops it replaces (MI355X_MICROARCH.md, filler prices)
+                if constexpr (ph == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) blend[c][e] = gv[c][0][e] * gw[c][0];
+                }
+                if constexpr (ph >= 1 && ph <= 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) blend[c][e] = __builtin_fmaf(gv[c][ph][e], gw[c][ph], blend[c][e]);
+                }
+                if constexpr (ph == 4) *reinterpret_cast<f32x4*>(a_dst + c * 32 * BKC) = blend[c];
+            }
+            // the ONE barrier of the chunk sits inside the MFMA stream: both tiles of chunk ch+1 are in LDS, the k 0..15 fragment
+            // registers are dead since slot 127 -> they are refilled for chunk ch+1 while the k 16..31 MFMAs of this chunk still run
+            if constexpr (K == 192) __syncthreads();
+            if constexpr (K >= 194 && K < 198) af[0][K - 194] = *reinterpret_cast<const f32x4*>(Abn + (K - 194) * 16 * BKC + fo0);
+            if constexpr (K >= 198 && K < 206) bf[0][K - 198] = *reinterpret_cast<const f32x4*>(Bbn + (K - 198) * 16 * BKC + fo0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float* Ab = As + buf * A_STAGE + wm * WTM * BKC + fo;
-        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC + fo;
-        f32x4 af[MT], bf[NT];
+    };
+
+    // fragments k 0..15 of chunk 0
+    {
+        const float* Ab = As + wm * WTM * BKC;
+        const float* Bb = Bs + wn * WTN * BKC;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * BKC);
+        for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * BKC + fo0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 16 * BKC);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            gather_finish(buf ^ 1);
-            advance();
+        for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 16 * BKC + fo0);
+    }
+    for (int ch = 0; ch < nchunks - 1; ++ch) {
+        const int buf = ch & 1;
+        if (ch_tap == 0 && ch_c == 0) {          // the next chunk opens a new deformable group: new sampling table
+            setups(ch_d);
+            __syncthreads();
         }
-        __syncthreads();
+        cb = (unsigned)(ch_d * cpg + ch_c * BKC + gq * 4) * 4u;
+        stage_src = wslab + (size_t)(ch + 1) * B_STAGE + wave * 256 + lane * 4;
+        stage_dst = Bs + (buf ^ 1) * B_STAGE + wave * 256 + lane * 4;
+        stage_dst_w = Bs + (buf ^ 1) * B_STAGE + wave * 256;
+        a_dst = As + (buf ^ 1) * A_STAGE + a_wr0;
+        const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
+        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
+        const float* Abn = As + (buf ^ 1) * A_STAGE + wm * WTM * BKC;
+        const float* Bbn = Bs + (buf ^ 1) * B_STAGE + wn * WTN * BKC;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 256>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
+        advance();
+    }
+    {
+        const int buf = (nchunks - 1) & 1;
+        const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
+        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
+        static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
     }
 
     // ---- epilogue: + bias, NHWC store ------------------------------------------------------------------------------------
@@ -224,18 +299,18 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const float* __restri
     }
 }
 
-// OIHW [Cout][C][3][3] -> [n_tiles][chunks][BN][16] with the slot swizzle; rows beyond Cout are zero
+// OIHW [Cout][C][3][3] -> [n_tiles][chunks][BN][32] with the slot swizzle; rows beyond Cout are zero
 __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int C, int dg, long long total) {
     const int cpg = C / dg, cpc = cpg / BKC, nchunks = dg * cpc * 9;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 3);
-        const int slot = (int)((i >> 2) & 3);
-        const int nl = (int)((i >> 4) % BN);
-        const long long t = (i >> 4) / BN;
+        const int slot = (int)((i >> 2) & 7);
+        const int nl = (int)((i >> 5) % BN);
+        const long long t = (i >> 5) / BN;
         const int chunk = (int)(t % nchunks);
         const int nt = (int)(t / nchunks);
-        const int q = slot ^ swz(nl);                 // logical quad stored in this physical slot
-        const int tap = chunk % 9, cc = chunk / 9;    // cc = d * cpc + c16
+        const int q = slot ^ (nl & 7);                // logical quad stored in this physical slot
+        const int tap = chunk % 9, cc = chunk / 9;    // cc = d * cpc + c32
         const int c = cc * BKC + q * 4 + e;
         const int n = nt * BN + nl;
         wp[i] = n < Cout ? w[((size_t)n * C + c) * 9 + tap] : 0.f;
@@ -264,20 +339,20 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     GSSD_CHECK_ARG(C % dg == 0 && (C / dg) % BKC == 0 && om_stride >= 27 * dg);
     GSSD_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0);
     const long long Mll = (long long)B * H * W;
-    GSSD_CHECK_ARG(Mll < (1ll << 30) && Mll * C < (1ll << 30));          // 30-bit pixel index + 2 flag bits; 32-bit byte offsets
+    GSSD_CHECK_ARG(Mll < (1ll << 31) && Mll * C < (1ll << 30));          // 32-bit byte offsets into x
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
     static bool attr_set[16] = {false};
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     constexpr int smem = LDS_FLOATS * (int)sizeof(float);
-    if (dev < 16 && !attr_set[dev]) {
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
             return GSSD_ELAUNCH;
         }
-        attr_set[dev] = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     // grid: ids round-robin over the 8 XCDs; slots cover ceil(mtiles / (8 / ntn)) groups when ntn divides 8
     int blocks;

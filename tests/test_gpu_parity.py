@@ -405,7 +405,7 @@ def test_dcn_im2col_and_identities(dev, ops):
     assert rel(nchw(y0), ident) < TOL
 
 
-@pytest.mark.parametrize('B,Cc,H,dg,Cout', [(2, 64, 9, 4, 32), (3, 128, 13, 1, 300), (1, 64, 5, 2, 256), (5, 256, 11, 4, 512)])
+@pytest.mark.parametrize('B,Cc,H,dg,Cout', [(2, 128, 9, 4, 32), (3, 128, 13, 1, 300), (1, 64, 5, 2, 256), (5, 256, 11, 4, 512)])
 def test_dcn_fused_forward(dev, ops, B, Cc, H, dg, Cout):
     """The fused deformable conv kernel (sampling + contraction, no column buffer) vs the oracle restatement of DCNv2 (parity
     unpinned upstream), on ragged tiles (M not a multiple of 128, Cout not a multiple of 256, tiles crossing images) with
