@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
         ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i), ('split_k', c_i),
+        ('out_b_stride', c_i), ('reserved0', c_i),
         ('in_batch_stride', c_i64), ('wgt_batch_stride', c_i64), ('out_batch_stride', c_i64),
         ('outb_batch_stride', c_i64), ('out_off', c_i64), ('outb_off', c_i64),
     ]
@@ -42,11 +43,12 @@ class SnItem(C.Structure):
     _fields_ = [('w', c_fp), ('u', c_fp), ('v', c_fp), ('inv_sigma', c_fp), ('rows', c_i), ('cols', c_i)]
 
 
-OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS = 0, 1, 2
+OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {
     'gssd_abi_version': (c_i, []),
+    'gssd_conv_desc_size': (c_i, []),
     'gssd_last_error': (C.c_char_p, []),
     'gssd_build_arch': (C.c_char_p, []),
     'gssd_pack_input_nhwc': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     'gssd_heads_gather_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_upsample_insert_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
+    'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),
@@ -86,8 +89,6 @@ SIGNATURES = {
     'gssd_eval_workspace_bytes': (C.c_longlong, [c_i]),
     'gssd_eval_ap': (c_i, [c_fp, c_fp, c_i, c_i, c_d, c_i, c_fp, C.c_longlong, c_fp, c_fp]),
     'gssd_gemm_nt_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
-    'gssd_gemm_nt_batched_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, C.c_longlong, C.c_longlong, C.c_longlong, c_i,
-                                        c_fp]),
     'gssd_gemm_tn_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_col2im_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
@@ -118,6 +119,9 @@ def _load():
             raise GssdError(f'{LIB_PATH} does not export {name}; rebuild it') from e
         fn.restype = res
         fn.argtypes = args
+    if lib.gssd_conv_desc_size() != C.sizeof(ConvDesc):
+        raise GssdError(f'{LIB_PATH}: struct gssd_conv_desc is {lib.gssd_conv_desc_size()} bytes in the library, '
+                        f'{C.sizeof(ConvDesc)} in this binding; rebuild the library')
     return lib
 
 

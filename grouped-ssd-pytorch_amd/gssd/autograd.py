@@ -59,7 +59,7 @@ class GssdTrainFn(torch.autograd.Function):
         if x.requires_grad:
             raise _lib.GssdError('the HIP path provides no gradient with respect to the input images '
                                  '(x.requires_grad=True); detach the input')
-        loc, conf, plan = net._engine.forward_plan(x, True, net.__dict__.get('_events'))
+        loc, conf, plan = net._engine.forward_plan(x, True, net.__dict__.get('_events'), bool(net.__dict__.get('_want_maps')))
         ctx.net, ctx.params = net, params
         ctx.plan, ctx.gen = plan, plan.generation
         ctx.lease = _Lease(plan)

@@ -258,8 +258,8 @@ class BackwardPlan:
         gx, existed = self._reserve(x, x.shape)
         B, N, Cc = self.B, r['N'], r['C']
         C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
-        tp, gT, S, ag = r['tp'], r['gT'], r['S'], r['ag']
-        a_tp, a_g, a_o = r['inv_sigma']
+        tp, gT, ag = r['tp'], r['gT'], r['ag']
+        a_tpg, a_o = r['inv_sigma']
         cv = {k: getattr(sa, 'snconv1x1_' + k) for k in ('theta', 'phi', 'g', 'attn')}
         pg = {k: (self._pgrad(m.weight_orig), self._pgrad(m.bias)) for k, m in cv.items()}
         pg_sigma = self._pgrad(sa.sigma)
@@ -277,14 +277,14 @@ class BackwardPlan:
             if g_out2 is not None:
                 dT = dT + g_out2.view(B, N, Cc)
             sig = sa.sigma.detach()
-            is_t, is_p, is_g, is_o = a_tp[0], a_tp[C8], a_g[0], a_o[0]           # 1 / sigma_sn of each conv (device scalars)
+            is_t, is_p, is_g, is_o = a_tpg[0], a_tpg[C8], a_tpg[C4], a_o[0]       # 1 / sigma_sn of each conv (device scalars)
             w_o = cv['attn'].weight_orig.detach().view(Cc, C2)
             w_g = cv['g'].weight_orig.detach().view(C2, Cc)
             w_t = cv['theta'].weight_orig.detach().view(C8, Cc)
             w_p = cv['phi'].weight_orig.detach().view(C8, Cc)
-            A = S[:, :, :N]
-            g_tok = gT[:, :, :N].transpose(1, 2)                                 # [B, N, C2] view
             theta, phi = tp[:, :, :C8], tp[:, :, C8:]
+            A = torch.softmax(torch.bmm(theta, phi.transpose(1, 2)), dim=-1)     # the forward is flash-style: no stored map
+            g_tok = gT[:, :, :N].transpose(1, 2)                                 # [B, N, C2] view
             # output conv and the gate
             o_raw = torch.matmul(ag, w_o.t()) * is_o + cv['attn'].bias.detach()
             pg_sigma.copy_((dT * o_raw).sum().view(pg_sigma.shape))

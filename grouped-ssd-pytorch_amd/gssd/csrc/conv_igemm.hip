@@ -244,7 +244,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
                 }
             }
             if (!n_ok) continue;
-            if (p.out_mode == GSSD_OUT_TRANSPOSED) {
+            if (p.out_mode == GSSD_OUT_SPLIT_T && n0g >= p.split_n) {
+                // second column range of a merged projection: per image [n - split_n][m], zero padded up to the row stride
+                if (mb < p.out_b_stride) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (mb + e < M) ? v[e] : 0.f;
+                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)img * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + mb) = o;
+                }
+            } else if (p.out_mode == GSSD_OUT_TRANSPOSED) {
                 if (mb < p.out_stride) {
                     f32x4 o;
 #pragma unroll
@@ -354,7 +362,12 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     GSSD_CHECK_ARG(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0);
     GSSD_CHECK_ARG(d.K == d.KH * d.KW * d.cin_g && d.wgt_row_stride >= d.K && d.wgt_row_stride % 4 == 0);
     GSSD_CHECK_ARG(((uintptr_t)d.in % 16) == 0 && ((uintptr_t)d.wgt % 16) == 0);
-    GSSD_CHECK_ARG(d.out_mode >= 0 && d.out_mode <= 2);
+    GSSD_CHECK_ARG(d.out_mode >= 0 && d.out_mode <= 3);
+    if (d.out_mode == GSSD_OUT_SPLIT_T) {
+        GSSD_CHECK_ARG(d.m_per_image && d.groups == 1 && d.out_b && d.split_n > 0 && d.split_n < d.Cout && d.split_n % 64 == 0);
+        GSSD_CHECK_ARG(d.out_b_stride % 4 == 0 && d.out_b_stride >= d.Ho * d.Wo && d.outb_batch_stride % 4 == 0 && ((uintptr_t)d.out_b % 16) == 0);
+        GSSD_CHECK_ARG(!d.gate && !d.resid && !d.relu && !d.stats && d.split_k == 1);
+    }
     if (d.out_mode == GSSD_OUT_TRANSPOSED) {
         GSSD_CHECK_ARG(d.m_per_image && d.out_stride % 4 == 0 && ((uintptr_t)d.out % 16) == 0);
         GSSD_CHECK_ARG(d.out_batch_stride % 4 == 0 && !d.gate && !d.resid);
@@ -400,7 +413,7 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const double e64 = 0.94 * (double)b64 / (double)(((b64 + 767) / 768) * 768);
         // short reductions (K <= 256: the attention output conv) are prologue / epilogue bound: three resident 128x64
         // workgroups per CU overlap those phases better than two 128x128 ones
-        if (e64 > e128 || d.K <= 256) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
+        if (e64 > e128 || d.K <= 256 || (d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 128 != 0)) return launch_cfg<128, 64, 2, 2>(d, M, images, s);
         return launch_cfg<128, 128, 2, 2>(d, M, images, s);
     }
     if (cout_g > 32) return launch_cfg<128, 64, 2, 2>(d, M, images, s);

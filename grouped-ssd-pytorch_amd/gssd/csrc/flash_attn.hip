@@ -1,0 +1,204 @@
+// Flash-style Self_Attn core for gfx950 (fp32 MFMA): attn_g[i][c] = sum_j softmax_j(theta_i . phi_j) * g[c][j], without ever
+// materialising the [N, N] attention map (layers/self_attn.py:68-80: bmm -> Softmax(dim=-1) -> bmm; no 1/sqrt(d) scaling).
+//
+//   tp  [B][N][2*D]   token-major projections, theta = channels [0, D), phi = channels [D, 2D)       (queries / keys)
+//   gT  [B][C2][Np]   value projection, channel-major, tokens contiguous (Np = N rounded up to 4, pad = 0)
+//   out [B][N][C2]    token-major attn_g (the input of the o 1x1 conv)
+//
+// A 256-thread workgroup owns 64 queries of one image; wave w owns 16 of them and ALL C2 value channels.  Everything is kept in the
+// "column = query" orientation of v_mfma_f32_16x16x4_f32's C layout, so no lane transposition is ever needed:
+//   S^T tile = K . Q^T   (A = keys [key][d] from LDS, B = queries [query][d] in registers)  -> lane (q = lane & 15, kq = lane >> 4)
+//                         holds S[q][key = 16*kt + 4*kq + reg]: exactly the B-operand layout (k = 4*kq + s) of the next product
+//   online softmax        row max / rescale per query: 4 registers x BKV/16 tiles, then two lane shuffles (xor 16, 32) across kq
+//   O^T += V . P^T        (A = values [channel][key] from LDS, B = P in registers) -> lane holds O[q][c = 16*ct + 4*kq + reg]:
+//                         four consecutive channels of one token = one 16-byte NHWC store
+// K and V tiles are staged by 16-byte LDS-DMA with a source-side XOR swizzle (quad' = quad ^ (row & 15)), which makes every
+// ds_read_b128 fragment read conflict free; two workgroups share a CU (80 KB of LDS each) and hide each other's staging.
+#include <math.h>
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Stage a [ROWS][QR quads] tile: lane L of a 1-KiB piece lands at (row_in = L / QR, slot = L % QR) and fetches logical quad
+// slot ^ (row & SW).  row_ptr(row) -> global pointer of that row's first float or nullptr (zero row); quad_ok(quad) masks columns.
+template <int ROWS, int QR, typename RowPtr, typename QuadOk>
+__device__ __forceinline__ void stage_tile(float* lds, int wave, int lane, RowPtr row_ptr, QuadOk quad_ok) {
+    constexpr int RPP = 64 / QR;                       // rows per 1-KiB piece
+    constexpr int PIECES = ROWS / RPP;
+    constexpr int SW = (QR < 16 ? QR : 16) - 1;
+    const int row_in = lane / QR, slot = lane % QR;
+#pragma unroll
+    for (int p0 = 0; p0 < PIECES; p0 += 4) {
+        const int piece = p0 + wave;
+        if (PIECES % 4 != 0 && piece >= PIECES) break;
+        const int row = piece * RPP + row_in;
+        const int quad = slot ^ (row & SW);
+        const float* rp = row_ptr(row);
+        const float* src = (rp != nullptr && quad_ok(quad)) ? rp + 4 * quad : g_zero16;
+        dma16(src, lds + piece * 256);
+    }
+}
+
+template <int D, int C2, int BKV>
+__global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ gT,
+                                                           float* __restrict__ out, int N, int Np, int qtiles, int d_real) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ks = smem;                    // [BKV][D]
+    float* const Vs = smem + BKV * D;          // [C2][BKV]
+    constexpr int QRK = D / 4, QRV = BKV / 4;
+    constexpr int SWK = (QRK < 16 ? QRK : 16) - 1, SWV = (QRV < 16 ? QRV : 16) - 1;
+    constexpr int KT = BKV / 16, CT = C2 / 16, DI = D / 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x / qtiles, qt = blockIdx.x - b * qtiles;
+    const int q = qt * 64 + wave * 16 + r;                       // this lane's query (column of every C-layout tile)
+    const int tps = 2 * d_real;                                   // floats per token of tp (d_real <= D; D - d_real zero filled)
+    const float* tpb = tp + (size_t)b * N * tps;
+    const float* gTb = gT + (size_t)b * C2 * Np;
+
+    // query fragments: B operand, lane (q, kq) holds theta[q][16 i + 4 kq + s]
+    f32x4 qf[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+        qf[i] = (q < N && 16 * i + 4 * kq < d_real) ? *reinterpret_cast<const f32x4*>(tpb + (size_t)q * tps + 16 * i + 4 * kq)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;                        // l_run: this lane's share (its kq keys) of the row sum
+
+    const int ntiles = (N + BKV - 1) / BKV;
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * BKV;
+        __syncthreads();                                          // every wave is done with the previous tiles
+        stage_tile<BKV, QRK>(Ks, wave, lane,
+                             [&](int row) { return key0 + row < N ? tpb + (size_t)(key0 + row) * tps + d_real : (const float*)nullptr; },
+                             [&](int quad) { return 4 * quad < d_real; });
+        stage_tile<C2, QRV>(Vs, wave, lane, [&](int row) { return gTb + (size_t)row * Np + key0; },
+                            [&](int quad) { return key0 + 4 * quad < Np; });
+        __syncthreads();                                          // (waits for the DMA: vmcnt(0) + barrier)
+
+        // ---- S^T = K . Q^T ----------------------------------------------------------------------------------------------------
+        // (independent accumulators back to back: a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one 32)
+        f32x4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            f32x4 kf[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int row = kt * 16 + r;
+                kf[kt] = *reinterpret_cast<const f32x4*>(Ks + row * D + (((4 * i + kq) ^ (row & SWK)) << 2));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][e], qf[i][e], s[kt], 0, 0, 0);
+        }
+        // ---- online softmax over the keys of this tile ----------------------------------------------------------------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (key0 + kt * 16 + 4 * kq + e >= N) s[kt][e] = -INFINITY;
+                mx = fmaxf(mx, s[kt][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                     // finite: every tile holds at least one valid key
+        const float alpha = __expf(m_run - m_new);                // 0 on the first tile (m_run = -inf)
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __expf(s[kt][e] - m_new);
+                s[kt][e] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o[c] *= alpha;
+        // ---- O^T += V . P^T -------------------------------------------------------------------------------------------------------
+        constexpr int CG = CT < 4 ? CT : 4;
+#pragma unroll
+        for (int cg = 0; cg < CT; cg += CG) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 vf[CG];
+#pragma unroll
+                for (int cc = 0; cc < CG; ++cc) {
+                    const int row = (cg + cc) * 16 + r;
+                    vf[cc] = *reinterpret_cast<const f32x4*>(Vs + row * BKV + (((4 * kt + kq) ^ (row & SWV)) << 2));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+                        o[cg + cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[cc][e], s[kt][e], o[cg + cc], 0, 0, 0);
+            }
+        }
+    }
+    // row sums: the four kq lanes of a query hold disjoint key subsets
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_run;
+    if (q < N) {
+        float* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(dst + 16 * c) = o[c] * inv;
+    }
+}
+
+template <int D, int C2, int BKV>
+int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, int d_real, hipStream_t stream) {
+    constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto kern = flash_attn_kernel<D, C2, BKV>;
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
+            return GSSD_ELAUNCH;
+        }
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    const int qtiles = (N + 63) / 64;
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np, qtiles, d_real);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+}  // namespace
+
+extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, float* out, int B, int N, int Np, int D, int C2,
+                                       gssd_stream_t stream) {
+    GSSD_CHECK_ARG(tp && gT && out && B > 0 && N > 0 && Np >= N && Np % 4 == 0);
+    GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)gT % 16) == 0 && ((uintptr_t)out % 16) == 0);
+    GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
+    hipStream_t s = as_stream(stream);
+    GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0);
+    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, gT, out, B, N, Np, D, s);
+    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, gT, out, B, N, Np, D, s);
+    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, gT, out, B, N, Np, D, s);
+    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, gT, out, B, N, Np, D, s);     // small maps (Self_Attn(64): op-level tests)
+    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, gT, out, B, N, Np, D, s);
+    gssd_set_error("self-attention core: unsupported (theta/phi channels %d, g channels %d); built: (64,256) (128,512) (32,128) (<=16,32|64)", D, C2);
+    return GSSD_EINVAL;
+}

@@ -77,20 +77,3 @@ extern "C" int gssd_gemm_tn_f32(const float* A, const float* B, float* C, int M,
     }
     return GSSD_OK;
 }
-
-// batched form: C_b[M][N] = A_b[M][K] . B_b[N][K]^T for b < batch (operands `stride*` floats apart): the two torch.bmm calls of
-// Self_Attn (layers/self_attn.py:71,80)
-extern "C" int gssd_gemm_nt_batched_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                                        long long strideA, long long strideB, long long strideC, int batch, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N && batch > 0);
-    hipStream_t s = as_stream(stream);
-    const int rc = ensure_handle(s);
-    if (rc != GSSD_OK) return rc;
-    const float alpha = 1.f, beta = 0.f;
-    if (rocblas_sgemm_strided_batched(g_handle, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &alpha, B, ldb,
-                                      strideB, A, lda, strideA, &beta, C, ldc, strideC, batch) != rocblas_status_success) {
-        gssd_set_error("rocblas_sgemm_strided_batched failed");
-        return GSSD_ELAUNCH;
-    }
-    return GSSD_OK;
-}

@@ -32,7 +32,6 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
-USE_LIB_BMM = os.environ.get('GSSD_NO_LIB_BMM', '0') != '1'
 
 class _Step:
     __slots__ = ('fn', 'args', 'keep', 'tag')
@@ -113,7 +112,7 @@ class GssdEngine:
     # ------------------------------------------------------------------------------------------
     MAX_PLANS_IN_FLIGHT = 4
 
-    def forward_plan(self, x, training, events=None):
+    def forward_plan(self, x, training, events=None, want_maps=False):
         """Run one forward; returns (loc, conf, plan).  A plan whose last grad-enabled forward still awaits its backward is busy
         (gssd/autograd.py) and is never reused: the call takes (or builds) another instance with its own buffers."""
         net = self.net
@@ -132,14 +131,14 @@ class GssdEngine:
         if tuple(x.shape[1:]) != (cin, 300, 300):
             raise _lib.GssdError(f'expected input [B,{cin},300,300], got {tuple(x.shape)}')
         bn_cfg = tuple((m.momentum, m.eps) for m in self._bn_list)
-        key = (B, bool(training), x.device.index, hash(bn_cfg))
+        key = (B, bool(training), x.device.index, hash(bn_cfg), bool(want_maps))
         plans = self._plans.setdefault(key, [])
         plan = next((pl for pl in plans if not pl.busy), None)
         if plan is None:
             if len(plans) >= self.MAX_PLANS_IN_FLIGHT:
                 raise _lib.GssdError(f'{len(plans)} forwards of batch {B} are still waiting for their backward; free their '
                                      f'outputs (or call backward) before running more')
-            plan = self._build(B, bool(training), x.device)
+            plan = self._build(B, bool(training), x.device, bool(want_maps))
             plans.append(plan)
             vers, ptrs = self._state()
         self._ptrs = ptrs
@@ -151,8 +150,8 @@ class GssdEngine:
         loc, conf = plan.run(x, events)
         return loc, conf, plan
 
-    def forward(self, x, training, events=None):
-        loc, conf, _ = self.forward_plan(x, training, events)
+    def forward(self, x, training, events=None, want_maps=False):
+        loc, conf, _ = self.forward_plan(x, training, events, want_maps)
         return loc, conf
 
     # ------------------------------------------------------------------------------------------
@@ -164,10 +163,10 @@ class GssdEngine:
             self._pack_jobs.append(lambda: build(self._packed[name]))
         return self._packed[name]
 
-    def _build(self, B, training, dev):
+    def _build(self, B, training, dev, want_maps=False):
         if getattr(self.net, 'vanilla', False):
             return _PlanVanilla(self, B, training, dev)
-        return _Plan(self, B, training, dev)
+        return _Plan(self, B, training, dev, want_maps)
 
 
 class _PlanBase:
@@ -184,8 +183,9 @@ class _PlanBase:
 
 
 class _Plan(_PlanBase):
-    def __init__(self, eng, B, training, dev):
+    def __init__(self, eng, B, training, dev, want_maps=False):
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
+        self.want_maps = want_maps                 # visualize=True: also materialise the attention maps
         net = eng.net
         self.steps = []
         self.bufs = []
@@ -268,7 +268,7 @@ class _Plan(_PlanBase):
         sources = [src0]
         sab_i, sa_i = 1, 1
         if net.use_self_attention_base:
-            cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)
+            cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False, want_map=self.want_maps)
             sab_i += 1
         sources.append(self._branch(cur, H, Cc, sa_i, '21'))
         sa_i += 1
@@ -283,7 +283,7 @@ class _Plan(_PlanBase):
                                            defer_bn=((k + 1) % 4 != 3))
             if (k + 1) % 4 == 3:
                 if net.use_self_attention_base:
-                    cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False)
+                    cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False, want_map=self.want_maps)
                     sab_i += 1
                 sources.append(self._branch(cur, H, Cc, sa_i, FUSE_NAMES[fi]))
                 sa_i += 1
@@ -343,16 +343,15 @@ class _Plan(_PlanBase):
         for lst_name, lst in lists:
             for i, sa in enumerate(lst):
                 Cc = sa.in_channels
-                a_tp = self._buf(Cc // 4)
-                a_g = self._buf(Cc // 2)
+                a_tpg = self._buf(Cc // 4 + Cc // 2)         # 1/sigma per output channel of the merged theta|phi|g projection
                 a_o = self._buf(Cc)
                 self.sn_items += [
-                    (sa.snconv1x1_theta.weight_orig, sa.snconv1x1_theta.weight_u, sa.snconv1x1_theta.weight_v, a_tp[:Cc // 8]),
-                    (sa.snconv1x1_phi.weight_orig, sa.snconv1x1_phi.weight_u, sa.snconv1x1_phi.weight_v, a_tp[Cc // 8:]),
-                    (sa.snconv1x1_g.weight_orig, sa.snconv1x1_g.weight_u, sa.snconv1x1_g.weight_v, a_g),
+                    (sa.snconv1x1_theta.weight_orig, sa.snconv1x1_theta.weight_u, sa.snconv1x1_theta.weight_v, a_tpg[:Cc // 8]),
+                    (sa.snconv1x1_phi.weight_orig, sa.snconv1x1_phi.weight_u, sa.snconv1x1_phi.weight_v, a_tpg[Cc // 8:Cc // 4]),
+                    (sa.snconv1x1_g.weight_orig, sa.snconv1x1_g.weight_u, sa.snconv1x1_g.weight_v, a_tpg[Cc // 4:]),
                     (sa.snconv1x1_attn.weight_orig, sa.snconv1x1_attn.weight_u, sa.snconv1x1_attn.weight_v, a_o),
                 ]
-                self.sa_state[(lst_name, i)] = (a_tp, a_g, a_o)
+                self.sa_state[(lst_name, i)] = (a_tpg, a_o)
         if self.sn_items:
             self.sn_dev = ops.sn_items_tensor([(w.detach(), u, v, s) for (w, u, v, s) in self.sn_items], self.dev)
             self._add(lib.gssd_spectral_norm_f32, (self.sn_dev.data_ptr(), len(self.sn_items), int(self.training), 1e-12))
@@ -429,7 +428,7 @@ class _Plan(_PlanBase):
         net, B = self.eng.net, self.B
         attn_g = None
         if net.use_self_attention_base:
-            x, attn_g = self._self_attn('self_attn_base_list', 0, x, H, Cc, need_out2=bool(net.dcn_cat_sab))
+            x, attn_g = self._self_attn('self_attn_base_list', 0, x, H, Cc, need_out2=bool(net.dcn_cat_sab), want_map=self.want_maps)
         if net.use_dcn:
             xin, Cin = x, Cc
             if net.dcn_cat_sab:
@@ -455,83 +454,82 @@ class _Plan(_PlanBase):
         """[SA] -> 1x1 fuse conv + BN + ReLU -> a multibox source (models/...group.py:284-297)."""
         net = self.eng.net
         if net.use_self_attention:
-            s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False)
+            s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False, want_map=self.want_maps)
         if net.use_fuseconv:
             conv, bn = getattr(net, f'fuse_{fuse}'), getattr(net, f'bn_fuse_{fuse}')
             s, H, Cc, _ = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
         return (s, H, Cc)
 
     def _self_attn(self, lst_name, idx, x, H, Cc, need_out2, want_map=False):
-        """layers/self_attn.py:46-89 as five launches (K9/K10): theta|phi conv, g conv (transposed), theta^T phi,
-        row softmax, attn.g^T, and the o conv with the sigma-gated residual epilogue."""
+        """layers/self_attn.py:46-89 as three launches: ONE pass over x for the theta | phi | g projections (K9; g written
+        transposed), the flash-style core theta^T phi -> softmax -> . g (K10, csrc/flash_attn.hip: the [N, N] map never exists),
+        and the o conv with the sigma-gated residual epilogue.  ``want_map`` (visualize=True, op-level tests) additionally
+        materialises the attention map with two extra launches; the output path does not read it."""
         eng, B = self.eng, self.B
         sa = getattr(eng.net, lst_name)[idx]
-        a_tp, a_g, a_o = self.sa_state[(lst_name, idx)]
+        a_tpg, a_o = self.sa_state[(lst_name, idx)]
         N = H * H
         Np = ops.round_up(N, 4)
         C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
         dev, f32 = self.dev, torch.float32
         name = f'{lst_name}.{idx}'
 
-        def build_tp(out):
+        def build_w(out):
             if out is None:
-                out = torch.empty(C4, Cc, device=dev, dtype=f32)
+                out = torch.empty(C4 + C2, Cc, device=dev, dtype=f32)
             out[:C8].copy_(sa.snconv1x1_theta.weight_orig.detach().view(C8, Cc))
-            out[C8:].copy_(sa.snconv1x1_phi.weight_orig.detach().view(C8, Cc))
+            out[C8:C4].copy_(sa.snconv1x1_phi.weight_orig.detach().view(C8, Cc))
+            out[C4:].copy_(sa.snconv1x1_g.weight_orig.detach().view(C2, Cc))
             return out
 
-        def build_tpb(out):
+        def build_b(out):
             if out is None:
-                out = torch.empty(C4, device=dev, dtype=f32)
+                out = torch.empty(C4 + C2, device=dev, dtype=f32)
             out[:C8].copy_(sa.snconv1x1_theta.bias.detach())
-            out[C8:].copy_(sa.snconv1x1_phi.bias.detach())
+            out[C8:C4].copy_(sa.snconv1x1_phi.bias.detach())
+            out[C4:].copy_(sa.snconv1x1_g.bias.detach())
             return out
-        w_tp = eng._pack(name + '.tp.w', build_tp)
-        b_tp = eng._pack(name + '.tp.b', build_tpb)
-        w_g = sa.snconv1x1_g.weight_orig.detach().view(C2, Cc)      # already K-major rows
-        w_o = sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)
+        w_tpg = eng._pack(name + '.tpg.w', build_w)
+        b_tpg = eng._pack(name + '.tpg.b', build_b)
+        w_o = sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)       # already K-major rows
         tp = self._buf(B, N, C4)
         gT = self._buf(B, C2, Np)
-        S = self._buf(B, N, Np)
         ag = self._buf(B, N, C2)
         out = self._buf(B, H, H, Cc)
         out2 = self._buf(B, H, H, Cc) if need_out2 else None
         mk = ops.make_conv_desc
-        d1, _, _ = mk(x, w_tp, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4, bias=b_tp, alpha=a_tp)
-        d2, _, _ = mk(x, w_g, gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=sa.snconv1x1_g.bias.detach(),
-                      alpha=a_g, out_mode=_lib.OUT_TRANSPOSED, out_stride=Np, m_per_image=True,
-                      in_batch_stride=N * Cc, out_batch_stride=C2 * Np)
-        # S[b,i,j] = sum_c theta[b,i,c] * phi[b,j,c]   (no 1/sqrt(d) scaling, self_attn.py:71)
-        d3, _, _ = mk(tp, tp[0, 0, C8:], S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
-                      in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
-        # attn_g[b,i,c] = sum_j attn[b,i,j] * g[b,c,j]
-        d4, _, _ = mk(S, gT, ag, B=B, H=H, W=H, in_stride=Np, cin_g=Np, Cout=C2, m_per_image=True, in_batch_stride=N * Np,
-                      wgt_batch_stride=C2 * Np, out_batch_stride=N * C2, wgt_row_stride=Np)
+        d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg,
+                      out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=True,
+                      in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np)
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
                       alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2)
         fn = lib.gssd_conv2d_nhwc_f32
-        self._add(fn, (C.byref(d1),), keep=(d1, w_tp, b_tp))
-        self._add(fn, (C.byref(d2),), keep=d2)
-        if USE_LIB_BMM:
-            # the reference's two torch.bmm calls: plain batched GEMMs -> rocBLAS (conv_igemm's K = C/8 = 64 product is
-            # prologue / epilogue bound at 42 TFLOP/s)
-            self._add(lib.gssd_gemm_nt_batched_f32, (tp.data_ptr(), tp[0, 0, C8:].data_ptr(), S.data_ptr(), N, N, C8, C4, C4, Np,
-                                                    N * C4, N * C4, N * Np, B), keep=d3,
-                      tag=('bmm_rocblas', 2.0 * B * N * N * C8, 4.0 * B * (2 * N * C8 + N * N)))
+        if C4 % 64 == 0:
+            self._add(fn, (C.byref(d1),), keep=(d1, w_tpg, b_tpg))
         else:
+            # narrow blocks (fewer than 64 theta|phi channels: not on the detector's path, op-level tests only): the merged
+            # launch's column split needs whole 64-channel tiles, so theta|phi and g go out as two launches over the same weights
+            d1a, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4, bias=b_tpg, alpha=a_tpg)
+            d1b, _, _ = mk(x, w_tpg[C4:], gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=b_tpg[C4:], alpha=a_tpg[C4:],
+                           out_mode=_lib.OUT_TRANSPOSED, out_stride=Np, m_per_image=True, in_batch_stride=N * Cc,
+                           out_batch_stride=C2 * Np)
+            self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
+            self._add(fn, (C.byref(d1b),), keep=d1b)
+        self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
+                  tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
+        S = None
+        if want_map:
+            # attn[b,i,j] = softmax_j(sum_c theta[b,i,c] * phi[b,j,c])   (no 1/sqrt(d) scaling, self_attn.py:71-72)
+            S = self._buf(B, N, Np)
+            d3, _, _ = mk(tp, tp[0, 0, C8:], S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
+                          in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
             self._add(fn, (C.byref(d3),), keep=d3)
-        self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
-        if USE_LIB_BMM:
-            self._add(lib.gssd_gemm_nt_batched_f32, (S.data_ptr(), gT.data_ptr(), ag.data_ptr(), N, C2, N, Np, Np, C2, N * Np,
-                                                    C2 * Np, N * C2, B), keep=d4,
-                      tag=('bmm_rocblas', 2.0 * B * N * N * C2, 4.0 * B * (N * N + 2 * N * C2)))
-        else:
-            self._add(fn, (C.byref(d4),), keep=d4)
+            self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, N, Np)
-        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, S=S, ag=ag, N=N, Np=Np,
-                                    inv_sigma=(a_tp, a_g, a_o))))
+        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, ag=ag, N=N, Np=Np,
+                                    inv_sigma=(a_tpg, a_o))))
         return out, out2
 
     def _dcn(self, li, x, H, Cin):

@@ -127,12 +127,13 @@ class SSD(nn.Module):
         return ops.slice_and_cat(ah, bh, self.groups_vgg).permute(0, 3, 1, 2)
 
     def forward(self, x, visualize=False):
+        self.__dict__['_want_maps'] = bool(visualize)      # visualize=True also materialises the attention maps
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # HIP forward plan + HIP backward plan (gssd/autograd.py); an eval-mode forward carries no autograd graph
             from gssd.autograd import GssdTrainFn
             loc, conf = GssdTrainFn.apply(self, x, *tuple(self.parameters()))
         else:
-            loc, conf = self._engine.forward(x, self.training, self.__dict__.get('_events'))
+            loc, conf = self._engine.forward(x, self.training, self.__dict__.get('_events'), bool(visualize))
         priors = self.priors if self.priors.device == x.device else self.priors.to(x.device)
         if self.phase == 'test':
             # softmax (reference :388) is fused into the Detect kernel (conf_is_logits)

@@ -34,6 +34,8 @@ extern "C" {
 typedef void* gssd_stream_t; /* hipStream_t */
 
 int gssd_abi_version(void);
+/* sizeof(gssd_conv_desc) as the library was built: a binding checks its own struct layout against it */
+int gssd_conv_desc_size(void);
 const char* gssd_last_error(void);
 /* name of the GPU architecture the library was built for ("gfx950") */
 const char* gssd_build_arch(void);
@@ -72,6 +74,10 @@ int gssd_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int ci
 #define GSSD_OUT_NHWC 0
 #define GSSD_OUT_TRANSPOSED 1 /* per image [n][m] with row stride out_stride (needs m_per_image) */
 #define GSSD_OUT_HEADS 2      /* n < split_n -> out (loc), else -> out_b (conf), SSD prior order */
+#define GSSD_OUT_SPLIT_T 3    /* merged projections (Self_Attn theta|phi|g, one pass over x): n < split_n -> out, NHWC rows of
+                                 out_stride floats; n >= split_n -> out_b, per image TRANSPOSED [n - split_n][m] with rows of
+                                 out_b_stride floats (zero padded), images outb_batch_stride apart; needs m_per_image, one group,
+                                 split_n a multiple of 64 */
 
 typedef struct gssd_conv_desc {
     const float* in;    /* NHWC activations */
@@ -107,6 +113,8 @@ typedef struct gssd_conv_desc {
     int split_n;        /* GSSD_OUT_HEADS: channels [0, split_n) are loc, the rest conf */
     int split_k;        /* >= 1; > 1 slices K over grid.z and accumulates with fp32 atomics into a zero-filled
                            output (small-M / long-K launches such as the heads); plain epilogues only */
+    int out_b_stride;   /* GSSD_OUT_SPLIT_T: floats between the transposed rows of out_b */
+    int reserved0;
     int64_t in_batch_stride, wgt_batch_stride, out_batch_stride, outb_batch_stride;
     int64_t out_off, outb_off; /* GSSD_OUT_HEADS: float offset of this source inside one image's rows */
 } gssd_conv_desc;
@@ -191,6 +199,13 @@ int gssd_upsample_insert_f32(const float* dy, float* u, int B, int Ho, int Wo, i
 /* x / (sqrt(sum_c x^2) + eps) * w_c per pixel.  Replaces layers/modules/l2norm.py:19-23. */
 int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pixels, int C, float eps,
                     gssd_stream_t stream);
+
+/* Self_Attn core, flash style (layers/self_attn.py:68-80: torch.bmm(theta^T, phi) -> Softmax(dim=-1) -> torch.bmm(g, attn^T)):
+ * out[b][i][c] = sum_j softmax_j(sum_d tp[b][i][d] * tp[b][j][D + d]) * gT[b][c][j]; the [N, N] attention map is never written.
+ * tp [B][N][2*D] token-major theta|phi, gT [B][C2][Np] (Np >= N, multiple of 4, pad columns zero), out [B][N][C2].
+ * Built for (D, C2) = (64, 256), (128, 512), (32, 128) -- Self_Attn on 512 / 1024 / 256 channels. */
+int gssd_self_attn_core_f32(const float* tp, const float* gT, float* out, int B, int N, int Np, int D, int C2,
+                            gssd_stream_t stream);
 
 /* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
  * Replaces nn.Softmax(dim=-1) on the attention logits (layers/self_attn.py:72). */
@@ -279,10 +294,6 @@ int gssd_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int
                      const float* bias, int accumulate, gssd_stream_t stream);
 int gssd_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K2, int lda, int ldb, int ldc, int accumulate,
                      gssd_stream_t stream);
-/* batched nt: C_b = A_b . B_b^T, operands stride* floats apart (the two torch.bmm of Self_Attn, layers/self_attn.py:71,80) */
-int gssd_gemm_nt_batched_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                             long long strideA, long long strideB, long long strideC, int batch, gssd_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------
  * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
  * ------------------------------------------------------------------------------------------ */

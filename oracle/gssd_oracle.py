@@ -458,7 +458,8 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
     sources = []
     x = _run_table(x, [l for l in vt if l[1] < split], sd, 'vgg', training, updates, taps)
     if use_self_attention_base:                                             # :261-265
-        x, attn_g, _ = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        tp[f'sab{sab_i}.attn'] = amap
         sab_i += 1
         tp['sab0.out'], tp['sab0.attn_g'] = x, attn_g
     if dcn_cat_sab:                                                         # :267-271
@@ -472,7 +473,8 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
     def branch(s, fuse):
         nonlocal sa_i
         if use_self_attention:
-            s, _, _ = self_attn(s, sd, f'self_attn_list.{sa_i}', training, max_pool_factor, updates)
+            s, _, amap = self_attn(s, sd, f'self_attn_list.{sa_i}', training, max_pool_factor, updates)
+            tp[f'sa{sa_i}.attn'] = amap
             sa_i += 1
         if use_fuseconv:
             s = F.conv2d(s, sd[f'fuse_{fuse}.weight'], sd[f'fuse_{fuse}.bias'])
@@ -481,7 +483,8 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
     sources.append(branch(s, '11'))                                         # :284-297
     x = _run_table(x, [l for l in vt if l[1] >= split], sd, 'vgg', training, updates, taps)   # :300-301
     if use_self_attention_base:                                             # :303-307
-        x, attn_g, _ = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        tp[f'sab{sab_i}.attn'] = amap
         sab_i += 1
     sources.append(branch(x, '21'))                                         # :309-325
     et = extras_layers(True, groups_extra)
@@ -493,8 +496,9 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
             x = F.relu(x)
         if idx % 4 == 3:
             if use_self_attention_base:
-                x, attn_g, _ = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor,
-                                         updates)
+                x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor,
+                                            updates)
+                tp[f'sab{sab_i}.attn'] = amap
                 sab_i += 1
             sources.append(branch(x, fuse_names[conv_i]))
             conv_i += 1

@@ -804,6 +804,13 @@ def test_visualize_outputs(dev):
     assert rel(offs[0], taps['dcn0.offset']) < TOL
     assert [a.shape[1] for a in attnb] == [1444, 361, 100, 25, 9, 1] and len(attn) == 6
     assert all(abs(a.sum(-1) - 1).max() < 1e-4 for a in attnb + attn)
+    # the materialised maps (extra launches of the visualize plan; the output path is flash-style and never reads them)
+    for i in range(6):
+        assert rel(attnb[i], taps[f'sab{i}.attn']) < TOL and rel(attn[i], taps[f'sa{i}.attn']) < TOL, i
+    # ... and the visualize plan's detections / train tuple equal the plain plan's
+    with torch.no_grad():
+        out_plain = net(x.to(dev))
+    assert rel(out[0], out_plain[0]) < 1e-5 and rel(out[1], out_plain[1]) < 1e-5
 
 
 @pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
