@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
         ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i), ('split_k', c_i),
-        ('out_b_stride', c_i), ('reserved0', c_i),
+        ('out_b_stride', c_i), ('flags', c_i),
         ('in_batch_stride', c_i64), ('wgt_batch_stride', c_i64), ('out_batch_stride', c_i64),
         ('outb_batch_stride', c_i64), ('out_off', c_i64), ('outb_off', c_i64),
     ]
@@ -44,6 +44,7 @@ class SnItem(C.Structure):
 
 
 OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
+CONV_OUT_F32 = 1
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {
@@ -55,6 +56,17 @@ SIGNATURES = {
     'gssd_unpack_nhwc_to_nchw': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_nhwc_f32': (c_i, [C.POINTER(ConvDesc), c_fp]),
+    'gssd_conv2d_nhwc_bf16': (c_i, [C.POINTER(ConvDesc), c_fp]),
+    'gssd_pack_conv_weight_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_cast_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_fp]),
+    'gssd_pack_input_nhwc_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_bn_relu_pool_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
+                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
+    'gssd_bn_finalize_bf16': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_l2norm_bf16': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
+    'gssd_dcn_packed_weight_elems_bf16': (C.c_longlong, [c_i, c_i]),
+    'gssd_dcn_pack_weight_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    'gssd_dcn_forward_bf16': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_winograd_weight_elems': (C.c_longlong, [c_i, c_i, c_i]),
     'gssd_winograd_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_wgrad_f32': (c_i, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp]),
@@ -72,7 +84,7 @@ SIGNATURES = {
     'gssd_heads_gather_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_upsample_insert_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
-    'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),

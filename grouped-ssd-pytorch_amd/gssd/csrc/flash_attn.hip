@@ -50,7 +50,8 @@ __device__ __forceinline__ void stage_tile(float* lds, int wave, int lane, RowPt
 
 template <int D, int C2, int BKV>
 __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ gT,
-                                                           float* __restrict__ out, int N, int Np, int qtiles, int d_real) {
+                                                           float* __restrict__ out, int N, int Np, int qtiles, int d_real,
+                                                           int out_bf16) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                    // [BKV][D]
     float* const Vs = smem + BKV * D;          // [C2][BKV]
@@ -159,14 +160,24 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_run;
     if (q < N) {
-        float* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+        if (out_bf16) {             // bf16 storage mode (configs[4]): the o conv reads bf16
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            unsigned short* dst = reinterpret_cast<unsigned short*>(out) + ((size_t)b * N + q) * C2 + 4 * kq;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(dst + 16 * c) = o[c] * inv;
+            for (int c = 0; c < CT; ++c) {
+                const f32x4 v = o[c] * inv;
+                *reinterpret_cast<bf16x4*>(dst + 16 * c) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            }
+        } else {
+            float* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(dst + 16 * c) = o[c] * inv;
+        }
     }
 }
 
 template <int D, int C2, int BKV>
-int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, int d_real, hipStream_t stream) {
+int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, int d_real, int out_bf16, hipStream_t stream) {
     constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
     static bool attr_set[16] = {false};
     int dev = 0;
@@ -180,25 +191,26 @@ int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, i
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np, qtiles, d_real);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np, qtiles, d_real, out_bf16);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
 }  // namespace
 
-extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, float* out, int B, int N, int Np, int D, int C2,
-                                       gssd_stream_t stream) {
+extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out_v, int B, int N, int Np, int D, int C2,
+                                       int out_bf16, gssd_stream_t stream) {
+    float* out = reinterpret_cast<float*>(out_v);
     GSSD_CHECK_ARG(tp && gT && out && B > 0 && N > 0 && Np >= N && Np % 4 == 0);
     GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)gT % 16) == 0 && ((uintptr_t)out % 16) == 0);
     GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
     hipStream_t s = as_stream(stream);
     GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0);
-    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, gT, out, B, N, Np, D, s);
-    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, gT, out, B, N, Np, D, s);
-    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, gT, out, B, N, Np, D, s);
-    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, gT, out, B, N, Np, D, s);     // small maps (Self_Attn(64): op-level tests)
-    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, gT, out, B, N, Np, D, s);
+    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
+    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, gT, out, B, N, Np, D, out_bf16, s);
+    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
+    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);     // small maps (Self_Attn(64): op-level tests)
+    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
     gssd_set_error("self-attention core: unsupported (theta/phi channels %d, g channels %d); built: (64,256) (128,512) (32,128) (<=16,32|64)", D, C2);
     return GSSD_EINVAL;
 }

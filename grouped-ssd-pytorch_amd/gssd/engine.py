@@ -40,7 +40,7 @@ class _Step:
         self.fn, self.args, self.keep, self.tag = fn, args, keep, tag
 
 
-def conv_tag(d, real_cin_g=None):
+def conv_tag(d, real_cin_g=None, bf16=False):
     """(kernel instance, algorithmic FLOPs, algorithmic bytes) of one gssd_conv2d launch; the instance name
     mirrors the tile selection in csrc/conv_igemm.hip so it can be matched against rocprofv3's kernel names."""
     cout_g = d.Cout // d.groups
@@ -54,8 +54,10 @@ def conv_tag(d, real_cin_g=None):
         e64 = 0.94 * b64 / (-(-b64 // 768) * 768)
         if e64 > e128 or d.K <= 256:
             inst = '128x64'
-    name = 'conv_igemm<' + inst + '>'
-    if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
+    name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
+    if bf16:
+        pass
+    elif (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
         if d.wgt_wino and (d.cin_g, cout_g) == (16, 16) and not d.resid:
@@ -66,7 +68,8 @@ def conv_tag(d, real_cin_g=None):
     M = d.B * d.Ho * d.Wo
     cin_g = real_cin_g if real_cin_g is not None else d.cin_g
     flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
-    byts = 4.0 * (d.B * d.H * d.W * cin_g * d.groups + M * d.Cout + d.Cout * d.KH * d.KW * cin_g)
+    esz = 2.0 if bf16 else 4.0
+    byts = esz * (d.B * d.H * d.W * cin_g * d.groups + M * d.Cout + d.Cout * d.KH * d.KW * cin_g)
     return (name, flops, byts)
 
 
@@ -131,7 +134,7 @@ class GssdEngine:
         if tuple(x.shape[1:]) != (cin, 300, 300):
             raise _lib.GssdError(f'expected input [B,{cin},300,300], got {tuple(x.shape)}')
         bn_cfg = tuple((m.momentum, m.eps) for m in self._bn_list)
-        key = (B, bool(training), x.device.index, hash(bn_cfg), bool(want_maps))
+        key = (B, bool(training), x.device.index, hash(bn_cfg), bool(want_maps), getattr(net, 'compute_dtype', 'f32'))
         plans = self._plans.setdefault(key, [])
         plan = next((pl for pl in plans if not pl.busy), None)
         if plan is None:
@@ -156,7 +159,10 @@ class GssdEngine:
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, name, build):
-        """Register a packed weight: ``build(out_or_None) -> tensor`` fills/refreshes it in place."""
+        """Register a packed weight: ``build(out_or_None) -> tensor`` fills/refreshes it in place.  The cache is per storage mode
+        (a module switched between fp32 and bf16 keeps both sets of packed weights)."""
+        if getattr(self.net, 'compute_dtype', 'f32') == 'bf16':
+            name = name + '@bf16'
         if name not in self._packed:
             t = build(None)
             self._packed[name] = t
@@ -176,6 +182,8 @@ class _PlanBase:
     _bwd = None
 
     def backward_plan(self):
+        if getattr(self, 'bf16', False):
+            raise _lib.GssdError('bf16 storage mode (net.compute_dtype = "bf16") is forward + loss only; train in fp32')
         if self._bwd is None:
             from .backward import BackwardPlan
             self._bwd = BackwardPlan(self)
@@ -186,6 +194,12 @@ class _Plan(_PlanBase):
     def __init__(self, eng, B, training, dev, want_maps=False):
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         self.want_maps = want_maps                 # visualize=True: also materialise the attention maps
+        # BASELINE.json configs[4]: bf16 NHWC activations + bf16 packed weights + bf16 MFMA, fp32 accumulation / BatchNorm
+        # statistics / softmax / offsets / loc + conf / loss / NMS (net.compute_dtype = 'bf16'; parameters stay fp32 masters)
+        self.bf16 = getattr(eng.net, 'compute_dtype', 'f32') == 'bf16'
+        self.adt = torch.bfloat16 if self.bf16 else torch.float32
+        self.conv_fn = lib.gssd_conv2d_nhwc_bf16 if self.bf16 else lib.gssd_conv2d_nhwc_f32
+        self.cpad = 8 if self.bf16 else 4          # channels per phase of the packed input (3 real)
         net = eng.net
         self.steps = []
         self.bufs = []
@@ -200,6 +214,7 @@ class _Plan(_PlanBase):
             t = torch.empty(*shape, device=dev, dtype=f32)
             self.bufs.append(t)
             return t
+        abuf = self._abuf
 
         # ---- batch-stat arena ------------------------------------------------------------------
         bn_mods = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
@@ -222,12 +237,15 @@ class _Plan(_PlanBase):
 
         # ---- input pack ------------------------------------------------------------------------------
         self.x_in = None   # set per run
-        x16 = buf(B, 300, 300, 4 * g)
+        x16 = abuf(B, 300, 300, self.cpad * g)
         self._pack_step = len(self.steps)
-        self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, 4])
+        if self.bf16:
+            self._add(lib.gssd_pack_input_nhwc_bf16, [0, x16.data_ptr(), B, 12, 300, 300, g])
+        else:
+            self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, 4])
 
         # ---- trunk -------------------------------------------------------------------------------------
-        cur, H, Cc = x16, 300, 4 * g
+        cur, H, Cc = x16, 300, self.cpad * g
         vi = 0
         cfg = list(VGG_CFG)
         i = 0
@@ -299,9 +317,10 @@ class _Plan(_PlanBase):
 
             def build_w(out, lw=lw, cw=cw, nloc=nloc, nconf=nconf, K=K):
                 if out is None:
-                    out = torch.empty(nloc + nconf, K, device=dev, dtype=f32)
-                ops.pack_weight(lw.weight, out, 0)
-                ops.pack_weight(cw.weight, out, nloc)
+                    out = torch.empty(nloc + nconf, K, device=dev, dtype=self.adt)
+                pk = ops.pack_weight_bf16 if self.bf16 else ops.pack_weight
+                pk(lw.weight, out, 0)
+                pk(cw.weight, out, nloc)
                 return out
 
             def build_b(out, lw=lw, cw=cw, nloc=nloc):
@@ -316,19 +335,26 @@ class _Plan(_PlanBase):
                                          pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
                                          out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
                                          out_off=off * 4, outb_off=off * self.nc,
-                                         split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
+                                         split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K), flags=_lib.CONV_OUT_F32)
             self.head_descs.append(d)
-            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+            self._add(self.conv_fn, (C.byref(d),), keep=d)
             self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
             off += Hs * Hs * A
         assert off == self.P, off
 
     # ------------------------------------------------------------------------------------------------
     def _add(self, fn, args, keep=None, tag=None):
-        if tag is None and fn is lib.gssd_conv2d_nhwc_f32:
+        if tag is None and fn in (lib.gssd_conv2d_nhwc_f32, lib.gssd_conv2d_nhwc_bf16):
             d = keep[0] if isinstance(keep, tuple) else keep
-            tag = conv_tag(d, 3 if (d.cin_g == 4 and d.groups == 4 and d.H == 300) else None)
+            tag = conv_tag(d, 3 if (d.cin_g in (4, 8) and d.groups == 4 and d.H == 300) else None,
+                           bf16=fn is lib.gssd_conv2d_nhwc_bf16)
         self.steps.append(_Step(fn, args, keep, tag))
+
+    def _abuf(self, *shape):
+        """Activation buffer in the plan's storage type (fp32, or bf16 in configs[4] mode)."""
+        t = torch.empty(*shape, device=self.dev, dtype=getattr(self, 'adt', torch.float32))
+        self.bufs.append(t)
+        return t
 
     def _buf(self, *shape):
         t = torch.empty(*shape, device=self.dev, dtype=torch.float32)
@@ -360,6 +386,8 @@ class _Plan(_PlanBase):
         eng = self.eng
 
         def build(out, conv=conv):
+            if self.bf16:
+                return ops.pack_weight_bf16(conv.weight, out)
             return ops.pack_weight(conv.weight, out)
         return eng._pack(name + '.w', build)
 
@@ -373,26 +401,26 @@ class _Plan(_PlanBase):
         cin_g = Cin // groups
         wp = self._packed_conv(name, conv)
         U = None
-        if USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups, groups):
+        if not self.bf16 and USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups, groups):
             def build_u(out, key=name + '.w', groups=groups, cin_g=cin_g):
                 return ops.winograd_weight(self.eng._packed[key], groups, cin_g, out)
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
-        raw = self._buf(B, Ho, Ho, Cout)
+        raw = self._abuf(B, Ho, Ho, Cout)
         st = self.eng_stat(bn)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None)
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self._add(self.conv_fn, (C.byref(d),), keep=d)
         rec = dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho, Cout=Cout,
                    desc=d, stats=st, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
         self.rec.append(('convbn', rec))
         if defer_bn:
             assert pool is None and relu
-            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._buf(Cout)
-            self._add(lib.gssd_bn_finalize_f32,
+            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._abuf(Cout)
+            self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                        int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
@@ -403,8 +431,8 @@ class _Plan(_PlanBase):
             Hp = ops.pool_out_size(Ho, pk, ps, pp, ceil)
         else:
             pk, ps, pp, Hp = 0, 1, 0, Ho
-        act = self._buf(B, Hp, Hp, Cout)
-        self._add(lib.gssd_bn_relu_pool_f32,
+        act = self._abuf(B, Hp, Hp, Cout)
+        self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
                   (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
                    bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                    float(bn.momentum), float(bn.eps), int(self.training), int(relu)))
@@ -417,9 +445,9 @@ class _Plan(_PlanBase):
     def _pool_only(self, x, H, Cc, k, s, p):
         B = self.B
         Hp = ops.pool_out_size(H, k, s, p, False)
-        out = self._buf(B, Hp, Hp, Cc)
-        self._add(lib.gssd_bn_relu_pool_f32, (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0,
-                                              0.1, 1e-5, 0, 0))
+        out = self._abuf(B, Hp, Hp, Cc)
+        self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
+                  (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0))
         self.rec.append(('pool', dict(x_in=x, out=out, H=H, C=Cc, k=k, s=s, p=p, Hp=Hp)))
         return out, Hp
 
@@ -432,8 +460,9 @@ class _Plan(_PlanBase):
         if net.use_dcn:
             xin, Cin = x, Cc
             if net.dcn_cat_sab:
-                xc = self._buf(B, H, H, 2 * Cc)
-                self._add(lib.gssd_slice_and_cat_f32, (x.data_ptr(), attn_g.data_ptr(), xc.data_ptr(), B * H * H, Cc, Cc,
+                xc = self._abuf(B, H, H, 2 * Cc)
+                esz = 2 if self.bf16 else 1          # a pure copy: bf16 pairs travel as one 4-byte word
+                self._add(lib.gssd_slice_and_cat_f32, (x.data_ptr(), attn_g.data_ptr(), xc.data_ptr(), B * H * H, Cc // esz, Cc // esz,
                                                        net.groups_vgg))
                 self.rec.append(('slice_cat', dict(a=x, b=attn_g, out=xc, H=H, Ca=Cc, Cb=Cc, groups=net.groups_vgg,
                                                    detach_b=bool(net.detach_sab))))
@@ -442,9 +471,9 @@ class _Plan(_PlanBase):
                 xin, Cin = self._dcn(li, xin, H, Cin)
             x, Cc = xin, Cin
         self.x_after_block = x
-        s = self._buf(B, H, H, Cc)
-        self._add(lib.gssd_l2norm_f32, (x.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc,
-                                        float(net.L2Norm.eps)))
+        s = self._abuf(B, H, H, Cc)
+        self._add(lib.gssd_l2norm_bf16 if self.bf16 else lib.gssd_l2norm_f32,
+                  (x.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc, float(net.L2Norm.eps)))
         self.rec.append(('l2norm', dict(x_in=x, out=s, H=H, C=Cc, mod=net.L2Norm)))
         src0 = self._branch(s, H, Cc, 0, '11')
         pooled, Hp = self._pool_only(x, H, Cc, 2, 2, 0)
@@ -476,10 +505,16 @@ class _Plan(_PlanBase):
 
         def build_w(out):
             if out is None:
-                out = torch.empty(C4 + C2, Cc, device=dev, dtype=f32)
-            out[:C8].copy_(sa.snconv1x1_theta.weight_orig.detach().view(C8, Cc))
+                out = torch.empty(C4 + C2, Cc, device=dev, dtype=self.adt)
+            out[:C8].copy_(sa.snconv1x1_theta.weight_orig.detach().view(C8, Cc))         # (copy_ rounds to bf16 in bf16 mode)
             out[C8:C4].copy_(sa.snconv1x1_phi.weight_orig.detach().view(C8, Cc))
             out[C4:].copy_(sa.snconv1x1_g.weight_orig.detach().view(C2, Cc))
+            return out
+
+        def build_wo(out):
+            if out is None:
+                out = torch.empty(Cc, C2, device=dev, dtype=self.adt)
+            out.copy_(sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2))
             return out
 
         def build_b(out):
@@ -491,22 +526,25 @@ class _Plan(_PlanBase):
             return out
         w_tpg = eng._pack(name + '.tpg.w', build_w)
         b_tpg = eng._pack(name + '.tpg.b', build_b)
-        w_o = sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)       # already K-major rows
-        tp = self._buf(B, N, C4)
+        # the o conv's weight is already K-major rows; bf16 mode keeps a rounded copy
+        w_o = eng._pack(name + '.o.w', build_wo) if self.bf16 else sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)
+        tp = self._buf(B, N, C4)               # theta | phi and g^T stay fp32: the softmax core is fp32 in both modes
         gT = self._buf(B, C2, Np)
-        ag = self._buf(B, N, C2)
-        out = self._buf(B, H, H, Cc)
-        out2 = self._buf(B, H, H, Cc) if need_out2 else None
+        ag = self._abuf(B, N, C2)
+        out = self._abuf(B, H, H, Cc)
+        out2 = self._abuf(B, H, H, Cc) if need_out2 else None
         mk = ops.make_conv_desc
         d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg,
                       out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=True,
-                      in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np)
+                      in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np, flags=_lib.CONV_OUT_F32)
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
                       alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2)
-        fn = lib.gssd_conv2d_nhwc_f32
+        fn = self.conv_fn
         if C4 % 64 == 0:
             self._add(fn, (C.byref(d1),), keep=(d1, w_tpg, b_tpg))
         else:
+            if self.bf16:
+                raise _lib.GssdError('bf16 mode: Self_Attn needs >= 64 theta|phi channels (in_channels >= 256)')
             # narrow blocks (fewer than 64 theta|phi channels: not on the detector's path, op-level tests only): the merged
             # launch's column split needs whole 64-channel tiles, so theta|phi and g go out as two launches over the same weights
             d1a, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4, bias=b_tpg, alpha=a_tpg)
@@ -515,7 +553,7 @@ class _Plan(_PlanBase):
                            out_batch_stride=C2 * Np)
             self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
             self._add(fn, (C.byref(d1b),), keep=d1b)
-        self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
+        self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2, int(self.bf16)),
                   tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
         S = None
         if want_map:
@@ -523,7 +561,7 @@ class _Plan(_PlanBase):
             S = self._buf(B, N, Np)
             d3, _, _ = mk(tp, tp[0, 0, C8:], S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
                           in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
-            self._add(fn, (C.byref(d3),), keep=d3)
+            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d3),), keep=d3)        # fp32 operands in both modes
             self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
@@ -541,29 +579,33 @@ class _Plan(_PlanBase):
         w_om = self._packed_conv(f'dcn_list.{li}.om', m.conv_offset_mask)
 
         def build_w(out, m=m, Cin=Cin, dg=dg):
+            elems = lib.gssd_dcn_packed_weight_elems_bf16 if self.bf16 else lib.gssd_dcn_packed_weight_elems
+            pack = lib.gssd_dcn_pack_weight_bf16 if self.bf16 else lib.gssd_dcn_pack_weight_f32
             if out is None:
-                n = int(lib.gssd_dcn_packed_weight_elems(m.out_channels, Cin))
+                n = int(elems(m.out_channels, Cin))
                 if n <= 0:
                     raise _lib.GssdError(f'deformable conv: unsupported shape Cin {Cin}, Cout {m.out_channels}')
-                out = torch.empty(n, device=self.dev, dtype=torch.float32)
-            _lib.check(lib.gssd_dcn_pack_weight_f32(m.weight.detach().contiguous().data_ptr(), out.data_ptr(), m.out_channels, Cin, dg,
-                                                    torch.cuda.current_stream().cuda_stream))
+                out = torch.empty(n, device=self.dev, dtype=self.adt)
+            _lib.check(pack(m.weight.detach().contiguous().data_ptr(), out.data_ptr(), m.out_channels, Cin, dg,
+                            torch.cuda.current_stream().cuda_stream))
             return out
         w_main = eng._pack(f'dcn_list.{li}.wt', build_w)
-        om = self._buf(B, H, H, 27 * dg)
-        out = self._buf(B, H, H, Cout)
+        om = self._buf(B, H, H, 27 * dg)       # offsets / mask logits stay fp32 in both modes
+        out = self._abuf(B, H, H, Cout)
         u_om = None
-        if USE_WINOGRAD and ops.winograd_eligible(3, 1, 1, 1, Cin, 27 * dg, 1):
+        if not self.bf16 and USE_WINOGRAD and ops.winograd_eligible(3, 1, 1, 1, Cin, 27 * dg, 1):
             def build_u(out, key=f'dcn_list.{li}.om.w', cin=Cin):
                 return ops.winograd_weight(eng._packed[key], 1, cin, out)
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1,
-                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om)
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d1),), keep=d1)
+                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om, flags=_lib.CONV_OUT_F32)
+        self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H
-        self._add(lib.gssd_dcn_forward_f32, (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H,
-                                             Cin, dg, 27 * dg, Cout), keep=w_main,
-                  tag=('dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin, 4.0 * (M * (Cin + Cout + 27 * dg) + Cout * 9 * Cin)))
+        esz = 2.0 if self.bf16 else 4.0
+        self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_f32,
+                  (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, 27 * dg, Cout),
+                  keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
+                                    esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
         self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, d_om=d1, dg=dg, li=li)))
@@ -718,6 +760,7 @@ class SelfAttnOp(_Plan):
         holder.self_attn_list = torch.nn.ModuleList([sa])
         self.eng = GssdEngine(holder)
         self.B, self.training, self.dev = B, bool(training), dev
+        self.bf16, self.adt, self.conv_fn = False, torch.float32, lib.gssd_conv2d_nhwc_f32
         self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []
         Cc = sa.in_channels
         self.H, self.C = H, Cc

@@ -72,6 +72,31 @@ def pack_weight(w_oihw, out=None, row_offset=0):
     return out
 
 
+def pack_weight_bf16(w_oihw, out=None, row_offset=0, cin_pad=None):
+    """OIHW fp32 -> bf16 [Cout][K] K-major rows (k = tap*cin_pad + c, cin_pad a multiple of 8) for gssd_conv2d_nhwc_bf16."""
+    _need_cuda(w_oihw)
+    w = w_oihw.detach().contiguous().float()
+    Cout, cin_g, KH, KW = w.shape
+    cin_pad = cin_pad or round_up(cin_g, 8)
+    K = KH * KW * cin_pad
+    if out is None:
+        out = torch.empty(Cout, K, device=w.device, dtype=torch.bfloat16)
+    assert out.shape[1] == K and out.dtype == torch.bfloat16
+    dst = out[row_offset:row_offset + Cout]
+    check(lib.gssd_pack_conv_weight_bf16(_p(w), _p(dst), Cout, cin_g, KH, KW, cin_pad, K, _stream()))
+    return out
+
+
+def cast_bf16(x, out=None):
+    """fp32 -> bf16 (round to nearest even) on the device."""
+    _need_cuda(x)
+    x = x.detach().contiguous().float()
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib.gssd_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # conv
 # ------------------------------------------------------------------------------------------------
@@ -80,7 +105,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0):
+                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -97,6 +122,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.wgt_wino = _p(wgt_wino)
     d.out_b_stride = out_b_stride
+    d.flags = flags
     d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride
     d.out_batch_stride, d.outb_batch_stride, d.out_off, d.outb_off = out_batch_stride, outb_batch_stride, out_off, outb_off
     return d, Ho, Wo

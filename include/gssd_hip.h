@@ -114,12 +114,34 @@ typedef struct gssd_conv_desc {
     int split_k;        /* >= 1; > 1 slices K over grid.z and accumulates with fp32 atomics into a zero-filled
                            output (small-M / long-K launches such as the heads); plain epilogues only */
     int out_b_stride;   /* GSSD_OUT_SPLIT_T: floats between the transposed rows of out_b */
-    int reserved0;
+    int flags;          /* GSSD_CONV_* bits (bf16 entry point only) */
     int64_t in_batch_stride, wgt_batch_stride, out_batch_stride, outb_batch_stride;
     int64_t out_off, outb_off; /* GSSD_OUT_HEADS: float offset of this source inside one image's rows */
 } gssd_conv_desc;
 
 int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
+
+/* bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations, bf16 MFMA v_mfma_f32_16x16x32_bf16, fp32
+ * accumulation).  Same descriptor; `in`, `wgt`, `resid`, `out`, `out2`, `in_pad` point to bf16 (uint16) data, element strides /
+ * offsets are in bf16 elements and must be multiples of 8; bias / alpha / gate / in_scale / in_shift / stats stay fp32 / fp64.
+ * flags & GSSD_CONV_OUT_F32: `out` (and `out_b`) are fp32 -- required for GSSD_OUT_HEADS (loc / conf stay fp32 for the loss and
+ * NMS), GSSD_OUT_TRANSPOSED and GSSD_OUT_SPLIT_T (the Self_Attn projections feed the fp32 softmax core). */
+#define GSSD_CONV_OUT_F32 1
+int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
+/* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
+int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,
+                               gssd_stream_t stream);
+int gssd_cast_f32_bf16(const float* x, void* y, int64_t n, gssd_stream_t stream);
+/* bf16 variants of the HBM-bound passes (fp32 arithmetic, one rounding on store): input pack (3 -> 8 channels per phase),
+ * BatchNorm + ReLU + max-pool, BN finalize with a bf16 pad vector, L2Norm */
+int gssd_pack_input_nhwc_bf16(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int groups, gssd_stream_t stream);
+int gssd_bn_relu_pool_bf16(const void* raw, void* out, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p,
+                           const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, int training, int relu, gssd_stream_t stream);
+int gssd_bn_finalize_bf16(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, int training, int C, float* scale, float* shift,
+                          void* pad_bf16, gssd_stream_t stream);
+int gssd_l2norm_bf16(const void* x, const float* weight, void* out, int64_t pixels, int C, float eps, gssd_stream_t stream);
 
 /* U[g][xi][co][ci] = (G g G^T)_xi of the packed K-major weights [Cout][tap*cin_g + ci] (row stride `row_stride`).
  * Winograd shapes: cin_g % 16 == 0 and cout_g % 32 == 0, or (one group) any cout_g >= 24 -- U's rows per group are then
@@ -204,8 +226,8 @@ int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pix
  * out[b][i][c] = sum_j softmax_j(sum_d tp[b][i][d] * tp[b][j][D + d]) * gT[b][c][j]; the [N, N] attention map is never written.
  * tp [B][N][2*D] token-major theta|phi, gT [B][C2][Np] (Np >= N, multiple of 4, pad columns zero), out [B][N][C2].
  * Built for (D, C2) = (64, 256), (128, 512), (32, 128) -- Self_Attn on 512 / 1024 / 256 channels. */
-int gssd_self_attn_core_f32(const float* tp, const float* gT, float* out, int B, int N, int Np, int D, int C2,
-                            gssd_stream_t stream);
+int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out, int B, int N, int Np, int D, int C2, int out_bf16,
+                            gssd_stream_t stream); /* out_bf16 != 0: `out` is bf16 (configs[4]); the softmax is fp32 either way */
 
 /* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
  * Replaces nn.Softmax(dim=-1) on the attention logits (layers/self_attn.py:72). */
@@ -250,6 +272,12 @@ long long gssd_dcn_packed_weight_elems(int Cout, int C);
 int gssd_dcn_pack_weight_f32(const float* w_oihw, float* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
 int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B, int H,
                          int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream);
+
+/* bf16 storage variant (configs[4]): x, w_packed, out bf16; om, bias fp32; fp32 blend and accumulation */
+long long gssd_dcn_packed_weight_elems_bf16(int Cout, int C);
+int gssd_dcn_pack_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
+int gssd_dcn_forward_bf16(const void* x, const float* om, const void* w_packed, const float* bias, void* out, int B, int H, int W,
+                          int C, int dg, int om_stride, int Cout, gssd_stream_t stream);
 
 /* Backward of gssd_dcn_im2col_f32 (what the reference gets from the dcn_v2 extension's backward through autograd,
  * layers/dcn_v2_custom.py:84-89): given d(cols), ADDS d(x) into `dx` (fp32 atomics; the caller zero-fills or pre-loads it)

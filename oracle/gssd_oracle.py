@@ -261,6 +261,17 @@ def multibox_loss(loc_data, conf_data, priors, targets, threshold=0.5, negpos_ra
 # ----------------------------------------------------------------------------------------
 # operators of the model graph (torch CPU fp32)
 # ----------------------------------------------------------------------------------------
+def bf16_round(t):
+    """Round-to-nearest-even to bfloat16 and back to fp32: the storage rounding of BASELINE.json configs[4] (bf16 weights /
+    activations, fp32 accumulation).  The bf16 mode of this oracle is NOT a reference code path (the reference has no bf16
+    mode): it restates the fp32 graph with a rounding at every point where the MI355X bf16 path stores a tensor in bf16."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _ident(t):
+    return t
+
+
 def l2norm(x, weight, eps=1e-10):  # layers/modules/l2norm.py:19-23
     norm = x.pow(2).sum(dim=1, keepdim=True).sqrt() + eps
     return weight.view(1, -1, 1, 1) * (x / norm)
@@ -277,8 +288,9 @@ def spectral_weight(w_orig, u, v, training, eps=1e-12):
     return w_orig / sigma, u, v
 
 
-def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None):
-    """layers/self_attn.py:46-89.  Returns (out, sigma*attn_g, attn)."""
+def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None, q=None):
+    """layers/self_attn.py:46-89.  Returns (out, sigma*attn_g, attn).  ``q`` (bf16 mode): the 1x1 weights are stored rounded
+    (1/sigma is applied in fp32 afterwards), theta / phi / g and the softmax stay fp32, attn.g and both outputs are stored rounded."""
     B, ch, h, w = x.shape
     ws = {}
     for name in ('theta', 'phi', 'g', 'attn'):
@@ -286,6 +298,10 @@ def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None):
         W, u, v = spectral_weight(sd[p + '.weight_orig'], sd[p + '.weight_u'], sd[p + '.weight_v'], training)
         if updates is not None and training:
             updates[p + '.weight_u'], updates[p + '.weight_v'] = u, v
+        if q is not None:
+            wo = sd[p + '.weight_orig']
+            sigma = torch.dot(u, torch.mv(wo.reshape(wo.shape[0], -1), v))     # from the fp32 master weight
+            W = q(wo) / sigma
         ws[name] = (W, sd[p + '.bias'])
     pool = max(int(h // max_pool_factor), 1)
     theta = F.conv2d(x, *ws['theta']).view(B, ch // 8, h * w)
@@ -294,8 +310,12 @@ def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None):
     attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
     g = F.adaptive_avg_pool2d(F.conv2d(x, *ws['g']), pool).view(B, ch // 2, -1)
     attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(B, ch // 2, h, w)
+    if q is not None:
+        attn_g = q(attn_g)
     attn_g = F.conv2d(attn_g, *ws['attn'])
     sig = sd[prefix + '.sigma']
+    if q is not None:
+        return q(x + sig * attn_g), q(sig * attn_g), attn
     return x + sig * attn_g, sig * attn_g, attn
 
 
@@ -305,7 +325,7 @@ def slice_and_cat(a, b, groups):  # models/ssd_multiphase_custom_group.py:185-19
     return torch.cat([torch.cat([a[i], b[i]], dim=1) for i in range(len(a))], dim=1)
 
 
-def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1, deformable_groups=1):
+def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1, deformable_groups=1, col_round=None):
     """Modulated deformable convolution (DCNv2).  PARITY UNPINNED -- see the module docstring.
 
     Follows CharlesShang/DCNv2 ``modulated_deformable_im2col`` + GEMM as called from
@@ -345,19 +365,23 @@ def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1, 
             val = val + v * (wgt * inside.to(x.dtype)).view(B, dg, 1, Ho * Wo)
         cols[:, :, :, k] = val * msk[:, :, k].reshape(B, dg, 1, Ho * Wo)
     cols = cols.view(B, Cin * K, Ho * Wo)                   # (c, k) flattened like weight.view
+    if col_round is not None:                               # bf16 mode: the sampled, modulated columns are the MFMA's bf16 operand
+        cols = col_round(cols)
     out = torch.matmul(weight.view(Cout, Cin * K), cols) + bias.view(1, Cout, 1)
     return out.view(B, Cout, Ho, Wo)
 
 
-def dcn(x, sd, prefix, deformable_groups):
-    """layers/dcn_v2_custom.py:79-89: offset/mask conv -> chunk(3) -> cat(o1,o2), sigmoid(mask)."""
-    om = F.conv2d(x, sd[prefix + '.conv_offset_mask.weight'], sd[prefix + '.conv_offset_mask.bias'],
+def dcn(x, sd, prefix, deformable_groups, q=None):
+    """layers/dcn_v2_custom.py:79-89: offset/mask conv -> chunk(3) -> cat(o1,o2), sigmoid(mask).  ``q`` (bf16 mode): rounded
+    weights, fp32 offsets / mask, rounded sampled columns, rounded output."""
+    qq = q or _ident
+    om = F.conv2d(x, qq(sd[prefix + '.conv_offset_mask.weight']), sd[prefix + '.conv_offset_mask.bias'],
                   stride=1, padding=1)
     o1, o2, m = torch.chunk(om, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)
-    out = dcn_v2_conv(x, offset, torch.sigmoid(m), sd[prefix + '.weight'], sd[prefix + '.bias'],
-                      1, 1, 1, deformable_groups)
-    return out, offset
+    out = dcn_v2_conv(x, offset, torch.sigmoid(m), qq(sd[prefix + '.weight']), sd[prefix + '.bias'],
+                      1, 1, 1, deformable_groups, col_round=q)
+    return qq(out), offset
 
 
 # ----------------------------------------------------------------------------------------
@@ -417,23 +441,41 @@ def extras_layers(batch_norm=True, groups=4, in_ch=1024):
 BN_MOMENTUM = [0.1]     # nn.BatchNorm2d default; tests set 1.0 to make running stats == batch stats
 
 
-def _bn(x, sd, prefix, training, updates):
+def _bn(x, sd, prefix, training, updates, q=None):
     rm, rv = sd[prefix + '.running_mean'].clone(), sd[prefix + '.running_var'].clone()
-    y = F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], training, BN_MOMENTUM[0], 1e-5)
+    if q is None:
+        y = F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], training, BN_MOMENTUM[0], 1e-5)
+    else:
+        # bf16 mode: the statistics come from the fp32 conv output, the normalisation reads its bf16-stored copy
+        if training:
+            mean = x.mean(dim=(0, 2, 3))
+            var = x.var(dim=(0, 2, 3), unbiased=False)
+            n = x.numel() / x.shape[1]
+            mom = BN_MOMENTUM[0]
+            rm.mul_(1 - mom).add_(mom * mean)
+            rv.mul_(1 - mom).add_(mom * var * (n / max(n - 1, 1)))
+        else:
+            mean, var = rm, rv
+        scale = sd[prefix + '.weight'] / torch.sqrt(var + 1e-5)
+        shift = sd[prefix + '.bias'] - mean * scale
+        y = q(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if training and updates is not None:
         updates[prefix + '.running_mean'], updates[prefix + '.running_var'] = rm, rv
     return y
 
 
-def _run_table(x, table, sd, prefix, training, updates, taps=None):
+def _run_table(x, table, sd, prefix, training, updates, taps=None, q=None):
     for kind, idx, a in table:
         name = f'{prefix}.{idx}'
         if kind == 'conv':
-            x = F.conv2d(x, sd[name + '.weight'], sd[name + '.bias'], a['s'], a['p'], a['d'], a['groups'])
+            w = sd[name + '.weight'] if q is None else q(sd[name + '.weight'])
+            x = F.conv2d(x, w, sd[name + '.bias'], a['s'], a['p'], a['d'], a['groups'])
         elif kind == 'bn':
-            x = _bn(x, sd, name, training, updates)
+            x = _bn(x, sd, name, training, updates, q)
         elif kind == 'relu':
             x = F.relu(x)
+            if q is not None:
+                x = q(x)                   # the activation is stored (or re-created by the consumer) in bf16
         elif kind == 'pool':
             x = F.max_pool2d(x, a['k'], a['s'], a['p'], ceil_mode=a['ceil'])
         if taps is not None:
@@ -443,47 +485,50 @@ def _run_table(x, table, sd, prefix, training, updates, taps=None):
 
 def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_extra=4, use_fuseconv=True,
                  use_self_attention=False, use_self_attention_base=False, num_dcn_layers=0, groups_dcn=1,
-                 dcn_cat_sab=False, max_pool_factor=1, training=True, taps=None):
+                 dcn_cat_sab=False, max_pool_factor=1, training=True, taps=None, bf16=False):
     """``SSD.forward`` train-phase return (:217-400): (loc[B,P,4], conf[B,P,C], updates).
 
     ``sd`` is a state dict with the reference's keys; ``updates`` holds the buffers a training
     forward mutates (BN running stats, spectral-norm u/v).  ``taps`` (dict) collects named
     intermediate activations for op-level parity tests."""
     assert batch_norm, 'the driver only builds the BN variant (train_lesion_multiphase_v2.py:77)'
+    q = bf16_round if bf16 else None          # BASELINE.json configs[4]: rounding at every bf16 storage point (see bf16_round)
+    qq = q or _ident
+    x = qq(x)
     updates = {}
     tp = taps if taps is not None else {}
     vt = vgg_layers(True, groups_vgg)
     split = 33                                                              # :257
     sa_i = sab_i = 0
     sources = []
-    x = _run_table(x, [l for l in vt if l[1] < split], sd, 'vgg', training, updates, taps)
+    x = _run_table(x, [l for l in vt if l[1] < split], sd, 'vgg', training, updates, taps, q)
     if use_self_attention_base:                                             # :261-265
-        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates, q)
         tp[f'sab{sab_i}.attn'] = amap
         sab_i += 1
         tp['sab0.out'], tp['sab0.attn_g'] = x, attn_g
     if dcn_cat_sab:                                                         # :267-271
         x = slice_and_cat(x, attn_g, groups_vgg)
     for i in range(num_dcn_layers):                                         # :273-278
-        x, offset = dcn(x, sd, f'dcn_list.{i}', groups_dcn)
+        x, offset = dcn(x, sd, f'dcn_list.{i}', groups_dcn, q)
         tp[f'dcn{i}.out'], tp[f'dcn{i}.offset'] = x, offset
-    s = l2norm(x, sd['L2Norm.weight'])                                      # :281
+    s = qq(l2norm(x, sd['L2Norm.weight']))                                  # :281
     tp['l2norm'] = s
 
     def branch(s, fuse):
         nonlocal sa_i
         if use_self_attention:
-            s, _, amap = self_attn(s, sd, f'self_attn_list.{sa_i}', training, max_pool_factor, updates)
+            s, _, amap = self_attn(s, sd, f'self_attn_list.{sa_i}', training, max_pool_factor, updates, q)
             tp[f'sa{sa_i}.attn'] = amap
             sa_i += 1
         if use_fuseconv:
-            s = F.conv2d(s, sd[f'fuse_{fuse}.weight'], sd[f'fuse_{fuse}.bias'])
-            s = F.relu(_bn(s, sd, f'bn_fuse_{fuse}', training, updates))
+            s = F.conv2d(s, qq(sd[f'fuse_{fuse}.weight']), sd[f'fuse_{fuse}.bias'])
+            s = qq(F.relu(_bn(s, sd, f'bn_fuse_{fuse}', training, updates, q)))
         return s
     sources.append(branch(s, '11'))                                         # :284-297
-    x = _run_table(x, [l for l in vt if l[1] >= split], sd, 'vgg', training, updates, taps)   # :300-301
+    x = _run_table(x, [l for l in vt if l[1] >= split], sd, 'vgg', training, updates, taps, q)   # :300-301
     if use_self_attention_base:                                             # :303-307
-        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates)
+        x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor, updates, q)
         tp[f'sab{sab_i}.attn'] = amap
         sab_i += 1
     sources.append(branch(x, '21'))                                         # :309-325
@@ -491,13 +536,13 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
     fuse_names = ['31', '41', '51', '61']
     conv_i = 0
     for kind, idx, a in et:                                                 # :350-372
-        x = _run_table(x, [(kind, idx, a)], sd, 'extras', training, updates, taps)
+        x = _run_table(x, [(kind, idx, a)], sd, 'extras', training, updates, taps, q)
         if idx % 2 == 1:
-            x = F.relu(x)
+            x = qq(F.relu(x))
         if idx % 4 == 3:
             if use_self_attention_base:
                 x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor,
-                                            updates)
+                                            updates, q)
                 tp[f'sab{sab_i}.attn'] = amap
                 sab_i += 1
             sources.append(branch(x, fuse_names[conv_i]))
@@ -506,8 +551,8 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
         tp[f'source{i}'] = s
     loc, conf = [], []
     for i, s in enumerate(sources):                                         # :375-380
-        loc.append(F.conv2d(s, sd[f'loc.{i}.weight'], sd[f'loc.{i}.bias'], padding=1).permute(0, 2, 3, 1))
-        conf.append(F.conv2d(s, sd[f'conf.{i}.weight'], sd[f'conf.{i}.bias'], padding=1).permute(0, 2, 3, 1))
+        loc.append(F.conv2d(s, qq(sd[f'loc.{i}.weight']), sd[f'loc.{i}.bias'], padding=1).permute(0, 2, 3, 1))
+        conf.append(F.conv2d(s, qq(sd[f'conf.{i}.weight']), sd[f'conf.{i}.bias'], padding=1).permute(0, 2, 3, 1))
     B = x.shape[0]
     loc = torch.cat([o.reshape(B, -1) for o in loc], 1).view(B, -1, 4)
     conf = torch.cat([o.reshape(B, -1) for o in conf], 1).view(B, -1, num_classes)
