@@ -57,3 +57,5 @@ int gssd_try_conv_thin_wino(const gssd_conv_desc& d, hipStream_t stream);
 int gssd_try_conv_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
 // conv_patch_wgrad.hip: conv2_1 .. conv3_3 shapes (patch-staged, one phase group per workgroup); else returns 1
 int gssd_try_conv_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
+// conv_thin_bf16.hip: bf16 thin trunk layers (conv1_1 .. conv2_2); returns 1 when the descriptor is not one of them
+int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream);

@@ -1,0 +1,248 @@
+// Thin grouped 3x3 convolutions of the trunk in bf16 storage mode (conv1_1 .. conv2_2: 4 phase groups with 8..32 input and
+// 16..32 output channels per group on the 300^2 / 150^2 maps -- 60 % of the trunk's bytes).  In bf16 these layers are pure HBM
+// streams (arithmetic intensity 10..40 FLOP/B against a ridge of ~310), so the kernel is organised around moving every byte once:
+//   * a persistent 256-thread workgroup walks 8 x 16-pixel tiles; wave g computes phase group g, so a pixel's whole channel
+//     vector (64..256 B) is fetched as one burst by 16-byte LDS-DMA together with the 1-pixel halo (patch = 10 x 18 pixels);
+//   * fused producer BatchNorm + ReLU (deferred BN of conv1_1 / conv2_1) is applied ONCE per patch element in LDS (fp32 math, one
+//     bf16 rounding -- the same rounding the separate BN pass applies), not once per tap; out-of-image pixels are staged as zeros
+//     and skipped by the transform, which is exactly zero padding after BN + ReLU;
+//   * the nine taps are shifted ds_read_b128 of the patch: a lane's 8 consecutive k of v_mfma_f32_16x16x32_bf16 lie inside one tap;
+//     the 16-byte units of a pixel are XOR-swizzled with the patch column on the DMA source side (conflict-free fragment reads);
+//   * the group's weights (<= 32 x 288 bf16) live in registers as MFMA operands for the workgroup's lifetime;
+//   * operand roles are swapped (A = weights, B = pixels) so a lane ends up with 4 (cout_g 16) or 8 (cout_g 32, staged in the
+//     channel order of conv_bf16.hip) consecutive output channels of one pixel: 8 / 16-byte NHWC stores straight from registers;
+//   * BatchNorm batch sums (of the fp32 accumulators) stay in registers across tiles: 16 shuffles + one fp64 atomic per channel
+//     per workgroup at the end.
+#include <stdlib.h>
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+namespace {
+
+__device__ __attribute__((aligned(16))) u16 g_zero_thin_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct ThinBfParams {
+    const u16* in;
+    const u16* wgt;      // packed bf16 [Cout][9*CIN_G]
+    const float* bias;
+    u16* out;
+    double* stats;
+    const float* in_scale;
+    const float* in_shift;
+    int B, H, W, tiles_y, tiles_x;
+};
+
+template <int UPR>
+__device__ __forceinline__ int swz(int col) {
+    return UPR >= 8 ? (col & (UPR - 1)) & 15 : ((col ^ (col >> 2)) & (UPR - 1));
+}
+
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPATCH = PH * PW;
+
+template <int CIN_G, int COUT_G, bool XF>
+__global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_kernel(const ThinBfParams p) {
+    constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
+    constexpr int UPR = CIN / 8;                   // 16-byte units per pixel
+    constexpr int PPI = 64 / UPR;                  // pixels per DMA wave instruction
+    constexpr int NT = COUT_G / 16;
+    constexpr int KS = (9 * CIN_G + 31) / 32;      // 32-k MFMA steps
+    constexpr int NINSTR = (NPATCH + PPI - 1) / PPI;
+    constexpr int CPL = NT == 1 ? 4 : 8;           // consecutive output channels per lane
+    extern __shared__ __attribute__((aligned(16))) u16 patch[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = conv group
+    const int r = lane & 15, kq = lane >> 4;
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const int ntiles = p.B * tiles_per_img;
+
+    // ---- weights -> registers (A operand): lane (row rho = r of tile j, kq) holds W[channel(j, rho)][32 ks + 8 kq .. +8] ------
+    bf16x8 wf[KS][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = NT == 1 ? r : 8 * (r >> 2) + 4 * j + (r & 3);
+        const u16* wr = p.wgt + (size_t)(g * COUT_G + ch) * (9 * CIN_G);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 32 * ks + 8 * kq;
+            wf[ks][j] = k < 9 * CIN_G ? *reinterpret_cast<const bf16x8*>(wr + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // this lane's output channels (inside the group): cb .. cb + CPL
+    const int cb = NT == 1 ? 4 * kq : 8 * kq;
+    float bias[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) bias[c] = p.bias ? p.bias[g * COUT_G + cb + c] : 0.f;
+
+    // ---- fragment offsets (elements) of M tile 0 per k-step: tap = k / CIN_G (clamped: zero weights beyond tap 8) ---------------
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 32 * ks + 8 * kq;
+        int tap = k / CIN_G;
+        const int coff = k - tap * CIN_G;
+        if (tap > 8) tap = 8;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int col = r + dx;
+        const int unit = (g * CIN_G + coff) >> 3;
+        foff[ks] = (dy * PW + col) * CIN + ((unit ^ swz<UPR>(col)) << 3);
+    }
+
+    float ssum[CPL], ssq[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ssum[c] = ssq[c] = 0.f;
+
+    const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+        const int y0 = tyi * TH, x0 = txi * TW;
+
+        // ---- stage the patch: pixel vectors of CIN bf16, units XOR-swizzled by the patch column --------------------------------
+        for (int i = g; i < NINSTR; i += 4) {
+            const int pp = i * PPI + lane / UPR;
+            const int py = pp / PW, pxx = pp - py * PW;
+            const int lu = (lane % UPR) ^ swz<UPR>(pxx);
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            const bool ok = pp < NPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const u16* src = ok ? p.in + ((size_t)(b * p.H + iy) * p.W + ix) * CIN + lu * 8 : g_zero_thin_h;
+            dma16(src, patch + i * PPI * CIN);
+        }
+        __syncthreads();
+        if constexpr (XF) {
+            // producer BatchNorm + ReLU once per patch element (in-image pixels only: the rest stays 0 = padding after the transform)
+            for (int u = tid; u < NPATCH * UPR; u += 256) {
+                const int pp = u / UPR, slot = u - pp * UPR;
+                const int py = pp / PW, pxx = pp - py * PW;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+                if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+                const int c0 = (slot ^ swz<UPR>(pxx)) << 3;             // logical first channel of this unit
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + u * 8);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.in_scale + c0), s1 = *reinterpret_cast<const f32x4*>(p.in_scale + c0 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.in_shift + c0), h1 = *reinterpret_cast<const f32x4*>(p.in_shift + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (__bf16)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
+                    v[e + 4] = (__bf16)fmaxf((float)v[e + 4] * s1[e] + h1[e], 0.f);
+                }
+                *reinterpret_cast<bf16x8*>(patch + u * 8) = v;
+            }
+            __syncthreads();
+        }
+
+        // ---- MFMAs straight from the patch: M tile i = tile row i (16 pixels wide) ---------------------------------------------
+        f32x4 acc[TH][NT];
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            bf16x8 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + i * PW * CIN);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
+        }
+
+        // ---- epilogue: + bias, batch sums, 8 / 16-byte NHWC stores (lane: pixel (y0 + i, x0 + r), CPL consecutive channels) ----
+        const int x = x0 + r;
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            const int y = y0 + i;
+            if (y >= p.H || x >= p.W) continue;
+            float v[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                v[c] = (NT == 1 ? acc[i][0][c] : acc[i][c >> 2][c & 3]) + bias[c];
+                ssum[c] += v[c];
+                ssq[c] += v[c] * v[c];
+            }
+            u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + cb;
+            if constexpr (CPL == 8) {
+                bf16x8 h;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) h[c] = (__bf16)v[c];
+                *reinterpret_cast<bf16x8*>(dst) = h;
+            } else {
+                *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            }
+        }
+        __syncthreads();          // every wave is done reading the patch
+    }
+
+    if (p.stats) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            double s = (double)ssum[c], q = (double)ssq[c];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s += __shfl_xor(s, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (r == 0) {
+                unsafeAtomicAdd(p.stats + g * COUT_G + cb + c, s);
+                unsafeAtomicAdd(p.stats + COUT + g * COUT_G + cb + c, q);
+            }
+        }
+    }
+}
+
+template <int CIN_G, int COUT_G, bool XF>
+int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
+    constexpr int CIN = 4 * CIN_G;
+    constexpr int UPR = CIN / 8, PPI = 64 / UPR;
+    ThinBfParams p;
+    p.in = reinterpret_cast<const u16*>(d.in);
+    p.wgt = reinterpret_cast<const u16*>(d.wgt);
+    p.bias = d.bias;
+    p.out = reinterpret_cast<u16*>(d.out);
+    p.stats = d.stats;
+    p.in_scale = d.in_scale;
+    p.in_shift = d.in_shift;
+    p.B = d.B;
+    p.H = d.H;
+    p.W = d.W;
+    p.tiles_y = (d.H + TH - 1) / TH;
+    p.tiles_x = (d.W + TW - 1) / TW;
+    const size_t smem = (size_t)((NPATCH + PPI - 1) / PPI) * PPI * CIN * sizeof(u16);
+    const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
+    int grid = 256 * (COUT_G > 16 ? 2 : 3);
+    if (ntiles < grid) grid = (int)ntiles;
+    hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF>), dim3(grid), dim3(256), smem, stream, p);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+}  // namespace
+
+// Eligibility + dispatch; called from gssd_conv2d_nhwc_bf16 (conv_bf16.hip).  Returns 1 if not eligible.
+int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
+    const int cout_g = d.Cout / d.groups;
+    const bool shape_ok = d.groups == 4 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 &&
+                          d.in_stride == 4 * d.cin_g && d.in_ch_off == 0 && d.out_mode == GSSD_OUT_NHWC && d.out_stride == d.Cout &&
+                          d.out_ch_off == 0 && !d.m_per_image && !d.relu && !d.gate && !d.resid && !d.alpha && d.split_k == 1 &&
+                          d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && d.flags == 0;
+    if (!shape_ok) return 1;
+#define THIN_CASE(CI, CO)                                                                     \
+    if (d.cin_g == CI && cout_g == CO)                                                        \
+        return d.in_scale ? launch_thin_bf16<CI, CO, true>(d, stream) : launch_thin_bf16<CI, CO, false>(d, stream);
+    THIN_CASE(8, 16)
+    THIN_CASE(16, 16)
+    THIN_CASE(16, 32)
+    THIN_CASE(32, 32)
+#undef THIN_CASE
+    return 1;
+}

@@ -56,7 +56,9 @@ def conv_tag(d, real_cin_g=None, bf16=False):
             inst = '128x64'
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if bf16:
-        pass
+        if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
+                and (d.cin_g, cout_g) in ((8, 16), (16, 16), (16, 32), (32, 32)) and not d.m_per_image and d.split_k == 1 and d.flags == 0):
+            name = f'conv_thin_bf16<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin_bf16 (csrc/conv_thin_bf16.hip)
     elif (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)

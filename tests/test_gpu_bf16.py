@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 from oracle import gssd_oracle as O          # noqa: E402
 from gssd import synth                       # noqa: E402
 
-BF_ULP = 2.0 ** -8
+BF_ULP = 2.0 ** -8          # spacing of bf16 just below a power of two, relative to the value
+BF_ULP_LOW = 2.0 ** -7      # ... just above a power of two: one ulp of the tensor's largest element can be this much of it
 
 
 def rel(a, b):
@@ -274,7 +275,7 @@ def test_bf16_end_to_end(dev, name):
     assert loc.dtype == torch.float32 and conf.dtype == torch.float32
     # (1) layer-local
     worst = _layer_local_checks(net._engine._last_plan, net, name)
-    bad = {k: v for k, v in worst.items() if v > 1.01 * BF_ULP}
+    bad = {k: v for k, v in worst.items() if v > 1.01 * BF_ULP_LOW}
     print(name, 'layer-local worst (units of max-abs):', {k: f'{v:.1e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
     assert not bad, bad
     # (2) whole network
