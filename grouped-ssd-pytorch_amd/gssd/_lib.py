@@ -100,8 +100,15 @@ SIGNATURES = {
     'gssd_eval_match': (c_i, [c_fp, C.c_longlong, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_d, c_fp, c_i, c_i, c_fp, c_fp, c_fp]),
     'gssd_eval_workspace_bytes': (C.c_longlong, [c_i]),
     'gssd_eval_ap': (c_i, [c_fp, c_fp, c_i, c_i, c_d, c_i, c_fp, C.c_longlong, c_fp, c_fp]),
-    'gssd_gemm_nt_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
-    'gssd_gemm_tn_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_bgemm_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_f,
+                             c_i, c_fp]),
+    'gssd_softmax_bwd_rows_f32': (c_i, [c_fp, c_fp, c_i64, c_i, c_i, c_fp]),
+    'gssd_sn_weight_grad_f32': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    'gssd_scaled_transpose_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    'gssd_dot_f32': (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
+    'gssd_axpby_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp]),
+    'gssd_scale_cast_f64_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_fp]),
+    'gssd_sa_sigma_grad_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp]),
     'gssd_dcn_col2im_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_match_batch': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_i, c_fp]),

@@ -11,8 +11,8 @@ Built from the forward plan's records (``engine._Plan.rec``) and walked in rever
 
 The consumer-side fused BN + ReLU of the forward (deferred BatchNorm) needs no activation buffer here either: wgrad
 re-applies the transform to the raw input, and the producer's BN backward recomputes its ReLU mask from raw.
-The deformable conv is HIP too (dcn.hip: col2im with atomics).  Self-attention blocks have no hand-written backward
-kernels yet: inside this plan they run block-local ATen autograd (token-major matmul / softmax); everything else is HIP.
+The deformable conv (dcn.hip: col2im with atomics; the contraction's two gradients on the conv kernels) and the
+self-attention blocks (csrc/sa_backward.hip) are HIP too: the plan is a list of C-ABI launches, no library GEMM, no ATen math.
 """
 import ctypes as C
 
@@ -245,72 +245,96 @@ class BackwardPlan:
         return buf, False
 
     def _sa(self, r):
-        """Self_Attn (layers/self_attn.py:46-89), interim: no hand-written kernels yet.  The block's backward is written out
-        by hand over the forward plan's own buffers (theta|phi, g^T, the softmaxed attention map, attn.g) as a dozen batched
-        ATen matmuls -- no autograd graph and no recomputation of the forward:
-            d_o = sigma dT;  d(ag) = d_o W_o;  dA = d(ag) g^T;  dS = A (dA - rowsum(A dA));  d theta = dS phi;
-            d phi = dS^T theta;  d g = A^T d(ag);  dx = d(out) + d(theta|phi) W_tp + d g W_g;  weight grads = d^T x,
-        and for every spectrally normalised conv (W_eff = W / s, s = u^T W v, u and v constants of the step)
-            dW = dW_eff / s - (sum dW_eff . W) / s^2 * u v^T."""
+        """Self_Attn (layers/self_attn.py:46-89), all HIP (csrc/sa_backward.hip + the conv kernels).  With T = d(out) + d(out2),
+        s = sigma, W_eff = W / sigma_sn (alpha = 1 / sigma_sn per conv; u, v constants of the step):
+            d(ag)' = T W_o^T alpha_o              (1x1 conv over T with the scaled, transposed o weights; everything below is
+                                                   linear in d(ag) = s d(ag)', so s is applied where the chain ends)
+            d sigma = <d(ag)', ag> + <b_o, colsum T>;   d b_o = s colsum T;   dW_o = SN(s T^T ag)
+            A = softmax(theta phi^T)              (the forward is flash-style and keeps no map: re-materialised here)
+            dA = d(ag)' g;  dS = A (dA - rowsum(A dA));  d theta = dS phi;  d phi = dS^T theta;  d g = A^T d(ag)'   (batched GEMMs)
+            dW_{theta,phi,g} = SN(s [d theta | d phi | d g]^T x);  biases = s colsum;  dx = d(out) + s [d theta | d phi | d g] W_tpg alpha
+        SN(G) = G / sigma_sn - <G, W> / sigma_sn^2 u v^T."""
         sa, x, out, out2 = r['mod'], r['x_in'], r['out'], r['out2']
         g_out = self._grad_of(out)
         g_out2 = self._grad_of(out2) if out2 is not None else None
         gx, existed = self._reserve(x, x.shape)
-        B, N, Cc = self.B, r['N'], r['C']
+        B, N, Np, Cc, H = self.B, r['N'], r['Np'], r['C'], r['H']
         C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+        CT = C4 + C2
+        M = B * N
         tp, gT, ag = r['tp'], r['gT'], r['ag']
         a_tpg, a_o = r['inv_sigma']
         cv = {k: getattr(sa, 'snconv1x1_' + k) for k in ('theta', 'phi', 'g', 'attn')}
-        pg = {k: (self._pgrad(m.weight_orig), self._pgrad(m.bias)) for k, m in cv.items()}
-        pg_sigma = self._pgrad(sa.sigma)
-
-        def sn_grad(conv, dw_eff, inv_s, dst):
-            """dW_orig from dW_eff (both [rows, cols])."""
-            w = conv.weight_orig.detach().view(dw_eff.shape)
-            dot = (dw_eff * w).sum()
-            dst.copy_((dw_eff * inv_s - torch.outer(conv.weight_u.detach(), conv.weight_v.detach()) * (dot * inv_s * inv_s))
-                      .view(dst.shape))
-
-        def step():
-            X = x.view(B, N, Cc)
-            dT = g_out.view(B, N, Cc)
-            if g_out2 is not None:
-                dT = dT + g_out2.view(B, N, Cc)
-            sig = sa.sigma.detach()
-            is_t, is_p, is_g, is_o = a_tpg[0], a_tpg[C8], a_tpg[C4], a_o[0]       # 1 / sigma_sn of each conv (device scalars)
-            w_o = cv['attn'].weight_orig.detach().view(Cc, C2)
-            w_g = cv['g'].weight_orig.detach().view(C2, Cc)
-            w_t = cv['theta'].weight_orig.detach().view(C8, Cc)
-            w_p = cv['phi'].weight_orig.detach().view(C8, Cc)
-            theta, phi = tp[:, :, :C8], tp[:, :, C8:]
-            A = torch.softmax(torch.bmm(theta, phi.transpose(1, 2)), dim=-1)     # the forward is flash-style: no stored map
-            g_tok = gT[:, :, :N].transpose(1, 2)                                 # [B, N, C2] view
-            # output conv and the gate
-            o_raw = torch.matmul(ag, w_o.t()) * is_o + cv['attn'].bias.detach()
-            pg_sigma.copy_((dT * o_raw).sum().view(pg_sigma.shape))
-            d_o = dT * sig
-            sn_grad(cv['attn'], torch.matmul(d_o.reshape(-1, Cc).t(), ag.reshape(-1, C2)), is_o, pg['attn'][0])
-            pg['attn'][1].copy_(d_o.sum((0, 1)))
-            dag = torch.matmul(d_o, w_o) * is_o                                  # [B, N, C2]
-            # attention
-            dA = torch.bmm(dag, g_tok.transpose(1, 2))                           # [B, N, N]
-            dS = A * (dA - (A * dA).sum(-1, keepdim=True))
-            d_theta = torch.bmm(dS, phi)
-            d_phi = torch.bmm(dS.transpose(1, 2), theta)
-            d_g = torch.bmm(A.transpose(1, 2), dag)                              # [B, N, C2] (token-major g)
-            # the three input convs
-            Xf = X.reshape(-1, Cc)
-            sn_grad(cv['theta'], torch.matmul(d_theta.reshape(-1, C8).t(), Xf), is_t, pg['theta'][0])
-            sn_grad(cv['phi'], torch.matmul(d_phi.reshape(-1, C8).t(), Xf), is_p, pg['phi'][0])
-            sn_grad(cv['g'], torch.matmul(d_g.reshape(-1, C2).t(), Xf), is_g, pg['g'][0])
-            pg['theta'][1].copy_(d_theta.sum((0, 1)))
-            pg['phi'][1].copy_(d_phi.sum((0, 1)))
-            pg['g'][1].copy_(d_g.sum((0, 1)))
-            # the residual branch carries d(out) only: out2 = sigma * o has no direct x term
-            dx = g_out.view(B, N, Cc) + torch.matmul(d_theta, w_t) * is_t + torch.matmul(d_phi, w_p) * is_p + torch.matmul(d_g, w_g) * is_g
-            dxn = dx.view(gx.shape)
-            gx.add_(dxn) if existed else gx.copy_(dxn)
-        self.steps.append((step, None))
+        name = r['name']
+        w_tpg = self.plan.eng._packed[name + '.tpg.w']                       # fp32 [C4 + C2][C]: theta | phi | g rows
+        w_o = cv['attn'].weight_orig.detach().view(Cc, C2)
+        sig = sa.sigma
+        mk = ops.make_conv_desc
+        fn = lib.gssd_conv2d_nhwc_f32
+        # T
+        T = g_out
+        if g_out2 is not None:
+            T = self._buf(B, H, H, Cc)
+            self._add(lib.gssd_axpby_f32, (g_out.data_ptr(), g_out2.data_ptr(), T.data_ptr(), M * Cc, 1.0, 1.0))
+        # d(ag)' = T . (W_o^T alpha_o)
+        wd_o = self._buf(C2, Cc)
+        self._add(lib.gssd_scaled_transpose_f32, (w_o.data_ptr(), a_o.data_ptr(), wd_o.data_ptr(), Cc, C2), keep=w_o)
+        dag = self._buf(B, N, C2)
+        d_dag, _, _ = mk(T, wd_o, dag, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2)
+        self._add(fn, (C.byref(d_dag),), keep=d_dag)
+        # sigma, o bias, o weight
+        dot = self._buf(1, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_dot_f32, (dag.data_ptr(), ag.data_ptr(), M * C2, dot.data_ptr()))
+        csT = self._buf(Cc, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (T.data_ptr(), M, Cc, Cc, csT.data_ptr()))
+        self._add(lib.gssd_sa_sigma_grad_f32, (dot.data_ptr(), csT.data_ptr(), cv['attn'].bias.data_ptr(), Cc, self._pgrad(sig).data_ptr()))
+        self._add(lib.gssd_scale_cast_f64_f32, (csT.data_ptr(), sig.data_ptr(), self._pgrad(cv['attn'].bias).data_ptr(), Cc))
+        d_o, _, _ = mk(ag, None, None, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc)
+        dwo = self._buf(Cc, C2, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_o), T.data_ptr(), dwo.data_ptr()), keep=d_o)
+        self._add(lib.gssd_sn_weight_grad_f32, (dwo.data_ptr(), C2, cv['attn'].weight_orig.data_ptr(), cv['attn'].weight_u.data_ptr(),
+                                                cv['attn'].weight_v.data_ptr(), a_o.data_ptr(), sig.data_ptr(),
+                                                self._pgrad(cv['attn'].weight_orig).data_ptr(), Cc, C2))
+        # attention map A (no stored copy: the forward is flash-style)
+        A = self._buf(B, N, Np)
+        d_qk, _, _ = mk(tp, tp[0, 0, C8:], A, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
+                        in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
+        self._add(fn, (C.byref(d_qk),), keep=d_qk)
+        self._add(lib.gssd_softmax_rows_f32, (A.data_ptr(), B * N, N, Np))
+        # dA = d(ag)' . g ;  dS in place
+        dA = self._buf(B, N, Np)
+        self._add(lib.gssd_bgemm_f32, (dag.data_ptr(), gT.data_ptr(), dA.data_ptr(), N, N, C2, C2, Np, Np, 0, 0, N * C2, C2 * Np, N * Np, B,
+                                       1.0, 0))
+        self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, N, Np))
+        # [d theta | d phi | d g] token-major, one buffer (the gradient of the merged projection's output)
+        dtpg = self._buf(B, N, CT)
+        self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp[0, 0, C8:].data_ptr(), dtpg.data_ptr(), N, C8, N, Np, C4, CT, 0, 0, N * Np, N * C4,
+                                       N * CT, B, 1.0, 0))
+        self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp.data_ptr(), dtpg[0, 0, C8:].data_ptr(), N, C8, N, Np, C4, CT, 1, 0, N * Np, N * C4,
+                                       N * CT, B, 1.0, 0))
+        self._add(lib.gssd_bgemm_f32, (A.data_ptr(), dag.data_ptr(), dtpg[0, 0, C4:].data_ptr(), N, C2, N, Np, C2, CT, 1, 0, N * Np, N * C2,
+                                       N * CT, B, 1.0, 0))
+        # projection weights / biases
+        d_p, _, _ = mk(x, None, None, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=CT)
+        dwp = self._buf(CT, Cc, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_p), dtpg.data_ptr(), dwp.data_ptr()), keep=d_p)
+        csP = self._buf(CT, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dtpg.data_ptr(), M, CT, CT, csP.data_ptr()))
+        for key, row0, rows in (('theta', 0, C8), ('phi', C8, C8), ('g', C4, C2)):
+            m_ = cv[key]
+            self._add(lib.gssd_sn_weight_grad_f32, (dwp[row0:].data_ptr(), Cc, m_.weight_orig.data_ptr(), m_.weight_u.data_ptr(),
+                                                    m_.weight_v.data_ptr(), a_tpg[row0:].data_ptr(), sig.data_ptr(),
+                                                    self._pgrad(m_.weight_orig).data_ptr(), rows, Cc))
+            self._add(lib.gssd_scale_cast_f64_f32, (csP[row0:].data_ptr(), sig.data_ptr(), self._pgrad(m_.bias).data_ptr(), rows))
+        # dx = d(out) (+ what was already there) + sigma * dtpg . (W_tpg alpha)
+        wd_p = self._buf(Cc, CT)
+        self._add(lib.gssd_scaled_transpose_f32, (w_tpg.data_ptr(), a_tpg.data_ptr(), wd_p.data_ptr(), CT, Cc), keep=w_tpg)
+        resid = g_out
+        if existed:
+            resid = self._buf(B, H, H, Cc)
+            self._add(lib.gssd_axpby_f32, (g_out.data_ptr(), gx.data_ptr(), resid.data_ptr(), M * Cc, 1.0, 1.0))
+        d_dx, _, _ = mk(dtpg, wd_p, gx, B=B, H=H, W=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
+        self._add(fn, (C.byref(d_dx),), keep=(d_dx, sig))
 
     def _slice_cat(self, r):
         a, b, out, groups, Ca, Cb = r['a'], r['b'], r['out'], r['groups'], r['Ca'], r['Cb']
@@ -341,17 +365,18 @@ class BackwardPlan:
         w_main = self._buf(Cout, Kc)
         self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
         # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- plain GEMMs (rocBLAS)
-        dwp = self._buf(Cout, Kc)
-        self._add(lib.gssd_gemm_tn_f32, (dy.data_ptr(), cols.data_ptr(), dwp.data_ptr(), B * H * H, Cout, Kc, Cout, Kc, Kc, 0))
+        dwp = self._buf(Cout, Kc, zero_each_run=True)
+        d_c, _, _ = ops.make_conv_desc(cols, None, None, B=B, H=H, W=H, in_stride=Kc, cin_g=Kc, Cout=Cout)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_c), dy.data_ptr(), dwp.data_ptr()), keep=d_c)
         self._unpack(dwp, Kc, 0, m.weight, Cin, Cin, 3)
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))
         self._bias_from_colsum(cs, m.bias)
         wt = self._buf(Kc, Cout)
-        self.steps.append((lambda w=w_main, wt=wt: wt.copy_(w.t()), None))
+        self._add(lib.gssd_scaled_transpose_f32, (w_main.data_ptr(), 0, wt.data_ptr(), Cout, Kc), keep=w_main)
         dcols = self._buf(B * H * H, Kc)
-        self._add(lib.gssd_gemm_nt_f32, (dy.data_ptr(), wt.data_ptr(), dcols.data_ptr(), B * H * H, Kc, Cout, Cout, Cout, Kc, 0, 0),
-                  keep=wt)
+        d_dc, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d_dc),), keep=(d_dc, wt))
         # sampling backward: d(x) by atomics, d(offset / mask logits) per pixel
         gx = self._grad_of(x)
         if gx is None:

@@ -1,0 +1,275 @@
+// Self_Attn backward building blocks for gfx950 (backward of layers/self_attn.py:46-89, which the
+// reference gets from autograd over bmm / softmax / conv2d):
+//   gssd_bgemm_f32            batched fp32 GEMM with independent transpose flags on the fp32 matrix cores -- the products of the
+//                             attention backward that are not "activations x K-major weights":
+//                               dA = d(ag) . g      dtheta = dS . phi      dphi = dS^T . theta      dg = A^T . d(ag)
+//   gssd_softmax_bwd_rows_f32 dS = A * (dA - rowsum(A * dA)) in place (one wave per row)
+//   gssd_sn_weight_grad_f32   spectral-norm chain rule: dW_orig = dW_eff / s - <dW_eff, W> / s^2 * u v^T  (u, v constants of the step)
+//   gssd_scaled_transpose_f32 Wd[c][n] = W[n][c] * alpha[n]: the data-gradient weights of a spectrally normalised 1x1 conv
+//   gssd_dot_f32              sum a[i] * b[i] into a double (the gradient of Self_Attn's scalar gate sigma)
+// The forward is flash-style and keeps no attention map; the backward re-materialises A per block (QK^T by the conv kernel + row
+// softmax) -- a flash-style backward is the next step.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16, LDS_LD = TK + 4;     // 80-byte rows: conflict-free ds_read_b128 of 16 consecutive rows
+
+struct BgemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, lda, ldb, ldc, transA, transB, accumulate;
+    long long sA, sB, sC;
+    float alpha;
+};
+
+// element (row, k) of op(X): X[row*ld + k] (not transposed) or X[k*ld + row] (transposed)
+__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int trans, int row0, int nrows, int k0, int K, float* lds,
+                                          int tid) {
+    if (!trans) {
+        // contiguous along k: thread -> (row = tid / 4, k quad = tid % 4)
+        const int row = tid >> 2, kq = (tid & 3) << 2;
+        const int gr = row0 + row, gk = k0 + kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < nrows) {
+            const float* p = X + (size_t)gr * ld + gk;
+            if (gk + 3 < K && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gk + e < K) v[e] = p[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(lds + row * LDS_LD + kq) = v;
+    } else {
+        // contiguous along the row index: thread -> (k = tid / 16, row quad = tid % 16)
+        const int k = tid >> 4, rq = (tid & 15) << 2;
+        const int gk = k0 + k, gr = row0 + rq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < K) {
+            const float* p = X + (size_t)gk * ld + gr;
+            if (gr + 3 < nrows && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gr + e < nrows) v[e] = p[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(rq + e) * LDS_LD + k] = v[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[TM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const float* A = p.A + (size_t)b * p.sA;
+    const float* B = p.B + (size_t)b * p.sB;
+    float* C = p.C + (size_t)b * p.sC;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += TK) {
+        load_tile(A, p.lda, p.transA, m0, p.M, k0, p.K, As, tid);
+        // op(B)[k][n]: stored B[k*ldb + n] (not transposed) = "row index n is the contiguous one" -> the transposed loader
+        load_tile(B, p.ldb, !p.transB, n0, p.N, k0, p.K, Bs, tid);
+        __syncthreads();
+        f32x4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + (wm * 32 + i * 16 + r) * LDS_LD + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + j * 16 + r) * LDS_LD + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 32 + i * 16 + kq * 4 + e;
+                if (m >= p.M) continue;
+                float* dst = C + (size_t)m * p.ldc + n;
+                const float v = acc[i][j][e] * p.alpha;
+                *dst = p.accumulate ? *dst + v : v;
+            }
+        }
+}
+
+// dS[row][j] = A[row][j] * (dA[row][j] - sum_j A[row][j] * dA[row][j]) written over dA; pad columns [n, stride) are zeroed
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ A, float* __restrict__ dA, long long rows, int n,
+                                                               int stride) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long rI = wave0; rI < rows; rI += nwaves) {
+        const float* a = A + rI * stride;
+        float* d = dA + rI * stride;
+        float s = 0.f;
+        for (int c = lane; c < n; c += 64) s += a[c] * d[c];
+        s = wave_sum(s);
+        for (int c = lane; c < stride; c += 64) d[c] = c < n ? a[c] * (d[c] - s) : 0.f;
+    }
+}
+
+// one workgroup per matrix: dW_eff' = scale * dW_eff; dot = <dW_eff', W>; dW = dW_eff' * is - dot * is^2 * u v^T
+__global__ __launch_bounds__(256) void sn_weight_grad_kernel(const float* __restrict__ dweff, int ld_dw, const float* __restrict__ w,
+                                                             const float* __restrict__ u, const float* __restrict__ v,
+                                                             const float* __restrict__ inv_sigma, const float* __restrict__ scale,
+                                                             float* __restrict__ dw, int rows, int cols) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const float sc = scale ? scale[0] : 1.f;
+    double acc = 0.0;
+    for (int i = tid; i < rows * cols; i += 256) {
+        const int rr = i / cols, cc = i - rr * cols;
+        acc += (double)(sc * dweff[(size_t)rr * ld_dw + cc]) * (double)w[i];
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const double dot = red[0] + red[1] + red[2] + red[3];
+    const float is = inv_sigma[0];
+    const float k = (float)(dot * (double)is * (double)is);
+    for (int i = tid; i < rows * cols; i += 256) {
+        const int rr = i / cols, cc = i - rr * cols;
+        dw[i] = sc * dweff[(size_t)rr * ld_dw + cc] * is - k * u[rr] * v[cc];
+    }
+}
+
+__global__ void scaled_transpose_kernel(const float* __restrict__ w, const float* __restrict__ alpha, float* __restrict__ out, int rows,
+                                        int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % rows), c = (int)(i / rows);          // out[c][n]
+        out[i] = w[(size_t)n * cols + c] * (alpha ? alpha[n] : 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, double* out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc += (double)a[i] * (double)b[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long long n, float a,
+                             float b) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
+// y[i] = scale[0] * x[i] (x fp64 column sums): bias gradients behind Self_Attn's gate
+__global__ void scale_cast_kernel(const double* __restrict__ x, const float* __restrict__ scale, float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)((double)(scale ? scale[0] : 1.f) * x[i]);
+}
+
+// d(sigma) = dot + sum_c bias[c] * colsum[c]
+__global__ __launch_bounds__(256) void sigma_grad_kernel(const double* __restrict__ dot, const double* __restrict__ colsum,
+                                                         const float* __restrict__ bias, int C, float* __restrict__ dsigma) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) acc += (double)bias[c] * colsum[c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dsigma[0] = (float)(dot[0] + red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int gssd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && out && n > 0);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpby_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, out, (long long)n, a, b);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_scale_cast_f64_f32(const double* x, const float* scale, float* y, int n, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(scale_cast_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, scale, y, n);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_sa_sigma_grad_f32(const double* dot, const double* colsum, const float* bias, int C, float* dsigma,
+                                      gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dot && colsum && bias && dsigma && C > 0);
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, as_stream(stream), dot, colsum, bias, C, dsigma);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                              int transB, long long strideA, long long strideB, long long strideC, int batch, float alpha, int accumulate,
+                              gssd_stream_t stream) {
+    GSSD_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
+    GSSD_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    BgemmParams p{A, B, C, M, N, K, lda, ldb, ldc, transA, transB, accumulate, strideA, strideB, strideC, alpha};
+    hipLaunchKernelGGL(bgemm_kernel, dim3((M + TM - 1) / TM, (N + TN - 1) / TN, batch), dim3(256), 0, as_stream(stream), p);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_softmax_bwd_rows_f32(const float* attn, float* dattn, int64_t rows, int n, int row_stride, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(attn && dattn && rows > 0 && n > 0 && row_stride >= n);
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), attn, dattn, (long long)rows, n,
+                       row_stride);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_sn_weight_grad_f32(const float* dw_eff, int ld_dw, const float* w_orig, const float* u, const float* v,
+                                       const float* inv_sigma, const float* scale, float* dw_orig, int rows, int cols,
+                                       gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dw_eff && w_orig && u && v && inv_sigma && dw_orig && rows > 0 && cols > 0 && ld_dw >= cols);
+    hipLaunchKernelGGL(sn_weight_grad_kernel, dim3(1), dim3(256), 0, as_stream(stream), dw_eff, ld_dw, w_orig, u, v, inv_sigma, scale,
+                       dw_orig, rows, cols);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, int rows, int cols, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(w && out && rows > 0 && cols > 0);
+    const long long total = (long long)rows * cols;
+    hipLaunchKernelGGL(scaled_transpose_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w, alpha, out, rows, cols);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_dot_f32(const float* a, const float* b, int64_t n, double* out, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(a && b && out && n > 0);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dot_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), a, b, (long long)n, out);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

@@ -568,7 +568,7 @@ class _Plan(_PlanBase):
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, N, Np)
-        self.rec.append(('sa', dict(mod=sa, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, ag=ag, N=N, Np=Np,
+        self.rec.append(('sa', dict(mod=sa, name=name, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, ag=ag, N=N, Np=Np,
                                     inv_sigma=(a_tpg, a_o))))
         return out, out2
 

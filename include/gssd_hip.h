@@ -313,15 +313,30 @@ int gssd_resize_u8_vertical(const uint8_t* in, uint8_t* out, const int32_t* boun
 int gssd_input_finish_f32(const uint8_t* img, const int32_t* minmax, float mean0, float mean1, float mean2, float* out_nchw,
                           int B, int phases, int S, int C, int normalize, gssd_stream_t stream);
 
-/* Plain library GEMMs (rocBLAS) for the contractions of the path that are nothing but a GEMM -- the deformable conv's
- * product over the sampled column matrix (layers/dcn_v2_custom.py:84-89 -> dcn_v2's gemm) forward, data gradient and weight
- * gradient.  Row-major operands.
- *   nt: C[M][N] = A[M][K] . B[N][K]^T (+ bias[N] on every row | + C when accumulate)
- *   tn: C[N][K2] (+)= A[M][N]^T . B[M][K2]     (reduction over the M rows of both operands) */
-int gssd_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                     const float* bias, int accumulate, gssd_stream_t stream);
-int gssd_gemm_tn_f32(const float* A, const float* B, float* C, int M, int N, int K2, int lda, int ldb, int ldc, int accumulate,
-                     gssd_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Self_Attn backward building blocks (what the reference gets from autograd over
+ * layers/self_attn.py:62-89 -- conv2d / bmm / softmax backward kernels)
+ * ------------------------------------------------------------------------------------------ */
+/* Batched fp32 GEMM on the matrix cores with independent transpose flags: C_b[M][N] (+)= alpha * op(A_b)[M][K] . op(B_b)[K][N];
+ * op(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k]; op(B)[k][n] = transB ? B[n*ldb + k] : B[k*ldb + n]; operands `stride*`
+ * floats apart.  (dA = d(ag).g, dtheta = dS.phi, dphi = dS^T.theta, dg = A^T.d(ag).) */
+int gssd_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
+                   long long strideA, long long strideB, long long strideC, int batch, float alpha, int accumulate,
+                   gssd_stream_t stream);
+/* Softmax backward over rows, in place: dattn[r][j] <- attn[r][j] * (dattn[r][j] - sum_j attn[r][j]*dattn[r][j]); pad columns zeroed */
+int gssd_softmax_bwd_rows_f32(const float* attn, float* dattn, int64_t rows, int n, int row_stride, gssd_stream_t stream);
+/* Spectral-norm chain rule (layers/spectral_norm.py:83-85 with u, v constants): dW_eff' = scale[0] * dW_eff (scale may be NULL);
+ * dW_orig = dW_eff' * is - <dW_eff', W_orig> * is^2 * u v^T, is = inv_sigma[0].  dw_eff rows are ld_dw floats apart. */
+int gssd_sn_weight_grad_f32(const float* dw_eff, int ld_dw, const float* w_orig, const float* u, const float* v, const float* inv_sigma,
+                            const float* scale, float* dw_orig, int rows, int cols, gssd_stream_t stream);
+/* out[c][n] = w[n][c] * alpha[n] (alpha may be NULL): data-gradient weights of a spectrally normalised 1x1 conv */
+int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, int rows, int cols, gssd_stream_t stream);
+/* *out += sum a[i]*b[i] (fp64); out = a*x + b*y; y = scale[0]*x (fp64 -> fp32); d(sigma) = dot[0] + sum_c bias[c]*colsum[c] */
+int gssd_dot_f32(const float* a, const float* b, int64_t n, double* out, gssd_stream_t stream);
+int gssd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, gssd_stream_t stream);
+int gssd_scale_cast_f64_f32(const double* x, const float* scale, float* y, int n, gssd_stream_t stream);
+int gssd_sa_sigma_grad_f32(const double* dot, const double* colsum, const float* bias, int C, float* dsigma, gssd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * MultiBoxLoss (layers/modules/multibox_loss.py:46-120, layers/box_utils.py:70-135,160-168)
  * ------------------------------------------------------------------------------------------ */

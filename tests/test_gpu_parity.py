@@ -437,25 +437,73 @@ def test_dcn_fused_forward(dev, ops, B, Cc, H, dg, Cout):
     assert rel(nchw(yi)[:, :, 1:H - 2, 3:H - 1], (shifted + bias.view(1, -1, 1, 1))[:, :, 1:H - 2, 3:H - 1]) < TOL
 
 
-def test_library_gemm_entry_points(dev):
-    """gssd_gemm_nt_f32 / gssd_gemm_tn_f32 (rocBLAS behind the C ABI): the DCN contraction forward, dgrad and wgrad forms."""
+def test_sa_backward_building_blocks(dev):
+    """gssd_bgemm_f32 (all four transpose forms, ragged sizes, batched), the row softmax backward, the spectral-norm chain rule and
+    the small helpers of csrc/sa_backward.hip against torch-CPU."""
     from gssd._lib import lib, check
-    rng = np.random.default_rng(21)
-    M, N, K = 300, 72, 200
-    a = torch.from_numpy(rng.normal(size=(M, K)).astype(np.float32)).to(dev)
-    b = torch.from_numpy(rng.normal(size=(N, K)).astype(np.float32)).to(dev)
-    bias = torch.from_numpy(rng.normal(size=(N,)).astype(np.float32)).to(dev)
-    c = torch.empty(M, N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    check(lib.gssd_gemm_nt_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, bias.data_ptr(), 0, st))
-    ref = a.cpu().double() @ b.cpu().double().t() + bias.cpu().double()
-    assert rel(c, ref.float()) < 1e-5
-    check(lib.gssd_gemm_nt_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, None, 1, st))       # accumulate
-    assert rel(c, (2 * ref - bias.cpu().double()).float()) < 1e-5
-    dy = torch.from_numpy(rng.normal(size=(M, N)).astype(np.float32)).to(dev)
-    dw = torch.empty(N, K, device=dev)
-    check(lib.gssd_gemm_tn_f32(dy.data_ptr(), a.data_ptr(), dw.data_ptr(), M, N, K, N, K, K, 0, st))
-    assert rel(dw, (dy.cpu().double().t() @ a.cpu().double()).float()) < 1e-5
+    rng = np.random.default_rng(4)
+    Bt, M, N, K = 3, 77, 50, 133
+    for ta in (0, 1):
+        for tb in (0, 1):
+            a = torch.from_numpy(rng.normal(size=(Bt, K, M) if ta else (Bt, M, K)).astype(np.float32))
+            b = torch.from_numpy(rng.normal(size=(Bt, N, K) if tb else (Bt, K, N)).astype(np.float32))
+            ref = torch.matmul(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b)
+            ad, bd = a.to(dev), b.to(dev)
+            c = torch.full((Bt, M, N + 3), 7.0, device=dev)          # ldc > N: the slack columns must stay untouched
+            check(lib.gssd_bgemm_f32(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, a.shape[2], b.shape[2], N + 3, ta, tb,
+                                     a[0].numel(), b[0].numel(), M * (N + 3), Bt, 0.5, 0, st))
+            assert rel(c[:, :, :N], 0.5 * ref) < 1e-5 and float((c[:, :, N:] - 7.0).abs().max()) == 0
+            check(lib.gssd_bgemm_f32(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, a.shape[2], b.shape[2], N + 3, ta, tb,
+                                     a[0].numel(), b[0].numel(), M * (N + 3), Bt, 1.0, 1, st))
+            assert rel(c[:, :, :N], 1.5 * ref) < 1e-5
+    # softmax backward over rows
+    R, n, stride = 37, 101, 104
+    logits = torch.from_numpy(rng.normal(0, 3, size=(R, n)).astype(np.float32)).requires_grad_()
+    attn = torch.softmax(logits, -1)
+    g = torch.from_numpy(rng.normal(size=(R, n)).astype(np.float32))
+    attn.backward(g)
+    A = torch.zeros(R, stride)
+    A[:, :n] = attn.detach()
+    dA = torch.full((R, stride), 3.0)
+    dA[:, :n] = g
+    Ad, dAd = A.to(dev), dA.to(dev)
+    check(lib.gssd_softmax_bwd_rows_f32(Ad.data_ptr(), dAd.data_ptr(), R, n, stride, st))
+    assert rel(dAd[:, :n], logits.grad) < 1e-5 and float(dAd[:, n:].abs().max()) == 0
+    # spectral-norm chain rule: W_eff = W / (u^T W v)
+    rows, cols = 24, 40
+    W = torch.from_numpy(rng.normal(size=(rows, cols)).astype(np.float32)).requires_grad_()
+    u = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=rows).astype(np.float32)), dim=0)
+    v = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=cols).astype(np.float32)), dim=0)
+    G = torch.from_numpy(rng.normal(size=(rows, cols + 5)).astype(np.float32))
+    sigma = torch.dot(u, torch.mv(W, v))
+    ((W / sigma) * (0.7 * G[:, :cols])).sum().backward()
+    Gd, Wd, ud, vd = G.to(dev), W.detach().to(dev), u.to(dev), v.to(dev)
+    isg = (1.0 / sigma.detach()).reshape(1).to(dev)
+    sc = torch.tensor([0.7], device=dev)
+    out = torch.empty(rows, cols, device=dev)
+    check(lib.gssd_sn_weight_grad_f32(Gd.data_ptr(), cols + 5, Wd.data_ptr(), ud.data_ptr(), vd.data_ptr(), isg.data_ptr(), sc.data_ptr(),
+                                      out.data_ptr(), rows, cols, st))
+    assert rel(out, W.grad) < 1e-5
+    # scaled transpose, dot, axpby, scaled cast, sigma gradient
+    al = torch.from_numpy(rng.uniform(0.5, 2, size=rows).astype(np.float32)).to(dev)
+    wt = torch.empty(cols, rows, device=dev)
+    check(lib.gssd_scaled_transpose_f32(Wd.data_ptr(), al.data_ptr(), wt.data_ptr(), rows, cols, st))
+    assert rel(wt, (Wd * al.view(-1, 1)).t()) < 1e-6
+    d64 = torch.zeros(1, dtype=torch.float64, device=dev)
+    check(lib.gssd_dot_f32(Wd.data_ptr(), Gd[:, :cols].contiguous().data_ptr(), rows * cols, d64.data_ptr(), st))
+    assert rel(d64, (W.detach().double() * G[:, :cols].double()).sum()) < 1e-9
+    z = torch.empty_like(Wd)
+    Gc = Gd[:, :cols].contiguous()
+    check(lib.gssd_axpby_f32(Wd.data_ptr(), Gc.data_ptr(), z.data_ptr(), rows * cols, 2.0, -1.0, st))
+    assert rel(z, 2 * Wd - Gc) < 1e-6
+    cs = torch.from_numpy(rng.normal(size=rows)).to(dev)
+    y = torch.empty(rows, device=dev)
+    check(lib.gssd_scale_cast_f64_f32(cs.data_ptr(), sc.data_ptr(), y.data_ptr(), rows, st))
+    assert rel(y, 0.7 * cs) < 1e-6
+    ds = torch.empty(1, device=dev)
+    check(lib.gssd_sa_sigma_grad_f32(d64.data_ptr(), cs.data_ptr(), al.data_ptr(), rows, ds.data_ptr(), st))
+    assert rel(ds, d64 + (al.double() * cs).sum()) < 1e-6
 
 
 def test_dcn_col2im_backward(dev, ops):
@@ -762,7 +810,7 @@ def test_training_steps_reduce_loss(dev):
     for tag, m in (('hip', net), ('aten', twin)):
         opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
         losses = []
-        for _ in range(6):
+        for _ in range(4):
             opt.zero_grad()
             if tag == 'hip':
                 ll, lc = crit(m(x), tg)
@@ -780,11 +828,13 @@ def test_training_steps_reduce_loss(dev):
             losses.append(float(ll + lc))
         hist[tag] = losses
     print('loss trajectories', hist)
-    assert all(np.isfinite(hist['hip'])) and hist['hip'][-1] < hist['hip'][0]
-    assert abs(hist['hip'][-1] - hist['aten'][-1]) < 0.05 * abs(hist['aten'][0])
+    assert all(np.isfinite(hist['hip'])) and hist['hip'][-1] < 0.7 * hist['hip'][0]
+    # SGD with momentum on a 20-layer train-mode-BN net amplifies rounding differences step by step (ReLU / arg-max flips, fp32
+    # atomics in the split-K weight gradients): four steps track within 1 %, per step
+    assert all(abs(a - b) < 1e-2 * abs(b) for a, b in zip(hist['hip'], hist['aten'])), hist
     w1, w2 = dict(net.named_parameters()), dict(twin.named_parameters())
     for k in ('vgg.0.weight', 'vgg.24.weight', 'fuse_21.weight', 'loc.2.weight'):
-        assert rel(w1[k], w2[k]) < 2e-2, k
+        assert rel(w1[k], w2[k]) < 1e-2, k
 
 
 def test_visualize_outputs(dev):
