@@ -265,11 +265,14 @@ def main():
         opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=5e-4)
         gd.broadcast_params(net)
 
+        red = gd.OverlappedGradReducer(world)         # ranges of the flat gradient buffer are all-reduced under the backward
+
         def train_step():
             opt.zero_grad(set_to_none=True)
             ll, lc = crit(net(x), tg)
+            red.arm(net)
             (ll + lc).backward()
-            n = gd.allreduce_grads(params, world)
+            n = red.finish() if world > 1 else gd.allreduce_grads(params, world)
             opt.step()
             return n
         for _ in range(2):

@@ -103,7 +103,7 @@ SIGNATURES = {
     'gssd_bgemm_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_f,
                              c_i, c_fp]),
     'gssd_softmax_bwd_rows_f32': (c_i, [c_fp, c_fp, c_i64, c_i, c_i, c_fp]),
-    'gssd_sn_weight_grad_f32': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    'gssd_sn_weight_grad_f32': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     'gssd_scaled_transpose_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     'gssd_dot_f32': (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     'gssd_axpby_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp]),

@@ -78,6 +78,7 @@ class GssdTrainFn(torch.autograd.Function):
         if dconf is None:
             dconf = torch.zeros(plan.B, plan.P, plan.nc, device=plan.dev)
         bwd = plan.backward_plan()
+        bwd.segment_hook = getattr(net._engine, 'grad_segment_hook', None)       # gssd.dist.OverlappedGradReducer
         direct = (net.__dict__.get('direct_grad_handout', True)
                   and all(p.is_leaf and not p._backward_hooks for p in params if p.requires_grad)
                   and _will_accumulate_all(ctx, params))

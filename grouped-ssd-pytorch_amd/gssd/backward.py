@@ -39,6 +39,9 @@ class BackwardPlan:
             n += (p.numel() + 3) // 4 * 4
         self.flat = torch.zeros(max(n, 4), device=self.dev, dtype=torch.float32)
         self._slices = {id(p): self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(plan.eng.net.parameters(), offs)}
+        self._offs = {id(p): (o, (p.numel() + 3) // 4 * 4) for p, o in zip(plan.eng.net.parameters(), offs)}
+        self._last_write = {}        # id(param) -> index of the last step that writes its gradient
+        self.segment_hook = None     # callable(k, flat[lo:hi]) invoked right after segment k's last writer was enqueued
         self.dloc = torch.empty(self.B, plan.P, 4, device=self.dev)
         self.dconf = torch.empty(self.B, plan.P, plan.nc, device=self.dev)
         net = plan.eng.net
@@ -78,6 +81,7 @@ class BackwardPlan:
         return t
 
     def _pgrad(self, p):
+        self._last_write[id(p)] = len(self.steps)        # (evaluated while the writing step's argument tuple is built)
         g = self.grads.get(id(p))
         if g is None:
             g = self._slices[id(p)]              # parameters the plan never writes keep no entry -> gradient None
@@ -291,9 +295,10 @@ class BackwardPlan:
         self._add(lib.gssd_scale_cast_f64_f32, (csT.data_ptr(), sig.data_ptr(), self._pgrad(cv['attn'].bias).data_ptr(), Cc))
         d_o, _, _ = mk(ag, None, None, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc)
         dwo = self._buf(Cc, C2, zero_each_run=True)
+        sndot = self._buf(4, dtype=torch.float64, zero_each_run=True)      # <dW_eff, W> of the block's four convs
         self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_o), T.data_ptr(), dwo.data_ptr()), keep=d_o)
         self._add(lib.gssd_sn_weight_grad_f32, (dwo.data_ptr(), C2, cv['attn'].weight_orig.data_ptr(), cv['attn'].weight_u.data_ptr(),
-                                                cv['attn'].weight_v.data_ptr(), a_o.data_ptr(), sig.data_ptr(),
+                                                cv['attn'].weight_v.data_ptr(), a_o.data_ptr(), sig.data_ptr(), sndot[3:].data_ptr(),
                                                 self._pgrad(cv['attn'].weight_orig).data_ptr(), Cc, C2))
         # attention map A (no stored copy: the forward is flash-style)
         A = self._buf(B, N, Np)
@@ -320,11 +325,11 @@ class BackwardPlan:
         self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_p), dtpg.data_ptr(), dwp.data_ptr()), keep=d_p)
         csP = self._buf(CT, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dtpg.data_ptr(), M, CT, CT, csP.data_ptr()))
-        for key, row0, rows in (('theta', 0, C8), ('phi', C8, C8), ('g', C4, C2)):
+        for si, (key, row0, rows) in enumerate((('theta', 0, C8), ('phi', C8, C8), ('g', C4, C2))):
             m_ = cv[key]
             self._add(lib.gssd_sn_weight_grad_f32, (dwp[row0:].data_ptr(), Cc, m_.weight_orig.data_ptr(), m_.weight_u.data_ptr(),
                                                     m_.weight_v.data_ptr(), a_tpg[row0:].data_ptr(), sig.data_ptr(),
-                                                    self._pgrad(m_.weight_orig).data_ptr(), rows, Cc))
+                                                    sndot[si:].data_ptr(), self._pgrad(m_.weight_orig).data_ptr(), rows, Cc))
             self._add(lib.gssd_scale_cast_f64_f32, (csP[row0:].data_ptr(), sig.data_ptr(), self._pgrad(m_.bias).data_ptr(), rows))
         # dx = d(out) (+ what was already there) + sigma * dtpg . (W_tpg alpha)
         wd_p = self._buf(Cc, CT)
@@ -396,23 +401,51 @@ class BackwardPlan:
         self._dgrad(r, dom, x, cm, 1, Cin, H, H, 27 * dg, 3, 1, 1, 1)
 
     # ------------------------------------------------------------------------------------------------
+    def segments(self, nseg=4):
+        """Split the flat gradient buffer into ``nseg`` contiguous ranges of about equal size (parameter granularity) and find, for
+        each, the step after which all of its gradients are final: [(lo, hi, ready_step)].  The backward walks the network in
+        reverse, so the LAST range (heads, extras) is ready first -- its all-reduce can overlap the trunk's backward."""
+        items = sorted(self._offs.items(), key=lambda kv: kv[1][0])          # (id, (offset, padded size))
+        total = self.flat.numel()
+        segs, lo, acc, ready = [], 0, 0, -1
+        for i, (pid, (o, n)) in enumerate(items):
+            acc += n
+            ready = max(ready, self._last_write.get(pid, -1))
+            if acc >= total * (len(segs) + 1) / nseg or i == len(items) - 1:
+                segs.append((lo, o + n, ready))
+                lo, ready = o + n, -1
+        return segs
+
     def run(self, dloc, dconf):
         self.dloc.copy_(dloc)
         self.dconf.copy_(dconf)
         if self.zero_list:
             torch._foreach_zero_(self.zero_list)
         stream = torch.cuda.current_stream().cuda_stream
-        for fn, args in self.steps:
-            if args is None:                     # block-local ATen autograd callback
-                fn()
-                continue
-            if fn is _pack_dgrad_from_packed:
-                fn(*args)
-                continue
+        hook = self.segment_hook
+        if hook is not None:
+            if getattr(self, '_segs', None) is None:
+                self._segs = self.segments()
+            fire = {}
+            for k, (lo, hi, ready) in enumerate(self._segs):
+                fire.setdefault(max(ready, 0), []).append(k)
+        for si, (fn, args) in enumerate(self.steps):
+            self._run_step(fn, args, stream)
+            if hook is not None and si in fire:
+                for k in fire[si]:
+                    lo, hi, _ = self._segs[k]
+                    hook(k, self.flat[lo:hi])
+        return [self.grads.get(id(p)) for p in self.param_order]
+
+    def _run_step(self, fn, args, stream):
+        if args is None:                         # host-side tensor bookkeeping (channel split of slice_and_cat's gradient)
+            fn()
+        elif fn is _pack_dgrad_from_packed:
+            fn(*args)
+        else:
             rc = fn(*args, stream)
             if rc != 0:
                 _lib.check(rc)
-        return [self.grads.get(id(p)) for p in self.param_order]
 
 
 def conv_weight_ptr(conv, cin_g_expected):

@@ -26,6 +26,18 @@ void gssd_set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(gssd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: every call site keeps one "done" bit per device id, so a
+// process that touches several GPUs (tests on cuda:1, one-process multi-device callers) never launches a > 48 KB-LDS kernel
+// without it.  Returns true once the attribute is set on the current device.
+static inline bool gssd_attr_needed(unsigned* mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return true;
+    if (*mask & (1u << dev)) return false;
+    *mask |= 1u << dev;
+    return true;
+}
+
 // 64-lane wavefront reductions (gfx950: wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

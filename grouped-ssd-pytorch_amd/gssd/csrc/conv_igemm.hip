@@ -328,17 +328,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
-    static bool attr_set = false;
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     constexpr size_t smem_base = 2 * (size_t)(BM + BN) * BK * sizeof(float);
     const size_t smem = smem_base + (d.in_scale ? 2 * (size_t)d.cin_g * sizeof(float) : 0);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
-    if (!attr_set) {
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(smem_base + 4096)) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", smem_base + 4096);
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;

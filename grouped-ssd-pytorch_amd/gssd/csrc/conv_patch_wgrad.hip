@@ -158,14 +158,13 @@ int launch_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipS
     p.tiles_x = (d.W + 15) / 16;
     const size_t smem = ((size_t)((180 + PPI - 1) / PPI) * PPI * CIN_G + 128 * COUT_G) * sizeof(float);
     auto kern = conv_patch_wgrad_kernel<CIN_G, COUT_G, XF>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (patch wgrad)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     static int per_cu = 0;                                // resident workgroups per CU: 2 for the 64-channel variant, up to 4

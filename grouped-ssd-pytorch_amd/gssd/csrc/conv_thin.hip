@@ -321,14 +321,13 @@ int launch_thin_impl(const gssd_conv_desc& d, hipStream_t stream) {
     p.acc_off = (int)(work / sizeof(float));
     const size_t smem = work + 2 * COUT * sizeof(double);
     auto kern = conv_thin_kernel<CIN_G, COUT_G, FIXED, XF>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 96 * 1024) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (thin conv)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     const int per_cu = smem > 60 * 1024 ? 2 : 3;

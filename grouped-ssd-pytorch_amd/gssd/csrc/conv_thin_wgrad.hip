@@ -164,14 +164,13 @@ int launch_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipSt
     p.tiles_x = (d.W + 15) / 16;
     const size_t smem = ((size_t)((180 + PPI - 1) / PPI) * PPI * CIN + 128 * 64) * sizeof(float);
     auto kern = conv_thin_wgrad_kernel<CIN_G, XF>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 96 * 1024) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (thin wgrad)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 512;

@@ -217,14 +217,13 @@ int launch_thin_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.tiles_x = (d.W + TW_TW - 1) / TW_TW;
     constexpr size_t smem = ((size_t)TW_PATCH_F + TW_STAGE_F) * sizeof(float) + 2 * TW_COUT * sizeof(double);
     auto kern = conv_thin_wino_kernel<XF>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (thin winograd)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 512;                                       // two resident workgroups per CU (80 KB of LDS, <= 256 VGPRs each)

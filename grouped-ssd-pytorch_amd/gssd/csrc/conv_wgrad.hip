@@ -223,14 +223,13 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     const int gx = (p.M + p.pix_per_slice - 1) / p.pix_per_slice;
     constexpr size_t smem = 2 * (size_t)BP * (BMW + BNW) * sizeof(float);
     auto kern = conv_wgrad_kernel<MT, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (wgrad)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)tiles), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();

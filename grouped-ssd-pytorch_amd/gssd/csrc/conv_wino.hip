@@ -379,14 +379,13 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.ntiles = d.B * p.tiles_y * p.tiles_x;
     constexpr size_t smem = 2 * (size_t)16 * NB * 16 * sizeof(float);
     auto kern = conv_wino_kernel<NB, XF, PERSIST>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (winograd)");
             return GSSD_ELAUNCH;
         }
-        attr_set = true;
     }
     const int nitems = (p.ntiles + 63) / 64;
     static int per_cu = 0;                                // resident workgroups per CU (registers / LDS decide: 1 or 2)

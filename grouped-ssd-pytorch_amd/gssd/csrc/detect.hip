@@ -255,12 +255,11 @@ extern "C" int gssd_detect(const float* loc, const float* conf, const float* pri
     GSSD_CHECK_ARG(nms_thresh > 0.f);   // the reference raises ValueError (detection_pytorch_ver_1point5.py:39-40)
     GSSD_CHECK_ARG(conf_thresh >= 0.f);
     GSSD_CHECK_ARG(((uintptr_t)loc % 16) == 0 && ((uintptr_t)priors % 16) == 0);
-    static bool attr_set = false;
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     const size_t smem = (size_t)P * sizeof(float);
-    if (!attr_set) {
+    if (gssd_attr_needed(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             120 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(detect_kernel, dim3(B * (C - 1)), dim3(DT), smem, as_stream(stream), loc, conf, priors, P, C,
                        top_k, conf_thresh, nms_thresh, var0, var1, conf_is_logits, loc_is_boxes, out, keep_idx, keep_cnt);

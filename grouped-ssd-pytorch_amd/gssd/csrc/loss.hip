@@ -354,12 +354,11 @@ extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* l
     GSSD_CHECK_ARG(loc && conf && loc_t && conf_t && xmax && xmax_n > 0 && sel && partial);
     GSSD_CHECK_ARG(B > 0 && P > 0 && P <= 36000 && C >= 2 && negpos_ratio >= 0);
     GSSD_CHECK_ARG(((uintptr_t)loc % 16) == 0 && ((uintptr_t)loc_t % 16) == 0);
-    static bool attr_set = false;
+    static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     const size_t smem = (size_t)P * sizeof(float);
-    if (!attr_set && smem > 48 * 1024) {
+    if (smem > 48 * 1024 && gssd_attr_needed(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hnm_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(hnm_loss_kernel, dim3(B), dim3(LT), smem, as_stream(stream), loc, conf, loc_t, conf_t, xmax, xmax_n, P,
                        C, negpos_ratio, sel, partial, loss_c_all);

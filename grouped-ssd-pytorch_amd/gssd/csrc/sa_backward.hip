@@ -4,7 +4,8 @@
 //                             attention backward that are not "activations x K-major weights":
 //                               dA = d(ag) . g      dtheta = dS . phi      dphi = dS^T . theta      dg = A^T . d(ag)
 //   gssd_softmax_bwd_rows_f32 dS = A * (dA - rowsum(A * dA)) in place (one wave per row)
-//   gssd_sn_weight_grad_f32   spectral-norm chain rule: dW_orig = dW_eff / s - <dW_eff, W> / s^2 * u v^T  (u, v constants of the step)
+//   gssd_sn_weight_grad_f32   spectral-norm chain rule: dW_orig = dW_eff / s - <dW_eff, W> / s^2 * u v^T  (u, v constants of the step;
+//                             two launches: a multi-workgroup dot product, then the elementwise update)
 //   gssd_scaled_transpose_f32 Wd[c][n] = W[n][c] * alpha[n]: the data-gradient weights of a spectrally normalised 1x1 conv
 //   gssd_dot_f32              sum a[i] * b[i] into a double (the gradient of Self_Attn's scalar gate sigma)
 // The forward is flash-style and keeps no attention map; the backward re-materialises A per block (QK^T by the conv kernel + row
@@ -130,26 +131,33 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
     }
 }
 
-// one workgroup per matrix: dW_eff' = scale * dW_eff; dot = <dW_eff', W>; dW = dW_eff' * is - dot * is^2 * u v^T
-__global__ __launch_bounds__(256) void sn_weight_grad_kernel(const float* __restrict__ dweff, int ld_dw, const float* __restrict__ w,
-                                                             const float* __restrict__ u, const float* __restrict__ v,
-                                                             const float* __restrict__ inv_sigma, const float* __restrict__ scale,
-                                                             float* __restrict__ dw, int rows, int cols) {
+// spectral-norm chain rule in two launches: (1) dot = <scale * dW_eff, W> (grid-stride partial sums, one fp64 atomic per
+// workgroup into a caller-zeroed scalar); (2) dW = scale * dW_eff * is - dot * is^2 * u v^T
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ dweff, int ld_dw, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, int rows, int cols, double* __restrict__ dot) {
     __shared__ double red[4];
-    const int tid = threadIdx.x;
     const float sc = scale ? scale[0] : 1.f;
     double acc = 0.0;
-    for (int i = tid; i < rows * cols; i += 256) {
+    const int total = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int rr = i / cols, cc = i - rr * cols;
         acc += (double)(sc * dweff[(size_t)rr * ld_dw + cc]) * (double)w[i];
     }
     acc = wave_sum(acc);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    const double dot = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sn_apply_kernel(const float* __restrict__ dweff, int ld_dw, const float* __restrict__ u,
+                                                       const float* __restrict__ v, const float* __restrict__ inv_sigma,
+                                                       const float* __restrict__ scale, const double* __restrict__ dot,
+                                                       float* __restrict__ dw, int rows, int cols) {
+    const float sc = scale ? scale[0] : 1.f;
     const float is = inv_sigma[0];
-    const float k = (float)(dot * (double)is * (double)is);
-    for (int i = tid; i < rows * cols; i += 256) {
+    const float k = (float)(dot[0] * (double)is * (double)is);
+    const int total = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int rr = i / cols, cc = i - rr * cols;
         dw[i] = sc * dweff[(size_t)rr * ld_dw + cc] * is - k * u[rr] * v[cc];
     }
@@ -247,11 +255,15 @@ extern "C" int gssd_softmax_bwd_rows_f32(const float* attn, float* dattn, int64_
 }
 
 extern "C" int gssd_sn_weight_grad_f32(const float* dw_eff, int ld_dw, const float* w_orig, const float* u, const float* v,
-                                       const float* inv_sigma, const float* scale, float* dw_orig, int rows, int cols,
-                                       gssd_stream_t stream) {
-    GSSD_CHECK_ARG(dw_eff && w_orig && u && v && inv_sigma && dw_orig && rows > 0 && cols > 0 && ld_dw >= cols);
-    hipLaunchKernelGGL(sn_weight_grad_kernel, dim3(1), dim3(256), 0, as_stream(stream), dw_eff, ld_dw, w_orig, u, v, inv_sigma, scale,
-                       dw_orig, rows, cols);
+                                       const float* inv_sigma, const float* scale, double* dot_scratch, float* dw_orig, int rows,
+                                       int cols, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dw_eff && w_orig && u && v && inv_sigma && dot_scratch && dw_orig && rows > 0 && cols > 0 && ld_dw >= cols);
+    GSSD_CHECK_ARG((long long)rows * cols < (1ll << 31));
+    int blocks = (rows * cols + 1023) / 1024;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dw_eff, ld_dw, w_orig, scale, rows, cols, dot_scratch);
+    hipLaunchKernelGGL(sn_apply_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dw_eff, ld_dw, u, v, inv_sigma, scale,
+                       dot_scratch, dw_orig, rows, cols);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

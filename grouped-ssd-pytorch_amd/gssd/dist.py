@@ -70,6 +70,39 @@ def allreduce_grads(params, world=None):
     return flat.numel()
 
 
+class OverlappedGradReducer:
+    """Gradient averaging overlapped with the backward (BASELINE.json configs[3]).  The HIP backward plan finishes the gradients of
+    the LAST layers first; its flat buffer is cut into ``nseg`` contiguous ranges and each range's all-reduce is started (async, on
+    the communication stream RCCL owns) the moment the last kernel writing into it has been enqueued -- the ring all-reduce of the
+    heads / extras / fuse ranges then runs under the trunk's backward, and only the first range (conv1_x .. conv3_x gradients,
+    finished last) is exposed.  Usage per step:  ``red.arm(net)`` before ``loss.backward()``, ``red.finish()`` after it."""
+
+    def __init__(self, world=None, nseg=4):
+        self.world = world or (dist.get_world_size() if dist.is_initialized() else 1)
+        self.nseg = nseg
+        self.works, self.ranges = [], []
+
+    def arm(self, net):
+        """Install the hook on every backward plan of ``net``'s engine that exists or gets built (cheap: one attribute)."""
+        self.works, self.ranges = [], []
+        eng = net._engine if hasattr(net, '_engine') else net.module._engine
+        eng.grad_segment_hook = self._hook if self.world > 1 else None
+
+    def _hook(self, k, flat_slice):
+        self.ranges.append(flat_slice)
+        self.works.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Wait for the ranges in flight, scale by 1 / world; returns the number of elements reduced."""
+        n = 0
+        for w, t in zip(self.works, self.ranges):
+            w.wait()
+            t.div_(self.world)
+            n += t.numel()
+        self.works, self.ranges = [], []
+        return n
+
+
 def broadcast_params(module, src=0):
     """Rank 0's weights and buffers to every rank before the first step."""
     if dist.is_initialized():

@@ -115,6 +115,15 @@ class SSD(nn.Module):
         object.__setattr__(new, '_engine', GssdEngine(new))
         return new
 
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel over ONE device calls the module directly (no replicas) and works; replicas on several devices are
+        # parameter-less views driven from one thread per GPU -- this path runs one PROCESS per GPU instead (gssd.dist,
+        # bench.py --gpus N: per-rank BatchNorm statistics exactly like DataParallel's replicas, RCCL gradient all-reduce)
+        from gssd._lib import GssdError
+        raise GssdError('multi-device nn.DataParallel replicas are not supported by the HIP engine: launch one process per GPU '
+                        '(python -m torch.distributed.run --nproc-per-node N ..., gssd.dist.allreduce_grads / '
+                        'OverlappedGradReducer average the gradients over RCCL)')
+
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
         self.priors = fn(self.priors)

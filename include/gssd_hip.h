@@ -328,7 +328,8 @@ int gssd_softmax_bwd_rows_f32(const float* attn, float* dattn, int64_t rows, int
 /* Spectral-norm chain rule (layers/spectral_norm.py:83-85 with u, v constants): dW_eff' = scale[0] * dW_eff (scale may be NULL);
  * dW_orig = dW_eff' * is - <dW_eff', W_orig> * is^2 * u v^T, is = inv_sigma[0].  dw_eff rows are ld_dw floats apart. */
 int gssd_sn_weight_grad_f32(const float* dw_eff, int ld_dw, const float* w_orig, const float* u, const float* v, const float* inv_sigma,
-                            const float* scale, float* dw_orig, int rows, int cols, gssd_stream_t stream);
+                            const float* scale, double* dot_scratch /* one zero-filled double */, float* dw_orig, int rows, int cols,
+                            gssd_stream_t stream);
 /* out[c][n] = w[n][c] * alpha[n] (alpha may be NULL): data-gradient weights of a spectrally normalised 1x1 conv */
 int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, int rows, int cols, gssd_stream_t stream);
 /* *out += sum a[i]*b[i] (fp64); out = a*x + b*y; y = scale[0]*x (fp64 -> fp32); d(sigma) = dot[0] + sum_c bias[c]*colsum[c] */

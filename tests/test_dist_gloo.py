@@ -71,3 +71,57 @@ def test_two_rank_harness():
     assert res2[0][1] == res2[1][1] == 15 and res2[0][2] == res2[1][2] == [1.5, 2.5]      # mean over ranks
     assert res2[0][3] == res2[1][3]                                                            # broadcast weights
     assert res2[0][4] == res2[1][4] == (16, True, 1.5, 15.0)                                   # flat-slice gradients, in place
+
+
+def _worker_overlap(rank, world, port, out):
+    """The segmented, overlapped reducer on a flat buffer laid out like BackwardPlan's (16-byte aligned parameter slices, ranges
+    becoming ready last-to-first): driven exactly as gssd/backward.py drives it."""
+    sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    from gssd import dist as gd
+    from gssd.backward import BackwardPlan
+    gd.init('gloo')
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (128,), (36, 128, 3, 3), (36,), (1,)]
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    bp = BackwardPlan.__new__(BackwardPlan)                       # only the flat-buffer bookkeeping of the plan, no kernels
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    bp.flat = torch.zeros(n)
+    bp._offs = {id(p): (o, (p.numel() + 3) // 4 * 4) for p, o in zip(params, offs)}
+    bp._slices = {id(p): bp.flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+    bp._last_write = {id(p): len(params) - 1 - i for i, p in enumerate(params)}      # reverse order, like a backward
+    segs = bp.segments(3)
+    assert segs[0][0] == 0 and segs[-1][1] == n and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    assert [s[2] for s in segs] == sorted([s[2] for s in segs], reverse=True)        # the last range is ready first
+    for p in params:
+        bp._slices[id(p)].fill_(float(rank + 1))
+        p.grad = bp._slices[id(p)]
+    net = types.SimpleNamespace(_engine=types.SimpleNamespace())
+    red = gd.OverlappedGradReducer(world, nseg=3)
+    red.arm(net)
+    hook = net._engine.grad_segment_hook
+    for k, (lo, hi, ready) in sorted(enumerate(segs), key=lambda kv: kv[1][2]):      # in the order the backward would fire them
+        hook(k, bp.flat[lo:hi])
+    nred = red.finish()
+    out.put((rank, nred == n, min(float(p.grad.min()) for p in params), float(bp.flat.max()),
+             [float(p.grad.mean()) for p in params][:3]))
+    gd.barrier()
+    gd.finish()
+
+
+def test_overlapped_reducer_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in got:
+        assert r[1] and r[2] == r[3] == 1.5 and r[4] == [1.5, 1.5, 1.5]              # every element averaged exactly once, in place

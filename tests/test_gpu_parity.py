@@ -482,8 +482,9 @@ def test_sa_backward_building_blocks(dev):
     isg = (1.0 / sigma.detach()).reshape(1).to(dev)
     sc = torch.tensor([0.7], device=dev)
     out = torch.empty(rows, cols, device=dev)
+    scratch = torch.zeros(1, dtype=torch.float64, device=dev)
     check(lib.gssd_sn_weight_grad_f32(Gd.data_ptr(), cols + 5, Wd.data_ptr(), ud.data_ptr(), vd.data_ptr(), isg.data_ptr(), sc.data_ptr(),
-                                      out.data_ptr(), rows, cols, st))
+                                      scratch.data_ptr(), out.data_ptr(), rows, cols, st))
     assert rel(out, W.grad) < 1e-5
     # scaled transpose, dot, axpby, scaled cast, sigma gradient
     al = torch.from_numpy(rng.uniform(0.5, 2, size=rows).astype(np.float32)).to(dev)
@@ -1080,6 +1081,71 @@ def test_plan_follows_reseated_storage(dev):
         sd2 = {k: v.clone() for k, v in net.state_dict().items()}
         lo, co, _ = O.gssd_forward({k: v.cpu() for k, v in sd2.items()}, x.cpu(), training=False, **flags)
     assert rel(l1, lo) < TOL and rel(c1, co) < TOL and rel(l1, l0) > 1e-3
+
+
+def test_reference_driver_sequence(dev, tmp_path):
+    """The call sequence of the reference driver (train_lesion_multiphase_v2.py:117-120 default CUDA tensor type; :142-145
+    positional 15-argument build_ssd; :587-601 weights_init on extras / loc / conf, .cuda(), nn.DataParallel, deepcopy per
+    cross-validation fold; :606-627 SGD with a separate DCN parameter group selected by the ``module.dcn_list`` name prefix;
+    :242-253 forward, zero_grad, MultiBoxLoss, backward, check_grad_norm, clip_grad_norm_, step; :647 module.load_weights;
+    :399-407 strict state-dict hand-over to a test-phase twin) -- replayed unchanged against the drop-in modules."""
+    import copy
+    import torch.nn as nn
+    from models.ssd_multiphase_custom_group import build_ssd, weights_init
+    from layers.modules import MultiBoxLoss
+    from gssd._lib import GssdError
+    torch.set_default_tensor_type('torch.cuda.FloatTensor')
+    try:
+        net = build_ssd('train', 300, 2, True, 4, 4, 1, True, True, True, 1, 4, True, False, 1)
+        net.extras.apply(weights_init)
+        net.loc.apply(weights_init)
+        net.conf.apply(weights_init)
+        net = net.cuda()
+        net = torch.nn.DataParallel(net)
+        net_cv = [copy.deepcopy(net) for _ in range(2)]
+        del net
+        opts = []
+        for m in net_cv:
+            named = list(m.named_parameters())
+            p_dcn = [p_ for k, p_ in named if k.startswith('module.dcn_list')]
+            p_rest = [p_ for k, p_ in named if not k.startswith('module.dcn_list')]
+            assert len(p_dcn) == 4 and len(p_rest) + 4 == len(named)
+            opts.append(torch.optim.SGD([{'params': p_rest}, {'params': p_dcn, 'lr': 1e-4}], lr=1e-3, momentum=0.9, weight_decay=5e-4))
+        criterion = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+        images = synth.synth_images(4, seed=41).cuda()
+        targets = [t.cuda() for t in synth.synth_targets(4, seed=41)]
+        losses = []
+        for idx in range(2):
+            net_cv[idx].train()
+            for it in range(2):
+                out = net_cv[idx](images)
+                opts[idx].zero_grad()
+                loss_l, loss_c = criterion(out, targets)
+                loss = loss_l + loss_c
+                loss.backward()
+                grad_norm = sum(float(p_.grad.data.norm(2)) ** 2 for p_ in net_cv[idx].parameters() if p_.grad is not None) ** 0.5
+                assert np.isfinite(grad_norm) and grad_norm > 0
+                nn.utils.clip_grad_norm_(net_cv[idx].parameters(), 10.0)
+                opts[idx].step()
+                losses.append(float(loss))
+        assert all(np.isfinite(losses)) and losses[1] < losses[0] and losses[0] == losses[2]     # the folds start as identical copies
+        # checkpoint round trip through the tolerant loader, then strict hand-over to the test-phase twin
+        path = str(tmp_path / 'ck.pth')
+        torch.save(net_cv[0].state_dict(), path)                     # keys carry DataParallel's 'module.' prefix
+        net_cv[1].module.load_weights(path)
+        for (k, a), (_, b) in zip(net_cv[0].module.state_dict().items(), net_cv[1].module.state_dict().items()):
+            assert torch.equal(a, b), k
+        net_t = build_ssd('test', 300, 2, True, 4, 4, 1, True, True, True, 1, 4, True, False, 1).cuda()
+        net_t.load_state_dict(net_cv[0].module.state_dict())          # strict
+        net_t.eval()
+        with torch.no_grad():
+            det = net_t(images)
+        assert det.shape == (4, 2, 200, 5) and torch.isfinite(det).all()
+        # replicas over several devices are refused with a pointer to the one-process-per-GPU path, not silently mis-run
+        with pytest.raises(GssdError):
+            net_cv[0].module._replicate_for_data_parallel()
+    finally:
+        torch.set_default_tensor_type('torch.FloatTensor')
 
 
 def test_cpu_input_fails_loudly():
