@@ -337,7 +337,9 @@ class _Plan(_PlanBase):
                                          pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
                                          out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
                                          out_off=off * 4, outb_off=off * self.nc,
-                                         split_k=ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K), flags=_lib.CONV_OUT_F32)
+                                         split_k=(ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K, target_blocks=256, max_split=8)
+                                                  if self.bf16 else ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K)),
+                                         flags=_lib.CONV_OUT_F32)
             self.head_descs.append(d)
             self._add(self.conv_fn, (C.byref(d),), keep=d)
             self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))

@@ -8,11 +8,13 @@ import bench
 from gssd import synth
 from models.ssd_multiphase_custom_group import build_ssd
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'gssd'
+dtype = sys.argv[2] if len(sys.argv) > 2 else 'f32'
 args = bench.CONFIGS[cfg][0]
 dev = torch.device('cuda:0')
 net = build_ssd('train', 300, 2, *args)
 net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
 net = net.to(dev).train()
+net.compute_dtype = dtype
 x = synth.synth_images(32, seed=100).to(dev)
 with torch.no_grad():
     for _ in range(3): net(x)
@@ -29,5 +31,5 @@ for i in range(n):
     ms = sum(ev[i + k * n][1].elapsed_time(ev[i + k * n][2]) for k in range(5)) / 5
     (tag, fl, by) = ev[i][0]
     tot += ms
-    print(f'{i:3d} {tag:22s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {fl / 1e9:7.2f} GF')
+    print(f'{i:3d} {tag:24s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {by / ms / 1e6:7.0f} GB/s  {fl / 1e9:7.2f} GF  {by / 1e6:7.1f} MB')
 print('total conv ms', tot)

@@ -5,7 +5,7 @@ cfg=${1:-gssdpp}
 dtype=${2:-f32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
 done
 key=$cfg; [ "$dtype" != f32 ] && key=${cfg}_$dtype
 python3 - "$GRAFT_REPO_ROOT" "$key" <<'PY'
@@ -25,6 +25,14 @@ def short(n):
     if 'conv_thin_wino_kernel' in n: return 'conv_thin_wino<16,16>'
     m = re.search(r'conv_wino_kernel<(\d+)', n)
     if m: return f'conv_wino<{m.group(1)}>'
+    m = re.search(r'conv_bf16_kernel<(\d+), (\d+)', n)
+    if m: return f'conv_bf16<{m.group(1)}x{m.group(2)}>'
+    m = re.search(r'conv_thin_bf16_kernel<(\d+), (\d+)', n)
+    if m: return f'conv_thin_bf16<{m.group(1)},{m.group(2)}>'
+    m = re.search(r'flash_attn_kernel<(\d+), (\d+)', n)
+    if m: return f'flash_attn<{m.group(1)},{m.group(2)}>'
+    if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
+    if 'dcn_bf16_kernel' in n: return 'dcn_bf16<128x256>'
     m = re.search(r'::(\w+_kernel)', n)
     return m.group(1) if m else n[:40]
 # template variants of one kernel family share a short name: their launches are pooled (not overwritten)
