@@ -26,18 +26,24 @@ from ._lib import lib
 VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'C', 512, 512, 512, 'M', 512, 512, 512]
 EXTRAS_CFG = [256, 'S', 512, 128, 'S', 256, 128, 256, 128, 256]
 MBOX = [4, 6, 6, 6, 4, 4]
+SRC_HW = [38, 19, 10, 5, 3, 1]
+HEAD_OFF = [sum(h * h * a for h, a in zip(SRC_HW[:i], MBOX[:i])) for i in range(6)]      # first prior of source i
 FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
 
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
+# GSSD_NO_GRAPH=1 keeps every forward an eager list of launches (debugging / ablation)
+USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
+# GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
+USE_BRANCH_STREAMS = os.environ.get('GSSD_NO_BRANCH_STREAMS', '0') != '1'
 
 class _Step:
-    __slots__ = ('fn', 'args', 'keep', 'tag')
+    __slots__ = ('fn', 'args', 'keep', 'tag', 'sid')
 
-    def __init__(self, fn, args, keep=None, tag=None):
-        self.fn, self.args, self.keep, self.tag = fn, args, keep, tag
+    def __init__(self, fn, args, keep=None, tag=None, sid=0):
+        self.fn, self.args, self.keep, self.tag, self.sid = fn, args, keep, tag, sid
 
 
 def conv_tag(d, real_cin_g=None, bf16=False):
@@ -309,42 +315,44 @@ class _Plan(_PlanBase):
                 sa_i += 1
                 fi += 1
         self.sources = sources
-        # ---- heads ------------------------------------------------------------------------------------------
-        off = 0
-        for i, (s, Hs, Cs) in enumerate(sources):
-            A = MBOX[i]
-            nloc, nconf = A * 4, A * self.nc
-            lw, cw = net.loc[i], net.conf[i]
-            cin_pad, K = ops.packed_k(Cs, 3, 3)
+        assert len(self.head_descs) == 6
 
-            def build_w(out, lw=lw, cw=cw, nloc=nloc, nconf=nconf, K=K):
-                if out is None:
-                    out = torch.empty(nloc + nconf, K, device=dev, dtype=self.adt)
-                pk = ops.pack_weight_bf16 if self.bf16 else ops.pack_weight
-                pk(lw.weight, out, 0)
-                pk(cw.weight, out, nloc)
-                return out
+    def _head(self, i, s, Hs, Cs):
+        """loc[i] / conf[i] (models/...group.py:375-380) as ONE merged 3x3 conv writing straight into the concatenated fp32
+        loc [B,8732,4] / conf [B,8732,C] at this source's prior offset."""
+        eng, net, B, dev, f32 = self.eng, self.eng.net, self.B, self.dev, torch.float32
+        off = HEAD_OFF[i]
+        A = MBOX[i]
+        nloc, nconf = A * 4, A * self.nc
+        lw, cw = net.loc[i], net.conf[i]
+        cin_pad, K = ops.packed_k(Cs, 3, 3)
 
-            def build_b(out, lw=lw, cw=cw, nloc=nloc):
-                if out is None:
-                    out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
-                out[:nloc].copy_(lw.bias.detach())
-                out[nloc:].copy_(cw.bias.detach())
-                return out
-            wp = eng._pack(f'heads.{i}.w', build_w)
-            bp = eng._pack(f'heads.{i}.b', build_b)
-            d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
-                                         pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
-                                         out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
-                                         out_off=off * 4, outb_off=off * self.nc,
-                                         split_k=(ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K, target_blocks=256, max_split=8)
-                                                  if self.bf16 else ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K)),
-                                         flags=_lib.CONV_OUT_F32)
-            self.head_descs.append(d)
-            self._add(self.conv_fn, (C.byref(d),), keep=d)
-            self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
-            off += Hs * Hs * A
-        assert off == self.P, off
+        def build_w(out, lw=lw, cw=cw, nloc=nloc, nconf=nconf, K=K):
+            if out is None:
+                out = torch.empty(nloc + nconf, K, device=dev, dtype=self.adt)
+            pk = ops.pack_weight_bf16 if self.bf16 else ops.pack_weight
+            pk(lw.weight, out, 0)
+            pk(cw.weight, out, nloc)
+            return out
+
+        def build_b(out, lw=lw, cw=cw, nloc=nloc):
+            if out is None:
+                out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
+            out[:nloc].copy_(lw.bias.detach())
+            out[nloc:].copy_(cw.bias.detach())
+            return out
+        wp = eng._pack(f'heads.{i}.w', build_w)
+        bp = eng._pack(f'heads.{i}.b', build_b)
+        d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
+                                     pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
+                                     out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
+                                     out_off=off * 4, outb_off=off * self.nc,
+                                     split_k=(ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K, target_blocks=256, max_split=8)
+                                              if self.bf16 else ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K)),
+                                     flags=_lib.CONV_OUT_F32)
+        self.head_descs.append(d)
+        self._add(self.conv_fn, (C.byref(d),), keep=d)
+        self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
 
     # ------------------------------------------------------------------------------------------------
     def _add(self, fn, args, keep=None, tag=None):
@@ -352,7 +360,7 @@ class _Plan(_PlanBase):
             d = keep[0] if isinstance(keep, tuple) else keep
             tag = conv_tag(d, 3 if (d.cin_g in (4, 8) and d.groups == 4 and d.H == 300) else None,
                            bf16=fn is lib.gssd_conv2d_nhwc_bf16)
-        self.steps.append(_Step(fn, args, keep, tag))
+        self.steps.append(_Step(fn, args, keep, tag, getattr(self, '_sid', 0)))
 
     def _abuf(self, *shape):
         """Activation buffer in the plan's storage type (fp32, or bf16 in configs[4] mode)."""
@@ -476,21 +484,28 @@ class _Plan(_PlanBase):
             x, Cc = xin, Cin
         self.x_after_block = x
         s = self._abuf(B, H, H, Cc)
+        self._sid = 1                              # L2Norm opens branch 0
         self._add(lib.gssd_l2norm_bf16 if self.bf16 else lib.gssd_l2norm_f32,
                   (x.data_ptr(), net.L2Norm.weight.data_ptr(), s.data_ptr(), B * H * H, Cc, float(net.L2Norm.eps)))
         self.rec.append(('l2norm', dict(x_in=x, out=s, H=H, C=Cc, mod=net.L2Norm)))
+        self._sid = 0
         src0 = self._branch(s, H, Cc, 0, '11')
         pooled, Hp = self._pool_only(x, H, Cc, 2, 2, 0)
         return pooled, Hp, Cc, src0
 
     def _branch(self, s, H, Cc, sa_i, fuse):
-        """[SA] -> 1x1 fuse conv + BN + ReLU -> a multibox source (models/...group.py:284-297)."""
+        """[SA] -> 1x1 fuse conv + BN + ReLU -> a multibox source (models/...group.py:284-297) -> its loc | conf head.  Nothing
+        downstream of the trunk reads a branch, so branch i is tagged with stream id i + 1: captured as a hipGraph the six branches
+        run beside the trunk's continuation (on the small maps a kernel has 1..100 workgroups for 256 CUs)."""
         net = self.eng.net
+        prev, self._sid = getattr(self, '_sid', 0), sa_i + 1
         if net.use_self_attention:
             s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False, want_map=self.want_maps)
         if net.use_fuseconv:
             conv, bn = getattr(net, f'fuse_{fuse}'), getattr(net, f'bn_fuse_{fuse}')
             s, H, Cc, _ = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
+        self._head(sa_i, s, H, Cc)
+        self._sid = prev
         return (s, H, Cc)
 
     def _self_attn(self, lst_name, idx, x, H, Cc, need_out2, want_map=False):
@@ -617,11 +632,28 @@ class _Plan(_PlanBase):
 
     # ------------------------------------------------------------------------------------------------
     def run(self, x, events=None):
-        """``events``: optional list; when given, every conv launch is bracketed by a pair of HIP events recorded
-        on the launch stream and (tag, start, end) is appended (bench.py's live roofline measurement)."""
-        B, dev = self.B, self.dev
+        """``events``: optional list; when given, every tagged launch (or only the kernel instances named in ``events.only``) is
+        bracketed by a pair of HIP events recorded on the launch stream and (tag, start, end) is appended (bench.py's live
+        roofline measurement).
+
+        From its third run on a plan replays itself from hipGraphs: the ~200-270 launches of a step are static (preallocated
+        buffers, descriptors by value), so the host side of a step shrinks from a ctypes call per kernel (~2.5 ms) to a few graph
+        launches.  Launches that must be bracketed by events stay eager and split the plan into graph segments around them."""
         self.generation += 1
         x = x.contiguous().float()
+        only = getattr(events, 'only', None) if events is not None else None
+        self._runs = getattr(self, '_runs', 0) + 1
+        if USE_GRAPH and (events is None or only) and self._runs > 2:
+            return self._run_graphs(x, events, only)
+        return self._run_eager(x, events, only)
+
+    def _launch(self, st, stream):
+        rc = st.fn(*st.args, stream)
+        if rc != 0:
+            _lib.check(rc)
+
+    def _run_eager(self, x, events, only):
+        B, dev = self.B, self.dev
         # zero-filled: the heads accumulate split-K slices with atomics
         loc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
         conf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
@@ -631,28 +663,102 @@ class _Plan(_PlanBase):
         if self.training:
             self.stats.zero_()
         stream = torch.cuda.current_stream().cuda_stream
-        if events is None:
-            for st in self.steps:
-                rc = st.fn(*st.args, stream)
-                if rc != 0:
-                    _lib.check(rc)
-        else:
-            only = getattr(events, 'only', None)       # optional set of kernel-instance names to bracket (bench.py)
-            for st in self.steps:
-                if st.tag is not None and (only is None or st.tag[0] in only):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    rc = st.fn(*st.args, stream)
-                    e1.record()
-                    events.append((st.tag, e0, e1))
-                else:
-                    rc = st.fn(*st.args, stream)
-                if rc != 0:
-                    _lib.check(rc)
+        for st in self.steps:
+            if events is not None and st.tag is not None and (only is None or st.tag[0] in only):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._launch(st, stream)
+                e1.record()
+                events.append((st.tag, e0, e1))
+            else:
+                self._launch(st, stream)
         if self.training and self.nbt:
             torch._foreach_add_(self.nbt, 1)
         self._x_keepalive = x
         return loc, conf
+
+    def _run_graphs(self, x, events, only):
+        key = tuple(sorted(only)) if only else None
+        cache = self.__dict__.setdefault('_graphs', {})
+        if key not in cache:
+            cache[key] = self._capture(x, only)
+        segs = cache[key]
+        self._gx.copy_(x)
+        stream = torch.cuda.current_stream().cuda_stream
+        for kind, obj in segs:
+            if kind == 'graph':
+                obj.replay()
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._launch(obj, stream)
+                e1.record()
+                events.append((obj.tag, e0, e1))
+        return self._gloc.clone(), self._gconf.clone()
+
+    def _side_stream(self, sid):
+        pool = self.__dict__.setdefault('_side_streams', {})
+        if sid not in pool:
+            pool[sid] = torch.cuda.Stream(device=self.dev)
+        return pool[sid]
+
+    def _capture(self, x, only):
+        """Capture the plan as hipGraph segments over static input / output buffers; the steps named in ``only`` stay eager."""
+        B, dev = self.B, self.dev
+        if getattr(self, '_gx', None) is None:
+            self._gx = torch.empty_like(x)
+            self._gloc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
+            self._gconf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
+        for d in self.head_descs:
+            d.out, d.out_b = self._gloc.data_ptr(), self._gconf.data_ptr()
+        self.steps[self._pack_step].args[0] = self._gx.data_ptr()
+        groups, cur = [], []
+        for st in self.steps:
+            if only and st.tag is not None and st.tag[0] in only:
+                groups.append(('graph', cur))
+                groups.append(('step', st))
+                cur = []
+            else:
+                cur.append(st)
+        groups.append(('graph', cur))
+        torch.cuda.synchronize(dev)
+        pool = torch.cuda.graph_pool_handle()
+        segs, n_graph = [], sum(1 for k, _ in groups if k == 'graph')
+        gi = 0
+        for kind, obj in groups:
+            if kind == 'step':
+                segs.append(('step', obj))
+                continue
+            first, last = gi == 0, gi == n_graph - 1
+            gi += 1
+            if not obj and not first and not (last and self.training and self.nbt):
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                if first:
+                    self._gloc.zero_()
+                    self._gconf.zero_()
+                    if self.training:
+                        self.stats.zero_()
+                main = torch.cuda.current_stream()
+                forked = {}
+                for st in obj:
+                    if st.sid == 0 or not USE_BRANCH_STREAMS:
+                        self._launch(st, main.cuda_stream)
+                        continue
+                    side = forked.get(st.sid)
+                    if side is None:                       # fork: the branch starts behind everything the trunk has enqueued
+                        side = self._side_stream(st.sid)
+                        side.wait_stream(main)
+                        forked[st.sid] = side
+                    self._launch(st, side.cuda_stream)
+                for side in forked.values():               # join: a graph segment ends with every branch folded back
+                    main.wait_stream(side)
+                if last and self.training and self.nbt:
+                    torch._foreach_add_(self.nbt, 1)
+            segs.append(('graph', g))
+        # the capture itself does not execute anything: the caller's replay is the run
+        return segs
 
 
 class _PlanVanilla(_Plan):

@@ -1148,6 +1148,60 @@ def test_reference_driver_sequence(dev, tmp_path):
         torch.set_default_tensor_type('torch.FloatTensor')
 
 
+@pytest.mark.parametrize('name', ['gssdpp', 'vanilla'])
+def test_graph_replay_equals_eager(dev, name):
+    """From its third run on a launch plan replays itself from hipGraphs (static buffers, descriptors by value).  The replayed
+    forward must equal the eager one bit for bit -- same kernels, same order -- including the state a training forward mutates
+    (BatchNorm running statistics, spectral norm's u / v), and the event-bracketed variant (graph segments around eager launches)
+    that bench.py's live roofline measurement uses."""
+    if name == 'vanilla':
+        from models.ssd import build_ssd as bs
+        net = bs('train', 300, 2)
+        x = synth.synth_images(2, seed=6, channels=3).to(dev)
+    else:
+        from models.ssd_multiphase_custom_group import build_ssd as bs
+        net = bs('train', 300, 2, *NETS['gssdpp'][1])
+        x = synth.synth_images(3, seed=6).to(dev)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
+    import copy
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    twin = copy.deepcopy(net)
+    os.environ['GSSD_NO_GRAPH'] = '0'
+    outs = []
+    with torch.no_grad():
+        for it in range(5):
+            outs.append(net(x))
+    plan = net._engine._last_plan
+    assert plan._runs == 5 and len(plan._graphs) == 1                 # runs 3..5 were graph replays
+    # the twin runs the same five training forwards eagerly
+    import gssd.engine as E
+    E.USE_GRAPH = False
+    try:
+        with torch.no_grad():
+            ref = [twin(x) for _ in range(5)]
+    finally:
+        E.USE_GRAPH = True
+    assert getattr(twin._engine._last_plan, '_graphs', None) is None
+    # split-K heads accumulate with fp32 atomics (order varies run to run): compare everything else exactly, loc / conf tightly
+    for a, b in zip(outs, ref):
+        assert rel(a[0], b[0]) < 1e-6 and rel(a[1], b[1]) < 1e-6
+    for (k, va), (_, vb) in zip(net.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(va, vb), k
+    if name == 'gssdpp':
+        class EL(list):
+            only = {'dcn_fused<128x256>'}
+        ev = EL()
+        net.__dict__['_events'] = ev
+        with torch.no_grad():
+            o6 = net(x)
+            r6 = twin(x)
+        net.__dict__['_events'] = None
+        torch.cuda.synchronize()
+        assert len(ev) == 1 and ev[0][1].elapsed_time(ev[0][2]) > 0 and len(plan._graphs) == 2
+        assert rel(o6[0], r6[0]) < 1e-6 and rel(o6[1], r6[1]) < 1e-6
+
+
 def test_cpu_input_fails_loudly():
     from models.ssd_multiphase_custom_group import build_ssd
     from gssd._lib import GssdError
