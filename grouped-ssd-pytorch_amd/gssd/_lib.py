@@ -44,7 +44,7 @@ class SnItem(C.Structure):
 
 
 OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
-CONV_OUT_F32 = 1
+CONV_OUT_F32, CONV_OUTB_BF16_PERM32 = 1, 2
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {
@@ -85,6 +85,8 @@ SIGNATURES = {
     'gssd_upsample_insert_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_gemm_slot_takes': (c_i, [c_fp]),
+    'gssd_self_attn_core_bf16v': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_spectral_norm_f32': (c_i, [c_fp, c_i, c_i, c_f, c_fp]),

@@ -262,9 +262,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
                 float* base = second ? p.out_b + (size_t)img * p.outb_batch_stride : p.out + (size_t)img * p.out_batch_stride;
                 const int nsub = second ? p.split_n : 0;
                 if (m < rs) {
+                    if (second && (p.flags & GSSD_CONV_OUTB_BF16_PERM32)) {
+                        // bf16 rows whose 32-token blocks are stored in the key order of the bf16-value attention core:
+                        // token 32 t + 16 a + 4 b + c  ->  position 32 t + 8 b + 4 a + c
+                        u16* hb = reinterpret_cast<u16*>(p.out_b) + (size_t)img * p.outb_batch_stride;
+                        const int mp = (m & ~31) | (((m >> 2) & 3) << 3) | (((m >> 4) & 1) << 2) | (m & 3);
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-                        if (nok[c]) base[(size_t)(n0 + c - nsub) * rs + m] = m_ok ? (p.relu ? fmaxf(v[c], 0.f) : v[c]) : 0.f;
+                        for (int c = 0; c < CPL; ++c)
+                            if (nok[c]) hb[(size_t)(n0 + c - nsub) * rs + mp] = f2bf(m_ok ? v[c] : 0.f);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c)
+                            if (nok[c]) base[(size_t)(n0 + c - nsub) * rs + m] = m_ok ? (p.relu ? fmaxf(v[c], 0.f) : v[c]) : 0.f;
+                    }
                 }
                 continue;
             }
@@ -449,6 +459,7 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
     if (d.out_mode == GSSD_OUT_SPLIT_T) {
         GSSD_CHECK_ARG(d.m_per_image && d.groups == 1 && d.out_b && d.split_n > 0 && d.split_n < d.Cout && d.split_n % 64 == 0 && out_f32);
         GSSD_CHECK_ARG(d.out_b_stride % 4 == 0 && d.out_b_stride >= d.Ho * d.Wo && d.outb_batch_stride % 4 == 0);
+        if (d.flags & GSSD_CONV_OUTB_BF16_PERM32) GSSD_CHECK_ARG(d.out_b_stride % 32 == 0 && d.outb_batch_stride % 8 == 0);
         GSSD_CHECK_ARG(!d.gate && !d.resid && !d.relu && !d.stats && d.split_k == 1);
     }
     if (d.out_mode == GSSD_OUT_NHWC) GSSD_CHECK_ARG((d.out_stride % 8 == 0 && d.out_ch_off % 8 == 0) || out_f32);

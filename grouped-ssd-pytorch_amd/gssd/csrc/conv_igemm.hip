@@ -403,6 +403,11 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         if (rc != 1) return rc;
     }
     if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 512 && !d.m_per_image);
+    {
+        static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr;      // ablation switch (scripts/layer_times.py)
+        const int rc = no_slot ? 1 : gssd_try_gemm_slot(d, s);                   // large plain 1x1 convs / GEMMs: 128 x 256 slot stream
+        if (rc != 1) return rc;
+    }
     if (cout_g > 64) {
         // 128x128 tiles run 2 workgroups per CU (LDS), 128x64 tiles 3: pick the one whose last round of workgroups is
         // fuller (wave quantisation decides small 19x19 / 38x38 layers); the wide tile wins ties (less B re-read).

@@ -60,14 +60,27 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
     }
 }
 
-// Backward of the sampling.  d(cols) arrives from the dgrad of the 1x1 GEMM.  d(x) contributions are accumulated in an LDS
-// window of (tile + 2R + 1)^2 pixels around the tile (trained offsets are a few pixels) and flushed to HBM with ONE fp32
-// atomic per window element; corners outside the window fall back to global atomics, so any offset is handled.  The three
-// scalars d(offset_y), d(offset_x), d(mask logit) are wave-reduced over the slice and added to d(om) (zero-filled by the
-// caller).  The corner validity masks and floor() are constants of the differentiation, exactly as in the gather
-// formulation (autograd of the oracle graph).
+// Backward of the sampling.  d(cols) arrives from the dgrad of the contraction.  A workgroup owns a TH x TW tile of output pixels
+// and one 64-channel slice (lane = channel) and is TWO waves with different jobs over the same (pixel, tap) units:
+//   wave 0 (reduce):  d(offset_y), d(offset_x), d(mask logit) = wave sums over the slice of g * (bilinear derivative of x) --
+//                     the x corners come from an LDS copy of the (tile + 2R + 1)^2 window, staged once by LDS-DMA;
+//   wave 1 (scatter): d(x) += g * m * bilinear weight into an LDS accumulator window, flushed with ONE fp32 atomic per element.
+// Both read d(cols) from a double-buffered LDS-DMA stage (2 pixels x 9 taps per chunk) and the per-unit sampling geometry from a
+// table built once per tile, so the main loop has no global load at all: the first version (one wave doing both, 5 global loads per
+// unit, 4 waves per CU) was latency bound at 8.1 ms; this one is bound by the VALU work of the two jobs running on separate SIMDs.
+// Units whose corners leave the window (offsets beyond R pixels; ~10 % with |offset| ~ 0.5) are skipped here and handled by
+// dcn_col2im_overflow_kernel straight from global memory, so any offset is handled.  The corner validity masks and
+// floor() are constants of the differentiation, exactly as in the gather formulation (autograd of the oracle).
 constexpr int DC_R = 2;                                               // window halo (pixels) around the tile
-constexpr int DC_U = 4;                                               // (pixel, tap) units in flight per wave
+constexpr int DC_CH = 18;                                             // units per d(cols) chunk: 2 pixels x 9 taps
+constexpr int DC_CHP = 20;                                            // ... padded to whole 1-KiB DMA pieces (4 units each)
+
+__device__ __attribute__((aligned(16))) float g_zero16_dcn[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16_dcn(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -84,18 +97,55 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
 }
 
-// One wave per workgroup: a TH x TW tile of output pixels and one 64-channel slice (lane = channel).  The window is private
-// to the wave and lanes never share an address, so the d(x) accumulation is a plain LDS read-modify-write (LDS float
-// atomics cost ~160 clocks per wave instruction on gfx950 -- measured; they were 70 % of the first version).
+// geometry word: bits 0-3 corner validity (00, 01, 10, 11), bit 4 unit contributes, bit 5 all four corners inside the LDS window,
+// bits 8.. window offset (pixels) of the (y0, x0) corner
+struct DcGeo {
+    int gi, gyx;
+    float ly, lx, m;
+};
 template <int TH, int TW>
-__global__ __launch_bounds__(64) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ om,
-                                                        const float* __restrict__ dcols, float* __restrict__ dx,
-                                                        float* __restrict__ dom, int B, int H, int W, int C, int dg,
-                                                        int om_stride, int tiles_y, int tiles_x) {
+__device__ __forceinline__ DcGeo dc_geometry(const float* __restrict__ om, int b, int h, int w, int tap, int d, int dg, int H, int W,
+                                             int om_stride, int wy0, int wx0) {
+    constexpr int WH = TH + 2 * DC_R + 1, WW = TW + 2 * DC_R + 1;
+    DcGeo r = {0, 0, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+        const float* omp = om + ((long long)b * H * W + h * W + w) * om_stride;
+        const float oy = omp[d * 18 + 2 * tap], ox = omp[d * 18 + 2 * tap + 1];
+        r.m = 1.f / (1.f + expf(-omp[dg * 18 + d * 9 + tap]));
+        const float py = (float)(h - 1 + tap / 3) + oy;
+        const float px = (float)(w - 1 + tap % 3) + ox;
+        if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
+            const float y0f = floorf(py), x0f = floorf(px);
+            const int y0 = (int)y0f, x0 = (int)x0f;
+            r.ly = py - y0f;
+            r.lx = px - x0f;
+            const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+            r.gi = ((y0ok && x0ok) ? 1 : 0) | ((y0ok && x1ok) ? 2 : 0) | ((y1ok && x0ok) ? 4 : 0) | ((y1ok && x1ok) ? 8 : 0) | 16;
+            const int wy = y0 - wy0, wx = x0 - wx0;
+            if (wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW) r.gi |= 32 | ((wy * WW + wx) << 8);
+            r.gyx = (y0 & 0xFFFF) | (x0 << 16);
+        }
+    }
+    return r;
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__(128) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ om,
+                                                         const float* __restrict__ dcols, float* __restrict__ dx,
+                                                         float* __restrict__ dom, int B, int H, int W, int C, int dg,
+                                                         int om_stride, int tiles_y, int tiles_x) {
     constexpr int WH = TH + 2 * DC_R + 1, WW = TW + 2 * DC_R + 1;     // +1: the far bilinear corner
-    __shared__ float win[WH * WW * 64];
-    __shared__ float oms[TH * TW * 27];                               // this group's (dy, dx) x 9 and 9 mask logits per pixel
-    const int lane = threadIdx.x;
+    constexpr int WPX = WH * WW, WPX4 = (WPX + 3) / 4 * 4;
+    constexpr int NU = TH * TW * 9, NCH = NU / DC_CH;
+    static_assert(NU % DC_CH == 0 && TW % 2 == 0, "tile");
+    __shared__ __attribute__((aligned(16))) float xw[WPX4 * 64];      // x window
+    __shared__ __attribute__((aligned(16))) float gb[2][DC_CHP * 64]; // d(cols) chunks
+    __shared__ float dw[WPX * 64];                                    // d(x) accumulator window
+    __shared__ int geo_i[NU];
+    __shared__ float geo_ly[NU], geo_lx[NU], geo_m[NU];
+    __shared__ float dacc[NU * 3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = H * W, cpg = C / dg;
     const int slices = C / 64;
     int bid = blockIdx.x;
@@ -105,92 +155,191 @@ __global__ __launch_bounds__(64) void dcn_col2im_kernel(const float* __restrict_
     const int b = bid / tiles_y;
     const int ch0 = sl * 64, d = ch0 / cpg;
     const int wy0 = ty * TH - DC_R, wx0 = tx * TW - DC_R;             // window origin (may be negative)
-#pragma unroll
-    for (int i = 0; i < WH * WW; ++i) win[i * 64 + lane] = 0.f;
-    for (int i = lane; i < TH * TW * 27; i += 64) {
-        const int pl = i / 27, j = i - pl * 27;
-        const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
-        float v = 0.f;
-        if (h < H && w < W) {
-            const float* omp = om + ((long long)b * HW + h * W + w) * om_stride;
-            v = j < 18 ? omp[d * 18 + j] : omp[dg * 18 + d * 9 + (j - 18)];
-        }
-        oms[i] = v;
-    }
-    __syncthreads();
-    const float* xb = x + (size_t)b * HW * C + ch0 + lane;
+    const float* xb = x + (size_t)b * HW * C + ch0;
     float* dxb = dx + (size_t)b * HW * C + ch0 + lane;
-    constexpr int NU = TH * TW * 9;
-    static_assert(NU % DC_U == 0, "tile");
-    for (int u0 = 0; u0 < NU; u0 += DC_U) {
-        float g[DC_U], v00[DC_U], v01[DC_U], v10[DC_U], v11[DC_U], ly[DC_U], lx[DC_U], m[DC_U];
-        int y0[DC_U], x0[DC_U], kk[DC_U];
-        long long bp[DC_U];
-        // ---- phase 1: sampling geometry (wave-uniform) and all loads of DC_U units -------------------------------------------
+    const float* dcb = dcols + (size_t)b * HW * 9 * C + ch0;
+
+    auto stage_chunk = [&](int c, float* buf) {                       // wave 0 only: 5 DMA pieces of 4 units x 256 B
+        const int q4 = lane >> 4, f4 = (lane & 15) * 4;
 #pragma unroll
-        for (int q = 0; q < DC_U; ++q) {
-            const int u = u0 + q;
-            const int tap = u % 9, pl = u / 9;
+        for (int j = 0; j < DC_CHP / 4; ++j) {
+            const int u = j * 4 + q4;
+            const int pl = c * 2 + (u >= 9 ? 1 : 0), tap = u >= 9 ? u - 9 : u;
             const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
-            bp[q] = (long long)b * HW + h * W + w;
-            const float oy = oms[pl * 27 + 2 * tap], ox = oms[pl * 27 + 2 * tap + 1];
-            m[q] = 1.f / (1.f + expf(-oms[pl * 27 + 18 + tap]));
-            const float py = (float)(h - 1 + tap / 3) + oy;
-            const float px = (float)(w - 1 + tap % 3) + ox;
-            const bool ok = h < H && w < W && py > -1.f && px > -1.f && py < (float)H && px < (float)W;
-            const float y0f = floorf(py), x0f = floorf(px);
-            y0[q] = (int)y0f;
-            x0[q] = (int)x0f;
-            ly[q] = py - y0f;
-            lx[q] = px - x0f;
-            const bool y0ok = y0[q] >= 0, y1ok = y0[q] + 1 <= H - 1, x0ok = x0[q] >= 0, x1ok = x0[q] + 1 <= W - 1;
-            kk[q] = ok ? ((y0ok && x0ok) ? 1 : 0) | ((y0ok && x1ok) ? 2 : 0) | ((y1ok && x0ok) ? 4 : 0) |
-                             ((y1ok && x1ok) ? 8 : 0) | 16
-                       : 0;
-            g[q] = (kk[q] & 16) ? dcols[(bp[q] * 9 + tap) * C + ch0 + lane] : 0.f;
-            v00[q] = (kk[q] & 1) ? xb[(size_t)(y0[q] * W + x0[q]) * C] : 0.f;
-            v01[q] = (kk[q] & 2) ? xb[(size_t)(y0[q] * W + x0[q] + 1) * C] : 0.f;
-            v10[q] = (kk[q] & 4) ? xb[(size_t)((y0[q] + 1) * W + x0[q]) * C] : 0.f;
-            v11[q] = (kk[q] & 8) ? xb[(size_t)((y0[q] + 1) * W + x0[q] + 1) * C] : 0.f;
+            const bool ok = u < DC_CH && h < H && w < W;
+            const float* src = ok ? dcb + ((size_t)(h * W + w) * 9 + tap) * C + f4 : g_zero16_dcn;
+            dma16_dcn(src, buf + j * 256);
         }
-        // ---- phase 2: gradients ---------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int q = 0; q < DC_U; ++q) {
-            if (!(kk[q] & 16)) continue;
-            const int tap = (u0 + q) % 9;
-            const float hy = 1.f - ly[q], hx = 1.f - lx[q];
-            const float s_m = g[q] * (v00[q] * (hy * hx) + v01[q] * (hy * lx[q]) + v10[q] * (ly[q] * hx) + v11[q] * (ly[q] * lx[q]));
-            const float s_y = g[q] * ((v10[q] - v00[q]) * hx + (v11[q] - v01[q]) * lx[q]);
-            const float s_x = g[q] * ((v01[q] - v00[q]) * hy + (v11[q] - v10[q]) * ly[q]);
-            const float gm = g[q] * m[q];
-            const int wy = y0[q] - wy0, wx = x0[q] - wx0;            // wave-uniform
-            if (wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW) {
-                float* wp = win + (wy * WW + wx) * 64 + lane;
-                if (kk[q] & 1) wp[0] += gm * (hy * hx);
-                if (kk[q] & 2) wp[64] += gm * (hy * lx[q]);
-                if (kk[q] & 4) wp[WW * 64] += gm * (ly[q] * hx);
-                if (kk[q] & 8) wp[WW * 64 + 64] += gm * (ly[q] * lx[q]);
-            } else {
-                float* gp = dxb + (size_t)(y0[q] * W + x0[q]) * C;
-                if (kk[q] & 1) unsafeAtomicAdd(gp, gm * (hy * hx));
-                if (kk[q] & 2) unsafeAtomicAdd(gp + C, gm * (hy * lx[q]));
-                if (kk[q] & 4) unsafeAtomicAdd(gp + (size_t)W * C, gm * (ly[q] * hx));
-                if (kk[q] & 8) unsafeAtomicAdd(gp + (size_t)W * C + C, gm * (ly[q] * lx[q]));
-            }
-            const float t_m = wave_sum_dpp(s_m), t_y = wave_sum_dpp(s_y), t_x = wave_sum_dpp(s_x);
-            if (lane == 0) {
-                float* domp = dom + bp[q] * om_stride;
-                unsafeAtomicAdd(domp + d * 18 + 2 * tap, t_y * m[q]);
-                unsafeAtomicAdd(domp + d * 18 + 2 * tap + 1, t_x * m[q]);
-                unsafeAtomicAdd(domp + dg * 18 + d * 9 + tap, t_m * m[q] * (1.f - m[q]));
-            }
+    };
+    // ---- prologue: x window (both waves), first d(cols) chunk, accumulator clear, geometry table --------------------------------
+    {
+        const int q4 = lane >> 4, f4 = (lane & 15) * 4;
+        for (int i = wave; i < WPX4 / 4; i += 2) {
+            const int px = i * 4 + q4;
+            const int y = wy0 + px / WW, xx = wx0 + px % WW;
+            const bool ok = px < WPX && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+            dma16_dcn(ok ? xb + (size_t)(y * W + xx) * C + f4 : g_zero16_dcn, xw + i * 256);
         }
     }
-    for (int i = 0; i < WH * WW; ++i) {
+    if (wave == 0) stage_chunk(0, gb[0]);
+    for (int i = wave; i < WPX; i += 2) dw[i * 64 + lane] = 0.f;
+    for (int u = tid; u < NU; u += 128) {
+        const int pl = u / 9, tap = u - pl * 9;
+        const DcGeo r = dc_geometry<TH, TW>(om, b, ty * TH + pl / TW, tx * TW + pl % TW, tap, d, dg, H, W, om_stride, wy0, wx0);
+        geo_i[u] = r.gi;
+        geo_ly[u] = r.ly;
+        geo_lx[u] = r.lx;
+        geo_m[u] = r.m;
+    }
+    __syncthreads();                                                  // (drains the DMA: window, chunk 0) + table visible
+
+    for (int c = 0; c < NCH; ++c) {
+        const float* gbuf = gb[c & 1];
+        if (wave == 0 && c + 1 < NCH) stage_chunk(c + 1, gb[(c + 1) & 1]);
+#pragma unroll 3
+        for (int q = 0; q < DC_CH; ++q) {
+            const int u = c * DC_CH + q;
+            const int gi = __builtin_amdgcn_readfirstlane(geo_i[u]);
+            if ((gi & 48) != 48) continue;                            // no contribution, or the overflow kernel's
+            const float g = gbuf[q * 64 + lane];
+            const float ly = geo_ly[u], lx = geo_lx[u], m = geo_m[u];
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const int wofs = gi >> 8;
+            if (wave == 0) {
+                const float* wp = xw + wofs * 64 + lane;
+                const float v00 = (gi & 1) ? wp[0] : 0.f;
+                const float v01 = (gi & 2) ? wp[64] : 0.f;
+                const float v10 = (gi & 4) ? wp[WW * 64] : 0.f;
+                const float v11 = (gi & 8) ? wp[WW * 64 + 64] : 0.f;
+                const float s_m = g * (v00 * (hy * hx) + v01 * (hy * lx) + v10 * (ly * hx) + v11 * (ly * lx));
+                const float s_y = g * ((v10 - v00) * hx + (v11 - v01) * lx);
+                const float s_x = g * ((v01 - v00) * hy + (v11 - v10) * ly);
+                const float t_m = wave_sum_dpp(s_m), t_y = wave_sum_dpp(s_y), t_x = wave_sum_dpp(s_x);
+                if (lane == 0) {
+                    dacc[u * 3] = t_y * m;
+                    dacc[u * 3 + 1] = t_x * m;
+                    dacc[u * 3 + 2] = t_m * m * (1.f - m);
+                }
+            } else {
+                const float gm = g * m;
+                float* wp = dw + wofs * 64 + lane;
+                if (gi & 1) wp[0] += gm * (hy * hx);
+                if (gi & 2) wp[64] += gm * (hy * lx);
+                if (gi & 4) wp[WW * 64] += gm * (ly * hx);
+                if (gi & 8) wp[WW * 64 + 64] += gm * (ly * lx);
+            }
+        }
+        __syncthreads();                                              // chunk c consumed by both waves, chunk c + 1 landed
+    }
+    // ---- flush: d(x) window (one atomic per element: neighbouring tiles' windows overlap) and the three d(om) scalars per unit ----
+    for (int i = wave; i < WPX; i += 2) {
         const int y = wy0 + i / WW, xx = wx0 + i % WW;
         if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-        const float v = win[i * 64 + lane];
+        const float v = dw[i * 64 + lane];
         if (v != 0.f) unsafeAtomicAdd(dxb + (size_t)(y * W + xx) * C, v);
+    }
+    for (int u = tid; u < NU; u += 128) {
+        if ((geo_i[u] & 48) != 48) continue;
+        const int pl = u / 9, tap = u - pl * 9;
+        const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
+        float* domp = dom + ((long long)b * HW + h * W + w) * om_stride;
+        unsafeAtomicAdd(domp + d * 18 + 2 * tap, dacc[u * 3]);        // the group's cpg / 64 slices add into the same scalars
+        unsafeAtomicAdd(domp + d * 18 + 2 * tap + 1, dacc[u * 3 + 1]);
+        unsafeAtomicAdd(domp + dg * 18 + d * 9 + tap, dacc[u * 3 + 2]);
+    }
+}
+
+// The units dcn_col2im_kernel leaves out (a corner outside its LDS window): one wave per (tile, 64-channel slice) lists them and does
+// both jobs straight from / to global memory, DC_U units (5 loads each) in flight.  No large LDS -> many resident waves, which is what
+// hides the load round trips; kept out of the main kernel so those round trips never sit between its barriers.
+template <int TH, int TW>
+__global__ __launch_bounds__(64) void dcn_col2im_overflow_kernel(const float* __restrict__ x, const float* __restrict__ om,
+                                                                 const float* __restrict__ dcols, float* __restrict__ dx,
+                                                                 float* __restrict__ dom, int B, int H, int W, int C, int dg,
+                                                                 int om_stride, int tiles_y, int tiles_x) {
+    constexpr int NU = TH * TW * 9, DC_U = 4;
+    __shared__ int o_u[NU], o_gi[NU], o_yx[NU];
+    __shared__ float o_ly[NU], o_lx[NU], o_m[NU];
+    __shared__ int novf;
+    const int lane = threadIdx.x;
+    const int HW = H * W, cpg = C / dg;
+    const int slices = C / 64;
+    int bid = blockIdx.x;
+    const int sl = bid % slices;  bid /= slices;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ch0 = sl * 64, d = ch0 / cpg;
+    const int wy0 = ty * TH - DC_R, wx0 = tx * TW - DC_R;
+    if (lane == 0) novf = 0;
+    __syncthreads();
+    for (int u = lane; u < NU; u += 64) {
+        const int pl = u / 9, tap = u - pl * 9;
+        const DcGeo r = dc_geometry<TH, TW>(om, b, ty * TH + pl / TW, tx * TW + pl % TW, tap, d, dg, H, W, om_stride, wy0, wx0);
+        if ((r.gi & 48) == 16) {
+            const int i = atomicAdd(&novf, 1);
+            o_u[i] = u;
+            o_gi[i] = r.gi;
+            o_yx[i] = r.gyx;
+            o_ly[i] = r.ly;
+            o_lx[i] = r.lx;
+            o_m[i] = r.m;
+        }
+    }
+    __syncthreads();
+    const int n = novf;
+    const float* xb = x + (size_t)b * HW * C + ch0 + lane;
+    float* dxb = dx + (size_t)b * HW * C + ch0 + lane;
+    const float* dcb = dcols + (size_t)b * HW * 9 * C + ch0 + lane;
+    for (int i0 = 0; i0 < n; i0 += DC_U) {
+        float g[DC_U], v00[DC_U], v01[DC_U], v10[DC_U], v11[DC_U];
+        int gis[DC_U], y0s[DC_U], x0s[DC_U];
+#pragma unroll
+        for (int q = 0; q < DC_U; ++q) {
+            const bool on = i0 + q < n;
+            const int i = on ? i0 + q : 0;
+            const int u = __builtin_amdgcn_readfirstlane(o_u[i]);
+            const int gi = on ? __builtin_amdgcn_readfirstlane(o_gi[i]) : 0;
+            const int gyx = __builtin_amdgcn_readfirstlane(o_yx[i]);
+            gis[q] = gi;
+            y0s[q] = (int)(short)(gyx & 0xFFFF);
+            x0s[q] = gyx >> 16;
+            const int pl = u / 9, tap = u - pl * 9;
+            const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
+            const float* gp = xb + (long long)(y0s[q] * W + x0s[q]) * C;
+            g[q] = (gi & 16) ? dcb[((size_t)(h * W + w) * 9 + tap) * C] : 0.f;
+            v00[q] = (gi & 1) ? gp[0] : 0.f;
+            v01[q] = (gi & 2) ? gp[C] : 0.f;
+            v10[q] = (gi & 4) ? gp[(long long)W * C] : 0.f;
+            v11[q] = (gi & 8) ? gp[(long long)W * C + C] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < DC_U; ++q) {
+            const int gi = gis[q];
+            if (!(gi & 16)) continue;
+            const int i = i0 + q;
+            const int u = __builtin_amdgcn_readfirstlane(o_u[i]);
+            const float ly = o_ly[i], lx = o_lx[i], m = o_m[i];
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const float s_m = g[q] * (v00[q] * (hy * hx) + v01[q] * (hy * lx) + v10[q] * (ly * hx) + v11[q] * (ly * lx));
+            const float s_y = g[q] * ((v10[q] - v00[q]) * hx + (v11[q] - v01[q]) * lx);
+            const float s_x = g[q] * ((v01[q] - v00[q]) * hy + (v11[q] - v10[q]) * ly);
+            const float t_m = wave_sum_dpp(s_m), t_y = wave_sum_dpp(s_y), t_x = wave_sum_dpp(s_x);
+            if (lane == 0) {
+                const int pl = u / 9, tap = u - pl * 9;
+                const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
+                float* domp = dom + ((long long)b * HW + h * W + w) * om_stride;
+                unsafeAtomicAdd(domp + d * 18 + 2 * tap, t_y * m);
+                unsafeAtomicAdd(domp + d * 18 + 2 * tap + 1, t_x * m);
+                unsafeAtomicAdd(domp + dg * 18 + d * 9 + tap, t_m * m * (1.f - m));
+            }
+            const float gm = g[q] * m;
+            float* gp = dxb + (long long)(y0s[q] * W + x0s[q]) * C;
+            if (gi & 1) unsafeAtomicAdd(gp, gm * (hy * hx));
+            if (gi & 2) unsafeAtomicAdd(gp + C, gm * (hy * lx));
+            if (gi & 4) unsafeAtomicAdd(gp + (long long)W * C, gm * (ly * hx));
+            if (gi & 8) unsafeAtomicAdd(gp + (long long)W * C + C, gm * (ly * lx));
+        }
     }
 }
 
@@ -212,13 +361,17 @@ extern "C" int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols,
 extern "C" int gssd_dcn_col2im_f32(const float* x, const float* om, const float* dcols, float* dx, float* dom, int B, int H,
                                    int W, int C, int dg, int om_stride, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && om && dcols && dx && dom && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0);
-    GSSD_CHECK_ARG(C % dg == 0 && (C / dg) % 64 == 0 && om_stride >= 27 * dg);
+    GSSD_CHECK_ARG(C % dg == 0 && (C / dg) % 64 == 0 && om_stride >= 27 * dg && H < 32768 && W < 32768);
+    GSSD_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dcols % 16) == 0);
     constexpr int TH = 4, TW = 8;
     const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
     const long long blocks = (long long)B * tiles_y * tiles_x * (C / 64);
     GSSD_CHECK_ARG(blocks < (1ll << 31));
-    hipLaunchKernelGGL((dcn_col2im_kernel<TH, TW>), dim3((int)blocks), dim3(64), 0, as_stream(stream), x, om, dcols, dx, dom, B, H, W, C,
+    hipLaunchKernelGGL((dcn_col2im_kernel<TH, TW>), dim3((int)blocks), dim3(128), 0, as_stream(stream), x, om, dcols, dx, dom, B, H, W, C,
                        dg, om_stride, tiles_y, tiles_x);
+    GSSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL((dcn_col2im_overflow_kernel<TH, TW>), dim3((int)blocks), dim3(64), 0, as_stream(stream), x, om, dcols, dx, dom, B,
+                       H, W, C, dg, om_stride, tiles_y, tiles_x);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

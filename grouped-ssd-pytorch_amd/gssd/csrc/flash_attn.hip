@@ -196,6 +196,154 @@ int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, i
     return GSSD_OK;
 }
 
+
+// ---- bf16 storage mode (configs[4]): fp32 logits, bf16 values -------------------------------------------------------------
+// theta / phi stay fp32 (a logit of magnitude ~50 rounded to bf16 would move its probability by tens of percent) and S^T = K . Q^T
+// stays on the fp32 matrix cores; the value product -- 80 % of the block's FLOPs -- runs on v_mfma_f32_16x16x32_bf16 with P rounded
+// to bf16 and g stored bf16.  The lane (q, kq) holds P for keys 16 kt + 4 kq + {0..3} of two adjacent 16-key tiles = the 8 k-values
+// of one bf16 MFMA if that MFMA's k index is DEFINED as k = 8 kq + e  <->  key 32 t + 16 (e >> 2) + 4 kq + (e & 3); the producer
+// conv writes g^T with the keys of every 32-block in that order (GSSD_CONV_OUTB_BF16_PERM32), so a lane's 8 values of V are one
+// contiguous 16-byte ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+template <int D, int C2, int BKV>
+__global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* __restrict__ tp, const u16* __restrict__ gT,
+                                                                  u16* __restrict__ out, int N, int Np32, int qtiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ks = smem;                                            // [BKV][D] fp32
+    u16* const Vs = reinterpret_cast<u16*>(smem + BKV * D);            // [C2][BKV] bf16, keys permuted inside 32-blocks
+    constexpr int QRK = D / 4, UV = BKV / 8;                           // 16-byte units per K row / per V row
+    constexpr int SWK = (QRK < 16 ? QRK : 16) - 1, SWV = UV - 1;
+    constexpr int KT = BKV / 16, KB = BKV / 32, CT = C2 / 16, DI = D / 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x / qtiles, qt = blockIdx.x - b * qtiles;
+    const int q = qt * 64 + wave * 16 + r;
+    const float* tpb = tp + (size_t)b * N * (2 * D);
+    const u16* gTb = gT + (size_t)b * C2 * Np32;
+
+    f32x4 qf[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i)
+        qf[i] = (q < N) ? *reinterpret_cast<const f32x4*>(tpb + (size_t)q * (2 * D) + 16 * i + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (N + BKV - 1) / BKV;
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * BKV;
+        __syncthreads();
+        stage_tile<BKV, QRK>(Ks, wave, lane,
+                             [&](int row) { return key0 + row < N ? tpb + (size_t)(key0 + row) * (2 * D) + D : (const float*)nullptr; },
+                             [&](int) { return true; });
+        {   // V tile: C2 rows of BKV bf16 (UV 16-byte units), unit' = unit ^ (row & SWV)
+            constexpr int RPP = 64 / UV, PIECES = C2 / RPP;
+            const int row_in = lane / UV, slot = lane % UV;
+#pragma unroll
+            for (int p0 = 0; p0 < PIECES; p0 += 4) {
+                const int piece = p0 + wave;
+                const int row = piece * RPP + row_in;
+                const int unit = slot ^ (row & SWV);
+                const bool ok = key0 + 8 * unit < Np32;
+                const float* src = ok ? reinterpret_cast<const float*>(gTb + (size_t)row * Np32 + key0 + 8 * unit) : g_zero16;
+                dma16(src, reinterpret_cast<float*>(Vs) + piece * 256);
+            }
+        }
+        __syncthreads();
+
+        f32x4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            f32x4 kf[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int row = kt * 16 + r;
+                kf[kt] = *reinterpret_cast<const f32x4*>(Ks + row * D + (((4 * i + kq) ^ (row & SWK)) << 2));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][e], qf[i][e], s[kt], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (key0 + kt * 16 + 4 * kq + e >= N) s[kt][e] = -INFINITY;
+                mx = fmaxf(mx, s[kt][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x8 pb[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 p = (__bf16)__expf(s[2 * kb + (e >> 2)][e & 3] - m_new);
+                pb[kb][e] = p;
+                psum += (float)p;                    // the denominator sums the ROUNDED probabilities the numerator uses
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o[c] *= alpha;
+        constexpr int CG = CT < 4 ? CT : 4;
+#pragma unroll
+        for (int cg = 0; cg < CT; cg += CG) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                bf16x8 vf[CG];
+#pragma unroll
+                for (int cc = 0; cc < CG; ++cc) {
+                    const int row = (cg + cc) * 16 + r;
+                    vf[cc] = *reinterpret_cast<const bf16x8*>(Vs + row * BKV + (((4 * kb + kq) ^ (row & SWV)) << 3));
+                }
+#pragma unroll
+                for (int cc = 0; cc < CG; ++cc) o[cg + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cc], pb[kb], o[cg + cc], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_run;
+    if (q < N) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        u16* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const f32x4 v = o[c] * inv;
+            *reinterpret_cast<bf16x4*>(dst + 16 * c) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+    }
+}
+
+template <int D, int C2, int BKV>
+int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np32, hipStream_t stream) {
+    constexpr int smem = BKV * D * (int)sizeof(float) + C2 * BKV * (int)sizeof(u16);
+    static unsigned attr_mask = 0;
+    auto kern = flash_attn_mixed_kernel<D, C2, BKV>;
+    if (gssd_attr_needed(&attr_mask) &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
+        return GSSD_ELAUNCH;
+    }
+    const int qtiles = (N + 63) / 64;
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
 }  // namespace
 
 extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out_v, int B, int N, int Np, int D, int C2,
@@ -212,5 +360,20 @@ extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* o
     if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);     // small maps (Self_Attn(64): op-level tests)
     if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
     gssd_set_error("self-attention core: unsupported (theta/phi channels %d, g channels %d); built: (64,256) (128,512) (32,128) (<=16,32|64)", D, C2);
+    return GSSD_EINVAL;
+}
+
+extern "C" int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,
+                                         gssd_stream_t stream) {
+    GSSD_CHECK_ARG(tp && gT_bf16 && out_bf16 && B > 0 && N > 0 && Np32 >= N && Np32 % 32 == 0);
+    GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)gT_bf16 % 16) == 0 && ((uintptr_t)out_bf16 % 8) == 0);
+    GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
+    hipStream_t s = as_stream(stream);
+    const u16* g = reinterpret_cast<const u16*>(gT_bf16);
+    u16* o = reinterpret_cast<u16*>(out_bf16);
+    if (D == 64 && C2 == 256) return launch_mixed<64, 256, 64>(tp, g, o, B, N, Np32, s);
+    if (D == 128 && C2 == 512) return launch_mixed<128, 512, 32>(tp, g, o, B, N, Np32, s);
+    if (D == 32 && C2 == 128) return launch_mixed<32, 128, 64>(tp, g, o, B, N, Np32, s);
+    gssd_set_error("self-attention core (bf16 values): unsupported (theta/phi channels %d, g channels %d)", D, C2);
     return GSSD_EINVAL;
 }

@@ -1,0 +1,345 @@
+// Large 1x1 convolutions / plain GEMMs on the fp32 matrix cores as ONE slot-scheduled instruction stream (the structure that took
+// the fused deformable conv from 0.55 to 0.76 of the fp32 peak, csrc/dcn_fused.hip, without its gather):
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * Wp[n][k] ),   A = NHWC activations (row stride in_stride), Wp = K-major weight rows
+//
+// A 256-thread workgroup (2 x 2 waves, ONE per CU, one wave per SIMD) owns BM = 128 rows x BN = 256 columns; a wave owns 64 x 128
+// = 4 x 8 tiles of v_mfma_f32_16x16x4_f32 (128 accumulator registers).  K runs in chunks of 32 floats: both tiles of chunk ch+1 land
+// in the other LDS stage by 16-byte LDS-DMA (8 rows x 128 B per wave instruction, source-side XOR swizzle: slot' = slot ^ (row & 7),
+// so every ds_read_b128 fragment read is conflict free) while the 256 MFMAs of chunk ch run.  Every staging instruction sits behind
+// a specific MFMA ("slot") and a scheduling fence after each slot keeps hipcc from regrouping them:
+//   0..11    second-half (k 16..31) fragment reads of this chunk        12, 14, .. 34    the 12 DMA pieces of the next chunk
+//   192      the chunk's single barrier                                 194..205        first-half fragment reads of the NEXT chunk
+// Compared with conv_igemm<128x64/128> (2-3 workgroups per CU, barrier at the chunk end, 0.57 of peak) the MFMA pipe never waits for
+// a barrier or a fragment read, and the 128 x 256 tile moves 0.19 B of LDS-DMA per FLOP instead of 0.38.
+// Taken for: KH = KW = 1, stride 1, groups 1, K % 32 == 0, no fused input transform, no split-K, wide enough (see gssd_try_gemm_slot);
+// everything else stays on conv_igemm.  Epilogue = conv_igemm's (alpha, bias, gate / residual / second output, ReLU, transposed and
+// split-transposed stores, BatchNorm statistics).
+#include <type_traits>
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 256, BK = 32;
+constexpr int WTM = 64, WTN = 128, MT = WTM / 16, NT = WTN / 16;
+constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK;
+constexpr int LDS_FLOATS = 2 * (A_STAGE + B_STAGE);
+#ifndef DMA_EVERY
+#define DMA_EVERY 2
+#endif
+
+__device__ __attribute__((aligned(16))) float g_zero_gs[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                     // [2][BM][32]
+    float* const Bs = smem + 2 * A_STAGE;       // [2][BN][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    // XCD-aware tile order: workgroup id L runs on XCD L & 7; when the N-tile count divides 8 an XCD keeps ONE weight slab and walks
+    // M tiles, otherwise consecutive ids share the M tile (A rows from that L2)
+    int mt, nt;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        if (8 % ntn == 0) {
+            nt = xcd % ntn;
+            mt = slot * (8 / ntn) + xcd / ntn;
+        } else {
+            const int id = slot * 8 + xcd;
+            nt = id % ntn;
+            mt = id / ntn;
+        }
+    }
+    if (mt >= mtiles) return;
+    const int img = p.m_per_image ? blockIdx.z : 0;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int K = p.K;
+    const int nchunks = K / BK;
+    const float* __restrict__ in = p.in + (size_t)img * p.in_batch_stride + p.in_ch_off;
+    const float* __restrict__ wgt = p.wgt + (size_t)img * p.wgt_batch_stride;
+
+    // DMA lane roles: lane L lands at (row_in = L >> 3, slot = L & 7) of its 8-row piece and fetches logical k-quad slot ^ row_in
+    const int row_in = lane >> 3;
+    const int lq = (lane & 7) ^ row_in;
+    const float* a_src[4];
+    int a_step[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 4 + wave) * 8 + row_in;
+        const bool ok = m < M;
+        a_src[j] = ok ? in + (size_t)m * p.in_stride + 4 * lq : g_zero_gs;
+        a_step[j] = ok ? BK : 0;
+    }
+    const float* b_src[8];
+    int b_step[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + (j * 4 + wave) * 8 + row_in;
+        const bool ok = n < p.Cout;
+        b_src[j] = ok ? wgt + (size_t)n * p.wgt_row_stride + 4 * lq : g_zero_gs;
+        b_step[j] = ok ? BK : 0;
+    }
+
+    f32x4 acc[MT][NT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
+
+    const int fo0 = r * BK + ((kq ^ (r & 7)) << 2);
+    const int fo1 = r * BK + (((4 + kq) ^ (r & 7)) << 2);
+
+    // ---- prologue: chunk 0 -------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dma16(a_src[j], As + (j * 4 + wave) * 256);
+        a_src[j] += a_step[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dma16(b_src[j], Bs + (j * 4 + wave) * 256);
+        b_src[j] += b_step[j];
+    }
+    __syncthreads();
+
+    f32x4 af[2][MT], bf[2][NT];
+    float* a_dst = nullptr;
+    float* b_dst = nullptr;
+    auto slot = [&](auto kc, auto stage_c, const float* Ab, const float* Bb, const float* Abn, const float* Bbn) {
+        constexpr int KK = decltype(kc)::value;
+        constexpr bool stage = decltype(stage_c)::value;
+        constexpr int ks = KK >> 7, s = (KK >> 5) & 3, i = (KK >> 3) & 3, j = KK & 7;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
+        if constexpr (KK < 4) af[1][KK] = *reinterpret_cast<const f32x4*>(Ab + KK * 16 * BK + fo1);
+        if constexpr (KK >= 4 && KK < 12) bf[1][KK - 4] = *reinterpret_cast<const f32x4*>(Bb + (KK - 4) * 16 * BK + fo1);
+        if constexpr (stage) {
+            if constexpr (KK >= 12 && KK < 12 + 12 * DMA_EVERY && (KK - 12) % DMA_EVERY == 0) {
+                constexpr int n = (KK - 12) / DMA_EVERY;
+                if constexpr (n < 4) {
+                    dma16(a_src[n], a_dst + n * 1024);
+                    a_src[n] += a_step[n];
+                } else {
+                    dma16(b_src[n - 4], b_dst + (n - 4) * 1024);
+                    b_src[n - 4] += b_step[n - 4];
+                }
+            }
+            // the ONE barrier of the chunk sits inside the MFMA stream: both tiles of chunk ch+1 are in LDS, the k 0..15 fragment
+            // registers are dead since slot 127 -> they are refilled for chunk ch+1 while the k 16..31 MFMAs of this chunk still run
+            if constexpr (KK == 192) __syncthreads();
+            if constexpr (KK >= 194 && KK < 198) af[0][KK - 194] = *reinterpret_cast<const f32x4*>(Abn + (KK - 194) * 16 * BK + fo0);
+            if constexpr (KK >= 198 && KK < 206) bf[0][KK - 198] = *reinterpret_cast<const f32x4*>(Bbn + (KK - 198) * 16 * BK + fo0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    {
+        const float* Ab = As + wm * WTM * BK;
+        const float* Bb = Bs + wn * WTN * BK;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * BK + fo0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 16 * BK + fo0);
+    }
+    for (int ch = 0; ch < nchunks - 1; ++ch) {
+        const int buf = ch & 1;
+        a_dst = As + (buf ^ 1) * A_STAGE + wave * 256;
+        b_dst = Bs + (buf ^ 1) * B_STAGE + wave * 256;
+        const float* Ab = As + buf * A_STAGE + wm * WTM * BK;
+        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BK;
+        const float* Abn = As + (buf ^ 1) * A_STAGE + wm * WTM * BK;
+        const float* Bbn = Bs + (buf ^ 1) * B_STAGE + wn * WTN * BK;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 256>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
+    }
+    {
+        const int buf = (nchunks - 1) & 1;
+        const float* Ab = As + buf * A_STAGE + wm * WTM * BK;
+        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BK;
+        static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
+    }
+
+    // ---- epilogue (conv_igemm's, groups == 1, no split-K, no head layout).  One workgroup per CU: nothing overlaps this phase, so the
+    //      common store path is kept to one FMA + one store per element (row pointers hoisted, statistics only when asked for) ------
+    const float gate = p.gate ? *p.gate : 0.f;
+    const bool want_stats = p.stats != nullptr;
+    const bool plain = p.out_mode == GSSD_OUT_NHWC && !p.gate && !p.resid;
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = 0.f;
+    float biasv[NT], alphav[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + r;
+        nok[j] = n < p.Cout;
+        biasv[j] = (p.bias && nok[j]) ? p.bias[n] : 0.f;
+        alphav[j] = (p.alpha && nok[j]) ? p.alpha[n] : 1.f;
+    }
+    if (plain) {
+        float* const obase = p.out + (size_t)img * p.out_batch_stride + p.out_ch_off + n0 + wn * WTN + r;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * WTM + i * 16 + kq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool mok = mb + e < M;
+                float* const orow = obase + (size_t)(mb + e) * p.out_stride;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float t = __builtin_fmaf(acc[i][j][e], alphav[j], biasv[j]);
+                    if (want_stats && mok && nok[j]) {
+                        ssum[j] += t;
+                        ssq[j] = __builtin_fmaf(t, t, ssq[j]);
+                    }
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (mok && nok[j]) orow[j * 16] = t;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + r;
+        const bool n_ok = nok[j];
+        const float bias = biasv[j], alpha = alphav[j];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * WTM + i * 16 + kq * 4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[i][j][e] * alpha + bias;
+                if (want_stats && mb + e < M && n_ok) {
+                    ssum[j] += v[e];
+                    ssq[j] += v[e] * v[e];
+                }
+            }
+            if (!n_ok) continue;
+            if (p.out_mode == GSSD_OUT_SPLIT_T && n >= p.split_n) {
+                if (mb < p.out_b_stride) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (mb + e < M) ? v[e] : 0.f;
+                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)img * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + mb) = o;
+                }
+            } else if (p.out_mode == GSSD_OUT_TRANSPOSED) {
+                if (mb < p.out_stride) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e];
+                        if (p.relu) t = fmaxf(t, 0.f);
+                        o[e] = (mb + e < M) ? t : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)img * p.out_batch_stride + (size_t)n * p.out_stride + mb) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = mb + e;
+                    if (m >= M) continue;
+                    float t = v[e];
+                    const size_t o = (size_t)img * p.out_batch_stride + (size_t)m * p.out_stride + p.out_ch_off + n;
+                    if (p.gate) {
+                        t *= gate;
+                        if (p.out2) p.out2[o] = t;
+                        if (p.resid) t += p.resid[o];
+                    } else if (p.resid) {
+                        t += p.resid[o];
+                    }
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    p.out[o] = t;
+                }
+            }
+        }
+    }
+    }
+    if (p.stats) {
+        // per-channel sum / sum^2 over this tile's rows: lanes sharing (lane & 15) -> LDS over wm -> fp64 atomics
+        __syncthreads();
+        float* red = smem;  // [2][BN][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = ssum[j], q = ssq[j];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (kq == 0) {
+                red[(wm * BN + wn * WTN + j * 16 + r) * 2 + 0] = s;
+                red[(wm * BN + wn * WTN + j * 16 + r) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (n0 + tid < p.Cout) {
+            const double s = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
+            const double q = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+            unsafeAtomicAdd(p.stats + n0 + tid, s);
+            unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, q);
+        }
+    }
+}
+
+}  // namespace
+
+static bool slot_shape(const gssd_conv_desc& d) {
+    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.groups != 1 || d.split_k != 1) return false;
+    if (d.in_scale || d.out_mode == GSSD_OUT_HEADS || d.K % BK != 0 || d.K < 2 * BK) return false;
+    if (d.out_mode == GSSD_OUT_SPLIT_T && (d.split_n % 16 != 0)) return false;
+    const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
+    const int images = d.m_per_image ? d.B : 1;
+    const int ntn = (d.Cout + BN - 1) / BN, mtiles = (int)((M + BM - 1) / BM);
+    // worth it when the 128 x 256 tiles are mostly full and the grid fills the 256 CUs about as well as the 128 x 64 / 128 x 128
+    // tiling would: column fill >= 0.9, and (last-round fill) x (column fill) >= 0.8 (one workgroup per CU;
+    // measured cross-over against conv_igemm's 2-3 resident workgroups, scripts/bench_gemm.py)
+    const double nfill = (double)d.Cout / (double)(ntn * BN);
+    const long long wgs = (long long)mtiles * ntn * images;
+    const double rounds = (double)wgs / 256.0;
+    const double qfill = rounds / (double)(long long)(rounds + 0.999999);
+    return nfill >= 0.9 && qfill * nfill >= 0.80;
+}
+
+extern "C" int gssd_gemm_slot_takes(const gssd_conv_desc* d) { return d && slot_shape(*d) ? 1 : 0; }
+
+// returns 1 when the descriptor is not a large plain 1x1 / GEMM shape (the caller falls through to conv_igemm)
+int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream) {
+    if (!slot_shape(d)) return 1;
+    const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
+    const int images = d.m_per_image ? d.B : 1;
+    const int ntn = (d.Cout + BN - 1) / BN, mtiles = (int)((M + BM - 1) / BM);
+    static unsigned attr_mask = 0;
+    constexpr int smem = LDS_FLOATS * (int)sizeof(float);
+    if (gssd_attr_needed(&attr_mask) &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
+        return GSSD_ELAUNCH;
+    }
+    int blocks;
+    if (8 % ntn == 0) {
+        const int per = 8 / ntn;
+        blocks = ((mtiles + per - 1) / per) * 8;
+    } else {
+        blocks = ((mtiles * ntn + 7) / 8) * 8;
+    }
+    hipLaunchKernelGGL(gemm_slot_kernel, dim3(blocks, 1, images), dim3(256), smem, stream, d, (int)M, ntn, mtiles);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

@@ -547,15 +547,20 @@ class _Plan(_PlanBase):
         b_tpg = eng._pack(name + '.tpg.b', build_b)
         # the o conv's weight is already K-major rows; bf16 mode keeps a rounded copy
         w_o = eng._pack(name + '.o.w', build_wo) if self.bf16 else sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2)
-        tp = self._buf(B, N, C4)               # theta | phi and g^T stay fp32: the softmax core is fp32 in both modes
-        gT = self._buf(B, C2, Np)
+        tp = self._buf(B, N, C4)               # theta | phi stay fp32 in both modes: the logits and the softmax are fp32
+        if self.bf16:                          # g^T bf16, rows in the key order of the bf16-value core (csrc/flash_attn.hip)
+            Np = ops.round_up(N, 32)
+            gT = self._abuf(B, C2, Np)
+        else:
+            gT = self._buf(B, C2, Np)
         ag = self._abuf(B, N, C2)
         out = self._abuf(B, H, H, Cc)
         out2 = self._abuf(B, H, H, Cc) if need_out2 else None
         mk = ops.make_conv_desc
         d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg,
                       out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=True,
-                      in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np, flags=_lib.CONV_OUT_F32)
+                      in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np,
+                      flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else 0))
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
                       alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2)
         fn = self.conv_fn
@@ -572,8 +577,12 @@ class _Plan(_PlanBase):
                            out_batch_stride=C2 * Np)
             self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
             self._add(fn, (C.byref(d1b),), keep=d1b)
-        self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2, int(self.bf16)),
-                  tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
+        if self.bf16:
+            self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
+                      tag=(f'flash_attn_bf16v<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), B * (4.0 * N * C4 + 2.0 * C2 * Np + 2.0 * N * C2)))
+        else:
+            self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2, 0),
+                      tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
         S = None
         if want_map:
             # attn[b,i,j] = softmax_j(sum_c theta[b,i,c] * phi[b,j,c])   (no 1/sqrt(d) scaling, self_attn.py:71-72)

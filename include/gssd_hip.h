@@ -127,6 +127,9 @@ int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
  * flags & GSSD_CONV_OUT_F32: `out` (and `out_b`) are fp32 -- required for GSSD_OUT_HEADS (loc / conf stay fp32 for the loss and
  * NMS), GSSD_OUT_TRANSPOSED and GSSD_OUT_SPLIT_T (the Self_Attn projections feed the fp32 softmax core). */
 #define GSSD_CONV_OUT_F32 1
+/* GSSD_OUT_SPLIT_T only: the transposed second range (`out_b`) is bf16, its rows out_b_stride (a multiple of 32) elements long, and
+ * inside every block of 32 tokens token 16a + 4b + c sits at position 8b + 4a + c (the key order of gssd_self_attn_core_bf16v) */
+#define GSSD_CONV_OUTB_BF16_PERM32 2
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,
@@ -228,6 +231,16 @@ int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pix
  * Built for (D, C2) = (64, 256), (128, 512), (32, 128) -- Self_Attn on 512 / 1024 / 256 channels. */
 int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out, int B, int N, int Np, int D, int C2, int out_bf16,
                             gssd_stream_t stream); /* out_bf16 != 0: `out` is bf16 (configs[4]); the softmax is fp32 either way */
+
+/* 1 when gssd_conv2d_nhwc_f32 runs this descriptor on the slot-scheduled 128 x 256 GEMM stream (csrc/gemm_slot.hip: large plain
+ * 1x1 convolutions / GEMMs), 0 when it stays on the generic implicit-GEMM kernel.  Host logic only. */
+int gssd_gemm_slot_takes(const gssd_conv_desc* d);
+
+/* bf16-storage variant (configs[4]): theta | phi fp32 and the logits on the fp32 matrix cores (a bf16 logit would move its
+ * probability by tens of percent), g^T and the probabilities bf16 on v_mfma_f32_16x16x32_bf16 (80 % of the block's FLOPs), out bf16.
+ * gT rows are Np32 (multiple of 32) bf16 long with the token order of GSSD_CONV_OUTB_BF16_PERM32. */
+int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,
+                              gssd_stream_t stream);
 
 /* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
  * Replaces nn.Softmax(dim=-1) on the attention logits (layers/self_attn.py:72). */

@@ -290,7 +290,9 @@ def spectral_weight(w_orig, u, v, training, eps=1e-12):
 
 def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None, q=None):
     """layers/self_attn.py:46-89.  Returns (out, sigma*attn_g, attn).  ``q`` (bf16 mode): the 1x1 weights are stored rounded
-    (1/sigma is applied in fp32 afterwards), theta / phi / g and the softmax stay fp32, attn.g and both outputs are stored rounded."""
+    (1/sigma is applied in fp32 afterwards), theta / phi and the logits stay fp32, g and the UNNORMALISED probabilities
+    exp(s - max) are rounded (the value product runs on the bf16 matrix cores, the denominator sums the rounded probabilities),
+    attn.g and both outputs are stored rounded."""
     B, ch, h, w = x.shape
     ws = {}
     for name in ('theta', 'phi', 'g', 'attn'):
@@ -309,9 +311,12 @@ def self_attn(x, sd, prefix, training, max_pool_factor=1, updates=None, q=None):
     phi = phi.view(B, ch // 8, -1)
     attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
     g = F.adaptive_avg_pool2d(F.conv2d(x, *ws['g']), pool).view(B, ch // 2, -1)
-    attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(B, ch // 2, h, w)
     if q is not None:
-        attn_g = q(attn_g)
+        s = torch.bmm(theta.permute(0, 2, 1), phi)
+        p = q(torch.exp(s - s.max(dim=-1, keepdim=True).values))
+        attn_g = q((torch.bmm(q(g), p.permute(0, 2, 1)) / p.sum(dim=-1).unsqueeze(1)).view(B, ch // 2, h, w))
+    else:
+        attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(B, ch // 2, h, w)
     attn_g = F.conv2d(attn_g, *ws['attn'])
     sig = sd[prefix + '.sigma']
     if q is not None:

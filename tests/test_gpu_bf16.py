@@ -317,3 +317,32 @@ def test_bf16_is_forward_only(dev):
     loc, conf, _ = net(synth.synth_images(2, seed=1).to(dev))
     with pytest.raises((GssdError, RuntimeError)):
         loc.sum().backward()
+
+
+@pytest.mark.parametrize('N,D,C2', [(38 * 38, 64, 256), (19 * 19, 128, 512), (100, 32, 128), (9, 32, 128), (1, 64, 256)])
+def test_self_attn_core_bf16_values(dev, N, D, C2):
+    """gssd_self_attn_core_bf16v (csrc/flash_attn.hip): fp32 logits, bf16 probabilities and values.  Checked against fp32
+    arithmetic on the operands the kernel multiplies: softmax numerators rounded to bf16, g rounded to bf16 (oracle self_attn,
+    q mode), within one bf16 ulp of the block's largest output; g^T handed over in the kernel's 32-token key order."""
+    from gssd import _lib
+    lib = _lib.lib
+    B = 2
+    gen = torch.Generator().manual_seed(5 + N)
+    tp = torch.randn(B, N, 2 * D, generator=gen) * 0.9
+    g = torch.randn(B, C2, N, generator=gen)
+    Np = (N + 31) // 32 * 32
+    m = torch.arange(Np)
+    perm = (m & ~31) | (((m >> 2) & 3) << 3) | (((m >> 4) & 1) << 2) | (m & 3)
+    gp = torch.zeros(B, C2, Np)
+    gp[:, :, perm[:N]] = g
+    d_tp, d_g = tp.to(dev), gp.to(dev).to(torch.bfloat16)
+    out = torch.full((B, N, C2), float('nan'), device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.gssd_self_attn_core_bf16v(d_tp.data_ptr(), d_g.data_ptr(), out.data_ptr(), B, N, Np, D, C2,
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    s = torch.bmm(tp[:, :, :D].double(), tp[:, :, D:].double().transpose(1, 2))
+    p = q(torch.exp(s - s.max(dim=-1, keepdim=True).values).float()).double()
+    ref = torch.bmm(p, q(g).double().transpose(1, 2)) / p.sum(dim=-1, keepdim=True)
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max() / ref.abs().max()) <= BF_ULP_LOW

@@ -1298,3 +1298,67 @@ def test_test_net_dropin(dev):
     from oracle import eval_oracle as EO
     for m in (True, False):
         assert abs(T.voc_ap(rec, prec, m) - EO.voc_ap(rec, prec, m)) < 1e-15
+
+
+@pytest.mark.parametrize('case', ['bn_relu', 'gate_resid', 'split_t', 'ragged'])
+def test_gemm_slot(dev, ops, case):
+    """csrc/gemm_slot.hip (large plain 1x1 convs / GEMMs: 128 x 256 slot-scheduled MFMA stream) through gssd_conv2d_nhwc_f32: every
+    epilogue it carries, checked against fp32 matmul on the CPU, after asserting the dispatcher really takes the slot kernel."""
+    from gssd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    t = lambda *s, sc=1.0: torch.from_numpy(rng.normal(0, sc, size=s).astype(np.float32))
+    if case == 'bn_relu':                     # alpha + bias + ReLU + BatchNorm statistics, M a tile multiple + tail
+        B, H, K, N = 10, 38, 512, 512
+        x, w, b, al = t(B, H, H, K), t(N, K, sc=0.05), t(N), t(N).abs() + 0.5
+        out = torch.empty(B, H, H, N, device=dev)
+        stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+        keep = [x.to(dev), w.to(dev), b.to(dev), al.to(dev)]
+        d, _, _ = ops.make_conv_desc(keep[0], keep[1], out, B=B, H=H, W=H, in_stride=K, cin_g=K, Cout=N, bias=keep[2], alpha=keep[3],
+                                     relu=True, stats=stats)
+        assert _lib.lib.gssd_gemm_slot_takes(C.byref(d)) == 1
+        ops.run_conv(d)
+        pre = (x.view(-1, K) @ w.t()) * al + b
+        assert rel(out.view(-1, N), pre.clamp_min(0)) < TOL
+        assert rel(stats[:N], pre.double().sum(0)) < 1e-5 and rel(stats[N:], (pre.double() ** 2).sum(0)) < 1e-5
+    elif case == 'gate_resid':                # the attention output conv: sigma gate, second output, residual
+        B, H, K, N = 10, 38, 256, 512
+        x, w, b, res, g = t(B, H, H, K), t(N, K, sc=0.05), t(N), t(B, H, H, N), torch.tensor([0.37])
+        out, out2 = torch.empty(B, H, H, N, device=dev), torch.empty(B, H, H, N, device=dev)
+        keep = [x.to(dev), w.to(dev), b.to(dev), res.to(dev), g.to(dev)]
+        d, _, _ = ops.make_conv_desc(keep[0], keep[1], out, B=B, H=H, W=H, in_stride=K, cin_g=K, Cout=N, bias=keep[2], gate=keep[4],
+                                     resid=keep[3], out2=out2)
+        assert _lib.lib.gssd_gemm_slot_takes(C.byref(d)) == 1
+        ops.run_conv(d)
+        o2 = ((x.view(-1, K) @ w.t()) + b) * 0.37
+        assert rel(out2.view(-1, N), o2) < TOL and rel(out.view(-1, N), o2 + res.view(-1, N)) < TOL
+    elif case == 'split_t':                   # merged theta | phi | g projection: per image, g written transposed
+        B, H, K, C4, C2 = 34, 37, 512, 256, 256          # 1369 tokens: the transposed rows carry 3 pad columns
+        Nn = H * H
+        Np = (Nn + 3) // 4 * 4
+        x, w, b = t(B, Nn, K), t(C4 + C2, K, sc=0.05), t(C4 + C2)
+        tp = torch.empty(B, Nn, C4, device=dev)
+        gT = torch.full((B, C2, Np), float("nan"), device=dev)
+        keep = [x.to(dev), w.to(dev), b.to(dev)]
+        d, _, _ = ops.make_conv_desc(keep[0], keep[1], tp, B=B, H=H, W=H, in_stride=K, cin_g=K, Cout=C4 + C2, bias=keep[2],
+                                     out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=True,
+                                     in_batch_stride=Nn * K, out_batch_stride=Nn * C4, outb_batch_stride=C2 * Np)
+        assert _lib.lib.gssd_gemm_slot_takes(C.byref(d)) == 1
+        ops.run_conv(d)
+        ref = x @ w.t() + b
+        assert rel(tp, ref[:, :, :C4]) < TOL
+        assert rel(gT[:, :, :Nn], ref[:, :, C4:].transpose(1, 2)) < TOL
+        assert float(gT[:, :, Nn:].abs().max()) == 0.0
+    else:                                     # ragged: M tail, 480 of 512 columns, K = 96, strided input / output channel windows
+        B, H, K, N = 11, 37, 96, 480
+        xs, os_ = K + 32, N + 64
+        x, w = t(B, H, H, xs), t(N, K, sc=0.05)
+        out = torch.full((B, H, H, os_), 7.0, device=dev)
+        keep = [x.to(dev), w.to(dev)]
+        d, _, _ = ops.make_conv_desc(keep[0], keep[1], out, B=B, H=H, W=H, in_stride=xs, in_ch_off=16, cin_g=K, Cout=N, out_stride=os_,
+                                     out_ch_off=32)
+        assert _lib.lib.gssd_gemm_slot_takes(C.byref(d)) == 1
+        ops.run_conv(d)
+        ref = x[..., 16:16 + K].reshape(-1, K) @ w.t()
+        assert rel(out.view(-1, os_)[:, 32:32 + N], ref) < TOL
+        assert float((out.view(-1, os_)[:, :32] - 7.0).abs().max()) == 0.0 and float((out.view(-1, os_)[:, 32 + N:] - 7.0).abs().max()) == 0.0
