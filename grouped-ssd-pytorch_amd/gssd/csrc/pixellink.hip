@@ -1,0 +1,376 @@
+// PixelLink++ tail for gfx950: everything of ssd_liverdet/pixel_link that the GSSD++ kernels do not already
+// cover.  The trunk, Self_Attn, the deformable conv, fuse conv + BatchNorm and the 1x1 score heads are launches of the existing
+// kernels (gssd/pixellink.py); this file holds
+//   - the upsample-add cascade (pixel_link/model.py:341-400): bilinear, align_corners=True, NHWC, the 2 pixel + 16 link channels of
+//     a stage travel as ONE 18-channel map (every cascade op is channel-wise), fused with the lateral add;
+//   - the final 1x1 convs over the concatenated cascade features, written NCHW like the reference returns them;
+//   - PixelLinkLoss (pixel_link/criterion.py:24-104): OHEM pixel loss (k-th smallest background probability by a bitonic sort in LDS)
+//     and the link loss, one workgroup per image, fp64 sums;
+//   - the link decoding of pixel_link/postprocess.py:178-234 (`func`): connected components under directed 8-neighbour links by
+//     min-label propagation in LDS, numbered in raster order of their first pixel exactly like the union-find + root_map of the
+//     reference, plus per-component pixel count, bounding box and score sum.
+// HBM-bound byte work on <= 75 x 75 maps: one workgroup per image (or per row block), no MFMA.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+// out = interp(src) [+ addend -> out2]; src [B][Hs][Ws][C], out [B][Hd][Wd][C]
+// at::native upsample_bilinear2d, align_corners=True: scale = (in - 1) / (out - 1) (0 when out == 1), src = scale * dst,
+// i0 = (int)src, i1 = i0 + (i0 < in - 1), l1 = src - i0, l0 = 1 - l1; value = h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
+__global__ __launch_bounds__(256) void interp_add_kernel(const float* __restrict__ src, const float* __restrict__ addend,
+                                                         float* __restrict__ out, float* __restrict__ out2, int B, int Hs, int Ws,
+                                                         int Hd, int Wd, int C) {
+    const long long total = (long long)B * Hd * Wd * C;
+    const float sh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+    const float sw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int x = (int)(t % Wd);
+        t /= Wd;
+        const int y = (int)(t % Hd);
+        const int b = (int)(t / Hd);
+        const float fy = sh * (float)y, fx = sw * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+        const float* sb = src + (size_t)b * Hs * Ws * C + c;
+        const float p00 = sb[(size_t)(y0 * Ws + x0) * C], p01 = sb[(size_t)(y0 * Ws + x1) * C];
+        const float p10 = sb[(size_t)(y1 * Ws + x0) * C], p11 = sb[(size_t)(y1 * Ws + x1) * C];
+        const float v = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11);
+        out[i] = v;
+        if (addend) out2[i] = v + addend[i];
+    }
+}
+
+// final_1 / final_2 (model.py:360,386 / 396,411): features f[k] [B][H][W][18] (channels 0-1 pixel, 2-17 link), k < nf;
+// out1[b][o][y][x] = b1[o] + sum_{k,c<2} w1[o][k*2 + c] * f[k][..][c];  out2[b][o][y][x] = b2[o] + sum_{k,c<16} w2[o][k*16 + c] * f[k][..][2 + c]
+__global__ __launch_bounds__(256) void pl_final_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                       const float* __restrict__ f2, const float* __restrict__ f3, int nf,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ out1, float* __restrict__ out2, int B, int HW) {
+    __shared__ float sw1[2 * 8], sw2[16 * 64], sb[18];
+    for (int i = threadIdx.x; i < 2 * 2 * nf; i += 256) sw1[i] = w1[i];
+    for (int i = threadIdx.x; i < 16 * 16 * nf; i += 256) sw2[i] = w2[i];
+    if (threadIdx.x < 2) sb[threadIdx.x] = b1[threadIdx.x];
+    if (threadIdx.x >= 2 && threadIdx.x < 18) sb[threadIdx.x] = b2[threadIdx.x - 2];
+    __syncthreads();
+    const float* fs[4] = {f0, f1, f2, f3};
+    const long long total = (long long)B * HW;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        float v[4][18];
+        for (int k = 0; k < nf; ++k)
+#pragma unroll
+            for (int c = 0; c < 18; ++c) v[k][c] = fs[k][p * 18 + c];
+        const int b = (int)(p / HW), pix = (int)(p - (long long)b * HW);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float a = sb[o];
+            for (int k = 0; k < nf; ++k)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a = __builtin_fmaf(sw1[o * 2 * nf + k * 2 + c], v[k][c], a);
+            out1[((size_t)b * 2 + o) * HW + pix] = a;
+        }
+        for (int o = 0; o < 16; ++o) {
+            float a = sb[2 + o];
+            for (int k = 0; k < nf; ++k)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a = __builtin_fmaf(sw2[o * 16 * nf + k * 16 + c], v[k][2 + c], a);
+            out2[((size_t)b * 16 + o) * HW + pix] = a;
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+// ---- PixelLinkLoss ------------------------------------------------------------------------------------------------------------------
+// One workgroup (1024 threads) per image.  out[b] = {pixel_pos, pixel_neg, link_pos, link_neg, area, neg_area} per image (the
+// reference's four batch means are the means of the first four columns).
+constexpr int PL_SORT = 8192;      // >= H*W of the score map (75 x 75 = 5625)
+
+__global__ __launch_bounds__(1024) void pl_loss_kernel(const float* __restrict__ out1, const float* __restrict__ out2,
+                                                       const long long* __restrict__ pixel_t, const unsigned char* __restrict__ neg_mask,
+                                                       const float* __restrict__ pos_w, const long long* __restrict__ link_t,
+                                                       double* __restrict__ res, float* __restrict__ neg_w_out, int HW, int ratio) {
+    __shared__ float key[PL_SORT];
+    __shared__ double red[16];
+    __shared__ int s_cnt[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* l0 = out1 + (size_t)b * 2 * HW;
+    const float* l1 = l0 + HW;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    // softmax probability of class 0 (background) as nn.Softmax2d computes it: exp(x0 - m) / (exp(x0 - m) + exp(x1 - m))
+    int area = 0, ncand = 0;
+    for (int i = tid; i < PL_SORT; i += 1024) {
+        float k = INFINITY;
+        if (i < HW) {
+            const float a = l0[i], c = l1[i];
+            const float m = fmaxf(a, c);
+            const float e0 = expf(a - m), e1 = expf(c - m);
+            const float p0 = e0 / (e0 + e1);
+            if (neg_mask[(size_t)b * HW + i] == 1) {
+                k = p0;
+                ++ncand;
+            }
+            area += (int)pixel_t[(size_t)b * HW + i];
+        }
+        key[i] = k;
+    }
+    area = wave_sum(area);
+    ncand = wave_sum(ncand);
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_cnt[0], area);
+        atomicAdd(&s_cnt[1], ncand);
+    }
+    __syncthreads();
+    area = s_cnt[0];
+    ncand = s_cnt[1];
+    int r_pos = area * ratio;
+    if (r_pos == 0) r_pos = 10000;                                   // criterion.py:41-43
+    const int neg_area = min(r_pos, ncand);
+    // ascending bitonic sort of the candidate probabilities (non-candidates = +inf at the end)
+    for (int k = 2; k <= PL_SORT; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < PL_SORT; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a = key[i], c = key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) {
+                        key[i] = c;
+                        key[ixj] = a;
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    // criterion.py:46-48: topk(-p0, neg_area)[-1] = the neg_area-th smallest p0; every candidate with p0 <= it is selected (ties too)
+    const float thr = neg_area > 0 ? key[neg_area - 1] : -INFINITY;
+    __syncthreads();
+    double s_pos = 0.0, s_neg = 0.0;
+    for (int i = tid; i < HW; i += 1024) {
+        const float a = l0[i], c = l1[i];
+        const float m = fmaxf(a, c);
+        const float e0 = expf(a - m), e1 = expf(c - m);
+        const float p0 = e0 / (e0 + e1);
+        const long long t = pixel_t[(size_t)b * HW + i];
+        const float ce = (m + logf(e0 + e1)) - (t ? c : a);           // CrossEntropyLoss(reduce=False)
+        const bool sel = neg_area > 0 && p0 <= thr && neg_mask[(size_t)b * HW + i] == 1;
+        if (neg_w_out) neg_w_out[(size_t)b * HW + i] = sel ? 1.f : 0.f;
+        s_pos += (double)(pos_w[(size_t)b * HW + i] * ce);
+        if (sel) s_neg += (double)ce;
+    }
+    s_pos = block_sum(s_pos, red);
+    s_neg = block_sum(s_neg, red);
+    // link loss (criterion.py:66-104): weights = pos_pixel_weight where the link target is 1 / 0
+    double wp = 0.0, wn = 0.0, lp = 0.0, ln = 0.0;
+    for (int i = tid; i < 8 * HW; i += 1024) {
+        const int n = i / HW, pix = i - n * HW;
+        const float a = out2[((size_t)b * 16 + 2 * n) * HW + pix], c = out2[((size_t)b * 16 + 2 * n + 1) * HW + pix];
+        const float m = fmaxf(a, c);
+        const long long t = link_t[((size_t)b * 8 + n) * HW + pix];
+        const float ce = (m + logf(expf(a - m) + expf(c - m))) - (t ? c : a);
+        const float w = pos_w[(size_t)b * HW + pix];
+        if (t == 1) {
+            wp += (double)w;
+            lp += (double)(w * ce);
+        } else if (t == 0) {
+            wn += (double)w;
+            ln += (double)(w * ce);
+        }
+    }
+    wp = block_sum(wp, red);
+    wn = block_sum(wn, red);
+    lp = block_sum(lp, red);
+    ln = block_sum(ln, red);
+    if (tid == 0) {
+        const double den = (double)area + (double)neg_area;
+        res[b * 6 + 0] = s_pos / den;
+        res[b * 6 + 1] = s_neg / den;
+        res[b * 6 + 2] = wp == 0.0 ? 0.0 : lp / wp;
+        res[b * 6 + 3] = wn == 0.0 ? 0.0 : ln / wn;
+        res[b * 6 + 4] = (double)area;
+        res[b * 6 + 5] = (double)neg_area;
+    }
+}
+
+// ---- link decoding ------------------------------------------------------------------------------------------------------------------
+// postprocess.py:104-121 thresholds + `func` (:178-234).  neighbour order (get_neighbors :166-176): (-1,-1) (-1,0) (-1,+1) (0,+1)
+// (+1,+1) (+1,0) (+1,-1) (0,-1).  Two positive pixels p, q are joined when link i of p towards q is on (either direction suffices:
+// joint() is symmetric).  Label = 1 + rank of the component's first pixel in raster order.
+constexpr int PL_MAXPIX = 8192;
+
+__global__ __launch_bounds__(1024) void pl_decode_kernel(const float* __restrict__ out1, const float* __restrict__ out2,
+                                                         int* __restrict__ labels, float* __restrict__ comps, int* __restrict__ ncomp,
+                                                         int H, int W, float pixel_thr, float link_thr, int max_comp) {
+    __shared__ int lab[PL_MAXPIX];
+    __shared__ unsigned char lk[PL_MAXPIX];
+    __shared__ int changed, nroot;
+    const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
+    const int dy[8] = {-1, -1, -1, 0, 1, 1, 1, 0}, dx[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+    for (int i = tid; i < HW; i += 1024) {
+        const float a = out1[((size_t)b * 2) * HW + i], c = out1[((size_t)b * 2 + 1) * HW + i];
+        const float m = fmaxf(a, c);
+        const float e0 = expf(a - m), e1 = expf(c - m);
+        const bool pos = e1 / (e0 + e1) > pixel_thr;
+        unsigned bits = 0;
+        if (pos)
+            for (int n = 0; n < 8; ++n) {
+                const float la = out2[((size_t)b * 16 + 2 * n) * HW + i], lc = out2[((size_t)b * 16 + 2 * n + 1) * HW + i];
+                const float lm = fmaxf(la, lc);
+                const float f0 = expf(la - lm), f1 = expf(lc - lm);
+                if (f1 / (f0 + f1) > link_thr) bits |= 1u << n;
+            }
+        lk[i] = (unsigned char)bits;
+        lab[i] = pos ? i : -1;
+    }
+    __syncthreads();
+    // min-label propagation until nothing changes; an edge p - q exists when q is positive and (link p->q or link q->p) is on
+    for (int it = 0; it < HW; ++it) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < HW; i += 1024) {
+            int l = lab[i];
+            if (l < 0) continue;
+            const int y = i / W, x = i - y * W;
+            int best = l;
+            for (int n = 0; n < 8; ++n) {
+                const int yy = y + dy[n], xx = x + dx[n];
+                if (yy < 0 || xx < 0 || yy >= H || xx >= W) continue;
+                const int q = yy * W + xx;
+                const int lq = lab[q];
+                if (lq < 0) continue;
+                const bool edge = ((lk[i] >> n) & 1) || ((lk[q] >> ((n + 4) & 7)) & 1);
+                if (edge && lq < best) best = lq;
+            }
+            if (best < l) {
+                // pointer jumping: follow the smaller label's own label once
+                const int bb = lab[best];
+                lab[i] = bb >= 0 && bb < best ? bb : best;
+                changed = 1;
+            }
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    // rank the roots (lab[i] == i) in raster order: serial over <= HW by one thread per 1024-chunk would do; a block scan is simpler
+    __shared__ int cnt[1024];
+    const int per = (HW + 1023) / 1024;
+    int mine = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < HW && lab[i] == i) ++mine;
+    }
+    cnt[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const int c = cnt[t];
+            cnt[t] = run;
+            run += c;
+        }
+        nroot = run;
+    }
+    __syncthreads();
+    int base = cnt[tid];
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < HW && lab[i] == i) labels[(size_t)b * HW + i] = ++base;       // roots first
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int i = tid; i < HW; i += 1024) {
+        const int l = lab[i];
+        if (l < 0) labels[(size_t)b * HW + i] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < HW; i += 1024) {
+        const int l = lab[i];
+        if (l >= 0 && l != i) labels[(size_t)b * HW + i] = labels[(size_t)b * HW + l];
+    }
+    __syncthreads();
+    // per-component statistics: count, min x, min y, max x, max y, score sum (score = softmax probability of class 1)
+    float* cb = comps + (size_t)b * max_comp * 6;
+    for (int i = tid; i < max_comp * 6; i += 1024) {
+        const int f = i % 6;
+        cb[i] = (f == 1 || f == 2) ? 1e9f : (f == 3 || f == 4) ? -1.f : 0.f;
+    }
+    __syncthreads();
+    __threadfence();
+    for (int i = tid; i < HW; i += 1024) {
+        const int l = lab[i];
+        if (l < 0) continue;
+        const int id = labels[(size_t)b * HW + i] - 1;
+        if (id >= max_comp) continue;
+        const int y = i / W, x = i - y * W;
+        const float a = out1[((size_t)b * 2) * HW + i], c = out1[((size_t)b * 2 + 1) * HW + i];
+        const float m = fmaxf(a, c);
+        const float e0 = expf(a - m), e1 = expf(c - m);
+        atomicAdd(cb + id * 6 + 0, 1.f);
+        atomicMin(reinterpret_cast<int*>(cb + id * 6 + 1), __float_as_int((float)x));      // non-negative floats order like ints
+        atomicMin(reinterpret_cast<int*>(cb + id * 6 + 2), __float_as_int((float)y));
+        atomicMax(reinterpret_cast<int*>(cb + id * 6 + 3), __float_as_int((float)x));
+        atomicMax(reinterpret_cast<int*>(cb + id * 6 + 4), __float_as_int((float)y));
+        atomicAdd(cb + id * 6 + 5, e1 / (e0 + e1));
+    }
+    if (tid == 0) ncomp[b] = nroot;
+}
+
+}  // namespace
+
+extern "C" int gssd_interp_add_f32(const float* src, const float* addend, float* out, float* out2, int B, int Hs, int Ws, int Hd,
+                                   int Wd, int C, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(src && out && B > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && ((addend == nullptr) == (out2 == nullptr)));
+    const long long total = (long long)B * Hd * Wd * C;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(interp_add_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, addend, out, out2, B, Hs, Ws, Hd, Wd, C);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pixellink_final_f32(const float* f0, const float* f1, const float* f2, const float* f3, int nf, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, float* out1, float* out2, int B, int HW,
+                                        gssd_stream_t stream) {
+    GSSD_CHECK_ARG(f0 && w1 && b1 && w2 && b2 && out1 && out2 && B > 0 && HW > 0 && nf >= 1 && nf <= 4);
+    GSSD_CHECK_ARG((nf < 2 || f1) && (nf < 3 || f2) && (nf < 4 || f3));
+    const long long total = (long long)B * HW;
+    hipLaunchKernelGGL(pl_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, as_stream(stream), f0, f1, f2, f3, nf, w1, b1, w2,
+                       b2, out1, out2, B, HW);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pixellink_loss_f32(const float* out1, const float* out2, const long long* pixel_target,
+                                       const unsigned char* neg_pixel_mask, const float* pixel_pos_weight, const long long* link_target,
+                                       double* per_image, float* neg_weight_out, int B, int H, int W, int neg_pos_ratio,
+                                       gssd_stream_t stream) {
+    GSSD_CHECK_ARG(out1 && out2 && pixel_target && neg_pixel_mask && pixel_pos_weight && link_target && per_image);
+    GSSD_CHECK_ARG(B > 0 && H > 0 && W > 0 && H * W <= PL_SORT && neg_pos_ratio > 0);
+    hipLaunchKernelGGL(pl_loss_kernel, dim3(B), dim3(1024), 0, as_stream(stream), out1, out2, pixel_target, neg_pixel_mask,
+                       pixel_pos_weight, link_target, per_image, neg_weight_out, H * W, neg_pos_ratio);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pixellink_decode_f32(const float* out1, const float* out2, int* labels, float* comps, int* ncomp, int B, int H,
+                                         int W, float pixel_thr, float link_thr, int max_comp, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(out1 && out2 && labels && comps && ncomp && B > 0 && H > 0 && W > 0 && H * W <= PL_MAXPIX && max_comp > 0);
+    hipLaunchKernelGGL(pl_decode_kernel, dim3(B), dim3(1024), 0, as_stream(stream), out1, out2, labels, comps, ncomp, H, W, pixel_thr,
+                       link_thr, max_comp);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

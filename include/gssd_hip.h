@@ -415,6 +415,37 @@ long long gssd_eval_workspace_bytes(int M);
 int gssd_eval_ap(const float* conf, const uint8_t* flags, int M, int n_metrics, double npos, int use_07_metric, void* workspace,
                  long long workspace_bytes, double* ap_out, gssd_stream_t stream);
 
+/* ---- PixelLink++ tail (ssd_liverdet/pixel_link) ------------------------------------------------------------
+ * The trunk / Self_Attn / DCN / fuse / score-head launches are gssd_conv2d_nhwc_f32 & co; these four are the rest. */
+
+/* out = bilinear(src -> Hd x Wd), align_corners=True (F.interpolate calls of pixel_link/model.py:342-411), NHWC [B][H][W][C];
+ * with `addend` [B][Hd][Wd][C] also out2 = out + addend (the lateral add of the cascade).  addend and out2 are both NULL or both set. */
+int gssd_interp_add_f32(const float* src, const float* addend, float* out, float* out2, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                        gssd_stream_t stream);
+
+/* final_1 / final_2 (model.py:118-123,360,386,396,411) over nf (1 = no cascade_fuse, 4 = cascade_fuse, version "4s") feature maps
+ * f[k] NHWC [B][HW][18] (channels 0-1 pixel, 2-17 link): out1 NCHW [B][2][HW], out2 NCHW [B][16][HW];
+ * w1 [2][2*nf], w2 [16][16*nf] (the Conv2d weights, input channel = k * {2,16} + c as torch.cat(features, dim=1) orders them). */
+int gssd_pixellink_final_f32(const float* f0, const float* f1, const float* f2, const float* f3, int nf, const float* w1,
+                             const float* b1, const float* w2, const float* b2, float* out1, float* out2, int B, int HW,
+                             gssd_stream_t stream);
+
+/* PixelLinkLoss.pixel_loss + link_loss (pixel_link/criterion.py:24-104).  out1 [B][2][H][W], out2 [B][16][H][W] fp32 NCHW;
+ * pixel_target [B][H][W] int64 (0/1), neg_pixel_mask [B][H][W] uint8, pixel_pos_weight [B][H][W] fp32, link_target [B][8][H][W] int64.
+ * per_image [B][6] fp64 = {pixel_pos, pixel_neg, link_pos, link_neg, area, neg_area}: the reference's four losses are the batch
+ * means of the first four columns.  neg_weight_out (optional) [B][H][W] = the mined-negative mask (criterion.py:47-48).
+ * H*W <= 8192.  An image without a negative candidate is an IndexError in the reference; here its pixel_neg term is 0. */
+int gssd_pixellink_loss_f32(const float* out1, const float* out2, const long long* pixel_target, const unsigned char* neg_pixel_mask,
+                            const float* pixel_pos_weight, const long long* link_target, double* per_image, float* neg_weight_out,
+                            int B, int H, int W, int neg_pos_ratio, gssd_stream_t stream);
+
+/* Link decoding (pixel_link/postprocess.py:104-121 thresholds, :178-234 `func`): labels [B][H][W] int32 = 0 for background, else
+ * 1 + rank of the pixel's connected component by its first pixel in raster order (the reference's root_map numbering; the reference
+ * stores it as uint8 and wraps beyond 255 components, this does not).  comps [B][max_comp][6] = {pixel count, min x, min y, max x,
+ * max y, sum of the positive-class probability}; ncomp [B].  H*W <= 8192. */
+int gssd_pixellink_decode_f32(const float* out1, const float* out2, int* labels, float* comps, int* ncomp, int B, int H, int W,
+                              float pixel_thr, float link_thr, int max_comp, gssd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
