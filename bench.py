@@ -226,6 +226,49 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
     return res, net, crit, x, tg, first_loss
 
 
+def measure_pixellink(B, dev, steps=20):
+    """PixelLink++ (cascade_fuse, fuse conv + BN, Self_Attn x 8, 1 DCN layer on slice_and_cat(x, SA-base)) forward
+    (train-mode BN, spectral-norm power iteration) + PixelLinkLoss + link decoding, B images, synthetic weights / images / masks."""
+    import numpy as np
+    from gssd import synth
+    from pixel_link.model import PixelLink
+    from pixel_link.criterion import PixelLinkLoss
+    from pixel_link import postprocess
+    net = PixelLink(cascade_fuse=True, use_fuseconv=True, batch_norm=True, use_self_attention=True, use_self_attention_base=True,
+                    num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True, detach_sab=False)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=2222))
+    net = net.to(dev).train()
+    x = synth.synth_images(B, seed=300).to(dev)
+    rng = np.random.default_rng(5)
+    pix = np.zeros((B, 75, 75), np.int64)
+    for b in range(B):
+        y, xx = rng.integers(5, 55, size=2)
+        pix[b, y:y + 12, xx:xx + 9] = 1
+    t = lambda v: torch.from_numpy(v).to(dev)
+    pix_t, neg_t = t(pix), t((pix == 0).astype(np.uint8))
+    posw_t, link_t = t(pix.astype(np.float32)), t(np.repeat(pix[:, None], 8, 1))
+    crit = PixelLinkLoss()
+
+    def step():
+        with torch.no_grad():
+            o1, o2 = net(x)
+            pp, pn = crit.pixel_loss(o1, pix_t, neg_t, posw_t, link=(o2, link_t))
+            lp, ln = crit.link_loss(o2, link_t)
+            postprocess.decode(o1, o2)
+        return pp + pn, lp + ln
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pl, ll = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(metric='512x512 4-phase CT img/s (PixelLink++ fwd + loss + link decoding)', value=round(B * steps / dt, 2), unit='img/s',
+                steps=steps, ms_per_step=round(1e3 * dt / steps, 3), batch=B, dtype='f32', loss=[round(float(pl), 5), round(float(ll), 5)],
+                workload='pixellink++ cascade_fuse=1 fuseconv=1 bn=1 sa=1 sab=1 dcn=1x4 cat_sab=1, 300x300x12 -> [B,2,75,75] | [B,16,75,75]')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -322,6 +365,11 @@ def main():
         secondary = dict(metric='512x512 4-phase CT img/s (fwd+loss)', unit='img/s', **sres)
         torch.cuda.empty_cache()
 
+    pixellink = None
+    if world == 1 and not a.no_secondary and a.config == 'gssdpp' and a.dtype == 'f32':
+        pixellink = measure_pixellink(B, dev)
+        torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(a.config, a.cpu_sample, gd.shard_seed(100, rank))
@@ -338,7 +386,7 @@ def main():
                        'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
             'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
             'first_step_loss': res['first_step_loss'],
-            'roofline': res['roofline'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary,
+            'roofline': res['roofline'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary, 'pixellink': pixellink,
             'full_step': full, 'input_stage': stage_info,
         }
         print(json.dumps(line))

@@ -71,5 +71,7 @@ int gssd_try_conv_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw
 int gssd_try_conv_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
 // gemm_slot.hip: large plain 1x1 convs / GEMMs as a slot-scheduled 128 x 256 MFMA stream; returns 1 for every other shape
 int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream);
+// wgrad_slot.hip: weight gradient of large plain 1x1 convs (and the DCN contraction) as a slot-scheduled TN GEMM; else returns 1
+int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
 // conv_thin_bf16.hip: bf16 thin trunk layers (conv1_1 .. conv2_2); returns 1 when the descriptor is not one of them
 int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream);

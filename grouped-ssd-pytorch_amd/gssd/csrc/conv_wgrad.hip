@@ -284,6 +284,11 @@ extern "C" int gssd_conv2d_wgrad_f32(const gssd_conv_desc* dp, const float* dy, 
         const int rc = gssd_try_conv_patch_wgrad(d, dy, dw_packed, as_stream(stream));   // conv2_1 .. conv3_3: patch-staged per group
         if (rc != 1) return rc;
     }
+    {
+        static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr;               // ablation switch
+        const int rc = no_slot ? 1 : gssd_try_wgrad_slot(d, dy, dw_packed, as_stream(stream));   // large plain 1x1 / DCN contraction
+        if (rc != 1) return rc;
+    }
     WgradParams p;
     p.in = d.in;
     p.dy = dy;

@@ -61,10 +61,10 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 }
 
 // Backward of the sampling.  d(cols) arrives from the dgrad of the contraction.  A workgroup owns a TH x TW tile of output pixels
-// and one 64-channel slice (lane = channel) and is TWO waves with different jobs over the same (pixel, tap) units:
-//   wave 0 (reduce):  d(offset_y), d(offset_x), d(mask logit) = wave sums over the slice of g * (bilinear derivative of x) --
-//                     the x corners come from an LDS copy of the (tile + 2R + 1)^2 window, staged once by LDS-DMA;
-//   wave 1 (scatter): d(x) += g * m * bilinear weight into an LDS accumulator window, flushed with ONE fp32 atomic per element.
+// and one 64-channel slice (lane = channel) and is THREE waves with different jobs over the same (pixel, tap) units:
+//   waves 0, 1 (reduce, alternate units):  d(offset_y), d(offset_x), d(mask logit) = wave sums over the slice of g * (bilinear
+//                     derivative of x) -- the x corners come from an LDS copy of the (tile + 2R + 1)^2 window, staged once by LDS-DMA;
+//   wave 2 (scatter): d(x) += g * m * bilinear weight into an LDS accumulator window, flushed with ONE fp32 atomic per element.
 // Both read d(cols) from a double-buffered LDS-DMA stage (2 pixels x 9 taps per chunk) and the per-unit sampling geometry from a
 // table built once per tile, so the main loop has no global load at all: the first version (one wave doing both, 5 global loads per
 // unit, 4 waves per CU) was latency bound at 8.1 ms; this one is bound by the VALU work of the two jobs running on separate SIMDs.
@@ -130,7 +130,7 @@ __device__ __forceinline__ DcGeo dc_geometry(const float* __restrict__ om, int b
 }
 
 template <int TH, int TW>
-__global__ __launch_bounds__(128) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(192) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                          const float* __restrict__ dcols, float* __restrict__ dx,
                                                          float* __restrict__ dom, int B, int H, int W, int C, int dg,
                                                          int om_stride, int tiles_y, int tiles_x) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(128) void dcn_col2im_kernel(const float* __restrict
     // ---- prologue: x window (both waves), first d(cols) chunk, accumulator clear, geometry table --------------------------------
     {
         const int q4 = lane >> 4, f4 = (lane & 15) * 4;
-        for (int i = wave; i < WPX4 / 4; i += 2) {
+        for (int i = wave; i < WPX4 / 4; i += 3) {
             const int px = i * 4 + q4;
             const int y = wy0 + px / WW, xx = wx0 + px % WW;
             const bool ok = px < WPX && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(128) void dcn_col2im_kernel(const float* __restrict
         }
     }
     if (wave == 0) stage_chunk(0, gb[0]);
-    for (int i = wave; i < WPX; i += 2) dw[i * 64 + lane] = 0.f;
-    for (int u = tid; u < NU; u += 128) {
+    for (int i = wave; i < WPX; i += 3) dw[i * 64 + lane] = 0.f;
+    for (int u = tid; u < NU; u += 192) {
         const int pl = u / 9, tap = u - pl * 9;
         const DcGeo r = dc_geometry<TH, TW>(om, b, ty * TH + pl / TW, tx * TW + pl % TW, tap, d, dg, H, W, om_stride, wy0, wx0);
         geo_i[u] = r.gi;
@@ -196,49 +196,85 @@ __global__ __launch_bounds__(128) void dcn_col2im_kernel(const float* __restrict
     for (int c = 0; c < NCH; ++c) {
         const float* gbuf = gb[c & 1];
         if (wave == 0 && c + 1 < NCH) stage_chunk(c + 1, gb[(c + 1) & 1]);
-#pragma unroll 3
-        for (int q = 0; q < DC_CH; ++q) {
-            const int u = c * DC_CH + q;
-            const int gi = __builtin_amdgcn_readfirstlane(geo_i[u]);
-            if ((gi & 48) != 48) continue;                            // no contribution, or the overflow kernel's
-            const float g = gbuf[q * 64 + lane];
-            const float ly = geo_ly[u], lx = geo_lx[u], m = geo_m[u];
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const int wofs = gi >> 8;
-            if (wave == 0) {
-                const float* wp = xw + wofs * 64 + lane;
-                const float v00 = (gi & 1) ? wp[0] : 0.f;
-                const float v01 = (gi & 2) ? wp[64] : 0.f;
-                const float v10 = (gi & 4) ? wp[WW * 64] : 0.f;
-                const float v11 = (gi & 8) ? wp[WW * 64 + 64] : 0.f;
-                const float s_m = g * (v00 * (hy * hx) + v01 * (hy * lx) + v10 * (ly * hx) + v11 * (ly * lx));
-                const float s_y = g * ((v10 - v00) * hx + (v11 - v01) * lx);
-                const float s_x = g * ((v01 - v00) * hy + (v11 - v10) * ly);
-                const float t_m = wave_sum_dpp(s_m), t_y = wave_sum_dpp(s_y), t_x = wave_sum_dpp(s_x);
-                if (lane == 0) {
-                    dacc[u * 3] = t_y * m;
-                    dacc[u * 3 + 1] = t_x * m;
-                    dacc[u * 3 + 2] = t_m * m * (1.f - m);
+        // the chunk's geometry: lane q holds unit q's table row; a unit's (wave-uniform) values then come out of the registers by
+        // v_readlane with a constant lane instead of one dependent LDS round trip per unit
+        const int gl = lane < DC_CH ? lane : 0;
+        const int v_gi = geo_i[c * DC_CH + gl];
+        const float v_ly = geo_ly[c * DC_CH + gl], v_lx = geo_lx[c * DC_CH + gl], v_m = geo_m[c * DC_CH + gl];
+        auto geo = [&](int q, int& gi, float& ly, float& lx, float& m) {
+            gi = __builtin_amdgcn_readlane(v_gi, q);
+            ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_ly), q));
+            lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_lx), q));
+            m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_m), q));
+        };
+        if (wave < 2) {
+            // reduce waves: units q = wave, wave + 2, ...; three units per trip, branch free (a unit that does not contribute reads
+            // window pixel 0 and multiplies by 0), so the nine wave sums and the LDS reads of a trip interleave
+#pragma unroll
+            for (int q0 = 0; q0 < DC_CH; q0 += 6) {
+                float s_m[3], s_y[3], s_x[3], mm[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int gi0, gi1;
+                    float ly0, lx0, m0, ly1, lx1, m1;
+                    geo(q0 + 2 * k, gi0, ly0, lx0, m0);
+                    geo(q0 + 2 * k + 1, gi1, ly1, lx1, m1);
+                    const int gi = wave ? gi1 : gi0;
+                    const float ly = wave ? ly1 : ly0, lx = wave ? lx1 : lx0;
+                    mm[k] = wave ? m1 : m0;
+                    const int q = q0 + 2 * k + wave;
+                    const bool on = (gi & 48) == 48;
+                    const float g = on ? gbuf[q * 64 + lane] : 0.f;
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    const float* wp = xw + (on ? gi >> 8 : 0) * 64 + lane;
+                    const float r00 = wp[0], r01 = wp[64], r10 = wp[WW * 64], r11 = wp[WW * 64 + 64];
+                    const float v00 = (gi & 1) ? r00 : 0.f, v01 = (gi & 2) ? r01 : 0.f;
+                    const float v10 = (gi & 4) ? r10 : 0.f, v11 = (gi & 8) ? r11 : 0.f;
+                    s_m[k] = g * (v00 * (hy * hx) + v01 * (hy * lx) + v10 * (ly * hx) + v11 * (ly * lx));
+                    s_y[k] = g * ((v10 - v00) * hx + (v11 - v01) * lx);
+                    s_x[k] = g * ((v01 - v00) * hy + (v11 - v10) * ly);
                 }
-            } else {
-                const float gm = g * m;
-                float* wp = dw + wofs * 64 + lane;
-                if (gi & 1) wp[0] += gm * (hy * hx);
-                if (gi & 2) wp[64] += gm * (hy * lx);
-                if (gi & 4) wp[WW * 64] += gm * (ly * hx);
-                if (gi & 8) wp[WW * 64 + 64] += gm * (ly * lx);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int u = c * DC_CH + q0 + 2 * k + wave;
+                    const float t_m = wave_sum_dpp(s_m[k]), t_y = wave_sum_dpp(s_y[k]), t_x = wave_sum_dpp(s_x[k]);
+                    if (lane == 0) {
+                        dacc[u * 3] = t_y * mm[k];
+                        dacc[u * 3 + 1] = t_x * mm[k];
+                        dacc[u * 3 + 2] = t_m * mm[k] * (1.f - mm[k]);
+                    }
+                }
+            }
+        } else {
+            // scatter wave: read-modify-write of the accumulator window; consecutive units may hit the same pixel, so they stay in
+            // order.  Branch free (a unit that does not contribute adds 0 to window pixel 0): the d(cols) reads of the whole chunk
+            // hoist above the chain
+#pragma unroll
+            for (int q = 0; q < DC_CH; ++q) {
+                int gi;
+                float ly, lx, m;
+                geo(q, gi, ly, lx, m);
+                const bool on = (gi & 48) == 48;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float gm = on ? gbuf[q * 64 + lane] * m : 0.f;
+                float* wp = dw + (on ? gi >> 8 : 0) * 64 + lane;
+                const float a00 = wp[0], a01 = wp[64], a10 = wp[WW * 64], a11 = wp[WW * 64 + 64];
+                wp[0] = a00 + ((gi & 1) ? gm * (hy * hx) : 0.f);
+                wp[64] = a01 + ((gi & 2) ? gm * (hy * lx) : 0.f);
+                wp[WW * 64] = a10 + ((gi & 4) ? gm * (ly * hx) : 0.f);
+                wp[WW * 64 + 64] = a11 + ((gi & 8) ? gm * (ly * lx) : 0.f);
             }
         }
-        __syncthreads();                                              // chunk c consumed by both waves, chunk c + 1 landed
+        __syncthreads();                                              // chunk c consumed by all waves, chunk c + 1 landed
     }
     // ---- flush: d(x) window (one atomic per element: neighbouring tiles' windows overlap) and the three d(om) scalars per unit ----
-    for (int i = wave; i < WPX; i += 2) {
+    for (int i = wave; i < WPX; i += 3) {
         const int y = wy0 + i / WW, xx = wx0 + i % WW;
         if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
         const float v = dw[i * 64 + lane];
         if (v != 0.f) unsafeAtomicAdd(dxb + (size_t)(y * W + xx) * C, v);
     }
-    for (int u = tid; u < NU; u += 128) {
+    for (int u = tid; u < NU; u += 192) {
         if ((geo_i[u] & 48) != 48) continue;
         const int pl = u / 9, tap = u - pl * 9;
         const int h = ty * TH + pl / TW, w = tx * TW + pl % TW;
@@ -367,7 +403,7 @@ extern "C" int gssd_dcn_col2im_f32(const float* x, const float* om, const float*
     const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
     const long long blocks = (long long)B * tiles_y * tiles_x * (C / 64);
     GSSD_CHECK_ARG(blocks < (1ll << 31));
-    hipLaunchKernelGGL((dcn_col2im_kernel<TH, TW>), dim3((int)blocks), dim3(128), 0, as_stream(stream), x, om, dcols, dx, dom, B, H, W, C,
+    hipLaunchKernelGGL((dcn_col2im_kernel<TH, TW>), dim3((int)blocks), dim3(192), 0, as_stream(stream), x, om, dcols, dx, dom, B, H, W, C,
                        dg, om_stride, tiles_y, tiles_x);
     GSSD_CHECK_LAUNCH();
     hipLaunchKernelGGL((dcn_col2im_overflow_kernel<TH, TW>), dim3((int)blocks), dim3(64), 0, as_stream(stream), x, om, dcols, dx, dom, B,

@@ -195,6 +195,8 @@ BWD_CASES = [
     (3, 33, 16, 64, 3, 1, 1, 1, 4),      # conv1_1: 4 (3 real) input channels per group
     (2, 83, 16, 64, 3, 1, 1, 1, 4),      # thin patch-staged wgrad <4>, ragged tiles
     (2, 80, 64, 64, 3, 1, 1, 1, 4),      # thin wgrad <16>
+    (8, 38, 512, 512, 1, 1, 0, 1, 1),    # large dense 1x1: slot-scheduled TN wgrad (csrc/wgrad_slot.hip) + NT dgrad (gemm_slot.hip)
+    (5, 37, 480, 120, 1, 1, 0, 1, 1),    # ... ragged: 6845 pixels (reduction tail), 120 of 128 rows, 480 of 512 columns
 ]
 
 
