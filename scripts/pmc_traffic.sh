@@ -29,6 +29,8 @@ def short(n):
     if m: return f'conv_bf16<{m.group(1)}x{m.group(2)}>'
     m = re.search(r'conv_thin_bf16_kernel<(\d+), (\d+)', n)
     if m: return f'conv_thin_bf16<{m.group(1)},{m.group(2)}>'
+    m = re.search(r'flash_attn_mixed_kernel<(\d+), (\d+)', n)
+    if m: return f'flash_attn_bf16v<{m.group(1)},{m.group(2)}>'
     m = re.search(r'flash_attn_kernel<(\d+), (\d+)', n)
     if m: return f'flash_attn<{m.group(1)},{m.group(2)}>'
     if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
