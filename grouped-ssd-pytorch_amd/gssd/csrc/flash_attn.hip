@@ -12,6 +12,10 @@
 //   online softmax        row max / rescale per query: 4 registers x BKV/16 tiles, then two lane shuffles (xor 16, 32) across kq
 //   O^T += V . P^T        (A = values [channel][key] from LDS, B = P in registers) -> lane holds O[q][c = 16*ct + 4*kq + reg]:
 //                         four consecutive channels of one token = one 16-byte NHWC store
+// (Measured and rejected, round 2, N = 1444: six waves = 96 queries per workgroup -- exactly one round of 512 workgroups, three waves
+// per SIMD -- 581 us against 418 us (the 168-register cap costs more than the fuller round gains); two LDS stages of 32 keys with
+// the next tile in flight under the current one, one barrier per tile: 420 us against 407 us -- the staging wait is already covered
+// by the CU's second workgroup.)
 // K and V tiles are staged by 16-byte LDS-DMA with a source-side XOR swizzle (quad' = quad ^ (row & 15)), which makes every
 // ds_read_b128 fragment read conflict free; two workgroups share a CU (80 KB of LDS each) and hide each other's staging.
 #include <math.h>
@@ -133,8 +137,10 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__any(alpha != 1.f)) {                                // the running maximum usually stops moving after a few tiles
 #pragma unroll
-        for (int c = 0; c < CT; ++c) o[c] *= alpha;
+            for (int c = 0; c < CT; ++c) o[c] *= alpha;
+        }
         // ---- O^T += V . P^T -------------------------------------------------------------------------------------------------------
         constexpr int CG = CT < 4 ? CT : 4;
 #pragma unroll
@@ -296,8 +302,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) o[c] *= alpha;
+            for (int c = 0; c < CT; ++c) o[c] *= alpha;
+        }
         constexpr int CG = CT < 4 ? CT : 4;
 #pragma unroll
         for (int cg = 0; cg < CT; cg += CG) {

@@ -3,29 +3,31 @@
 //
 //   out[m][n] = epilogue( sum_k A[m][k] * Wp[n][k] ),   A = NHWC activations (row stride in_stride), Wp = K-major weight rows
 //
-// A 256-thread workgroup (2 x 2 waves, ONE per CU, one wave per SIMD) owns BM = 128 rows x BN = 256 columns; a wave owns 64 x 128
-// = 4 x 8 tiles of v_mfma_f32_16x16x4_f32 (128 accumulator registers).  K runs in chunks of 32 floats: both tiles of chunk ch+1 land
+// A 256-thread workgroup (2 x 2 waves) owns BM = 128 rows x BN = 128 columns, TWO workgroups per CU (64 KB of LDS each); a wave owns
+// 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x4_f32 (64 accumulator registers).  (BN = 256, one workgroup per CU, 128 accumulators: the
+// tiling of dcn_fused; kept as a template instance for ablation, see slot_shape.)  K runs in chunks of 32 floats: both tiles of chunk ch+1 land
 // in the other LDS stage by 16-byte LDS-DMA (8 rows x 128 B per wave instruction, source-side XOR swizzle: slot' = slot ^ (row & 7),
-// so every ds_read_b128 fragment read is conflict free) while the 256 MFMAs of chunk ch run.  Every staging instruction sits behind
+// so every ds_read_b128 fragment read is conflict free) while the 128 MFMAs of chunk ch run.  Every staging instruction sits behind
 // a specific MFMA ("slot") and a scheduling fence after each slot keeps hipcc from regrouping them:
-//   0..11    second-half (k 16..31) fragment reads of this chunk        12, 14, .. 34    the 12 DMA pieces of the next chunk
-//   192      the chunk's single barrier                                 194..205        first-half fragment reads of the NEXT chunk
-// Compared with conv_igemm<128x64/128> (2-3 workgroups per CU, barrier at the chunk end, 0.57 of peak) the MFMA pipe never waits for
-// a barrier or a fragment read, and the 128 x 256 tile moves 0.19 B of LDS-DMA per FLOP instead of 0.38.
-// Taken for: KH = KW = 1, stride 1, groups 1, K % 32 == 0, no fused input transform, no split-K, wide enough (see gssd_try_gemm_slot);
+//   (128 slots per chunk)   0..7  second-half (k 16..31) fragment reads of this chunk     8, 10, .. 22  the 8 DMA pieces of the next chunk
+//   96   the chunk's single barrier                                    98..105  first-half fragment reads of the NEXT chunk
+// Compared with conv_igemm<128x128> (same tile and residency, barrier at the chunk end, fragments read after it: 0.57-0.65 of peak)
+// the MFMA pipe never waits for a barrier or a fragment read: 0.61-0.84 of peak on the shapes of scripts/bench_gemm.py
+// (M = 46 208: K = 256 -> 97 TFLOP/s, K = 1024 -> 119-127, K = 4096 -> 132; the DCN d(cols) GEMM 133; generic kernel 77 / 100 / 113 / 107).
+// Taken for: KH = KW = 1, stride 1, groups 1, K % 32 == 0, no fused input transform, no split-K, wide enough (see slot_shape);
 // everything else stays on conv_igemm.  Epilogue = conv_igemm's (alpha, bias, gate / residual / second output, ReLU, transposed and
 // split-transposed stores, BatchNorm statistics).
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 256, BK = 32;
-constexpr int WTM = 64, WTN = 128, MT = WTM / 16, NT = WTN / 16;
-constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK;
-constexpr int LDS_FLOATS = 2 * (A_STAGE + B_STAGE);
+constexpr int BM = 128, BK = 32;
+constexpr int WTM = 64, MT = WTM / 16;
+constexpr int A_STAGE = BM * BK;
 #ifndef DMA_EVERY
 #define DMA_EVERY 2
 #endif
@@ -45,7 +47,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles) {
+// BN = 256: one workgroup per CU (96 KB of LDS, 128 accumulator registers per lane);  BN = 128: two per CU (64 KB, 64 registers) --
+// the second one's MFMAs cover the first one's prologue / epilogue, which is what short reductions (K <= 512) and grids of about one
+// round need.
+template <int BN>
+__global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles) {
+    constexpr int WTN = BN / 2, NT = WTN / 16, B_STAGE = BN * BK, NBP = BN / 32;     // NBP: B DMA pieces per wave per chunk
+    constexpr int SL = MT * NT * 8;                                                  // MFMAs (slots) per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                     // [2][BM][32]
     float* const Bs = smem + 2 * A_STAGE;       // [2][BN][32]
@@ -87,10 +95,10 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
         a_src[j] = ok ? in + (size_t)m * p.in_stride + 4 * lq : g_zero_gs;
         a_step[j] = ok ? BK : 0;
     }
-    const float* b_src[8];
-    int b_step[8];
+    const float* b_src[NBP];
+    int b_step[NBP];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NBP; ++j) {
         const int n = n0 + (j * 4 + wave) * 8 + row_in;
         const bool ok = n < p.Cout;
         b_src[j] = ok ? wgt + (size_t)n * p.wgt_row_stride + 4 * lq : g_zero_gs;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
         a_src[j] += a_step[j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NBP; ++j) {
         dma16(b_src[j], Bs + (j * 4 + wave) * 256);
         b_src[j] += b_step[j];
     }
@@ -126,13 +134,14 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
     auto slot = [&](auto kc, auto stage_c, const float* Ab, const float* Bb, const float* Abn, const float* Bbn) {
         constexpr int KK = decltype(kc)::value;
         constexpr bool stage = decltype(stage_c)::value;
-        constexpr int ks = KK >> 7, s = (KK >> 5) & 3, i = (KK >> 3) & 3, j = KK & 7;
+        constexpr int ks = KK / (SL / 2), s = (KK / (MT * NT)) & 3, i = (KK / NT) & 3, j = KK % NT;
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
-        if constexpr (KK < 4) af[1][KK] = *reinterpret_cast<const f32x4*>(Ab + KK * 16 * BK + fo1);
-        if constexpr (KK >= 4 && KK < 12) bf[1][KK - 4] = *reinterpret_cast<const f32x4*>(Bb + (KK - 4) * 16 * BK + fo1);
+        if constexpr (KK < MT) af[1][KK] = *reinterpret_cast<const f32x4*>(Ab + KK * 16 * BK + fo1);
+        if constexpr (KK >= MT && KK < MT + NT) bf[1][KK - MT] = *reinterpret_cast<const f32x4*>(Bb + (KK - MT) * 16 * BK + fo1);
         if constexpr (stage) {
-            if constexpr (KK >= 12 && KK < 12 + 12 * DMA_EVERY && (KK - 12) % DMA_EVERY == 0) {
-                constexpr int n = (KK - 12) / DMA_EVERY;
+            constexpr int D0 = MT + NT;                     // the 4 + NBP DMA pieces of the next chunk, every DMA_EVERY slots
+            if constexpr (KK >= D0 && KK < D0 + (4 + NBP) * DMA_EVERY && (KK - D0) % DMA_EVERY == 0) {
+                constexpr int n = (KK - D0) / DMA_EVERY;
                 if constexpr (n < 4) {
                     dma16(a_src[n], a_dst + n * 1024);
                     a_src[n] += a_step[n];
@@ -141,11 +150,13 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
                     b_src[n - 4] += b_step[n - 4];
                 }
             }
-            // the ONE barrier of the chunk sits inside the MFMA stream: both tiles of chunk ch+1 are in LDS, the k 0..15 fragment
-            // registers are dead since slot 127 -> they are refilled for chunk ch+1 while the k 16..31 MFMAs of this chunk still run
-            if constexpr (KK == 192) __syncthreads();
-            if constexpr (KK >= 194 && KK < 198) af[0][KK - 194] = *reinterpret_cast<const f32x4*>(Abn + (KK - 194) * 16 * BK + fo0);
-            if constexpr (KK >= 198 && KK < 206) bf[0][KK - 198] = *reinterpret_cast<const f32x4*>(Bbn + (KK - 198) * 16 * BK + fo0);
+            // the ONE barrier of the chunk sits inside the MFMA stream: both tiles of chunk ch+1 are in LDS, the first-half fragment
+            // registers are dead since slot SL/2 - 1 -> they are refilled for chunk ch+1 while the second-half MFMAs of this chunk run
+            constexpr int BAR = SL * 3 / 4;
+            if constexpr (KK == BAR) __syncthreads();
+            if constexpr (KK >= BAR + 2 && KK < BAR + 2 + MT) af[0][KK - BAR - 2] = *reinterpret_cast<const f32x4*>(Abn + (KK - BAR - 2) * 16 * BK + fo0);
+            if constexpr (KK >= BAR + 2 + MT && KK < BAR + 2 + MT + NT)
+                bf[0][KK - BAR - 2 - MT] = *reinterpret_cast<const f32x4*>(Bbn + (KK - BAR - 2 - MT) * 16 * BK + fo0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -167,13 +178,13 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
         const float* Abn = As + (buf ^ 1) * A_STAGE + wm * WTM * BK;
         const float* Bbn = Bs + (buf ^ 1) * B_STAGE + wn * WTN * BK;
         __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 256>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
+        static_for<0, SL>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
     }
     {
         const int buf = (nchunks - 1) & 1;
         const float* Ab = As + buf * A_STAGE + wm * WTM * BK;
         const float* Bb = Bs + buf * B_STAGE + wn * WTN * BK;
-        static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
+        static_for<0, SL>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
     }
 
     // ---- epilogue (conv_igemm's, groups == 1, no split-K, no head layout).  One workgroup per CU: nothing overlaps this phase, so the
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
             }
         }
         __syncthreads();
-        if (n0 + tid < p.Cout) {
+        if (tid < BN && n0 + tid < p.Cout) {
             const double s = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
             const double q = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
             unsafeAtomicAdd(p.stats + n0 + tid, s);
@@ -300,35 +311,52 @@ __global__ __launch_bounds__(256, 1) void gemm_slot_kernel(const gssd_conv_desc 
 
 }  // namespace
 
-static bool slot_shape(const gssd_conv_desc& d) {
-    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.groups != 1 || d.split_k != 1) return false;
-    if (d.in_scale || d.out_mode == GSSD_OUT_HEADS || d.K % BK != 0 || d.K < 2 * BK) return false;
-    if (d.out_mode == GSSD_OUT_SPLIT_T && (d.split_n % 16 != 0)) return false;
+// shape classes: 256 = the 128 x 256 stream (one workgroup per CU), 128 = the 128 x 128 stream (two per CU), 0 = not taken
+static int slot_shape(const gssd_conv_desc& d) {
+    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.groups != 1 || d.split_k != 1) return 0;
+    if (d.in_scale || d.out_mode == GSSD_OUT_HEADS || d.K % BK != 0 || d.K < 2 * BK) return 0;
+    if (d.out_mode == GSSD_OUT_SPLIT_T && (d.split_n % 16 != 0)) return 0;
     const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
     const int images = d.m_per_image ? d.B : 1;
-    const int ntn = (d.Cout + BN - 1) / BN, mtiles = (int)((M + BM - 1) / BM);
-    // worth it when the 128 x 256 tiles are mostly full and the grid fills the 256 CUs about as well as the 128 x 64 / 128 x 128
-    // tiling would: column fill >= 0.9, and (last-round fill) x (column fill) >= 0.8 (one workgroup per CU;
-    // measured cross-over against conv_igemm's 2-3 resident workgroups, scripts/bench_gemm.py)
-    const double nfill = (double)d.Cout / (double)(ntn * BN);
-    const long long wgs = (long long)mtiles * ntn * images;
-    const double rounds = (double)wgs / 256.0;
-    const double qfill = rounds / (double)(long long)(rounds + 0.999999);
-    return nfill >= 0.9 && qfill * nfill >= 0.80;
+    const int mtiles = (int)((M + BM - 1) / BM);
+    // The 128 x 256 / one-workgroup-per-CU form (the tiling of dcn_fused, where the gather forces it) is kept for ablation only
+    // (GSSD_GEMM_SLOT256=1): on every shape of scripts/bench_gemm.py the 128 x 128 form with two resident workgroups is as fast or
+    // faster (K = 512, N = 9216: 3.28 vs 3.38 ms; K = 256: 125 vs 127 us) -- the second workgroup's MFMAs cover the ~20 us of prologue
+    // + epilogue a lone workgroup leaves exposed per tile.
+    {
+        static const bool want256 = getenv("GSSD_GEMM_SLOT256") != nullptr;
+        const int ntn = (d.Cout + 255) / 256;
+        const double nfill = (double)d.Cout / (double)(ntn * 256);
+        const double rounds = (double)((long long)mtiles * ntn * images) / 256.0;
+        const double qfill = rounds / (double)(long long)(rounds + 0.999999);
+        if (want256 && d.K >= 512 && nfill >= 0.9 && qfill * nfill >= 0.80) return 256;
+    }
+    static const bool no128 = getenv("GSSD_NO_GEMM_SLOT128") != nullptr;            // ablation switch
+    // 128 x 128: any wide enough plain GEMM with at least ~3/8 of a round of workgroups (below that the generic kernel's 128 x 64
+    // tiles spread the work over more CUs: M = 3200, N = 512 measures 55 us there, 64 us here)
+    const int ntn = (d.Cout + 127) / 128;
+    const double nfill = (double)d.Cout / (double)(ntn * 128);
+    if (no128 || nfill < 0.75 || (long long)mtiles * ntn * images < 192) return 0;
+    // last-round fill against the generic kernel's 128 x 64 tiling (three resident workgroups per CU): the slot stream is worth about
+    // 1.2x at equal fill (scripts/bench_gemm.py), so it must not lose more than that to quantisation (B = 32 x 19 x 19 tokens x 768
+    // columns per image: 576 workgroups = 1.1 rounds of 512 here, 1152 = 1.5 rounds of 768 there -- measured 252 vs 200 us)
+    auto fill = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+    const long long w128 = (long long)mtiles * ntn * images, w64 = (long long)mtiles * ((d.Cout + 63) / 64) * images;
+    if (fill(w128, 512) * 1.2 >= fill(w64, 768)) return 128;
+    return 0;
 }
 
 extern "C" int gssd_gemm_slot_takes(const gssd_conv_desc* d) { return d && slot_shape(*d) ? 1 : 0; }
 
-// returns 1 when the descriptor is not a large plain 1x1 / GEMM shape (the caller falls through to conv_igemm)
-int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream) {
-    if (!slot_shape(d)) return 1;
+template <int BN>
+static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
     const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
     const int images = d.m_per_image ? d.B : 1;
     const int ntn = (d.Cout + BN - 1) / BN, mtiles = (int)((M + BM - 1) / BM);
     static unsigned attr_mask = 0;
-    constexpr int smem = LDS_FLOATS * (int)sizeof(float);
+    constexpr int smem = 2 * (A_STAGE + BN * BK) * (int)sizeof(float);
     if (gssd_attr_needed(&attr_mask) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
@@ -339,7 +367,15 @@ int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream) {
     } else {
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
-    hipLaunchKernelGGL(gemm_slot_kernel, dim3(blocks, 1, images), dim3(256), smem, stream, d, (int)M, ntn, mtiles);
+    hipLaunchKernelGGL(gemm_slot_kernel<BN>, dim3(blocks, 1, images), dim3(256), smem, stream, d, (int)M, ntn, mtiles);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
+}
+
+// returns 1 when the descriptor is not a plain 1x1 / GEMM shape worth a slot stream (the caller falls through to conv_igemm)
+int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream) {
+    const int cls = slot_shape(d);
+    if (cls == 256) return launch_slot<256>(d, stream);
+    if (cls == 128) return launch_slot<128>(d, stream);
+    return 1;
 }

@@ -1,5 +1,7 @@
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fs_prof -o p -- python3 $R/bench.py --cpu-sample 0 --no-input-stage --no-secondary --no-events --steps 2 --warmup 1 --steady 0 --full-step 6 > $R/gpurun_out/fs_bench.json 2>$R/gpurun_out/fs_err.txt
-f=$(find $R/gpurun_out/fs_prof -name '*kernel_stats.csv' | head -1)
-cp $f $R/gpurun_out/fs_kernel_stats.csv
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 400 python bench.py --cpu-sample 0 --no-input-stage --no-secondary --steps 50 --warmup 10 --steady 50 --full-step 8 > gpurun_out/b_f32.json 2>gpurun_out/b_err.txt
+python - <<'PY'
+import json
+r=json.loads(open('gpurun_out/b_f32.json').read().strip().splitlines()[-1])
+print(r['value'], r['ms_per_step'], r.get('steady'), r['roofline']['kernel'], r['roofline']['frac'], r['full_step'])
+PY

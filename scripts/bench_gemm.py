@@ -6,8 +6,8 @@ import ctypes as C
 import torch
 from gssd import ops, _lib
 dev = torch.device('cuda:0')
-shapes = [(46208, 512, k) for k in (256, 512, 1024, 2048, 4096)] + [(46208, 1024, 512), (46208, 256, 1024), (11552, 1024, 512),
-                                                                    (11552, 1024, 2048), (46208, 9216, 512)]
+shapes = [(46208, 512, k) for k in (256, 512, 1024, 4096)] + [(46208, 1024, 512), (46208, 256, 1024), (46208, 384, 512), (11552, 1024, 512),
+                                                              (11552, 768, 1024), (11552, 1024, 2048), (3200, 512, 1024), (46208, 9216, 512)]
 for M, N, K in shapes:
     x = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.05

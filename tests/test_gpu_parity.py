@@ -1098,6 +1098,8 @@ def test_reference_driver_sequence(dev, tmp_path):
     from gssd._lib import GssdError
     torch.set_default_tensor_type('torch.cuda.FloatTensor')
     try:
+        torch.manual_seed(1111)                                      # the driver seeds too (:4); keeps the test independent of test order
+        torch.cuda.manual_seed(1111)
         net = build_ssd('train', 300, 2, True, 4, 4, 1, True, True, True, 1, 4, True, False, 1)
         net.extras.apply(weights_init)
         net.loc.apply(weights_init)
@@ -1130,7 +1132,8 @@ def test_reference_driver_sequence(dev, tmp_path):
                 nn.utils.clip_grad_norm_(net_cv[idx].parameters(), 10.0)
                 opts[idx].step()
                 losses.append(float(loss))
-        assert all(np.isfinite(losses)) and losses[1] < losses[0] and losses[0] == losses[2]     # the folds start as identical copies
+        # the folds start as identical copies (BatchNorm sums and split-K heads accumulate with atomics: equal to rounding, not bitwise)
+        assert all(np.isfinite(losses)) and losses[1] < losses[0] and abs(losses[0] - losses[2]) <= 1e-5 * abs(losses[0]), losses
         # checkpoint round trip through the tolerant loader, then strict hand-over to the test-phase twin
         path = str(tmp_path / 'ck.pth')
         torch.save(net_cv[0].state_dict(), path)                     # keys carry DataParallel's 'module.' prefix
