@@ -38,12 +38,14 @@ USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
 USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
 # GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
 USE_BRANCH_STREAMS = os.environ.get('GSSD_NO_BRANCH_STREAMS', '0') != '1'
+SN_STREAM = 9               # stream id of the spectral-norm launch inside a captured graph
 
 class _Step:
-    __slots__ = ('fn', 'args', 'keep', 'tag', 'sid')
+    __slots__ = ('fn', 'args', 'keep', 'tag', 'sid', 'wait')
 
-    def __init__(self, fn, args, keep=None, tag=None, sid=0):
-        self.fn, self.args, self.keep, self.tag, self.sid = fn, args, keep, tag, sid
+    def __init__(self, fn, args, keep=None, tag=None, sid=0, wait=None):
+        # sid: stream id inside a captured graph (0 = trunk);  wait: a stream id whose work this step consumes (joined before it)
+        self.fn, self.args, self.keep, self.tag, self.sid, self.wait = fn, args, keep, tag, sid, wait
 
 
 def conv_tag(d, real_cin_g=None, bf16=False):
@@ -360,7 +362,7 @@ class _Plan(_PlanBase):
             d = keep[0] if isinstance(keep, tuple) else keep
             tag = conv_tag(d, 3 if (d.cin_g in (4, 8) and d.groups == 4 and d.H == 300) else None,
                            bf16=fn is lib.gssd_conv2d_nhwc_bf16)
-        self.steps.append(_Step(fn, args, keep, tag, getattr(self, '_sid', 0)))
+        self.steps.append(_Step(fn, args, keep, tag, getattr(self, '_sid', 0), self.__dict__.pop('_pending_wait', None)))
 
     def _abuf(self, *shape):
         """Activation buffer in the plan's storage type (fp32, or bf16 in configs[4] mode)."""
@@ -392,7 +394,12 @@ class _Plan(_PlanBase):
                 self.sa_state[(lst_name, i)] = (a_tpg, a_o)
         if self.sn_items:
             self.sn_dev = ops.sn_items_tensor([(w.detach(), u, v, s) for (w, u, v, s) in self.sn_items], self.dev)
+            # one workgroup per matrix (48 of 256 CUs, ~180 us): on its own stream beside conv1_1 .. conv4_3 inside the graph; the
+            # first Self_Attn launch joins it (every later one forks from the trunk after that point)
+            prev, self._sid = getattr(self, '_sid', 0), SN_STREAM
             self._add(lib.gssd_spectral_norm_f32, (self.sn_dev.data_ptr(), len(self.sn_items), int(self.training), 1e-12))
+            self._sid = prev
+            self._sn_unjoined = True
 
     def _packed_conv(self, name, conv):
         eng = self.eng
@@ -516,6 +523,8 @@ class _Plan(_PlanBase):
         eng, B = self.eng, self.B
         sa = getattr(eng.net, lst_name)[idx]
         a_tpg, a_o = self.sa_state[(lst_name, idx)]
+        if self.__dict__.pop('_sn_unjoined', False):
+            self._pending_wait = SN_STREAM          # the next launch added (this block's projection) waits for the 1/sigma vectors
         N = H * H
         Np = ops.round_up(N, 4)
         C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
@@ -753,6 +762,8 @@ class _Plan(_PlanBase):
                 forked = {}
                 for st in obj:
                     if st.sid == 0 or not USE_BRANCH_STREAMS:
+                        if st.wait is not None and st.wait in forked:
+                            main.wait_stream(forked[st.wait])
                         self._launch(st, main.cuda_stream)
                         continue
                     side = forked.get(st.sid)
@@ -760,6 +771,8 @@ class _Plan(_PlanBase):
                         side = self._side_stream(st.sid)
                         side.wait_stream(main)
                         forked[st.sid] = side
+                    if st.wait is not None and st.wait in forked:
+                        side.wait_stream(forked[st.wait])
                     self._launch(st, side.cuda_stream)
                 for side in forked.values():               # join: a graph segment ends with every branch folded back
                     main.wait_stream(side)
