@@ -11,6 +11,7 @@
 // kernel, and the epilogue holds 4 consecutive k per lane.  Split over the reduction (grid z) with fp32 atomics into the zero-filled
 // dW, like conv_wgrad.  Replaces conv_wgrad<4,2,2> (0.5 of peak: transposing ds_reads, barrier at the chunk end) for these shapes.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,11 +40,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 struct WsParams {
     const float* dy;      // [R][Cout]
-    const float* x;       // [R][x_stride] (+ channel offset already applied)
+    const float* x;       // [R][x_stride] (+ channel offset already applied); CONV: the NHWC input [B][H][W][x_stride]
     float* dw;            // [Cout][dw_stride]
     int R, Cout, K, x_stride, dw_stride, split, ntn, mtiles;
+    // CONV (3x3 / strided / dilated / grouped): K = KH*KW*cin_g per group, Cout = cout_g per group in the tile arithmetic
+    int H, W, Ho, Wo, KW, stride, pad, dil, cin_g, cout_g, cout_total;
 };
 
+// CONV: the B rows of tap (ty, tx) are the input pixel rows shifted by that tap -- lane l of a B piece owns k' = k0 + 4 l, i.e. one
+// (tap, channel quad), and computes its own shifted source pixel and border predicate per reduction row; the group is blockIdx.y.
+template <bool CONV>
 __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                     // [2][32][BM]
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
     const int r = lane & 15, kq = lane >> 4;
     const int nt = blockIdx.x % p.ntn, mt = blockIdx.x / p.ntn;
     const int co0 = mt * BM, k0 = nt * BN;
+    const int g = CONV ? blockIdx.y : 0;
     const int nchunks_all = (p.R + BK - 1) / BK;
     const int cps = (nchunks_all + p.split - 1) / p.split;
     const int ch_begin = blockIdx.z * cps, ch_end = min(nchunks_all, ch_begin + cps);
@@ -61,10 +68,31 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
 
     // DMA roles.  A piece (2 rows x 128 co): lane -> row lane >> 5, co quad lane & 31;  B piece (1 row x 256 k): lane -> k quad lane
     const int a_row = lane >> 5, a_q = lane & 31;
+    const int a_stride = CONV ? p.cout_total : p.Cout;
     const bool a_ok = co0 + 4 * a_q < p.Cout, b_ok = k0 + 4 * lane < p.K;
-    const float* a_src = p.dy + (size_t)(ch_begin * BK) * p.Cout + co0 + 4 * a_q;
-    const float* b_src = p.x + (size_t)(ch_begin * BK) * p.x_stride + k0 + 4 * lane;
+    const float* a_src = p.dy + (size_t)(ch_begin * BK) * a_stride + g * p.Cout + co0 + 4 * a_q;
+    const float* b_src = p.x + (CONV ? 0 : (size_t)(ch_begin * BK) * p.x_stride + k0 + 4 * lane);
     int r_next = ch_begin * BK;                  // first reduction row of the chunk being staged
+    // CONV: this lane's tap offset / channel, and the (image, y, x) of the eight reduction rows its wave stages per chunk
+    int l_dy = 0, l_dx = 0, l_ch = 0;
+    int pb[8], py[8], px[8];
+    if (CONV) {
+        const int kk = b_ok ? k0 + 4 * lane : 0;
+        const int tap = kk / p.cin_g, c = kk - tap * p.cin_g;
+        const int ty = tap / p.KW, tx = tap - ty * p.KW;
+        l_dy = ty * p.dil - p.pad;
+        l_dx = tx * p.dil - p.pad;
+        l_ch = g * p.cin_g + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = r_next + j * 4 + wave;
+            const int hw = p.Ho * p.Wo;
+            pb[j] = m / hw;
+            const int rem = m - pb[j] * hw;
+            py[j] = rem / p.Wo;
+            px[j] = rem - py[j] * p.Wo;
+        }
+    }
 
     f32x4 acc[MT][NT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -76,17 +104,37 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
     auto stage_a = [&](int j, float* dst) {      // piece j * 4 + wave: rows 2 * piece + a_row
         const int rr = 2 * (j * 4 + wave) + a_row;
         const bool ok = a_ok && r_next + rr < p.R;
-        dma16(ok ? a_src + (size_t)rr * p.Cout : g_zero_ws, dst + (j * 4 + wave) * 256);
+        dma16(ok ? a_src + (size_t)rr * a_stride : g_zero_ws, dst + (j * 4 + wave) * 256);
     };
     auto stage_b = [&](int j, float* dst) {      // piece j * 4 + wave: row = piece
         const int rr = j * 4 + wave;
-        const bool ok = b_ok && r_next + rr < p.R;
-        dma16(ok ? b_src + (size_t)rr * p.x_stride : g_zero_ws, dst + (j * 4 + wave) * 256);
+        if (CONV) {
+            const int iy = py[j] * p.stride + l_dy, ix = px[j] * p.stride + l_dx;
+            const bool row_ok = b_ok && r_next + rr < p.R;
+            const bool ok = row_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            dma16(ok ? b_src + ((size_t)(pb[j] * p.H + iy) * p.W + ix) * p.x_stride + l_ch : g_zero_ws, dst + (j * 4 + wave) * 256);
+        } else {
+            const bool ok = b_ok && r_next + rr < p.R;
+            dma16(ok ? b_src + (size_t)rr * p.x_stride : g_zero_ws, dst + (j * 4 + wave) * 256);
+        }
     };
     auto advance = [&]() {
-        a_src += (size_t)BK * p.Cout;
-        b_src += (size_t)BK * p.x_stride;
+        a_src += (size_t)BK * a_stride;
+        if (!CONV) b_src += (size_t)BK * p.x_stride;
         r_next += BK;
+        if (CONV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                px[j] += BK;
+                while (px[j] >= p.Wo) {
+                    px[j] -= p.Wo;
+                    if (++py[j] == p.Ho) {
+                        py[j] = 0;
+                        ++pb[j];
+                    }
+                }
+            }
+        }
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) stage_a(j, As);
@@ -154,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
         for (int e = 0; e < 4; ++e) {
             const int co = co0 + wm * 64 + 4 * (4 * kq + e) + i;
             if (co >= p.Cout) continue;
-            float* row = p.dw + (size_t)co * p.dw_stride;
+            float* row = p.dw + (size_t)(g * p.Cout + co) * p.dw_stride;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = k0 + wn * 128 + 64 * h + 4 * r;
@@ -174,28 +222,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
 
 }  // namespace
 
-// returns 1 when the descriptor is not a large plain 1x1 shape (the caller falls through to conv_wgrad / the patch kernels)
-int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream) {
-    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.groups != 1 || d.in_scale || d.m_per_image) return 1;
-    const long long R = (long long)d.B * d.Ho * d.Wo;
-    if (d.K % 4 != 0 || d.Cout % 4 != 0 || d.K < 192 || d.Cout < 96 || R < 4096 || R >= (1ll << 31)) return 1;
-    if (((uintptr_t)dw % 16) != 0 || d.in_stride % 4 != 0 || d.in_ch_off % 4 != 0) return 1;
-    WsParams p;
-    p.dy = dy;
-    p.x = d.in + d.in_ch_off;
-    p.dw = dw;
-    p.R = (int)R;
-    p.Cout = d.Cout;
-    p.K = d.K;
-    p.x_stride = d.in_stride;
-    p.dw_stride = d.K;                          // the packed gradient matrix is [Cout][K] like conv_wgrad writes it
-    p.ntn = (d.K + BN - 1) / BN;
-    p.mtiles = (d.Cout + BM - 1) / BM;
-    // tile fill (ragged Cout / K tails waste MFMA work): stay on the generic kernel below 0.7
-    const double fill = ((double)d.Cout / (p.mtiles * BM)) * ((double)d.K / (p.ntn * BN));
-    if (fill < 0.7) return 1;
+static int pick_split(int tiles, int nchunks) {
     // split the reduction so that the grid is a whole number of 256-CU rounds (about), each slice >= 8 chunks
-    const int tiles = p.ntn * p.mtiles, nchunks = (p.R + BK - 1) / BK;
     int best = 1;
     double best_eff = 0.0;
     for (int s = 1; s <= 64 && nchunks / s >= 8; ++s) {
@@ -208,15 +236,65 @@ int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hip
             best = s;
         }
     }
-    p.split = best;
+    return best;
+}
+
+template <bool CONV>
+static int launch_ws(const WsParams& p, int groups, hipStream_t stream) {
     static unsigned attr_mask = 0;
     constexpr int smem = LDS_FLOATS * (int)sizeof(float);
+    auto kern = wgrad_slot_kernel<CONV>;
     if (gssd_attr_needed(&attr_mask) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_slot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
-    hipLaunchKernelGGL(wgrad_slot_kernel, dim3(tiles, 1, p.split), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.ntn * p.mtiles, groups, p.split), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
+}
+
+// returns 1 when the descriptor is not a shape this kernel takes (the caller falls through to conv_wgrad / the patch kernels)
+int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream) {
+    if (d.m_per_image) return 1;
+    const long long R = (long long)d.B * d.Ho * d.Wo;
+    if (R < 4096 || R >= (1ll << 31) || ((uintptr_t)dw % 16) != 0 || d.in_stride % 4 != 0 || d.in_ch_off % 4 != 0) return 1;
+    const bool plain = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && !d.in_scale;
+    const int cout_g = d.Cout / d.groups;
+    WsParams p = {};
+    p.dy = dy;
+    p.x = d.in + d.in_ch_off;
+    p.dw = dw;
+    p.R = (int)R;
+    p.K = d.K;
+    p.x_stride = d.in_stride;
+    p.dw_stride = d.K;                          // the packed gradient matrix is [Cout][K] like conv_wgrad writes it
+    p.ntn = (d.K + BN - 1) / BN;
+    const int nchunks = (p.R + BK - 1) / BK;
+    if (plain) {
+        if (d.K % 4 != 0 || d.Cout % 4 != 0 || d.K < 192 || d.Cout < 96) return 1;
+        p.Cout = d.Cout;
+        p.mtiles = (d.Cout + BM - 1) / BM;
+        // tile fill (ragged Cout / K tails waste MFMA work): stay on the generic kernel below 0.7
+        if (((double)d.Cout / (p.mtiles * BM)) * ((double)d.K / (p.ntn * BN)) < 0.7) return 1;
+        p.split = pick_split(p.ntn * p.mtiles, nchunks);
+        return launch_ws<false>(p, 1, stream);
+    }
+    // convolutions with taps (stride / dilation / padding; the group index is a grid dimension)
+    static const bool no_conv = getenv("GSSD_NO_WGRAD_SLOT_CONV") != nullptr;           // ablation switch
+    // Dense layers only (the DCN offset conv: 1.75 -> 1.06 ms).  Measured and rejected for the grouped trunk layers: conv4_2 (4 groups x
+    // 128 x 1152 weights, 25 reduction slices so that 500 workgroups fill the chip) runs 765 us here against 484 us on conv_wgrad<4,2,2>
+    // (112 TFLOP/s: its 128 x 128 tiles need 22 slices only and two workgroups share a CU) -- with so little output per group the
+    // one-workgroup-per-CU stream spends its time in prologues and atomic epilogues.
+    if (no_conv || d.groups != 1 || d.in_scale || d.cin_g % 4 != 0 || cout_g % 4 != 0 || cout_g < 96 || d.K < 192) return 1;
+    if ((long long)d.B * d.H * d.W * d.in_stride >= (1ll << 31)) return 1;
+    p.Cout = cout_g;
+    p.cout_total = d.Cout;
+    p.cout_g = cout_g;
+    p.cin_g = d.cin_g;
+    p.mtiles = (cout_g + BM - 1) / BM;
+    if (((double)cout_g / (p.mtiles * BM)) * ((double)d.K / (p.ntn * BN)) < 0.7) return 1;
+    p.H = d.H; p.W = d.W; p.Ho = d.Ho; p.Wo = d.Wo; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad; p.dil = d.dil;
+    p.split = pick_split(p.ntn * p.mtiles * d.groups, nchunks);
+    return launch_ws<true>(p, d.groups, stream);
 }

@@ -118,6 +118,31 @@ def test_conv_fused_input_bn_relu(dev, ops, Cin, Cout, H, k, st, pd):
     assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5
 
 
+@pytest.mark.parametrize('B,H,Cin,Cout,k,pd,dl', [(4, 38, 512, 512, 3, 1, 1), (12, 19, 512, 1024, 3, 6, 6), (4, 37, 1024, 512, 1, 0, 1)])
+def test_conv_wgrad_fused_input(dev, ops, B, H, Cin, Cout, k, pd, dl):
+    """Weight gradient of a conv that applies its producer's BatchNorm + ReLU on the fly (csrc/wgrad_slot.hip XF path for the wide
+    layers): d/dw of conv2d(relu(x * scale + shift)) with zero padding AFTER the transform."""
+    rng = np.random.default_rng(B * 1000 + H)
+    g = 4
+    x = torch.from_numpy(rng.normal(0.1, 1.0, size=(B, Cin, H, H)).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
+    sh = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, k, k)).astype(np.float32)).requires_grad_()
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y = torch.nn.functional.conv2d(a, w, None, 1, pd, dl, g)
+    dy = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    # the pad value is what the transform maps to 0 (gssd_bn_finalize_f32 writes it): -shift / scale, or anything <= that for scale > 0
+    pad = torch.where(sc != 0, -sh / sc, torch.zeros_like(sc))
+    pad = torch.where((pad * sc + sh) > 0, torch.nextafter(pad, -torch.sign(sc) * torch.full_like(pad, float('inf'))), pad)
+    assert float(torch.relu(pad * sc + sh).abs().max()) == 0.0
+    keep = [nhwc(x).to(dev), sc.to(dev), sh.to(dev), pad.to(dev)]
+    desc, _, _ = ops.make_conv_desc(keep[0], None, None, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g, k=k, stride=1,
+                                    pad=pd, dil=dl, in_scale=keep[1], in_shift=keep[2], in_pad=keep[3])
+    dw = ops.conv_wgrad(desc, nhwc(dy).to(dev), Cout, Cin // g, k)
+    assert rel(dw, w.grad) < TOL
+
+
 WINO_CASES = [
     # B, H, Cin, Cout, groups          (3x3 / stride 1 / pad 1)
     (2, 38, 512, 512, 4),      # conv4_2: cout_g 128 -> two 64-channel blocks, 8 chunks, even map
@@ -197,6 +222,11 @@ BWD_CASES = [
     (2, 80, 64, 64, 3, 1, 1, 1, 4),      # thin wgrad <16>
     (8, 38, 512, 512, 1, 1, 0, 1, 1),    # large dense 1x1: slot-scheduled TN wgrad (csrc/wgrad_slot.hip) + NT dgrad (gemm_slot.hip)
     (5, 37, 480, 120, 1, 1, 0, 1, 1),    # ... ragged: 6845 pixels (reduction tail), 120 of 128 rows, 480 of 512 columns
+    (4, 38, 512, 512, 3, 1, 1, 1, 4),    # conv4_x: slot-scheduled TN wgrad with taps and groups (one tap per 128 columns)
+    (12, 19, 512, 1024, 3, 1, 6, 6, 4),  # conv6: dilation 6, cout_g 256 (two row tiles per group)
+    (16, 38, 512, 512, 3, 2, 1, 1, 4),   # stride 2 (wgrad only)
+    (4, 38, 512, 108, 3, 1, 1, 1, 1),    # DCN offset conv: 108 of 128 rows, K = 4608
+    (12, 19, 1024, 1024, 1, 1, 0, 1, 4), # conv7: grouped 1x1
 ]
 
 
