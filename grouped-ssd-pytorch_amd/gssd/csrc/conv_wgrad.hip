@@ -193,17 +193,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 
     // ---- epilogue: undo the 4*r + j column permutation, fp32 atomics into the packed gradient ----------------------------
+    // Straight from the accumulator layout an atomic instruction would touch 8 cache lines with 8 floats each (lanes r are 16 bytes
+    // apart, the four kq groups in different rows) -- measured on the slot kernel at 37 G atomics/s, i.e. more than the MFMAs of a
+    // short reduction slice.  Each wave transposes its block through 32 x 65 floats of the (idle) stage memory, 32 rows per pass, so
+    // that one instruction adds 64 consecutive floats of one row = two full lines.
+    __syncthreads();                                          // every wave is done reading the stages
+    constexpr int TP = 65;
+    float* const tb = smem + wave * (32 * TP);
+    constexpr int PASSES = MT == 4 ? 2 : 1;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = kq * 4 + e;                                   // MFMA row
-                const int co = (MT == 4) ? co0 + wm * 64 + 4 * rr + i : co0 + wm * 16 + rr;
-                const int k = k0 + wn * 64 + 4 * r + j;                      // MFMA column r
-                if (co < cout_g && k < p.K) unsafeAtomicAdd(p.dw + (size_t)(g * cout_g + co) * p.K + k, acc[i][j][e]);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e1 = 0; e1 < (MT == 4 ? 2 : 4); ++e1) {
+                    const int e = MT == 4 ? 2 * ps + e1 : e1;
+                    const int local = MT == 4 ? (kq * 2 + e1) * 4 + i : kq * 4 + e;
+                    tb[local * TP + 4 * r + j] = acc[i][j][e];
+                }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own writes have landed (nobody else reads them)
+        __builtin_amdgcn_wave_barrier();
+        const int k = k0 + wn * 64 + lane;
+        if (k < p.K) {
+#pragma unroll 8
+            for (int local = 0; local < (MT == 4 ? 32 : 16); ++local) {
+                const int co = MT == 4 ? co0 + wm * 64 + 4 * (4 * (local >> 3) + 2 * ps + ((local >> 2) & 1)) + (local & 3)
+                                       : co0 + wm * 16 + local;
+                if (co < cout_g) unsafeAtomicAdd(p.dw + (size_t)(g * cout_g + co) * p.K + k, tb[local * TP + lane]);
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <int MT, int WM, int WN>
@@ -285,7 +307,7 @@ extern "C" int gssd_conv2d_wgrad_f32(const gssd_conv_desc* dp, const float* dy, 
         if (rc != 1) return rc;
     }
     {
-        static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr;               // ablation switch
+        static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr || getenv("GSSD_NO_WGRAD_SLOT") != nullptr;   // ablation switches
         const int rc = no_slot ? 1 : gssd_try_wgrad_slot(d, dy, dw_packed, as_stream(stream));   // large plain 1x1 / DCN contraction
         if (rc != 1) return rc;
     }

@@ -195,34 +195,61 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
         static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
     }
 
-    // ---- epilogue: tile (i, j) element e of lane (r, kq) is dW[co0 + wm*64 + 4*(4*kq + e) + i][k0 + wn*128 + 64*(j>>2) + 4*r + (j&3)] ----
+    // ---- epilogue: tile (i, j) element e of lane (r, kq) is dW[co0 + wm*64 + 4*(4*kq + e) + i][k0 + wn*128 + 64*(j>>2) + 4*r + (j&3)].
+    // The reduction slices meet in fp32 atomics on the zero-filled dW.  Issued straight from the accumulator layout an atomic
+    // instruction would touch 8 cache lines with 8 floats each (measured: 37 G atomics/s -- the epilogue of a 45-chunk slice cost
+    // more than its MFMAs); each wave therefore transposes its 64 x 128 block through its own 16 KB of the (now idle) stage memory,
+    // 64 columns at a time, so that one instruction adds 64 consecutive floats = two full lines.
+    const int cog = g * p.Cout;
+    if (p.split == 1) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = co0 + wm * 64 + 4 * (4 * kq + e) + i;
-            if (co >= p.Cout) continue;
-            float* row = p.dw + (size_t)(g * p.Cout + co) * p.dw_stride;
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wm * 64 + 4 * (4 * kq + e) + i;
+                if (co >= p.Cout) continue;
+                float* row = p.dw + (size_t)(cog + co) * p.dw_stride;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + wn * 128 + 64 * h + 4 * r;
-                if (k >= p.K) continue;                       // K % 4 == 0: a quad is in or out as a whole
-                if (p.split == 1) {
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k0 + wn * 128 + 64 * h + 4 * r;
+                    if (k >= p.K) continue;                       // K % 4 == 0: a quad is in or out as a whole
                     f32x4 v = *reinterpret_cast<f32x4*>(row + k);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] += acc[i][4 * h + c][e];
                     *reinterpret_cast<f32x4*>(row + k) = v;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(row + k + c, acc[i][4 * h + c][e]);
                 }
             }
+        return;
+    }
+    __syncthreads();                                          // every wave is done reading the stages
+    constexpr int TP = 65;                                    // row pitch (floats): column reads and row writes both conflict free
+    float* const tb = smem + wave * (64 * TP);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tb[(4 * (4 * kq + e) + i) * TP + 4 * r + c] = acc[i][4 * h + c][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this wave's own writes have landed (no other wave reads them)
+        __builtin_amdgcn_wave_barrier();
+        const int k = k0 + wn * 128 + 64 * h + lane;
+        if (k < p.K) {
+#pragma unroll 8
+            for (int row = 0; row < 64; ++row) {
+                const int co = co0 + wm * 64 + row;
+                if (co < p.Cout) unsafeAtomicAdd(p.dw + (size_t)(cog + co) * p.dw_stride + k, tb[row * TP + lane]);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 }  // namespace
 
 static int pick_split(int tiles, int nchunks) {
+    if (const char* f = getenv("GSSD_WS_SPLIT")) return atoi(f);          // experiment knob
     // split the reduction so that the grid is a whole number of 256-CU rounds (about), each slice >= 8 chunks
     int best = 1;
     double best_eff = 0.0;
