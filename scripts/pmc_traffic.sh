@@ -33,6 +33,7 @@ def short(n):
     if m: return f'flash_attn_bf16v<{m.group(1)},{m.group(2)}>'
     m = re.search(r'flash_attn_kernel<(\d+), (\d+)', n)
     if m: return f'flash_attn<{m.group(1)},{m.group(2)}>'
+    if 'gemm_slot_kernel' in n: return 'gemm_slot<128x128>'
     if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
     if 'dcn_bf16_kernel' in n: return 'dcn_bf16<128x256>'
     m = re.search(r'::(\w+_kernel)', n)
