@@ -415,7 +415,9 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
     if (!ok) return 1;
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
-    // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent
+    // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent.  (Round 2: the persistent NB = 32
+    // variant forced onto the 64 / 128-channel layers measures 15-30 % slower -- conv3_2 489 vs 415 us, conv4_2 436 vs 336 us: it
+    // transforms every input tile once per 32-channel block.)
     if (wino_nb(cout_g, d.groups) == 64) return d.in_scale ? launch_wino<64, true, false>(d, stream) : launch_wino<64, false, false>(d, stream);
     return d.in_scale ? launch_wino<32, true, true>(d, stream) : launch_wino<32, false, true>(d, stream);
 }

@@ -249,7 +249,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_slot_kernel(const WsParams p) {
 }  // namespace
 
 static int pick_split(int tiles, int nchunks) {
-    if (const char* f = getenv("GSSD_WS_SPLIT")) return atoi(f);          // experiment knob
     // split the reduction so that the grid is a whole number of 256-CU rounds (about), each slice >= 8 chunks
     int best = 1;
     double best_eff = 0.0;
