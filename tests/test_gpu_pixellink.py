@@ -156,3 +156,41 @@ def test_decode_vs_reference_fixture(dev, golden):
     a2[:, 1::2] = 5.0
     l1, c1, n1 = postprocess.decode(a1, a2)
     assert int(n1[0]) == 1 and int(l1.min()) == 1 and int(l1.max()) == 1 and float(c1[0, 0, 0]) == 400.0
+
+
+def test_full_size_properties(dev):
+    """B = 32 (the bench batch), size-independent properties: eval-mode outputs of an image do not depend on its batch neighbours
+    (plain graph: convolutions + BatchNorm on running statistics only); PixelLinkLoss on the device predictions equals the oracle
+    criterion on the same predictions; the decoded label maps equal the oracle's decoding of the same predictions."""
+    from pixel_link.criterion import PixelLinkLoss
+    from pixel_link import postprocess
+    B = 32
+    net = build(PLAIN).to(dev).eval()
+    x = synth.synth_images(B, seed=310).to(dev)
+    with torch.no_grad():
+        o1, o2 = net(x)
+        s1, s2 = net(x[5:7].contiguous())
+    assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+    assert rel(s1.cpu(), o1[5:7].cpu()) < 1e-5 and rel(s2.cpu(), o2[5:7].cpu()) < 1e-5
+    # masks: a box of positives per image, every other pixel a negative candidate
+    rng = np.random.default_rng(3)
+    pix = np.zeros((B, 75, 75), np.int64)
+    for b in range(B):
+        y, xx = rng.integers(5, 55, size=2)
+        pix[b, y:y + 10 + b % 5, xx:xx + 8] = 1
+    neg = (pix == 0).astype(np.uint8)
+    posw = pix.astype(np.float32) * rng.uniform(0.5, 1.5, size=pix.shape).astype(np.float32)
+    link = np.repeat(pix[:, None], 8, 1) * (rng.random((B, 8, 75, 75)) > 0.3)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    # scale the (untrained, huge) logits into a numerically meaningful range before the loss / decoding comparison
+    p1 = (o1 / o1.abs().max() * 6).contiguous()
+    p2 = (o2 / o2.abs().max() * 6).contiguous()
+    crit = PixelLinkLoss()
+    pp, pn = crit.pixel_loss(p1, t(pix), t(neg), t(posw), link=(p2, t(link.astype(np.int64))))
+    lp, ln = crit.link_loss(p2, t(link.astype(np.int64)))
+    rp, rn, rlp, rln, _ = PO.pixel_link_loss(p1.cpu(), p2.cpu(), torch.from_numpy(pix), torch.from_numpy(neg), torch.from_numpy(posw),
+                                             torch.from_numpy(link.astype(np.int64)))
+    assert rel([float(pp), float(pn), float(lp), float(ln)], [rp, rn, rlp, rln]) < 1e-5
+    labels, _, ncomp = postprocess.decode(p1, p2)
+    ref = PO.decode_links(p1.cpu(), p2.cpu())
+    assert np.array_equal(labels.cpu().numpy(), ref) and int(ncomp.sum()) == int(sum(r.max() for r in ref))
