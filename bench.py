@@ -222,6 +222,24 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                          + ('; achieved = ALGORITHMIC (direct-convolution) FLOPs per second: the Winograd F(2x2,3x3) kernel '
                             'issues 2.25x fewer MFMA FLOPs than that, so its MFMA-pipe utilisation is achieved/2.25/peak'
                             if dom.startswith('conv_wino') else ''))
+    # the HBM-side companion of `roofline`: the heaviest of the byte-bound trunk layers (the patch-staged thin kernels of conv1_1 ..
+    # conv2_2: arithmetic intensity below the ridge in both storage modes), from the untimed survey passes' per-launch HIP events
+    roof_hbm = None
+    if events and sagg:
+        thin = {k: v for k, v in sagg.items() if k.startswith('conv_thin')}
+        if thin:
+            k = max(thin, key=lambda q: thin[q][3] / max(thin[q][0], 1))          # most algorithmic bytes per launch
+            n, ms, fl, by = thin[k]
+            ach = by / (ms * 1e-3) / 1e9
+            t2 = None
+            try:
+                t2 = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json'))).get(
+                    cfg if dtype == 'f32' else f'{cfg}_{dtype}', {}).get(k, {}).get('hbm_bytes_per_launch')
+            except (OSError, ValueError):
+                pass
+            roof_hbm = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
+                            traffic=t2, kernel=k, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
+                            alg_bytes_per_launch=round(by / n), note='survey passes (eager, every tagged launch bracketed)')
     value = gd.aggregate_rate(world, B, a.steps, dt)
     res = dict(value=round(value, 2), ms_per_step=round(1e3 * dt / a.steps, 3), loss=[round(loss[0], 5), round(loss[1], 5)],
                steady=(dict(steps=a.steady, ms_per_step=round(1e3 * sdt / a.steady, 3),
@@ -232,7 +250,8 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                                frac_mfma_peak=round(value * gflop_img / 1e3 / (peak_t * world), 4),
                                alg_gbs=round(value * mb_img / 1e3, 1),
                                frac_hbm_peak=round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)),
-               first_step_loss=[round(first_loss[0], 5), round(first_loss[1], 5)], roofline=roof, kernels=kernels)
+               first_step_loss=[round(first_loss[0], 5), round(first_loss[1], 5)], roofline=roof, roofline_hbm_trunk=roof_hbm,
+               kernels=kernels)
     return res, net, crit, x, tg, first_loss
 
 
@@ -396,7 +415,7 @@ def main():
                        'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
             'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
             'first_step_loss': res['first_step_loss'],
-            'roofline': res['roofline'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary, 'pixellink': pixellink,
+            'roofline': res['roofline'], 'roofline_hbm_trunk': res['roofline_hbm_trunk'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary, 'pixellink': pixellink,
             'full_step': full, 'input_stage': stage_info,
         }
         print(json.dumps(line))
