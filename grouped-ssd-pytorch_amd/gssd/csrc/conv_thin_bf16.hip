@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     constexpr int NINSTR = (NPATCH + PPI - 1) / PPI;
     constexpr int CPL = NT == 1 ? 4 : 8;           // consecutive output channels per lane
     extern __shared__ __attribute__((aligned(16))) u16 patch[];
+    // the producer's BatchNorm scale | shift, read once per workgroup: the per-element transform below used to fetch them from global
+    // memory inside its loop (four dependent-latency loads per iteration, ~6 us per tile -- most of a tile's time)
+    __shared__ __attribute__((aligned(16))) float xf_tab[XF ? 2 * CIN : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = conv group
@@ -100,6 +103,13 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     float ssum[CPL], ssq[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) ssum[c] = ssq[c] = 0.f;
+    if constexpr (XF) {
+        for (int c = tid; c < CIN; c += 256) {
+            xf_tab[c] = p.in_scale[c];
+            xf_tab[CIN + c] = p.in_shift[c];
+        }
+        __syncthreads();
+    }
 
     const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
@@ -128,8 +138,8 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                 if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
                 const int c0 = (slot ^ swz<UPR>(pxx)) << 3;             // logical first channel of this unit
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + u * 8);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.in_scale + c0), s1 = *reinterpret_cast<const f32x4*>(p.in_scale + c0 + 4);
-                const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.in_shift + c0), h1 = *reinterpret_cast<const f32x4*>(p.in_shift + c0 + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(xf_tab + c0), s1 = *reinterpret_cast<const f32x4*>(xf_tab + c0 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(xf_tab + CIN + c0), h1 = *reinterpret_cast<const f32x4*>(xf_tab + CIN + c0 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = (__bf16)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
