@@ -13,6 +13,10 @@
 //     channel order of conv_bf16.hip) consecutive output channels of one pixel: 8 / 16-byte NHWC stores straight from registers;
 //   * BatchNorm batch sums (of the fp32 accumulators) stay in registers across tiles: 16 shuffles + one fp64 atomic per channel
 //     per workgroup at the end.
+// Measured and rejected (round 2, conv1_1 190 us / conv1_2 232 us / conv2_1 142 us): a second patch stage with the next tile's DMA in
+// flight under the current tile (179 / 303 / 138 us), a persistent grid of 5 instead of 3 workgroups per CU (199 / 237 / 176 us), and
+// whole-pixel-vector stores through an LDS output tile instead of one 32 / 64-byte group slice per wave (196 / 256 / 152 us): neither
+// the load round trip, nor the tiles in flight, nor partial-line writes is what holds these layers at 2.0-3.2 TB/s.
 #include <stdlib.h>
 #include "common.h"
 
