@@ -337,9 +337,12 @@ static int slot_shape(const gssd_conv_desc& d) {
     const int ntn = (d.Cout + 127) / 128;
     const double nfill = (double)d.Cout / (double)(ntn * 128);
     if (no128 || nfill < 0.75 || (long long)mtiles * ntn * images < 192) return 0;
-    // last-round fill against the generic kernel's 128 x 64 tiling (three resident workgroups per CU): the slot stream is worth about
-    // 1.2x at equal fill (scripts/bench_gemm.py), so it must not lose more than that to quantisation (B = 32 x 19 x 19 tokens x 768
-    // columns per image: 576 workgroups = 1.1 rounds of 512 here, 1152 = 1.5 rounds of 768 there -- measured 252 vs 200 us)
+    // Per-image batched projections only: last-round fill against the generic kernel's 128 x 64 tiling (three resident workgroups per
+    // CU).  B = 32 x 19 x 19 tokens x 768 columns per image is 576 workgroups = 1.1 rounds of 512 here and 1152 = 1.5 rounds of 768
+    // there: measured 252 vs 200 us.  Plain (non-batched) GEMMs are faster here at every fill measured (scripts/bench_gemm.py:
+    // M = 46 208, N = 256 -> 1.4 rounds: 192 vs 240 us; N = 384 -> 2.1 rounds: 166 vs 189 us): a CU left with one workgroup in the
+    // last round runs it at nearly twice the shared rate.
+    if (!d.m_per_image) return 128;
     auto fill = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
     const long long w128 = (long long)mtiles * ntn * images, w64 = (long long)mtiles * ((d.Cout + 63) / 64) * images;
     if (fill(w128, 512) * 1.2 >= fill(w64, 768)) return 128;
