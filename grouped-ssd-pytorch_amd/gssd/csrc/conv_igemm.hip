@@ -245,12 +245,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
             }
             if (!n_ok) continue;
             if (p.out_mode == GSSD_OUT_SPLIT_T && n0g >= p.split_n) {
-                // second column range of a merged projection: per image [n - split_n][m], zero padded up to the row stride
-                if (mb < p.out_b_stride) {
+                // second column range of a merged projection: per image [n - split_n][m], zero padded up to the row stride.  With all
+                // images in one M range (m_per_image == 0: Ho*Wo % 4 == 0, so the four rows of a lane stay inside one image) the image
+                // index comes from the row
+                const int bi = p.m_per_image ? img : mb / HoWo;
+                const int ml = p.m_per_image ? mb : mb - bi * HoWo;
+                if (ml < p.out_b_stride && (p.m_per_image || mb < M)) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (mb + e < M) ? v[e] : 0.f;
-                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)img * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + mb) = o;
+                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)bi * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + ml) = o;
                 }
             } else if (p.out_mode == GSSD_OUT_TRANSPOSED) {
                 if (mb < p.out_stride) {
@@ -363,7 +367,8 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     GSSD_CHECK_ARG(((uintptr_t)d.in % 16) == 0 && ((uintptr_t)d.wgt % 16) == 0);
     GSSD_CHECK_ARG(d.out_mode >= 0 && d.out_mode <= 3);
     if (d.out_mode == GSSD_OUT_SPLIT_T) {
-        GSSD_CHECK_ARG(d.m_per_image && d.groups == 1 && d.out_b && d.split_n > 0 && d.split_n < d.Cout && d.split_n % 64 == 0);
+        GSSD_CHECK_ARG((d.m_per_image || (d.Ho * d.Wo) % 4 == 0) && d.groups == 1 && d.out_b && d.split_n > 0 && d.split_n < d.Cout &&
+                       d.split_n % 64 == 0);
         GSSD_CHECK_ARG(d.out_b_stride % 4 == 0 && d.out_b_stride >= d.Ho * d.Wo && d.outb_batch_stride % 4 == 0 && ((uintptr_t)d.out_b % 16) == 0);
         GSSD_CHECK_ARG(!d.gate && !d.resid && !d.relu && !d.stats && d.split_k == 1);
     }

@@ -245,11 +245,14 @@ __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const
             }
             if (!n_ok) continue;
             if (p.out_mode == GSSD_OUT_SPLIT_T && n >= p.split_n) {
-                if (mb < p.out_b_stride) {
+                const int hw = p.Ho * p.Wo;                   // all images in one M range: the image index comes from the row
+                const int bi = p.m_per_image ? img : mb / hw;
+                const int ml = p.m_per_image ? mb : mb - bi * hw;
+                if (ml < p.out_b_stride && (p.m_per_image || mb < M)) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (mb + e < M) ? v[e] : 0.f;
-                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)img * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + mb) = o;
+                    *reinterpret_cast<f32x4*>(p.out_b + (size_t)bi * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + ml) = o;
                 }
             } else if (p.out_mode == GSSD_OUT_TRANSPOSED) {
                 if (mb < p.out_stride) {

@@ -568,8 +568,11 @@ class _Plan(_PlanBase):
         out = self._abuf(B, H, H, Cc)
         out2 = self._abuf(B, H, H, Cc) if need_out2 else None
         mk = ops.make_conv_desc
+        # fp32, N % 4 == 0 (38 x 38): all images as ONE M range -- 361 full row tiles instead of 12 per image with a ragged last one,
+        # and the plain-GEMM dispatch (slot stream) instead of the per-image one
+        flat = not self.bf16 and N % 4 == 0 and Np == N
         d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg,
-                      out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=True,
+                      out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=not flat,
                       in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np,
                       flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else 0))
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),

@@ -76,8 +76,8 @@ int gssd_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int ci
 #define GSSD_OUT_HEADS 2      /* n < split_n -> out (loc), else -> out_b (conf), SSD prior order */
 #define GSSD_OUT_SPLIT_T 3    /* merged projections (Self_Attn theta|phi|g, one pass over x): n < split_n -> out, NHWC rows of
                                  out_stride floats; n >= split_n -> out_b, per image TRANSPOSED [n - split_n][m] with rows of
-                                 out_b_stride floats (zero padded), images outb_batch_stride apart; needs m_per_image, one group,
-                                 split_n a multiple of 64 */
+                                 out_b_stride floats (zero padded), images outb_batch_stride apart; one group, split_n a multiple
+                                 of 64; m_per_image, or (fp32 entry) all images in one M range when Ho*Wo % 4 == 0 */
 
 typedef struct gssd_conv_desc {
     const float* in;    /* NHWC activations */
