@@ -194,3 +194,23 @@ def test_full_size_properties(dev):
     labels, _, ncomp = postprocess.decode(p1, p2)
     ref = PO.decode_links(p1.cpu(), p2.cpu())
     assert np.array_equal(labels.cpu().numpy(), ref) and int(ncomp.sum()) == int(sum(r.max() for r in ref))
+
+
+@pytest.mark.parametrize('kw', [
+    dict(cascade_fuse=False, use_fuseconv=True, batch_norm=False, use_self_attention=True, use_self_attention_base=False,
+         num_dcn_layers=2, groups_dcn=1, dcn_cat_sab=False, detach_sab=False),
+    dict(cascade_fuse=True, use_fuseconv=False, batch_norm=False, use_self_attention=False, use_self_attention_base=True,
+         num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True, detach_sab=True),
+], ids=['sa_2dcn_nobn', 'sab_detach_nofuse'])
+def test_flag_combinations_vs_oracle(dev, kw):
+    """Constructor flags off the bench configuration (model.py:20-188): Self_Attn without the base blocks, two stacked DCN layers
+    without the concatenation, fuse conv without BatchNorm, no fuse conv at all, detach_sab (a forward no-op) -- vs the CPU oracle."""
+    net = build(kw)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = synth.synth_images(2, seed=305)
+    with torch.no_grad():
+        r1, r2, _ = PO.pixellink_forward(sd, x, training=True, **kw)
+    net = net.to(dev).train()
+    with torch.no_grad():
+        o1, o2 = net(x.to(dev))
+    assert rel(o1.cpu(), r1) < TOL and rel(o2.cpu(), r2) < TOL
