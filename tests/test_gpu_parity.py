@@ -813,6 +813,28 @@ def test_backward_gradients(dev, name):
     # self-attention's sigma is a scalar whose gradient is one heavily cancelling sum over the whole map: looser bound
     assert max(v for k, v in errs.items() if not k.endswith('sigma')) < 2e-2, errs
     assert all(v < 6e-2 for k, v in errs.items() if k.endswith('sigma')), errs
+    # The arbiter: the same graph in float64 (CPU autograd through the oracle with double weights / input).  Both fp32 results -- the
+    # HIP backward and the CPU fp32 autograd -- leave it through ONE mechanism: ReLU / max-pool decisions at |z| <~ 1e-5 that a 1e-6
+    # forward difference flips.  scripts/dbg_grad_taps.py on this very case: every backward kernel reproduces float64 to 5e-8 on the
+    # same inputs and d(source_i) to 3e-7; at source 0 three of 2 957 312 ReLU decisions differ from float64 on the HIP path and none on
+    # the CPU fp32 path -- those three units ARE the 1.9e-3 of fuse_11 / L2Norm (sqrt(3 / 1.5 M active units)); in the trunk, where
+    # both paths flip hundreds of decisions, both sit at the same 5-6e-3.  So: per tensor, HIP must be as close to float64 as CPU fp32
+    # is, up to a handful of flips (3x + 5e-3); the head layers (no decision downstream) must match to 1e-5.
+    sd64 = {k: (v.double().requires_grad_() if (v.is_floating_point() and not k.endswith(('running_mean', 'running_var', 'weight_u',
+                                                                                          'weight_v')))
+                else (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    lo64, co64, _ = O.gssd_forward(sd64, x.double(), **flags)
+    ((lo64 * r1.double()).sum() + (co64 * r2.double()).sum()).backward()
+    e_hip64 = {k: l2rel(named[k].grad, sd64[k].grad) for k in keys if k != 'vgg.30.bias'}
+    e_cpu64 = {k: l2rel(sdg[k].grad, sd64[k].grad) for k in keys if k != 'vgg.30.bias'}
+    print('vs float64: HIP', {k: f'{v:.1e}' for k, v in e_hip64.items()}, 'CPU fp32', {k: f'{v:.1e}' for k, v in e_cpu64.items()})
+    for k in e_hip64:
+        # Self_Attn's projection weights and sigma: gradients that are heavily cancelling sums over the 1444 x 1444 map (the float64
+        # value is ~1e-3 of the sum of magnitudes), so fp32 accumulation ORDER shows: MFMA chains of ~2000 sequential terms here,
+        # blocked sums in oneDNN -- 1.2e-2 vs 4e-4 on theta, 1.1e-2 vs 1.1e-3 on sigma
+        slack = 3e-2 if ('snconv1x1' in k or k.endswith('sigma')) else 5e-3
+        assert e_hip64[k] <= 3.0 * e_cpu64[k] + slack, (k, e_hip64[k], e_cpu64[k])
+    assert e_hip64['loc.0.weight'] < 1e-5 and e_hip64['conf.3.bias'] < 1e-5
     # the HIP backward plan against the whole-graph ATen recomputation on the same device (tests/aten_shadow.py); the
     # spectral-norm u / v the HIP forward used are the ones the module holds now
     from aten_shadow import shadow_param_grads
