@@ -44,7 +44,7 @@ class SnItem(C.Structure):
 
 
 OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
-CONV_OUT_F32, CONV_OUTB_BF16_PERM32 = 1, 2
+CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES = 1, 2, 4
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {
@@ -86,6 +86,7 @@ SIGNATURES = {
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_gemm_slot_takes': (c_i, [c_fp]),
+    'gssd_heads_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_interp_add_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pixellink_final_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     'gssd_pixellink_loss_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),

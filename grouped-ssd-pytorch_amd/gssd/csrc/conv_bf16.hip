@@ -288,7 +288,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
                     float* dst = (n < p.split_n) ? p.out + ((size_t)b * p.out_batch_stride + p.out_off + (size_t)pix * p.split_n + n)
                                                  : p.out_b + ((size_t)b * p.outb_batch_stride + p.outb_off +
                                                               (size_t)pix * (p.Cout - p.split_n) + (n - p.split_n));
-                    if (p.split_k > 1) unsafeAtomicAdd(dst, v[c]);
+                    if (p.flags & GSSD_CONV_HEADS_SLICES)             // deterministic split-K: one output copy per slice (see conv_igemm.hip)
+                        dst[(size_t)kz * ((n < p.split_n) ? (size_t)p.B * p.out_batch_stride : (size_t)p.B * p.outb_batch_stride)] = v[c];
+                    else if (p.split_k > 1) unsafeAtomicAdd(dst, v[c]);
                     else *dst = v[c];
                 }
                 continue;

@@ -279,8 +279,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
                                          ? p.out + ((size_t)b * p.out_batch_stride + p.out_off + (size_t)pix * p.split_n + n)
                                          : p.out_b + ((size_t)b * p.outb_batch_stride + p.outb_off +
                                                       (size_t)pix * (p.Cout - p.split_n) + (n - p.split_n));
-                        if (p.split_k > 1) unsafeAtomicAdd(dst, t);   // caller zero-fills the buffers
-                        else *dst = t;
+                        if (p.flags & GSSD_CONV_HEADS_SLICES) {        // deterministic split-K: slice kz has its own copy of the
+                            dst[(size_t)kz * ((n < p.split_n) ? (size_t)p.B * p.out_batch_stride      // outputs, summed in order by
+                                                                   : (size_t)p.B * p.outb_batch_stride)] = t;   // gssd_heads_reduce_f32
+                        } else if (p.split_k > 1) {
+                            unsafeAtomicAdd(dst, t);                    // caller zero-fills the buffers
+                        } else {
+                            *dst = t;
+                        }
                     } else {
                         const size_t o = (size_t)img * p.out_batch_stride + (size_t)m * p.out_stride + p.out_ch_off + n;
                         if (p.gate) {

@@ -345,6 +345,20 @@ __global__ __launch_bounds__(256) void reduce_max_kernel(const float* __restrict
     if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+
+// Deterministic split-K for the multibox heads: slice k of a head wrote its partial sums to ws[k] (same layout as the output);
+// out[b][p][c] = sum over k < splits[p] of ws[k][b][p][c], in slice order -- no atomics, run-to-run identical bits.
+__global__ __launch_bounds__(256) void heads_reduce_kernel(const float* __restrict__ ws, const signed char* __restrict__ splits,
+                                                          float* __restrict__ out, long long total, int P, int C) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)((i / C) % P);
+        const int n = splits[p];
+        float a = ws[i];
+        for (int k = 1; k < n; ++k) a += ws[(size_t)k * total + i];
+        out[i] = a;
+    }
+}
+
 }  // namespace
 
 extern "C" int gssd_pack_input_nhwc(const float* x, float* y, int B, int C, int H, int W, int groups, int cpg_out,
@@ -455,6 +469,16 @@ extern "C" int gssd_softmax_lastdim_f32(const float* x, float* y, int64_t rows, 
 extern "C" int gssd_reduce_max_f32(const float* x, int64_t n, float* out, int out_n, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && out && n > 0 && out_n > 0 && out_n <= 1024 && ((uintptr_t)x % 16) == 0);
     hipLaunchKernelGGL(reduce_max_kernel, dim3(out_n), dim3(256), 0, as_stream(stream), x, (long long)n, out);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_heads_reduce_f32(const float* ws, const signed char* splits, float* out, int B, int P, int C, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(ws && splits && out && B > 0 && P > 0 && C > 0);
+    const long long total = (long long)B * P * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(heads_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), ws, splits, out, total, P, C);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -39,6 +39,7 @@ USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
 # GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
 USE_BRANCH_STREAMS = os.environ.get('GSSD_NO_BRANCH_STREAMS', '0') != '1'
 SN_STREAM = 9               # stream id of the spectral-norm launch inside a captured graph
+ALL_STREAMS = -1            # _Step.wait value: join every forked stream before this step
 
 class _Step:
     __slots__ = ('fn', 'args', 'keep', 'tag', 'sid', 'wait')
@@ -320,6 +321,38 @@ class _Plan(_PlanBase):
                 fi += 1
         self.sources = sources
         assert len(self.head_descs) == 6
+        self._finish_heads()
+
+    def _finish_heads(self):
+        """Deterministic split-K for the heads: every reduction slice of a head conv writes its partial sums to its own copy of the
+        outputs (GSSD_CONV_HEADS_SLICES); two launches then add the slices of every prior in order into loc / conf.  (With fp32
+        atomics loc / conf -- and with them Detect's index output -- differed in their last bits from run to run.)"""
+        B, dev = self.B, self.dev
+        smax = max(d.split_k for d in self.head_descs)
+        splits = torch.ones(self.P, dtype=torch.int8)
+        off = 0
+        for d in self.head_descs:
+            A = d.split_n // 4
+            n = d.Ho * d.Wo * A
+            splits[off:off + n] = d.split_k
+            off += n
+        assert off == self.P
+        self._head_splits = splits.to(dev)
+        self._ws_loc = torch.empty(smax, B, self.P, 4, device=dev, dtype=torch.float32)
+        self._ws_conf = torch.empty(smax, B, self.P, self.nc, device=dev, dtype=torch.float32)
+        for d in self.head_descs:
+            d.out, d.out_b = self._ws_loc.data_ptr(), self._ws_conf.data_ptr()
+            d.flags |= _lib.CONV_HEADS_SLICES
+        prev, self._sid = getattr(self, '_sid', 0), 0
+        self._pending_wait = ALL_STREAMS                      # the heads run on the branch streams: join them all first
+        self._reduce_steps = (len(self.steps), len(self.steps) + 1)
+        self._add(lib.gssd_heads_reduce_f32, [self._ws_loc.data_ptr(), self._head_splits.data_ptr(), 0, B, self.P, 4])
+        self._add(lib.gssd_heads_reduce_f32, [self._ws_conf.data_ptr(), self._head_splits.data_ptr(), 0, B, self.P, self.nc])
+        self._sid = prev
+
+    def _set_outputs(self, loc, conf):
+        self.steps[self._reduce_steps[0]].args[2] = loc.data_ptr()
+        self.steps[self._reduce_steps[1]].args[2] = conf.data_ptr()
 
     def _head(self, i, s, Hs, Cs):
         """loc[i] / conf[i] (models/...group.py:375-380) as ONE merged 3x3 conv writing straight into the concatenated fp32
@@ -678,10 +711,9 @@ class _Plan(_PlanBase):
     def _run_eager(self, x, events, only):
         B, dev = self.B, self.dev
         # zero-filled: the heads accumulate split-K slices with atomics
-        loc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
-        conf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
-        for d in self.head_descs:
-            d.out, d.out_b = loc.data_ptr(), conf.data_ptr()
+        loc = torch.empty(B, self.P, 4, device=dev, dtype=torch.float32)
+        conf = torch.empty(B, self.P, self.nc, device=dev, dtype=torch.float32)
+        self._set_outputs(loc, conf)
         self.steps[self._pack_step].args[0] = x.data_ptr()
         if self.training:
             self.stats.zero_()
@@ -732,8 +764,7 @@ class _Plan(_PlanBase):
             self._gx = torch.empty_like(x)
             self._gloc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
             self._gconf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
-        for d in self.head_descs:
-            d.out, d.out_b = self._gloc.data_ptr(), self._gconf.data_ptr()
+        self._set_outputs(self._gloc, self._gconf)
         self.steps[self._pack_step].args[0] = self._gx.data_ptr()
         groups, cur = [], []
         for st in self.steps:
@@ -759,15 +790,16 @@ class _Plan(_PlanBase):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 if first:
-                    self._gloc.zero_()
-                    self._gconf.zero_()
                     if self.training:
                         self.stats.zero_()
                 main = torch.cuda.current_stream()
                 forked = {}
                 for st in obj:
                     if st.sid == 0 or not USE_BRANCH_STREAMS:
-                        if st.wait is not None and st.wait in forked:
+                        if st.wait == ALL_STREAMS:
+                            for side in forked.values():
+                                main.wait_stream(side)
+                        elif st.wait is not None and st.wait in forked:
                             main.wait_stream(forked[st.wait])
                         self._launch(st, main.cuda_stream)
                         continue
@@ -865,6 +897,7 @@ class _PlanVanilla(_Plan):
             self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))
             off += Hs * Hs * A
         assert off == self.P, off
+        self._finish_heads()
 
     def _conv_relu(self, name, conv, x, H, Cin):
         B = self.B

@@ -130,6 +130,10 @@ int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
 /* GSSD_OUT_SPLIT_T only: the transposed second range (`out_b`) is bf16, its rows out_b_stride (a multiple of 32) elements long, and
  * inside every block of 32 tokens token 16a + 4b + c sits at position 8b + 4a + c (the key order of gssd_self_attn_core_bf16v) */
 #define GSSD_CONV_OUTB_BF16_PERM32 2
+/* GSSD_OUT_HEADS with split_k > 1: instead of fp32 atomics into zero-filled outputs, reduction slice k writes its partial sums
+ * with plain stores to out + k * B * out_batch_stride (and out_b + k * B * outb_batch_stride); gssd_heads_reduce_f32 then adds
+ * the slices in order: run-to-run identical loc / conf */
+#define GSSD_CONV_HEADS_SLICES 4
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,
@@ -414,6 +418,10 @@ int gssd_eval_match(const float* det, long long img_stride, int N, int top_k, co
 long long gssd_eval_workspace_bytes(int M);
 int gssd_eval_ap(const float* conf, const uint8_t* flags, int M, int n_metrics, double npos, int use_07_metric, void* workspace,
                  long long workspace_bytes, double* ap_out, gssd_stream_t stream);
+
+/* out[b][p][c] = sum_{k < splits[p]} ws[k][b][p][c] (ws slices B*P*C floats apart), in slice order: the deterministic reduction of
+ * the multibox heads' split-K slices (GSSD_CONV_HEADS_SLICES).  splits: int8 [P], the slice count of the head that owns prior p. */
+int gssd_heads_reduce_f32(const float* ws, const signed char* splits, float* out, int B, int P, int C, gssd_stream_t stream);
 
 /* ---- PixelLink++ tail (ssd_liverdet/pixel_link) ------------------------------------------------------------
  * The trunk / Self_Attn / DCN / fuse / score-head launches are gssd_conv2d_nhwc_f32 & co; these four are the rest. */

@@ -1259,6 +1259,29 @@ def test_graph_replay_equals_eager(dev, name):
         assert rel(o6[0], r6[0]) < 1e-6 and rel(o6[1], r6[1]) < 1e-6
 
 
+@pytest.mark.parametrize('name', ['gssdpp', 'vanilla'])
+def test_forward_is_run_to_run_deterministic(dev, name):
+    """loc / conf carry identical bits from run to run (eval mode: nothing mutates between the calls): the heads' split-K slices are
+    summed in a fixed order (GSSD_CONV_HEADS_SLICES + gssd_heads_reduce_f32), not by atomics; eager and hipGraph replay alike."""
+    if name == 'vanilla':
+        from models.ssd import build_ssd
+        net = build_ssd('train', 300, 2)
+        x = torch.from_numpy(np.random.default_rng(3).normal(size=(2, 3, 300, 300)).astype(np.float32)).to(dev)
+    else:
+        from models.ssd_multiphase_custom_group import build_ssd
+        net = build_ssd('train', 300, 2, *NETS['gssdpp'][1])
+        x = synth.synth_images(3, seed=77).to(dev)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).eval()
+    outs = []
+    with torch.no_grad():
+        for _ in range(5):                                   # runs 1-2 eager, 3+ replayed
+            loc, conf, _ = net(x)
+            outs.append((loc.clone(), conf.clone()))
+    for loc, conf in outs[1:]:
+        assert torch.equal(loc, outs[0][0]) and torch.equal(conf, outs[0][1])
+
+
 def test_cpu_input_fails_loudly():
     from models.ssd_multiphase_custom_group import build_ssd
     from gssd._lib import GssdError
