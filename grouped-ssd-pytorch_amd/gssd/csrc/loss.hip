@@ -3,7 +3,7 @@
 // reference's separate fp32 torch ops (layers/box_utils.py:28-67,114-135) so that every integer
 // output (conf_t, positive / negative masks) is bit-identical.
 //
-//   gssd_match_batch : one 256-thread workgroup per image (box_utils.py:70-111)
+//   gssd_match_batch : one 1024-thread workgroup per image (box_utils.py:70-111)
 //   gssd_hnm_loss    : one workgroup per image; mining scores live in LDS, the per-row
 //                      "rank < num_neg" of the reference's double sort (multibox_loss.py:101-106) is an
 //                      8-bit x 4-pass radix select of the num_neg-th largest score, ties by lower index
@@ -13,7 +13,7 @@
 namespace {
 
 constexpr int MAX_GT = 64;
-constexpr int LT = 256;
+constexpr int LT = 1024;     // one workgroup per image: 16 waves hide the fp64 exp / log chains and quarter the per-thread loops
 
 __device__ __forceinline__ float iou_pf(float ax1, float ay1, float ax2, float ay2, float area_a, float bx1, float by1,
                                         float bx2, float by2) {
