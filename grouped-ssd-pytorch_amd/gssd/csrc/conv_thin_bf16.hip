@@ -17,6 +17,9 @@
 // flight under the current tile (179 / 303 / 138 us), a persistent grid of 5 instead of 3 workgroups per CU (199 / 237 / 176 us), and
 // whole-pixel-vector stores through an LDS output tile instead of one 32 / 64-byte group slice per wave (196 / 256 / 152 us): neither
 // the load round trip, nor the tiles in flight, nor partial-line writes is what holds these layers at 2.0-3.2 TB/s.
+// Also measured and rejected: this kernel for the 64-channel groups of conv3_x (weights of a group = 144 / 288 registers per lane, one
+// workgroup per CU, rows in blocks of four): conv3_1 114 us vs 99 us, conv3_2 213 us vs 189 us on the generic conv_bf16 -- one wave
+// per SIMD cannot hide the 92 KB patch load, the transform pass and the fragment reads behind its own MFMAs.
 #include <stdlib.h>
 #include "common.h"
 

@@ -60,6 +60,12 @@ CASES = [
     (2, 19, 256, 512, 3, 2, 1, 1, 4),    # extras stride 2
     (5, 3, 128, 256, 3, 1, 0, 1, 4),     # 3 -> 1
     (2, 10, 512, 512, 1, 1, 0, 1, 1),    # dense 1x1 fuse
+    (1, 83, 32, 64, 3, 1, 1, 1, 4),      # patch-staged thin kernels (maps >= 75 x 75, bf16 output): <8,16>, ragged 8 x 16 tiles
+    (1, 83, 64, 64, 3, 1, 1, 1, 4),      # <16,16>
+    (1, 80, 64, 128, 3, 1, 1, 1, 4),     # <16,32>
+    (1, 77, 128, 128, 3, 1, 1, 1, 4),    # <32,32>
+    (2, 77, 128, 256, 3, 1, 1, 1, 4),    # conv3_1 shape on a large map (generic kernel)
+    (2, 75, 256, 256, 3, 1, 1, 1, 4),    # conv3_2 / conv3_3
 ]
 
 
@@ -96,7 +102,7 @@ def test_conv_bf16(dev, case):
 
 
 @pytest.mark.parametrize('Cin,Cout,H,k,st,pd', [(64, 64, 40, 3, 1, 1), (128, 128, 40, 3, 1, 1), (512, 512, 19, 3, 1, 1),
-                                               (1024, 1024, 19, 1, 1, 0), (256, 512, 19, 3, 2, 1)])
+                                               (1024, 1024, 19, 1, 1, 0), (256, 512, 19, 3, 2, 1), (256, 256, 77, 3, 1, 1)])
 def test_conv_bf16_fused_input_bn_relu(dev, Cin, Cout, H, k, st, pd):
     """Consumer-side BatchNorm + ReLU on bf16 raw input: conv2d(q(relu(q(x) * scale + shift))) with zero padding after the transform."""
     from gssd import ops, _lib
