@@ -450,7 +450,8 @@ int gssd_pixellink_loss_f32(const float* out1, const float* out2, const long lon
 /* Link decoding (pixel_link/postprocess.py:104-121 thresholds, :178-234 `func`): labels [B][H][W] int32 = 0 for background, else
  * 1 + rank of the pixel's connected component by its first pixel in raster order (the reference's root_map numbering; the reference
  * stores it as uint8 and wraps beyond 255 components, this does not).  comps [B][max_comp][6] = {pixel count, min x, min y, max x,
- * max y, sum of the positive-class probability}; ncomp [B].  H*W <= 8192. */
+ * max y, sum of the positive-class probability} for the first min(max_comp, 1024) components (the rest: count 0); ncomp [B].
+ * H*W <= 8192. */
 int gssd_pixellink_decode_f32(const float* out1, const float* out2, int* labels, float* comps, int* ncomp, int B, int H, int W,
                               float pixel_thr, float link_thr, int max_comp, gssd_stream_t stream);
 
