@@ -198,7 +198,7 @@ class BackwardPlan:
             self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
 
     def _convrelu(self, r, need_dgrad=True):
-        """conv + ReLU of the vanilla SSD (models/ssd.py:104-118, no BatchNorm): dz = d(out) * [out > 0] (the mask of the
+        """conv + ReLU without BatchNorm (vanilla SSD, models/ssd.py:104-118; the grouped batch_norm=False graph): dz = d(out) * [out > 0] (the mask of the
         stored post-ReLU output equals the pre-activation's), bias gradient = column sums, then wgrad / dgrad."""
         B, H, Ho, Cin, Cout, conv, out = self.B, r['H'], r['Ho'], r['Cin'], r['Cout'], r['conv'], r['out']
         dout = self._grad_of(out)
@@ -210,11 +210,12 @@ class BackwardPlan:
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dz.data_ptr(), B * Ho * Ho, Cout, Cout, cs.data_ptr()))
         self._bias_from_colsum(cs, conv.bias)
-        cin_real = conv.weight.shape[1]
-        dwp, K = self._wgrad(r['desc'], dz, conv, cin_real, Cin, r['k'], Cout)
-        self._unpack(dwp, K, 0, conv.weight, cin_real, Cin, r['k'])
+        groups = r.get('groups', 1)
+        cin_g_real, cin_g_pad = conv.weight.shape[1], Cin // groups
+        dwp, K = self._wgrad(r['desc'], dz, conv, cin_g_real, cin_g_pad, r['k'], Cout)
+        self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
         if need_dgrad:
-            self._dgrad(r, dz, r['x_in'], conv, 1, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
+            self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
 
     def _pool(self, r):
         B, H, Cc, Hp = self.B, r['H'], r['C'], r['Hp']
@@ -300,25 +301,37 @@ class BackwardPlan:
         self._add(lib.gssd_sn_weight_grad_f32, (dwo.data_ptr(), C2, cv['attn'].weight_orig.data_ptr(), cv['attn'].weight_u.data_ptr(),
                                                 cv['attn'].weight_v.data_ptr(), a_o.data_ptr(), sig.data_ptr(), sndot[3:].data_ptr(),
                                                 self._pgrad(cv['attn'].weight_orig).data_ptr(), Cc, C2))
-        # attention map A (no stored copy: the forward is flash-style)
-        A = self._buf(B, N, Np)
-        d_qk, _, _ = mk(tp, tp[0, 0, C8:], A, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
-                        in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
+        # attention map A (no stored copy: the forward is flash-style).  Keys / values: phi / g of the same tokens, or their P x P
+        # average-pooled copies (max_pool_factor > 1) -- then the key-side gradients come out per cell and are un-pooled below
+        Nk, Nkp, pooled = r['Nk'], r['Nkp'], r['kp'] is not None
+        keys, krow, vals = (r['kp'], C8, r['gTp']) if pooled else (tp[0, 0, C8:], C4, gT)
+        A = self._buf(B, N, Nkp)
+        d_qk, _, _ = mk(tp, keys, A, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=Nk, out_stride=Nkp, m_per_image=True,
+                        in_batch_stride=N * C4, wgt_batch_stride=Nk * krow, out_batch_stride=N * Nkp, wgt_row_stride=krow)
         self._add(fn, (C.byref(d_qk),), keep=d_qk)
-        self._add(lib.gssd_softmax_rows_f32, (A.data_ptr(), B * N, N, Np))
+        self._add(lib.gssd_softmax_rows_f32, (A.data_ptr(), B * N, Nk, Nkp))
         # dA = d(ag)' . g ;  dS in place
-        dA = self._buf(B, N, Np)
-        self._add(lib.gssd_bgemm_f32, (dag.data_ptr(), gT.data_ptr(), dA.data_ptr(), N, N, C2, C2, Np, Np, 0, 0, N * C2, C2 * Np, N * Np, B,
-                                       1.0, 0))
-        self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, N, Np))
+        dA = self._buf(B, N, Nkp)
+        self._add(lib.gssd_bgemm_f32, (dag.data_ptr(), vals.data_ptr(), dA.data_ptr(), N, Nk, C2, C2, Nkp, Nkp, 0, 0, N * C2, C2 * Nkp,
+                                       N * Nkp, B, 1.0, 0))
+        self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, Nk, Nkp))
         # [d theta | d phi | d g] token-major, one buffer (the gradient of the merged projection's output)
         dtpg = self._buf(B, N, CT)
-        self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp[0, 0, C8:].data_ptr(), dtpg.data_ptr(), N, C8, N, Np, C4, CT, 0, 0, N * Np, N * C4,
+        self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), keys.data_ptr(), dtpg.data_ptr(), N, C8, Nk, Nkp, krow, CT, 0, 0, N * Nkp, Nk * krow,
                                        N * CT, B, 1.0, 0))
-        self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp.data_ptr(), dtpg[0, 0, C8:].data_ptr(), N, C8, N, Np, C4, CT, 1, 0, N * Np, N * C4,
-                                       N * CT, B, 1.0, 0))
-        self._add(lib.gssd_bgemm_f32, (A.data_ptr(), dag.data_ptr(), dtpg[0, 0, C4:].data_ptr(), N, C2, N, Np, C2, CT, 1, 0, N * Np, N * C2,
-                                       N * CT, B, 1.0, 0))
+        if pooled:
+            CW = C8 + C2
+            dkg = self._buf(B, Nk, CW)                                        # d(pooled phi) | d(pooled g) per cell
+            self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp.data_ptr(), dkg.data_ptr(), Nk, C8, N, Nkp, C4, CW, 1, 0, N * Nkp, N * C4,
+                                           Nk * CW, B, 1.0, 0))
+            self._add(lib.gssd_bgemm_f32, (A.data_ptr(), dag.data_ptr(), dkg[0, 0, C8:].data_ptr(), Nk, C2, N, Nkp, C2, CW, 1, 0, N * Nkp,
+                                           N * C2, Nk * CW, B, 1.0, 0))
+            self._add(lib.gssd_sa_unpool_f32, (dkg.data_ptr(), dtpg[0, 0, C8:].data_ptr(), B, H, r['P'], CW, CT))
+        else:
+            self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), tp.data_ptr(), dtpg[0, 0, C8:].data_ptr(), N, C8, N, Np, C4, CT, 1, 0, N * Np,
+                                           N * C4, N * CT, B, 1.0, 0))
+            self._add(lib.gssd_bgemm_f32, (A.data_ptr(), dag.data_ptr(), dtpg[0, 0, C4:].data_ptr(), N, C2, N, Np, C2, CT, 1, 0, N * Np,
+                                           N * C2, N * CT, B, 1.0, 0))
         # projection weights / biases
         d_p, _, _ = mk(x, None, None, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=CT)
         dwp = self._buf(CT, Cc, zero_each_run=True)

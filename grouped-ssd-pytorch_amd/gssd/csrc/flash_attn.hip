@@ -53,9 +53,9 @@ __device__ __forceinline__ void stage_tile(float* lds, int wave, int lane, RowPt
 }
 
 template <int D, int C2, int BKV>
-__global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ gT,
-                                                           float* __restrict__ out, int N, int Np, int qtiles, int d_real,
-                                                           int out_bf16) {
+__global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ kp,
+                                                           const float* __restrict__ gT, float* __restrict__ out, int N, int Nk,
+                                                           int Np, int qtiles, int d_real, int kstride, int out_bf16) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                    // [BKV][D]
     float* const Vs = smem + BKV * D;          // [C2][BKV]
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     const int q = qt * 64 + wave * 16 + r;                       // this lane's query (column of every C-layout tile)
     const int tps = 2 * d_real;                                   // floats per token of tp (d_real <= D; D - d_real zero filled)
     const float* tpb = tp + (size_t)b * N * tps;
-    const float* gTb = gT + (size_t)b * C2 * Np;
+    const float* kpb = kp + (size_t)b * Nk * kstride;            // keys: phi of the same tokens (kp = tp + d_real, Nk = N) or
+    const float* gTb = gT + (size_t)b * C2 * Np;                  // the pooled phi / g of max_pool_factor > 1 (Nk < N)
 
     // query fragments: B operand, lane (q, kq) holds theta[q][16 i + 4 kq + s]
     f32x4 qf[DI];
@@ -84,12 +85,12 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     for (int c = 0; c < CT; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;                        // l_run: this lane's share (its kq keys) of the row sum
 
-    const int ntiles = (N + BKV - 1) / BKV;
+    const int ntiles = (Nk + BKV - 1) / BKV;
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * BKV;
         __syncthreads();                                          // every wave is done with the previous tiles
         stage_tile<BKV, QRK>(Ks, wave, lane,
-                             [&](int row) { return key0 + row < N ? tpb + (size_t)(key0 + row) * tps + d_real : (const float*)nullptr; },
+                             [&](int row) { return key0 + row < Nk ? kpb + (size_t)(key0 + row) * kstride : (const float*)nullptr; },
                              [&](int quad) { return 4 * quad < d_real; });
         stage_tile<C2, QRV>(Vs, wave, lane, [&](int row) { return gTb + (size_t)row * Np + key0; },
                             [&](int quad) { return key0 + 4 * quad < Np; });
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (key0 + kt * 16 + 4 * kq + e >= N) s[kt][e] = -INFINITY;
+                if (key0 + kt * 16 + 4 * kq + e >= Nk) s[kt][e] = -INFINITY;
                 mx = fmaxf(mx, s[kt][e]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
 }
 
 template <int D, int C2, int BKV>
-int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, int d_real, int out_bf16, hipStream_t stream) {
+int launch(const float* tp, const float* kp, const float* gT, float* out, int B, int N, int Nk, int Np, int d_real, int kstride,
+           int out_bf16, hipStream_t stream) {
     constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
     static bool attr_set[16] = {false};
     int dev = 0;
@@ -197,7 +199,7 @@ int launch(const float* tp, const float* gT, float* out, int B, int N, int Np, i
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np, qtiles, d_real, out_bf16);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -354,21 +356,27 @@ int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np3
 
 }  // namespace
 
-extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out_v, int B, int N, int Np, int D, int C2,
-                                       int out_bf16, gssd_stream_t stream) {
+extern "C" int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, const float* gT, void* out_v, int B, int N, int Nk, int Nkp,
+                                          int D, int C2, int kstride, int out_bf16, gssd_stream_t stream) {
     float* out = reinterpret_cast<float*>(out_v);
-    GSSD_CHECK_ARG(tp && gT && out && B > 0 && N > 0 && Np >= N && Np % 4 == 0);
-    GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)gT % 16) == 0 && ((uintptr_t)out % 16) == 0);
+    GSSD_CHECK_ARG(tp && kp && gT && out && B > 0 && N > 0 && Nk > 0 && Nkp >= Nk && Nkp % 4 == 0);
+    GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)gT % 16) == 0 && ((uintptr_t)out % 16) == 0);
     GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
     hipStream_t s = as_stream(stream);
-    GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0);
-    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
-    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, gT, out, B, N, Np, D, out_bf16, s);
-    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
-    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);     // small maps (Self_Attn(64): op-level tests)
-    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, gT, out, B, N, Np, D, out_bf16, s);
+    GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0 && kstride >= D && kstride % 4 == 0);
+    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
+    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
+    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
+    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);     // small maps (Self_Attn(64): op-level tests)
+    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
     gssd_set_error("self-attention core: unsupported (theta/phi channels %d, g channels %d); built: (64,256) (128,512) (32,128) (<=16,32|64)", D, C2);
     return GSSD_EINVAL;
+}
+
+extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out_v, int B, int N, int Np, int D, int C2,
+                                       int out_bf16, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(tp && D > 0);
+    return gssd_self_attn_core_kv_f32(tp, tp + D, gT, out_v, B, N, N, Np, D, C2, 2 * D, out_bf16, stream);   // keys = phi of the same tokens
 }
 
 extern "C" int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,

@@ -257,6 +257,19 @@ class _Plan(_PlanBase):
         else:
             self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, 4])
 
+        if not net.batch_norm:
+            if self.bf16:
+                raise _lib.GssdError('bf16 storage mode is built for the batch_norm=True graph (BASELINE.json configs[4])')
+            self._build_plain_graph(x16)
+        else:
+            self._build_bn_graph(x16)
+        assert len(self.head_descs) == 6
+        self._finish_heads()
+
+    def _build_bn_graph(self, x16):
+        """models/...group.py:254-372, batch_norm=True (the driver's graph, train_lesion_multiphase_v2.py:77)."""
+        net = self.eng.net
+        g = net.groups_vgg
         # ---- trunk -------------------------------------------------------------------------------------
         cur, H, Cc = x16, 300, self.cpad * g
         vi = 0
@@ -320,8 +333,60 @@ class _Plan(_PlanBase):
                 sa_i += 1
                 fi += 1
         self.sources = sources
-        assert len(self.head_descs) == 6
-        self._finish_heads()
+
+    def _build_plain_graph(self, x16):
+        """batch_norm=False (models/...group.py:254-256, 329-349; vgg() / add_extras() without BatchNorm, multibox sources [21, -2]):
+        every conv carries bias + ReLU in its epilogue, pools are the identity-affine pool pass, fuse convs have no BatchNorm."""
+        net = self.eng.net
+        g, ge = net.groups_vgg, net.groups_extra
+        cur, H, Cc = x16, 300, self.cpad * g
+        mods = list(net.vgg)
+        i = 0
+        src0 = None
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, torch.nn.Conv2d):
+                cur, H, Cc = self._conv_act(f'vgg.{i}', m, cur, H, Cc, g)
+                i += 2                                   # conv + ReLU
+                if i - 2 == 21:                          # conv4_3 (ReLU at 22, idx_until_conv4_3 = 23): the first source's block
+                    cur, H, Cc, src0 = self._after_conv4_3(cur, H, Cc)      # ... which also runs pool4 (vgg[23])
+                    i += 1
+            else:
+                cur, H = self._pool_only(cur, H, Cc, m.kernel_size, m.stride, m.padding, m.ceil_mode)
+                i += 1
+        sources = [src0]
+        sab_i, sa_i = 1, 1
+        if net.use_self_attention_base:
+            cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False, want_map=self.want_maps)
+            sab_i += 1
+        sources.append(self._branch(cur, H, Cc, sa_i, '21'))
+        sa_i += 1
+        fi = 2
+        for k, m in enumerate(net.extras):
+            cur, H, Cc = self._conv_act(f'extras.{k}', m, cur, H, Cc, ge)
+            if k % 2 == 1:
+                if net.use_self_attention_base:
+                    cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False, want_map=self.want_maps)
+                    sab_i += 1
+                sources.append(self._branch(cur, H, Cc, sa_i, FUSE_NAMES[fi]))
+                sa_i += 1
+                fi += 1
+        self.sources = sources
+
+    def _conv_act(self, name, conv, x, H, Cin, groups):
+        """(grouped) conv + bias + ReLU in ONE launch (ReLU in the conv epilogue): the batch_norm=False layers."""
+        B = self.B
+        k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+        Cout = conv.out_channels
+        wp = self._packed_conv(name, conv)
+        Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
+        out = self._buf(B, Ho, Ho, Cout)
+        d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // groups, Cout=Cout, groups=groups, k=k,
+                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(), relu=True)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self.rec.append(('convrelu', dict(name=name, conv=conv, x_in=x, out=out, H=H, Cin=Cin, Ho=Ho, Cout=Cout, desc=d, k=k,
+                                          stride=s, pad=p, dil=dl, groups=groups)))
+        return out, Ho, Cout
 
     def _finish_heads(self):
         """Deterministic split-K for the heads: every reduction slice of a head conv writes its partial sums to its own copy of the
@@ -496,9 +561,9 @@ class _Plan(_PlanBase):
     def eng_stat(self, bn):
         return self.stat_of[id(bn)]
 
-    def _pool_only(self, x, H, Cc, k, s, p):
+    def _pool_only(self, x, H, Cc, k, s, p, ceil=False):
         B = self.B
-        Hp = ops.pool_out_size(H, k, s, p, False)
+        Hp = ops.pool_out_size(H, k, s, p, ceil)
         out = self._abuf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
                   (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0))
@@ -543,9 +608,11 @@ class _Plan(_PlanBase):
         prev, self._sid = getattr(self, '_sid', 0), sa_i + 1
         if net.use_self_attention:
             s, _ = self._self_attn('self_attn_list', sa_i, s, H, Cc, need_out2=False, want_map=self.want_maps)
-        if net.use_fuseconv:
+        if net.use_fuseconv and net.batch_norm:
             conv, bn = getattr(net, f'fuse_{fuse}'), getattr(net, f'bn_fuse_{fuse}')
             s, H, Cc, _ = self._conv_bn(f'fuse_{fuse}', conv, bn, s, H, Cc, 1, relu=True)
+        elif net.use_fuseconv:
+            s, H, Cc = self._conv_act(f'fuse_{fuse}', getattr(net, f'fuse_{fuse}'), s, H, Cc, 1)
         self._head(sa_i, s, H, Cc)
         self._sid = prev
         return (s, H, Cc)
@@ -624,7 +691,20 @@ class _Plan(_PlanBase):
                            out_batch_stride=C2 * Np)
             self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
             self._add(fn, (C.byref(d1b),), keep=d1b)
-        if self.bf16:
+        # max_pool_factor > 1 (layers/self_attn.py:57-59, 67, 76): keys / values average-pooled to a P x P grid before the core
+        P = max(H // int(sa.max_pool_factor), 1)
+        pooled = P != H
+        Nk, Nkp, kp, gTp = N, Np, None, None
+        if pooled:
+            if self.bf16:
+                raise _lib.GssdError('bf16 storage mode is built for max_pool_factor = 1 (BASELINE.json configs[4])')
+            Nk, Nkp = P * P, ops.round_up(P * P, 4)
+            kp, gTp = self._buf(B, Nk, C8), self._buf(B, C2, Nkp)
+            self._add(lib.gssd_sa_pool_kv_f32, (tp.data_ptr(), gT.data_ptr(), kp.data_ptr(), gTp.data_ptr(), B, H, P, C8, C2, Np, Nkp))
+            self._add(lib.gssd_self_attn_core_kv_f32, (tp.data_ptr(), kp.data_ptr(), gTp.data_ptr(), ag.data_ptr(), B, N, Nk, Nkp, C8, C2,
+                                                       C8, 0),
+                      tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * Nk * (C8 + C2), 4.0 * B * (N * C8 + Nk * C8 + C2 * Nkp + N * C2)))
+        elif self.bf16:
             self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
                       tag=(f'flash_attn_bf16v<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), B * (4.0 * N * C4 + 2.0 * C2 * Np + 2.0 * N * C2)))
         else:
@@ -633,16 +713,17 @@ class _Plan(_PlanBase):
         S = None
         if want_map:
             # attn[b,i,j] = softmax_j(sum_c theta[b,i,c] * phi[b,j,c])   (no 1/sqrt(d) scaling, self_attn.py:71-72)
-            S = self._buf(B, N, Np)
-            d3, _, _ = mk(tp, tp[0, 0, C8:], S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=N, out_stride=Np, m_per_image=True,
-                          in_batch_stride=N * C4, wgt_batch_stride=N * C4, out_batch_stride=N * Np, wgt_row_stride=C4)
+            S = self._buf(B, N, Nkp)
+            keys, krow = (kp, C8) if pooled else (tp[0, 0, C8:], C4)
+            d3, _, _ = mk(tp, keys, S, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=Nk, out_stride=Nkp, m_per_image=True,
+                          in_batch_stride=N * C4, wgt_batch_stride=Nk * krow, out_batch_stride=N * Nkp, wgt_row_stride=krow)
             self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d3),), keep=d3)        # fp32 operands in both modes
-            self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, N, Np))
+            self._add(lib.gssd_softmax_rows_f32, (S.data_ptr(), B * N, Nk, Nkp))
         self._add(fn, (C.byref(d5),), keep=d5)
         self.attn_maps = getattr(self, 'attn_maps', {})
-        self.attn_maps[(lst_name, idx)] = (S, N, Np)
+        self.attn_maps[(lst_name, idx)] = (S, Nk, Nkp)
         self.rec.append(('sa', dict(mod=sa, name=name, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, ag=ag, N=N, Np=Np,
-                                    inv_sigma=(a_tpg, a_o))))
+                                    inv_sigma=(a_tpg, a_o), P=P, Nk=Nk, Nkp=Nkp, kp=kp, gTp=gTp)))
         return out, out2
 
     def _dcn(self, li, x, H, Cin):

@@ -55,9 +55,6 @@ class Self_Attn(nn.Module):
 
     def __init__(self, in_channels, max_pool_factor=1):
         super().__init__()
-        if max_pool_factor != 1:
-            raise NotImplementedError('max_pool_factor != 1 (key/value average pooling, self_attn.py:57-59) is not '
-                                      'built in the HIP path yet; the driver default is 1')
         self.in_channels = in_channels
         self.snconv1x1_theta = SNConv1x1(in_channels, in_channels // 8)
         self.snconv1x1_phi = SNConv1x1(in_channels, in_channels // 8)

@@ -36,11 +36,6 @@ class SSD(nn.Module):
                  use_fuseconv, use_self_attention, use_self_attention_base, num_dcn_layers, groups_dcn, dcn_cat_sab,
                  detach_sab, max_pool_factor):
         super().__init__()
-        if not batch_norm:
-            raise NotImplementedError('the HIP path builds the batch_norm=True graph, the only one the driver uses '
-                                      '(train_lesion_multiphase_v2.py:77)')
-        if feature_scale != 1 or not use_fuseconv:
-            raise NotImplementedError('feature_scale != 1 / use_fuseconv=False are not built in the HIP path')
         if groups_vgg != 4 or groups_extra != 4:
             raise NotImplementedError('the HIP path is laid out for 4 phases (groups_vgg = groups_extra = 4)')
         self.phase = phase
@@ -57,7 +52,7 @@ class SSD(nn.Module):
         self.num_dcn_layers = num_dcn_layers
 
         self.vgg = nn.ModuleList(base)
-        self.L2Norm = L2Norm(512, 20)
+        self.L2Norm = L2Norm(512 * feature_scale, 20)
         self.extras = nn.ModuleList(extras)
         self.loc = nn.ModuleList(head[0])
         self.conf = nn.ModuleList(head[1])
@@ -65,17 +60,21 @@ class SSD(nn.Module):
             self.softmax = nn.Softmax(dim=-1)
             self.detect = Detect      # new-style autograd.Function: used via .apply (reference :75,:384)
 
-        for name, ch in (('11', 512), ('21', 1024), ('31', 512), ('41', 256), ('51', 256), ('61', 256)):
-            conv = nn.Conv2d(ch, ch, kernel_size=1)
-            conv.apply(weights_init)
-            setattr(self, f'fuse_{name}', conv)
-            setattr(self, f'bn_fuse_{name}', nn.BatchNorm2d(ch))
-        # the same modules registered a second time, like the reference (:135-139) -> duplicate state-dict keys
-        self.fuse_list1 = nn.ModuleList([self.fuse_31, self.fuse_41, self.fuse_51, self.fuse_61])
-        self.bn_fuse_list1 = nn.ModuleList([self.bn_fuse_31, self.bn_fuse_41, self.bn_fuse_51, self.bn_fuse_61])
+        fs = feature_scale
+        if use_fuseconv:                                   # reference :79-139 (fuse convs only with use_fuseconv, their BN only with
+            for name, ch in (('11', 512), ('21', 1024), ('31', 512), ('41', 256), ('51', 256), ('61', 256)):   # batch_norm)
+                conv = nn.Conv2d(ch * fs, ch * fs, kernel_size=1)
+                conv.apply(weights_init)
+                setattr(self, f'fuse_{name}', conv)
+                if batch_norm:
+                    setattr(self, f'bn_fuse_{name}', nn.BatchNorm2d(ch * fs))
+            # the same modules registered a second time, like the reference (:135-139) -> duplicate state-dict keys
+            self.fuse_list1 = nn.ModuleList([self.fuse_31, self.fuse_41, self.fuse_51, self.fuse_61])
+            if batch_norm:
+                self.bn_fuse_list1 = nn.ModuleList([self.bn_fuse_31, self.bn_fuse_41, self.bn_fuse_51, self.bn_fuse_61])
 
         self.max_pool_factor = max_pool_factor
-        chans = [512, 1024, 512, 256, 256, 256]
+        chans = [c * fs for c in (512, 1024, 512, 256, 256, 256)]
         if use_self_attention:
             self.self_attn_list = nn.ModuleList([Self_Attn(c, max_pool_factor) for c in chans])
         if use_self_attention_base:
@@ -90,11 +89,11 @@ class SSD(nn.Module):
             layers = []
             if dcn_cat_sab:
                 assert use_self_attention_base is True, "dcn_cat_sab requires use_self_attention_base=True"
-                layers.append(DCN(1024, 512, 3, 1, 1, deformable_groups=groups_dcn))
+                layers.append(DCN(1024 * fs, 512 * fs, 3, 1, 1, deformable_groups=groups_dcn))
             else:
-                layers.append(DCN(512, 512, 3, 1, 1, deformable_groups=groups_dcn))
+                layers.append(DCN(512 * fs, 512 * fs, 3, 1, 1, deformable_groups=groups_dcn))
             for _ in range(num_dcn_layers - 1):
-                layers.append(DCN(512, 512, 3, 1, 1, deformable_groups=groups_dcn))
+                layers.append(DCN(512 * fs, 512 * fs, 3, 1, 1, deformable_groups=groups_dcn))
             self.dcn_list = nn.ModuleList(layers)
         else:
             self.use_dcn = False

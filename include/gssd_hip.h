@@ -236,6 +236,22 @@ int gssd_l2norm_f32(const float* x, const float* weight, float* out, int64_t pix
 int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out, int B, int N, int Np, int D, int C2, int out_bf16,
                             gssd_stream_t stream); /* out_bf16 != 0: `out` is bf16 (configs[4]); the softmax is fp32 either way */
 
+/* The same core with the keys / values as their own tensors: kp [B][Nk][kstride] (first D floats of a row = the key), gT [B][C2][Nkp].
+ * gssd_self_attn_core_f32 is the case kp = tp + D, Nk = N, kstride = 2 D; Self_Attn with max_pool_factor > 1 passes the pooled
+ * phi / g of gssd_sa_pool_kv_f32 (layers/self_attn.py:57-59, 67, 76: Nk = max(H / factor, 1)^2 keys for N = H^2 queries). */
+int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, const float* gT, void* out, int B, int N, int Nk, int Nkp, int D,
+                               int C2, int kstride, int out_bf16, gssd_stream_t stream);
+
+/* F.adaptive_avg_pool2d(phi, P) / (g, P) of Self_Attn (layers/self_attn.py:67, 76) on the projection outputs: tp [B][H*H][2*C8]
+ * (theta | phi) -> kp [B][P*P][C8]; gT [B][C2][Np] -> gTp [B][C2][Nkp] (pad columns zero).  Cell o of the P-grid covers rows
+ * [floor(o H / P), ceil((o + 1) H / P)). */
+int gssd_sa_pool_kv_f32(const float* tp, const float* gT, float* kp, float* gTp, int B, int H, int P, int C8, int C2, int Np, int Nkp,
+                        gssd_stream_t stream);
+
+/* Backward of that pooling: dkg [B][P*P][CW] (gradients of the pooled phi | g, token-major) -> dst[b][n][j] for j < CW, rows `ld`
+ * floats apart = sum over the cells containing token n of dkg[cell][j] / |cell|. */
+int gssd_sa_unpool_f32(const float* dkg, float* dst, int B, int H, int P, int CW, int ld, gssd_stream_t stream);
+
 /* 1 when gssd_conv2d_nhwc_f32 runs this descriptor on the slot-scheduled 128 x 256 GEMM stream (csrc/gemm_slot.hip: large plain
  * 1x1 convolutions / GEMMs), 0 when it stays on the generic implicit-GEMM kernel.  Host logic only. */
 int gssd_gemm_slot_takes(const gssd_conv_desc* d);

@@ -392,7 +392,7 @@ def dcn(x, sd, prefix, deformable_groups, q=None):
 # ----------------------------------------------------------------------------------------
 # the model graph -- models/ssd_multiphase_custom_group.py
 # ----------------------------------------------------------------------------------------
-def vgg_layers(batch_norm=True, groups=4, in_ch=12):
+def vgg_layers(batch_norm=True, groups=4, in_ch=12, fs=1):
     """Layer table of ``vgg()`` (:434-460): list of (kind, module_index, attrs)."""
     layers, idx, cin = [], 0, in_ch
     for v in VGG_CFG:
@@ -400,17 +400,17 @@ def vgg_layers(batch_norm=True, groups=4, in_ch=12):
             layers.append(('pool', idx, dict(k=2, s=2, p=0, ceil=(v == 'C'))))
             idx += 1
         else:
-            layers.append(('conv', idx, dict(cin=cin, cout=v, k=3, s=1, p=1, d=1, groups=groups)))
+            layers.append(('conv', idx, dict(cin=cin, cout=v * fs, k=3, s=1, p=1, d=1, groups=groups)))
             idx += 1
             if batch_norm:
-                layers.append(('bn', idx, dict(c=v)))
+                layers.append(('bn', idx, dict(c=v * fs)))
                 idx += 1
             layers.append(('relu', idx, {}))
             idx += 1
-            cin = v
+            cin = v * fs
     layers.append(('pool', idx, dict(k=3, s=1, p=1, ceil=False)))
     idx += 1
-    for (cout, k, p, d) in ((1024, 3, 6, 6), (1024, 1, 0, 1)):
+    for (cout, k, p, d) in ((1024 * fs, 3, 6, 6), (1024 * fs, 1, 0, 1)):
         layers.append(('conv', idx, dict(cin=cin, cout=cout, k=k, s=1, p=p, d=d, groups=groups)))
         idx += 1
         if batch_norm:
@@ -422,24 +422,24 @@ def vgg_layers(batch_norm=True, groups=4, in_ch=12):
     return layers
 
 
-def extras_layers(batch_norm=True, groups=4, in_ch=1024):
+def extras_layers(batch_norm=True, groups=4, in_ch=1024, fs=1):
     """Layer table of ``add_extras()`` (:463-490)."""
     layers, idx, cin, flag = [], 0, in_ch, False
     cfg = EXTRAS_CFG
     for k, v in enumerate(cfg):
         if cin != 'S':
             if v == 'S':
-                layers.append(('conv', idx, dict(cin=cin, cout=cfg[k + 1], k=(1, 3)[flag], s=2, p=1, d=1,
+                layers.append(('conv', idx, dict(cin=cin, cout=cfg[k + 1] * fs, k=(1, 3)[flag], s=2, p=1, d=1,
                                                  groups=groups)))
             else:
-                layers.append(('conv', idx, dict(cin=cin, cout=v, k=(1, 3)[flag], s=1, p=0, d=1,
+                layers.append(('conv', idx, dict(cin=cin, cout=v * fs, k=(1, 3)[flag], s=1, p=0, d=1,
                                                  groups=groups)))
             idx += 1
             if batch_norm:
                 layers.append(('bn', idx, dict(c=layers[-1][2]['cout'])))
                 idx += 1
             flag = not flag
-        cin = v
+        cin = v if v == 'S' else v * fs
     return layers
 
 
@@ -490,20 +490,20 @@ def _run_table(x, table, sd, prefix, training, updates, taps=None, q=None):
 
 def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_extra=4, use_fuseconv=True,
                  use_self_attention=False, use_self_attention_base=False, num_dcn_layers=0, groups_dcn=1,
-                 dcn_cat_sab=False, max_pool_factor=1, training=True, taps=None, bf16=False):
+                 dcn_cat_sab=False, max_pool_factor=1, training=True, taps=None, bf16=False, feature_scale=1):
     """``SSD.forward`` train-phase return (:217-400): (loc[B,P,4], conf[B,P,C], updates).
 
     ``sd`` is a state dict with the reference's keys; ``updates`` holds the buffers a training
     forward mutates (BN running stats, spectral-norm u/v).  ``taps`` (dict) collects named
     intermediate activations for op-level parity tests."""
-    assert batch_norm, 'the driver only builds the BN variant (train_lesion_multiphase_v2.py:77)'
+    assert batch_norm or not bf16, 'bf16 storage mode is defined for the BatchNorm graph only'
     q = bf16_round if bf16 else None          # BASELINE.json configs[4]: rounding at every bf16 storage point (see bf16_round)
     qq = q or _ident
     x = qq(x)
     updates = {}
     tp = taps if taps is not None else {}
-    vt = vgg_layers(True, groups_vgg)
-    split = 33                                                              # :257
+    vt = vgg_layers(batch_norm, groups_vgg, fs=feature_scale)
+    split = 33 if batch_norm else 23                                        # :254-257
     sa_i = sab_i = 0
     sources = []
     x = _run_table(x, [l for l in vt if l[1] < split], sd, 'vgg', training, updates, taps, q)
@@ -528,7 +528,7 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
             sa_i += 1
         if use_fuseconv:
             s = F.conv2d(s, qq(sd[f'fuse_{fuse}.weight']), sd[f'fuse_{fuse}.bias'])
-            s = qq(F.relu(_bn(s, sd, f'bn_fuse_{fuse}', training, updates, q)))
+            s = qq(F.relu(_bn(s, sd, f'bn_fuse_{fuse}', training, updates, q))) if batch_norm else F.relu(s)   # :284-290
         return s
     sources.append(branch(s, '11'))                                         # :284-297
     x = _run_table(x, [l for l in vt if l[1] >= split], sd, 'vgg', training, updates, taps, q)   # :300-301
@@ -537,14 +537,14 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
         tp[f'sab{sab_i}.attn'] = amap
         sab_i += 1
     sources.append(branch(x, '21'))                                         # :309-325
-    et = extras_layers(True, groups_extra)
+    et = extras_layers(batch_norm, groups_extra, 1024 * feature_scale, feature_scale)
     fuse_names = ['31', '41', '51', '61']
     conv_i = 0
-    for kind, idx, a in et:                                                 # :350-372
-        x = _run_table(x, [(kind, idx, a)], sd, 'extras', training, updates, taps, q)
-        if idx % 2 == 1:
+    for kind, idx, a in et:                                                 # :329-372 (no BN: ReLU after every conv, a source
+        x = _run_table(x, [(kind, idx, a)], sd, 'extras', training, updates, taps, q)   # after every second one)
+        if idx % 2 == 1 or not batch_norm:
             x = qq(F.relu(x))
-        if idx % 4 == 3:
+        if (idx % 4 == 3) if batch_norm else (idx % 2 == 1):
             if use_self_attention_base:
                 x, attn_g, amap = self_attn(x, sd, f'self_attn_base_list.{sab_i}', training, max_pool_factor,
                                             updates, q)

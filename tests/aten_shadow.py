@@ -28,12 +28,13 @@ def _sn_weight(sn):
 
 
 def _self_attn(sa, x):
-    """layers/self_attn.py:46-89 (max_pool_factor = 1)."""
+    """layers/self_attn.py:46-89."""
     B, ch, h, w = x.shape
+    pool = max(int(h // sa.max_pool_factor), 1)
     theta = F.conv2d(x, _sn_weight(sa.snconv1x1_theta), sa.snconv1x1_theta.bias).view(B, ch // 8, h * w)
-    phi = F.conv2d(x, _sn_weight(sa.snconv1x1_phi), sa.snconv1x1_phi.bias).view(B, ch // 8, h * w)
+    phi = F.adaptive_avg_pool2d(F.conv2d(x, _sn_weight(sa.snconv1x1_phi), sa.snconv1x1_phi.bias), pool).view(B, ch // 8, -1)
     attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
-    g = F.conv2d(x, _sn_weight(sa.snconv1x1_g), sa.snconv1x1_g.bias).view(B, ch // 2, h * w)
+    g = F.adaptive_avg_pool2d(F.conv2d(x, _sn_weight(sa.snconv1x1_g), sa.snconv1x1_g.bias), pool).view(B, ch // 2, -1)
     attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(B, ch // 2, h, w)
     attn_g = F.conv2d(attn_g, _sn_weight(sa.snconv1x1_attn), sa.snconv1x1_attn.bias)
     return x + sa.sigma * attn_g, sa.sigma * attn_g
@@ -99,9 +100,13 @@ def shadow_forward(net, x):
         if net.use_self_attention:
             s, _ = _self_attn(net.self_attn_list[sa_i], s)
             sa_i += 1
-        return F.relu(_bn(getattr(net, f'bn_fuse_{name}'), _conv(getattr(net, f'fuse_{name}'), s)))
+        if not net.use_fuseconv:
+            return s
+        s = _conv(getattr(net, f'fuse_{name}'), s)
+        return F.relu(_bn(getattr(net, f'bn_fuse_{name}'), s) if net.batch_norm else s)
 
-    x = run(list(net.vgg)[:33], x)
+    split = 33 if net.batch_norm else 23
+    x = run(list(net.vgg)[:split], x)
     attn_g = None
     if net.use_self_attention_base:
         x, attn_g = _self_attn(net.self_attn_base_list[sab_i], x)
@@ -114,7 +119,7 @@ def shadow_forward(net, x):
     w = net.L2Norm.weight.view(1, -1, 1, 1)
     s = w * (x / (x.pow(2).sum(dim=1, keepdim=True).sqrt() + net.L2Norm.eps))
     sources = [branch(s, '11')]
-    x = run(list(net.vgg)[33:], x)
+    x = run(list(net.vgg)[split:], x)
     if net.use_self_attention_base:
         x, _ = _self_attn(net.self_attn_base_list[sab_i], x)
         sab_i += 1
@@ -123,9 +128,9 @@ def shadow_forward(net, x):
     fi = 0
     for k, m in enumerate(net.extras):
         x = _conv(m, x) if isinstance(m, torch.nn.Conv2d) else _bn(m, x)
-        if k % 2 == 1:
+        if k % 2 == 1 or not net.batch_norm:
             x = F.relu(x)
-        if k % 4 == 3:
+        if (k % 4 == 3) if net.batch_norm else (k % 2 == 1):
             if net.use_self_attention_base:
                 x, _ = _self_attn(net.self_attn_base_list[sab_i], x)
                 sab_i += 1

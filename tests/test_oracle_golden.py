@@ -216,6 +216,40 @@ def same_detections(det, ref, atol):
     return True
 
 
+FLAG_NETS = {       # tests/golden/make_golden_flags.py: the driver-reachable non-default constructor flags
+    'nofuse': dict(use_fuseconv=False, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                   dcn_cat_sab=True),
+    'nobn': dict(batch_norm=False, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                 dcn_cat_sab=True),
+    'nobn_plain': dict(batch_norm=False, use_fuseconv=False),
+    'mpf2': dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True,
+                 max_pool_factor=2),
+    'mpf3_sa': dict(use_self_attention=True, use_self_attention_base=True, max_pool_factor=3),
+    'fs2': dict(feature_scale=2),
+}
+
+
+@pytest.mark.parametrize('name', ['nofuse', 'nobn', 'nobn_plain', 'mpf2', 'mpf3_sa', 'fs2'])
+def test_constructor_flags_vs_reference(golden, name):
+    """--use_fuseconv False / --batch_norm False / --max_pool_factor / --feature_scale (train_lesion_multiphase_v2.py:49-77):
+    the oracle graph against what the imported reference computed (flags.npz)."""
+    g = golden('flags')
+    keys = [str(k) for k in g[f'{name}.keys']]
+    shapes = {k: eval(s) for k, s in zip(keys, g[f'{name}.shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    x = synth.synth_images(2, seed=5)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        loc, conf, upd = O.gssd_forward(sd, x, **FLAG_NETS[name])
+    l, c = loc.numpy().reshape(-1), conf.numpy().reshape(-1)
+    assert np.abs(l[g[f'{name}.loc_idx']] - g[f'{name}.loc_val']).max() / g[f'{name}.loc_absmax'] < 1e-5
+    assert np.abs(c[g[f'{name}.conf_idx']] - g[f'{name}.conf_val']).max() / g[f'{name}.conf_absmax'] < 1e-5
+    ll, lc = O.multibox_loss(loc.numpy(), conf.numpy(), O.prior_box(), [t.numpy() for t in synth.synth_targets(2, 5)])
+    assert rel(ll, g[f'{name}.loss'][0]) < 1e-4 and rel(lc, g[f'{name}.loss'][1]) < 1e-4
+    for k in [k for k in g.files if k.startswith(f'{name}.after.')]:
+        assert rel(upd[k[len(name) + 7:]].numpy(), g[k]) < 1e-5, k
+
+
 def test_vanilla_ssd_config0(golden):
     """BASELINE.json configs[0]: vanilla VGG-SSD300, 1 phase, batch 2, CPU forward + MultiBoxLoss."""
     g = golden('e2e')
