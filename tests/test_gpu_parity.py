@@ -781,16 +781,18 @@ FLAG_NETS = {       # tests/golden/make_golden_flags.py: (oracle flags, build_ss
     'nobn_plain': (dict(batch_norm=False, use_fuseconv=False), (False, 4, 4, 1, False, False, False, 0, 1, False, False, 1),
                    ['vgg.0.weight', 'vgg.10.bias', 'vgg.31.weight', 'extras.0.weight', 'extras.7.bias', 'loc.1.weight',
                     'conf.5.weight', 'L2Norm.weight']),
+    # (a single pooled key -- maps of 3 x 3 and below at factor 2 -- makes attn_g the same vector at every token, so g's BIAS only
+    # adds a constant in front of the fuse BatchNorm: its gradient is mathematically zero there; g's weight is not)
     'mpf2': (dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True,
                   max_pool_factor=2), (True, 4, 4, 1, True, True, True, 1, 4, True, False, 2),
              ['vgg.0.weight', 'vgg.40.weight', 'fuse_21.weight', 'loc.0.weight', 'self_attn_list.0.snconv1x1_phi.weight_orig',
               'self_attn_base_list.1.snconv1x1_g.weight_orig', 'self_attn_list.3.snconv1x1_theta.weight_orig',
-              'self_attn_list.4.snconv1x1_g.bias', 'dcn_list.0.weight']),
+              'self_attn_list.4.snconv1x1_g.weight_orig', 'self_attn_base_list.2.snconv1x1_g.bias', 'dcn_list.0.weight']),
     'mpf3_sa': (dict(use_self_attention=True, use_self_attention_base=True, max_pool_factor=3),
                 (True, 4, 4, 1, True, True, True, 0, 1, False, False, 3),
                 ['vgg.0.weight', 'fuse_11.weight', 'loc.2.weight', 'self_attn_list.0.snconv1x1_phi.weight_orig',
-                 'self_attn_base_list.2.snconv1x1_g.weight_orig', 'self_attn_list.4.snconv1x1_phi.weight_orig',
-                 'self_attn_list.3.snconv1x1_g.bias']),
+                 'self_attn_base_list.2.snconv1x1_g.weight_orig', 'self_attn_list.2.snconv1x1_phi.weight_orig',
+                 'self_attn_list.3.snconv1x1_g.weight_orig', 'self_attn_base_list.1.snconv1x1_g.bias']),
     'fs2': (dict(feature_scale=2), (True, 4, 4, 2, True, False, False, 0, 1, False, False, 1),
             ['vgg.0.weight', 'vgg.24.weight', 'vgg.44.weight', 'extras.4.weight', 'fuse_31.weight', 'loc.0.weight', 'conf.4.bias']),
 }
@@ -1011,6 +1013,45 @@ def test_visualize_outputs(dev):
         out_vis = net(x.to(dev), visualize=True)[0]
         out_plain = net(x.to(dev))
     assert rel(out_vis[0], out_plain[0]) < 1e-6 and rel(out_vis[1], out_plain[1]) < 1e-6
+
+
+def test_visualize_outputs_pooled_keys(dev):
+    """visualize=True with max_pool_factor = 3 (layers/self_attn.py:57-59): the maps are [B, N, Nk], Nk = max(H // 3, 1)^2 pooled keys;
+    test phase (eval-mode BatchNorm, Detect) runs on the same plan."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args, _ = FLAG_NETS['mpf3_sa']
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = synth.synth_images(2, seed=5)
+    with torch.no_grad():
+        out, offs, attnb, attn = net(x.to(dev), visualize=True)
+        taps = {}
+        O.gssd_forward(sd, x, training=True, taps=taps, **flags)
+    assert offs == [] and [tuple(a.shape[1:]) for a in attn] == [(1444, 144), (361, 36), (100, 9), (25, 1), (9, 1), (1, 1)]
+    assert all(abs(a.sum(-1) - 1).max() < 1e-4 for a in attnb + attn)
+    errs = [(rel(attnb[i], taps[f'sab{i}.attn']), rel(attn[i], taps[f'sa{i}.attn'])) for i in range(6)]
+    print('pooled attention map errors', errs)
+    assert max(max(e) for e in errs) < 1e-3, errs
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():
+        net(x.to(dev))
+    net_t = build_ssd('test', 300, 2, *args)
+    net_t.load_state_dict(net.state_dict())
+    net_t = net_t.to(dev).eval()
+    with torch.no_grad():
+        det = net_t(x.to(dev))
+        lo, co, _ = O.gssd_forward({k: v.cpu() for k, v in net.state_dict().items()}, x, training=False, **flags)
+    ref = O.detect(2, 0, 200, 0.01, 0.45, lo.numpy(), O.softmax_scores(co.numpy()), O.prior_box())
+    assert det.shape == (2, 2, 200, 5)
+    assert np.array_equal(det.cpu().numpy()[..., 0] > 0, ref[..., 0] > 0)
+    # (B = 2: the running variances of the 1 x 1 map's BatchNorms come from two values per channel and can be ~eps, so eval mode
+    # divides by sqrt(~eps) there and a 1e-6 forward difference becomes 1e-3 on that map's four boxes)
+    assert same_detections(det.cpu().numpy(), ref, 2e-3)
 
 
 @pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
