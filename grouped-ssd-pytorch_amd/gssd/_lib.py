@@ -88,6 +88,7 @@ SIGNATURES = {
     'gssd_self_attn_core_kv_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_sa_pool_kv_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_sa_unpool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_pack_conv_weights_batched': (c_i, [c_fp, c_i, c_fp]),
     'gssd_gemm_slot_takes': (c_i, [c_fp]),
     'gssd_heads_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_interp_add_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),

@@ -433,7 +433,14 @@ class BackwardPlan:
         self.dloc.copy_(dloc)
         self.dconf.copy_(dconf)
         if self.zero_list:
-            torch._foreach_zero_(self.zero_list)
+            # one multi-tensor launch per dtype (a mixed fp32 / fp64 list takes _foreach_zero_'s slow path: ~180 fill launches a step)
+            if getattr(self, '_zero_groups', None) is None or sum(len(g) for g in self._zero_groups) != len(self.zero_list):
+                by = {}
+                for t in self.zero_list:
+                    by.setdefault(t.dtype, []).append(t)
+                self._zero_groups = list(by.values())
+            for grp in self._zero_groups:
+                torch._foreach_zero_(grp)
         stream = torch.cuda.current_stream().cuda_stream
         hook = self.segment_hook
         if hook is not None:

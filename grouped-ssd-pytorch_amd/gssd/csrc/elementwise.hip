@@ -61,6 +61,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// The same packing for a whole table of weights in ONE launch (blockIdx.y = item): after an optimizer step every packed weight of the
+// model is stale, and ~130 pack / copy launches of 5-8 us each sat in front of the next forward.  A plain copy of n floats is the item
+// (Cout 1, cin_g n, taps 1, cin_g_pad n, Kpad n).
+__global__ void pack_weight_batched_kernel(const gssd_pack_item* __restrict__ items) {
+    const gssd_pack_item it = items[blockIdx.y];
+    const long long total = (long long)it.Cout * it.Kpad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % it.Kpad);
+        const int o = (int)(i / it.Kpad);
+        const int tap = k / it.cin_g_pad, c = k - tap * it.cin_g_pad;
+        float v = 0.f;
+        if (tap < it.taps && c < it.cin_g) v = it.w[((long long)o * it.cin_g + c) * it.taps + tap];
+        it.wp[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm + ReLU + max-pool.  Each block derives (scale, shift) for all C channels into LDS from
 // the fp64 batch sums (train) or the running statistics (eval), then grid-strides over output float4s.
@@ -387,6 +403,13 @@ extern "C" int gssd_pack_conv_weight(const float* w, float* wp, int Cout, int ci
     GSSD_CHECK_ARG(cin_g_pad >= cin_g && cin_g_pad % 4 == 0 && Kpad >= KH * KW * cin_g_pad && Kpad % 4 == 0);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_blocks((long long)Cout * Kpad)), dim3(EW_THREADS), 0,
                        as_stream(stream), w, wp, Cout, cin_g, KH * KW, cin_g_pad, Kpad);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pack_conv_weights_batched(const gssd_pack_item* items_dev, int n_items, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(items_dev && n_items > 0 && n_items < 65536);
+    hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(48, n_items), dim3(EW_THREADS), 0, as_stream(stream), items_dev);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

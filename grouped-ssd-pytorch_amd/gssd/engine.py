@@ -92,6 +92,7 @@ class GssdEngine:
         self._plans = {}
         self._packed = {}        # name -> packed weight tensor
         self._pack_jobs = []     # (callable) refreshers
+        self._pack_table = None  # (device table, items, kept tensors, jobs that stay individual launches): see _refresh_packed
         self._versions = None
         self._ptrs = None
         self._param_list = None
@@ -119,6 +120,7 @@ class GssdEngine:
         self._plans.clear()
         self._packed.clear()
         self._pack_jobs = []
+        self._pack_table = None
         self._versions = None
         self._ptrs = None
         self._param_list = None
@@ -159,8 +161,7 @@ class GssdEngine:
             vers, ptrs = self._state()
         self._ptrs = ptrs
         if vers != self._versions:
-            for job in self._pack_jobs:
-                job()
+            self._refresh_packed(x.device)
             self._versions = vers
         self._last_plan = plan
         loc, conf = plan.run(x, events)
@@ -180,7 +181,35 @@ class GssdEngine:
             t = build(None)
             self._packed[name] = t
             self._pack_jobs.append(lambda: build(self._packed[name]))
+            self._pack_table = None
         return self._packed[name]
+
+    def _refresh_packed(self, dev):
+        """Re-derive every packed weight from the (changed) parameters.  Jobs made only of ops.pack_weight / ops.copy_into from the
+        parameters' own storage are recorded ONCE into a device table and from then on refreshed by a single launch
+        (gssd_pack_conv_weights_batched: ~130 launches of 5-8 us after every optimizer step otherwise); the rest -- Winograd
+        transforms of packed weights, the DCN layout, bf16 rounding -- run after it, in registration order."""
+        if self._pack_table is None:
+            rec, rest = ops.PackRecorder(), []
+            for job in self._pack_jobs:
+                n0, k0 = len(rec.items), len(rec.keep)
+                ops.recorder = rec
+                try:
+                    job()
+                except ops.PackRecorder.Unstable:
+                    del rec.items[n0:], rec.keep[k0:]
+                    rest.append(job)
+                finally:
+                    ops.recorder = None
+                if len(rec.items) == n0 and job not in rest:
+                    rest.append(job)               # recorded nothing: a job of other launches only
+            table = ops.pack_table(rec, dev) if rec.items else None
+            self._pack_table = (table, len(rec.items), rec.keep, rest)
+        table, n, _, rest = self._pack_table
+        if n:
+            ops.run_pack_table(table, n)
+        for job in rest:
+            job()
 
     def _build(self, B, training, dev, want_maps=False):
         if getattr(self.net, 'vanilla', False):
@@ -440,8 +469,8 @@ class _Plan(_PlanBase):
         def build_b(out, lw=lw, cw=cw, nloc=nloc):
             if out is None:
                 out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
-            out[:nloc].copy_(lw.bias.detach())
-            out[nloc:].copy_(cw.bias.detach())
+            ops.copy_into(out[:nloc], lw.bias)
+            ops.copy_into(out[nloc:], cw.bias)
             return out
         wp = eng._pack(f'heads.{i}.w', build_w)
         bp = eng._pack(f'heads.{i}.b', build_b)
@@ -636,23 +665,23 @@ class _Plan(_PlanBase):
         def build_w(out):
             if out is None:
                 out = torch.empty(C4 + C2, Cc, device=dev, dtype=self.adt)
-            out[:C8].copy_(sa.snconv1x1_theta.weight_orig.detach().view(C8, Cc))         # (copy_ rounds to bf16 in bf16 mode)
-            out[C8:C4].copy_(sa.snconv1x1_phi.weight_orig.detach().view(C8, Cc))
-            out[C4:].copy_(sa.snconv1x1_g.weight_orig.detach().view(C2, Cc))
+            ops.copy_into(out[:C8], sa.snconv1x1_theta.weight_orig)                     # (rounds to bf16 in bf16 mode)
+            ops.copy_into(out[C8:C4], sa.snconv1x1_phi.weight_orig)
+            ops.copy_into(out[C4:], sa.snconv1x1_g.weight_orig)
             return out
 
         def build_wo(out):
             if out is None:
                 out = torch.empty(Cc, C2, device=dev, dtype=self.adt)
-            out.copy_(sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2))
+            ops.copy_into(out, sa.snconv1x1_attn.weight_orig)
             return out
 
         def build_b(out):
             if out is None:
                 out = torch.empty(C4 + C2, device=dev, dtype=f32)
-            out[:C8].copy_(sa.snconv1x1_theta.bias.detach())
-            out[C8:C4].copy_(sa.snconv1x1_phi.bias.detach())
-            out[C4:].copy_(sa.snconv1x1_g.bias.detach())
+            ops.copy_into(out[:C8], sa.snconv1x1_theta.bias)
+            ops.copy_into(out[C8:C4], sa.snconv1x1_phi.bias)
+            ops.copy_into(out[C4:], sa.snconv1x1_g.bias)
             return out
         w_tpg = eng._pack(name + '.tpg.w', build_w)
         b_tpg = eng._pack(name + '.tpg.b', build_b)
@@ -963,8 +992,8 @@ class _PlanVanilla(_Plan):
             def build_b(out, lw=lw, cw=cw, nloc=nloc):
                 if out is None:
                     out = torch.empty(nloc + cw.bias.numel(), device=dev, dtype=f32)
-                out[:nloc].copy_(lw.bias.detach())
-                out[nloc:].copy_(cw.bias.detach())
+                ops.copy_into(out[:nloc], lw.bias)
+                ops.copy_into(out[nloc:], cw.bias)
                 return out
             wp = eng._pack(f'heads.{i}.w', build_w)
             bp = eng._pack(f'heads.{i}.b', build_b)

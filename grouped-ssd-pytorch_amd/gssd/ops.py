@@ -57,19 +57,76 @@ def packed_k(cin_g, kh, kw):
     return cin_pad, kh * kw * cin_pad
 
 
+class PackRecorder:
+    """While installed (``ops.recorder = PackRecorder()``), pack_weight / copy_into append table items instead of launching:
+    gssd.engine builds ONE device table out of every weight-refresh job and replays it with a single launch per optimizer step."""
+
+    class Unstable(Exception):
+        """a source that is not the parameter's own fp32 storage (its pointer would not survive to the next refresh)"""
+
+    def __init__(self):
+        self.items, self.keep = [], []
+
+    def add(self, src, dst, Cout, cin_g, taps, cin_pad, K):
+        self.items.append((src.data_ptr(), dst.data_ptr(), Cout, cin_g, taps, cin_pad, K))
+        self.keep += [src, dst]
+
+
+recorder = None
+
+
+def _stable_f32(t):
+    # only a parameter's own storage may enter the table: anything derived from it (a padded / cast / transposed temporary) would be
+    # packed again from its stale copy at the next refresh
+    d = t.detach()
+    if not isinstance(t, torch.nn.Parameter) or d.dtype != torch.float32 or not d.is_contiguous():
+        raise PackRecorder.Unstable()
+    return d
+
+
 def pack_weight(w_oihw, out=None, row_offset=0):
     """OIHW -> [Cout][K] K-major rows (k = tap*cin_g_pad + c).  ``out``/``row_offset`` let several
     weights share one packed matrix (loc+conf heads)."""
     _need_cuda(w_oihw)
-    w = w_oihw.detach().contiguous().float()
+    w = _stable_f32(w_oihw) if recorder is not None else w_oihw.detach().contiguous().float()
     Cout, cin_g, KH, KW = w.shape
     cin_pad, K = packed_k(cin_g, KH, KW)
     if out is None:
         out = torch.empty(Cout, K, device=w.device, dtype=torch.float32)
     assert out.shape[1] == K
     dst = out[row_offset:row_offset + Cout]
+    if recorder is not None:
+        recorder.add(w, dst, Cout, cin_g, KH * KW, cin_pad, K)
+        return out
     check(lib.gssd_pack_conv_weight(_p(w), _p(dst), Cout, cin_g, KH, KW, cin_pad, K, _stream()))
     return out
+
+
+def copy_into(dst, src):
+    """dst.copy_(src) for fp32 contiguous tensors of equal size -- as a table item while a PackRecorder is installed."""
+    if recorder is not None and dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == src.numel():
+        s = _stable_f32(src)
+        n = s.numel()
+        recorder.add(s, dst, 1, n, 1, n, n)
+        return dst
+    if recorder is not None:
+        raise PackRecorder.Unstable()
+    return dst.copy_(src.detach().reshape(dst.shape) if src.numel() == dst.numel() else src.detach())
+
+
+def pack_table(rec, device):
+    """Device table (gssd_pack_item[n]) of a PackRecorder's items."""
+    import numpy as np
+    dt = np.dtype([('w', np.uint64), ('wp', np.uint64), ('Cout', np.int32), ('cin_g', np.int32), ('taps', np.int32),
+                   ('cin_pad', np.int32), ('K', np.int32), ('reserved', np.int32)])
+    arr = np.zeros(len(rec.items), dt)
+    for i, it in enumerate(rec.items):
+        arr[i] = it + (0,)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def run_pack_table(table, n):
+    check(lib.gssd_pack_conv_weights_batched(_p(table), n, _stream()))
 
 
 def pack_weight_bf16(w_oihw, out=None, row_offset=0, cin_pad=None):

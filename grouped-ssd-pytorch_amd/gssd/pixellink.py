@@ -169,15 +169,15 @@ class _PlanPixelLink(_Plan):
         def build_w(out, o1=o1, o2=o2, Cc=Cc):
             if out is None:
                 out = torch.empty(18, Cc, device=self.dev)
-            out[:2].copy_(o1.weight.detach().view(2, Cc))
-            out[2:].copy_(o2.weight.detach().view(16, Cc))
+            ops.copy_into(out[:2], o1.weight)
+            ops.copy_into(out[2:], o2.weight)
             return out
 
         def build_b(out, o1=o1, o2=o2):
             if out is None:
                 out = torch.empty(18, device=self.dev)
-            out[:2].copy_(o1.bias.detach())
-            out[2:].copy_(o2.bias.detach())
+            ops.copy_into(out[:2], o1.bias)
+            ops.copy_into(out[2:], o2.bias)
             return out
         w = self.eng._pack(f'out{k}.w', build_w)
         bb = self.eng._pack(f'out{k}.b', build_b)

@@ -59,6 +59,15 @@ int gssd_unpack_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int B, int C, i
 int gssd_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int cin_g, int KH, int KW,
                           int cin_g_pad, int Kpad, gssd_stream_t stream);
 
+/* One launch for a table of such packs (device array of items; a plain copy of n floats is {Cout 1, cin_g n, taps 1, cin_g_pad n,
+ * Kpad n}): the refresh of every packed weight after an optimizer step. */
+typedef struct gssd_pack_item {
+    const float* w;  /* OIHW source */
+    float* wp;       /* packed rows [Cout][Kpad] */
+    int32_t Cout, cin_g, taps, cin_g_pad, Kpad, reserved;
+} gssd_pack_item;
+int gssd_pack_conv_weights_batched(const gssd_pack_item* items_dev, int n_items, gssd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32)
  * ------------------------------------------------------------------------------------------
