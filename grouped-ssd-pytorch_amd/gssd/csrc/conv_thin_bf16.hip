@@ -13,10 +13,21 @@
 //     channel order of conv_bf16.hip) consecutive output channels of one pixel: 8 / 16-byte NHWC stores straight from registers;
 //   * BatchNorm batch sums (of the fp32 accumulators) stay in registers across tiles: 16 shuffles + one fp64 atomic per channel
 //     per workgroup at the end.
-// Measured and rejected (round 2, conv1_1 190 us / conv1_2 232 us / conv2_1 142 us): a second patch stage with the next tile's DMA in
-// flight under the current tile (179 / 303 / 138 us), a persistent grid of 5 instead of 3 workgroups per CU (199 / 237 / 176 us), and
-// whole-pixel-vector stores through an LDS output tile instead of one 32 / 64-byte group slice per wave (196 / 256 / 152 us): neither
-// the load round trip, nor the tiles in flight, nor partial-line writes is what holds these layers at 2.0-3.2 TB/s.
+// Where the time goes (round 2, B = 32; -DTHIN_TIMING builds the per-phase shader-clock breakdown that scripts/thin_timing.py prints):
+//   * the epilogue's stores are the largest single cost: with the stores compiled out conv1_1 ran 2.5 x faster and conv1_2 1.5 x; the
+//     L2 receives the output as 32-byte write requests (TCP_TCC_WRITE_REQ = bytes / 32: a wave owns one group's 32-byte slice of each
+//     pixel's 128 / 256-byte vector) and every EA write is a full 64-byte one (TCC_EA0_WRREQ_64B = all), so the slices do merge in L2;
+//   * pairing rows through v_permlane16_swap (16-byte instead of 8-byte stores, half the store instructions) gave conv1_1 177 -> 161 us
+//     and conv1_2 nothing: part issue-bound, mostly bound by the number of write requests;  nontemporal stores are much worse
+//     (conv1_2 +48 %: the slices then reach HBM unmerged);
+//   * 16-row patches (half the barriers and load round trips per pixel, 1.27 x instead of 1.41 x halo): -4 .. -7 %;
+//   * the producer BatchNorm constants in registers instead of an LDS table (the table reads were 4 x the patch bytes): conv1_2 -5 %.
+//   conv1_1 194 -> 161 us, conv1_2 231 -> 211 us, conv2_1 142 -> 135 us, conv2_2 176 -> 172 us.  The next step would be whole-line
+//   stores without a workgroup barrier (one wave computing two groups, 64-byte slices); the LDS-output-tile form of that idea was
+//   measured earlier and lost its gain to the extra barrier and LDS pass.
+// Measured and rejected earlier (conv1_1 190 us / conv1_2 232 us / conv2_1 142 us at the time): a second patch stage with the next
+// tile's DMA in flight under the current tile (179 / 303 / 138 us), a persistent grid of 5 instead of 3 workgroups per CU
+// (199 / 237 / 176 us), whole-pixel-vector stores through an LDS output tile (196 / 256 / 152 us).
 // Also measured and rejected: this kernel for the 64-channel groups of conv3_x (weights of a group = 144 / 288 registers per lane, one
 // workgroup per CU, rows in blocks of four): conv3_1 114 us vs 99 us, conv3_2 213 us vs 189 us on the generic conv_bf16 -- one wave
 // per SIMD cannot hide the 92 KB patch load, the transform pass and the fragment reads behind its own MFMAs.
@@ -27,6 +38,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
+
+#ifdef THIN_TIMING
+__device__ unsigned long long g_thin_timing[8];
+extern "C" int gssd_thin_timing_read(unsigned long long* out8) {
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_thin_timing), 64);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_thin_timing), z, 64);
+    return 0;
+}
+#define TSTAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; }
+#else
+#define TSTAMP(k)
+#endif
 
 namespace {
 
@@ -53,10 +77,14 @@ __device__ __forceinline__ int swz(int col) {
     return UPR >= 8 ? (col & (UPR - 1)) & 15 : ((col ^ (col >> 2)) & (UPR - 1));
 }
 
-constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPATCH = PH * PW;
+constexpr int RH = 8, TW = 16, PW = TW + 2;       // rows per MFMA / epilogue batch, tile width, patch width
 
-template <int CIN_G, int COUT_G, bool XF>
+// TH = output rows per staged patch (a multiple of RH): one DMA round trip, one transform pass and three barriers per TH x 16 pixels.
+// 16 rows where the (TH + 2) x 18 patch still lets 2-3 workgroups share a CU (<= 64 input channels): half the barriers and exposed
+// load latency per pixel of the 8-row tile and 10 % less halo (1.27 x instead of 1.41 x).
+template <int CIN_G, int COUT_G, bool XF, int TH>
 __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_kernel(const ThinBfParams p) {
+    constexpr int PH = TH + 2, NPATCH = PH * PW;
     constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
     constexpr int UPR = CIN / 8;                   // 16-byte units per pixel
     constexpr int PPI = 64 / UPR;                  // pixels per DMA wave instruction
@@ -65,10 +93,6 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     constexpr int NINSTR = (NPATCH + PPI - 1) / PPI;
     constexpr int CPL = NT == 1 ? 4 : 8;           // consecutive output channels per lane
     extern __shared__ __attribute__((aligned(16))) u16 patch[];
-    // the producer's BatchNorm scale | shift, read once per workgroup: the per-element transform below used to fetch them from global
-    // memory inside its loop (four dependent-latency loads per iteration, ~6 us per tile -- most of a tile's time)
-    __shared__ __attribute__((aligned(16))) float xf_tab[XF ? 2 * CIN : 4];
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = conv group
     const int r = lane & 15, kq = lane >> 4;
@@ -110,14 +134,18 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     float ssum[CPL], ssq[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) ssum[c] = ssq[c] = 0.f;
+    float xs[8], xh[8];                                    // producer BatchNorm scale / shift of this thread's eight channels
     if constexpr (XF) {
-        for (int c = tid; c < CIN; c += 256) {
-            xf_tab[c] = p.in_scale[c];
-            xf_tab[CIN + c] = p.in_shift[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xs[e] = p.in_scale[(tid % UPR) * 8 + e];
+            xh[e] = p.in_shift[(tid % UPR) * 8 + e];
         }
-        __syncthreads();
     }
 
+#ifdef THIN_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img;
@@ -135,71 +163,115 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
             const u16* src = ok ? p.in + ((size_t)(b * p.H + iy) * p.W + ix) * CIN + lu * 8 : g_zero_thin_h;
             dma16(src, patch + i * PPI * CIN);
         }
+        TSTAMP(0)
         __syncthreads();
+        TSTAMP(1)
         if constexpr (XF) {
-            // producer BatchNorm + ReLU once per patch element (in-image pixels only: the rest stays 0 = padding after the transform)
-            for (int u = tid; u < NPATCH * UPR; u += 256) {
-                const int pp = u / UPR, slot = u - pp * UPR;
+            // producer BatchNorm + ReLU once per patch element (in-image pixels only: the rest stays 0 = padding after the transform).
+            // A thread always transforms the SAME eight channels (unit tid % UPR of every (256 / UPR)-th pixel; the swizzle only
+            // moves where that unit sits inside the pixel), so its scale / shift live in 16 registers for the kernel's lifetime.
+            for (int pp = tid / UPR; pp < NPATCH; pp += 256 / UPR) {
                 const int py = pp / PW, pxx = pp - py * PW;
                 const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
                 if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
-                const int c0 = (slot ^ swz<UPR>(pxx)) << 3;             // logical first channel of this unit
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + u * 8);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(xf_tab + c0), s1 = *reinterpret_cast<const f32x4*>(xf_tab + c0 + 4);
-                const f32x4 h0 = *reinterpret_cast<const f32x4*>(xf_tab + CIN + c0), h1 = *reinterpret_cast<const f32x4*>(xf_tab + CIN + c0 + 4);
+                u16* at = patch + (pp * UPR + ((tid % UPR) ^ swz<UPR>(pxx))) * 8;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(at);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = (__bf16)fmaxf((float)v[e] * s0[e] + h0[e], 0.f);
-                    v[e + 4] = (__bf16)fmaxf((float)v[e + 4] * s1[e] + h1[e], 0.f);
-                }
-                *reinterpret_cast<bf16x8*>(patch + u * 8) = v;
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * xs[e] + xh[e], 0.f);
+                *reinterpret_cast<bf16x8*>(at) = v;
             }
+            TSTAMP(2)
             __syncthreads();
+            TSTAMP(3)
         }
 
-        // ---- MFMAs straight from the patch: M tile i = tile row i (16 pixels wide) ---------------------------------------------
-        f32x4 acc[TH][NT];
-#pragma unroll
-        for (int i = 0; i < TH; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            bf16x8 af[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + i * PW * CIN);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
-        }
-
-        // ---- epilogue: + bias, batch sums, 8 / 16-byte NHWC stores (lane: pixel (y0 + i, x0 + r), CPL consecutive channels) ----
+        // ---- MFMAs straight from the patch: M tile i = tile row i (16 pixels wide), RH rows per batch ---------------------------
         const int x = x0 + r;
+#pragma unroll 1
+        for (int rb = 0; rb < TH; rb += RH) {
+            if (y0 + rb >= p.H) break;
+            f32x4 acc[RH][NT];
 #pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            const int y = y0 + i;
-            if (y >= p.H || x >= p.W) continue;
-            float v[CPL];
+            for (int i = 0; i < RH; ++i)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                v[c] = (NT == 1 ? acc[i][0][c] : acc[i][c >> 2][c & 3]) + bias[c];
-                ssum[c] += v[c];
-                ssq[c] += v[c] * v[c];
+                for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < RH; ++i) {
+                bf16x8 af[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + (rb + i) * PW * CIN);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
             }
-            u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + cb;
-            if constexpr (CPL == 8) {
-                bf16x8 h;
+            // ---- epilogue: + bias, batch sums, 16-byte NHWC stores (lane: pixel (y0 + rb + i, x0 + r), CPL consecutive channels) -----
+            if constexpr (CPL == 4) {
+                // 4 channels = 8 bytes per lane and row: rows are taken in pairs and the kq-even / kq-odd lane rows swap halves
+                // (v_permlane16_swap), so an even lane stores 16 contiguous bytes of row i (its own 4 channels | its neighbour's) and
+                // an odd lane 16 bytes of row i + 1 -- half the store instructions for the same bytes (the epilogue was store-ISSUE
+                // bound: without its stores the conv1_1 kernel ran 2.5 x faster)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) h[c] = (__bf16)v[c];
-                *reinterpret_cast<bf16x8*>(dst) = h;
+                for (int i = 0; i < RH; i += 2) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool ok = y0 + rb + i + h < p.H && x < p.W;
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            v[c] = acc[i + h][0][c] + bias[c];
+                            ssum[c] += ok ? v[c] : 0.f;
+                            ssq[c] += ok ? v[c] * v[c] : 0.f;
+                        }
+                        const bf16x4 hv = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        pk[h][0] = reinterpret_cast<const unsigned*>(&hv)[0];
+                        pk[h][1] = reinterpret_cast<const unsigned*>(&hv)[1];
+                    }
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(pk[0][d], pk[1][d], false, false);
+                        pk[0][d] = sw[0];
+                        pk[1][d] = sw[1];
+                    }
+                    const int y = y0 + rb + i + (kq & 1);
+                    if (y < p.H && x < p.W) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + 4 * (kq & ~1);
+                        *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                    }
+                }
             } else {
-                *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+#pragma unroll
+                for (int i = 0; i < RH; ++i) {
+                    const int y = y0 + rb + i;
+                    if (y >= p.H || x >= p.W) continue;
+                    float v[CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        v[c] = acc[i][c >> 2][c & 3] + bias[c];
+                        ssum[c] += v[c];
+                        ssq[c] += v[c] * v[c];
+                    }
+                    u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + cb;
+                    bf16x8 h;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) h[c] = (__bf16)v[c];
+                    *reinterpret_cast<bf16x8*>(dst) = h;
+                }
             }
         }
+        TSTAMP(4)
         __syncthreads();          // every wave is done reading the patch
+        TSTAMP(5)
     }
 
+#ifdef THIN_TIMING
+    if (lane == 0 && g == 1)
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_thin_timing[k], tacc[k]);
+    if (tid == 0) atomicAdd(&g_thin_timing[7], 1ull);
+#endif
     if (p.stats) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -220,6 +292,8 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
 template <int CIN_G, int COUT_G, bool XF>
 int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     constexpr int CIN = 4 * CIN_G;
+    constexpr int TH = CIN <= 64 ? 16 : 8;
+    constexpr int NPATCH = (TH + 2) * PW;
     constexpr int UPR = CIN / 8, PPI = 64 / UPR;
     ThinBfParams p;
     p.in = reinterpret_cast<const u16*>(d.in);
@@ -238,7 +312,7 @@ int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 256 * (COUT_G > 16 ? 2 : 3);
     if (ntiles < grid) grid = (int)ntiles;
-    hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF>), dim3(grid), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF, TH>), dim3(grid), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
