@@ -379,7 +379,8 @@ class BackwardPlan:
         Kc = 9 * Cin
         # the fused forward keeps no column matrix: rebuild it here for the weight gradient
         cols = self._buf(B * H * H, Kc)
-        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, 27 * dg))
+        OMC = r['omc']                           # channel stride of the offset / mask rows (27 * dg rounded up to 4)
+        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, OMC))
         w_main = self._buf(Cout, Kc)
         self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
         # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- plain GEMMs (rocBLAS)
@@ -400,18 +401,31 @@ class BackwardPlan:
         if gx is None:
             gx = self._buf(B, H, H, Cin, zero_each_run=True)
             self.gbuf[x.data_ptr()] = gx
-        dom = self._buf(B, H, H, 27 * dg, zero_each_run=True)
+        dom = self._buf(B, H, H, OMC, zero_each_run=True)
         self._add(lib.gssd_dcn_col2im_f32, (x.data_ptr(), om.data_ptr(), dcols.data_ptr(), gx.data_ptr(), dom.data_ptr(), B, H, H,
-                                            Cin, dg, 27 * dg))
-        # offset / mask conv
+                                            Cin, dg, OMC))
+        # offset / mask conv (its gradients on the padded channel count: the pad channel of d(om) is zero, its weight row is dropped)
         cm = m.conv_offset_mask
-        dwo = self._buf(27 * dg, Kc, zero_each_run=True)
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(r['d_om']), dom.data_ptr(), dwo.data_ptr()), keep=r['d_om'])
+        d_w = r['d_om']
+        if OMC != 27 * dg:
+            d_w, _, _ = ops.make_conv_desc(x, None, None, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=OMC, k=3, pad=1)
+        dwo = self._buf(OMC, Kc, zero_each_run=True)
+        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_w), dom.data_ptr(), dwo.data_ptr()), keep=d_w)
         self._unpack(dwo, Kc, 0, cm.weight, Cin, Cin, 3)
-        cs2 = self._buf(27 * dg, dtype=torch.float64, zero_each_run=True)
-        self._add(lib.gssd_colsum_f32, (dom.data_ptr(), B * H * H, 27 * dg, 27 * dg, cs2.data_ptr()))
+        cs2 = self._buf(OMC, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dom.data_ptr(), B * H * H, OMC, OMC, cs2.data_ptr()))
         self._bias_from_colsum(cs2, cm.bias)
-        self._dgrad(r, dom, x, cm, 1, Cin, H, H, 27 * dg, 3, 1, 1, 1)
+        if OMC == 27 * dg:
+            self._dgrad(r, dom, x, cm, 1, Cin, H, H, OMC, 3, 1, 1, 1)
+        else:
+            # the data-gradient packer reads an OIHW weight with OMC output channels: a zero-padded copy, refreshed every run
+            wpad = torch.zeros(OMC, Cin, 3, 3, device=self.dev)
+            self.keep.append(wpad)
+
+            def refresh(wpad=wpad, cm=cm, n=27 * dg):
+                wpad[:n].copy_(cm.weight.detach())
+            self.steps.append((refresh, None))
+            self._dgrad(r, dom, x, _PaddedWeight(wpad), 1, Cin, H, H, OMC, 3, 1, 1, 1)
 
     # ------------------------------------------------------------------------------------------------
     def segments(self, nseg=4):
@@ -466,6 +480,13 @@ class BackwardPlan:
             rc = fn(*args, stream)
             if rc != 0:
                 _lib.check(rc)
+
+
+class _PaddedWeight:
+    """Stands in for a conv module where only ``.weight`` is read (the dgrad packer)."""
+
+    def __init__(self, w):
+        self.weight = w
 
 
 def conv_weight_ptr(conv, cin_g_expected):

@@ -775,25 +775,30 @@ class _Plan(_PlanBase):
                             torch.cuda.current_stream().cuda_stream))
             return out
         w_main = eng._pack(f'dcn_list.{li}.wt', build_w)
-        om = self._buf(B, H, H, 27 * dg)       # offsets / mask logits stay fp32 in both modes
+        # offsets / mask logits stay fp32 in both modes; rows padded to a multiple of 4 channels (27 * dg is one only for dg = 4, 8, ..):
+        # the weight-gradient and data-gradient kernels of the offset conv want 16-byte aligned channel vectors
+        OMC = ops.round_up(27 * dg, 4)
+        om = self._buf(B, H, H, OMC)
+        if OMC != 27 * dg:
+            om.zero_()
         out = self._abuf(B, H, H, Cout)
         u_om = None
         if not self.bf16 and USE_WINOGRAD and ops.winograd_eligible(3, 1, 1, 1, Cin, 27 * dg, 1):
             def build_u(out, key=f'dcn_list.{li}.om.w', cin=Cin):
                 return ops.winograd_weight(eng._packed[key], 1, cin, out)
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
-        d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1,
+        d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1, out_stride=OMC,
                                       bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om, flags=_lib.CONV_OUT_F32)
         self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H
         esz = 2.0 if self.bf16 else 4.0
         self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_f32,
-                  (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, 27 * dg, Cout),
+                  (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout),
                   keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
                                     esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
-        self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, d_om=d1, dg=dg, li=li)))
+        self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, d_om=d1, dg=dg, li=li, omc=OMC)))
         return out, Cout
 
     # ------------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@ FLAG_NETS = {
     'mpf2': (True, 4, 4, 1, True, True, True, 1, 4, True, False, 2),
     'mpf3_sa': (True, 4, 4, 1, True, True, True, 0, 1, False, False, 3),
     'fs2': (True, 4, 4, 2, True, False, False, 0, 1, False, False, 1),
+    'dcn2_detach': (True, 4, 4, 1, True, True, True, 2, 1, True, True, 1),      # two DCN layers, one deformable group, detached SAB
+    'dcn_nocat': (True, 4, 4, 1, True, False, False, 1, 4, False, False, 1),     # DCN on the plain conv4_3 map (512 -> 512)
 }
 EB = 2
 

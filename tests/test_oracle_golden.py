@@ -226,10 +226,12 @@ FLAG_NETS = {       # tests/golden/make_golden_flags.py: the driver-reachable no
                  max_pool_factor=2),
     'mpf3_sa': dict(use_self_attention=True, use_self_attention_base=True, max_pool_factor=3),
     'fs2': dict(feature_scale=2),
+    'dcn2_detach': dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=2, groups_dcn=1, dcn_cat_sab=True),
+    'dcn_nocat': dict(num_dcn_layers=1, groups_dcn=4),
 }
 
 
-@pytest.mark.parametrize('name', ['nofuse', 'nobn', 'nobn_plain', 'mpf2', 'mpf3_sa', 'fs2'])
+@pytest.mark.parametrize('name', ['nofuse', 'nobn', 'nobn_plain', 'mpf2', 'mpf3_sa', 'fs2', 'dcn2_detach', 'dcn_nocat'])
 def test_constructor_flags_vs_reference(golden, name):
     """--use_fuseconv False / --batch_norm False / --max_pool_factor / --feature_scale (train_lesion_multiphase_v2.py:49-77):
     the oracle graph against what the imported reference computed (flags.npz)."""
