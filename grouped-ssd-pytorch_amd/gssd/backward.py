@@ -16,10 +16,15 @@ self-attention blocks (csrc/sa_backward.hip) are HIP too: the plan is a list of 
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib, ops
 from ._lib import lib
+
+
+BWD_STREAMS = os.environ.get('GSSD_BWD_STREAMS', '1') != '0'
 
 
 class BackwardPlan:
@@ -45,31 +50,77 @@ class BackwardPlan:
         self.dloc = torch.empty(self.B, plan.P, 4, device=self.dev)
         self.dconf = torch.empty(self.B, plan.P, plan.nc, device=self.dev)
         net = plan.eng.net
-        first_in = plan.rec[0][1]['x_in'].data_ptr()
+        self.first_in = plan.rec[0][1]['x_in'].data_ptr()
+        # Branch blocks 1 .. 5 ([SA] -> fuse conv -> loc | conf head on the 19 x 19 .. 1 x 1 maps: dozens of launches of 1 .. 100
+        # workgroups each) depend only on d(loc) / d(conf): their backward is hoisted to the front and tagged with the branch's stream
+        # id, so the five chains run beside each other and beside the trunk's backward; the trunk waits for branch k exactly where the
+        # sequential order had branch k's steps.  (Any order of the contributions to a shared activation gradient is handled: whoever
+        # comes second accumulates.)  Branch 0 -- L2Norm, the 1444-token attention block, fuse_11, head 0 -- is made of chip-filling
+        # launches and stays in line.  The step list in build order is also a valid single-stream order (run() uses it that way
+        # when a gradient-segment hook is installed or GSSD_BWD_STREAMS=0).
+        self.step_sid = []           # stream id per step
+        self.step_wait = {}          # step index -> [stream ids the step's stream waits for first]
+        self._cur_sid = 0
+        hoisted = sorted({r.get('sid', 0) for _, r in plan.rec if r.get('sid', 0) >= 2}, reverse=True) if BWD_STREAMS else []
+        for sid in hoisted:
+            self._cur_sid = sid
+            for kind, r in reversed(plan.rec):
+                if r.get('sid', 0) == sid:
+                    self._one(kind, r)
+        self._cur_sid = 0
+
+        def inputs(kind, r):
+            ts = [r['src']] if kind == 'head' else [r['a'], r['b']] if kind == 'slice_cat' else [r['x_in']]
+            return {t.data_ptr() for t in ts}
+        root = {}                    # branch -> the trunk activation it hangs off (input of its first forward record)
+        for kind, r in plan.rec:
+            if r.get('sid', 0) in hoisted and r['sid'] not in root:
+                root[r['sid']] = inputs(kind, r)
+        joined = set()
+
+        def join(sid):
+            if sid not in joined:
+                joined.add(sid)
+                self.step_wait.setdefault(len(self.steps), []).append(sid)
         for kind, r in reversed(plan.rec):
-            if kind == 'head':
-                self._head(r)
-            elif kind == 'convbn':
-                self._convbn(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
-            elif kind == 'convrelu':
-                self._convrelu(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
-            elif kind == 'pool':
-                self._pool(r)
-            elif kind == 'l2norm':
-                self._l2norm(r)
-            elif kind == 'sa':
-                self._sa(r)
-            elif kind == 'slice_cat':
-                self._slice_cat(r)
-            elif kind == 'dcn':
-                self._dcn(r)
-            else:
-                raise _lib.GssdError(f'no HIP backward for {kind}')
+            sid = r.get('sid', 0)
+            if sid in hoisted:
+                join(sid)            # where the sequential order had this branch's steps
+                continue
+            for b, ptrs in root.items():
+                if ptrs & inputs(kind, r):
+                    join(b)          # a trunk layer reading the same activation accumulates into the gradient the branch writes
+            self._one(kind, r)
+        self.hoisted = hoisted
         self.param_order = [p for p in net.parameters()]
+
+    def _one(self, kind, r):
+        first_in = self.first_in
+        if kind == 'head':
+            self._head(r)
+        elif kind == 'convbn':
+            self._convbn(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
+        elif kind == 'convrelu':
+            self._convrelu(r, need_dgrad=(r['x_in'].data_ptr() != first_in))
+        elif kind == 'pool':
+            self._pool(r)
+        elif kind == 'l2norm':
+            self._l2norm(r)
+        elif kind == 'sa':
+            self._sa(r)
+        elif kind == 'slice_cat':
+            self._slice_cat(r)
+        elif kind == 'dcn':
+            self._dcn(r)
+        else:
+            raise _lib.GssdError(f'no HIP backward for {kind}')
+        while len(self.step_sid) < len(self.steps):          # (handlers also append host-side steps directly)
+            self.step_sid.append(self._cur_sid)
 
     # ------------------------------------------------------------------------------------------------
     def _add(self, fn, args, keep=None):
         self.steps.append((fn, args))
+        self.step_sid.append(self._cur_sid)
         if keep is not None:
             self.keep.append(keep)
 
@@ -463,12 +514,36 @@ class BackwardPlan:
             fire = {}
             for k, (lo, hi, ready) in enumerate(self._segs):
                 fire.setdefault(max(ready, 0), []).append(k)
+        if hook is not None or not self.hoisted:
+            for si, (fn, args) in enumerate(self.steps):
+                self._run_step(fn, args, stream)
+                if hook is not None and si in fire:
+                    for k in fire[si]:
+                        lo, hi, _ = self._segs[k]
+                        hook(k, self.flat[lo:hi])
+            return [self.grads.get(id(p)) for p in self.param_order]
+        # branch chains on their own streams (forked behind the zeroing / d(loc), d(conf) copies above), joined where the trunk needs them
+        main = torch.cuda.current_stream()
+        sides = {}
+        for sid in self.hoisted:
+            st = self.plan._side_stream(100 + sid)
+            st.wait_stream(main)
+            sides[sid] = st
         for si, (fn, args) in enumerate(self.steps):
-            self._run_step(fn, args, stream)
-            if hook is not None and si in fire:
-                for k in fire[si]:
-                    lo, hi, _ = self._segs[k]
-                    hook(k, self.flat[lo:hi])
+            for w in self.step_wait.get(si, ()):
+                main.wait_stream(sides[w])
+            sid = self.step_sid[si]
+            if sid == 0:
+                self._run_step(fn, args, stream)
+            else:
+                st = sides[sid]
+                if args is None or fn is _pack_dgrad_from_packed:
+                    with torch.cuda.stream(st):
+                        self._run_step(fn, args, st.cuda_stream)
+                else:
+                    self._run_step(fn, args, st.cuda_stream)
+        for w in self.step_wait.get(len(self.steps), ()):
+            main.wait_stream(sides[w])
         return [self.grads.get(id(p)) for p in self.param_order]
 
     def _run_step(self, fn, args, stream):

@@ -217,6 +217,18 @@ class GssdEngine:
         return _Plan(self, B, training, dev, want_maps)
 
 
+class _RecList(list):
+    """The forward graph records; append() notes which branch (stream id of the launch plan, 0 = trunk) the record belongs to."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self._plan = plan
+
+    def append(self, item):
+        item[1].setdefault('sid', getattr(self._plan, '_sid', 0))
+        super().append(item)
+
+
 class _PlanBase:
     """State shared by the grouped and the vanilla launch plans."""
     generation = 0        # bumped by every run(): a backward checks it ran against the forward that produced it
@@ -246,7 +258,7 @@ class _Plan(_PlanBase):
         self.steps = []
         self.bufs = []
         self.head_descs = []
-        self.rec = []          # forward graph records, consumed by gssd/backward.py
+        self.rec = _RecList(self)   # forward graph records, consumed by gssd/backward.py (each tagged with its branch stream id)
         self.P = 8732
         self.nc = net.num_classes
         g = net.groups_vgg
@@ -942,7 +954,7 @@ class _PlanVanilla(_Plan):
     def __init__(self, eng, B, training, dev):   # noqa: super().__init__ builds the grouped graph; not called on purpose
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         net = eng.net
-        self.steps, self.bufs, self.head_descs, self.rec = [], [], [], []
+        self.steps, self.bufs, self.head_descs, self.rec = [], [], [], _RecList(self)
         self.P, self.nc = 8732, net.num_classes
         self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
         self.nbt = []
@@ -1046,7 +1058,7 @@ class SelfAttnOp(_Plan):
         self.eng = GssdEngine(holder)
         self.B, self.training, self.dev = B, bool(training), dev
         self.bf16, self.adt, self.conv_fn = False, torch.float32, lib.gssd_conv2d_nhwc_f32
-        self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []
+        self.steps, self.bufs, self.rec, self.head_descs = [], [], _RecList(self), []
         Cc = sa.in_channels
         self.H, self.C = H, Cc
         self.x = self._buf(B, H, H, Cc)

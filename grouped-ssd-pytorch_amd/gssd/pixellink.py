@@ -34,7 +34,7 @@ class _PlanPixelLink(_Plan):
         self.want_maps = False
         self.bf16, self.adt, self.conv_fn, self.cpad = False, torch.float32, lib.gssd_conv2d_nhwc_f32, 4
         net = eng.net
-        self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []
+        self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []  # (forward only: plain record list)
         g = net.vgg_groups
         # ---- batch-stat arena (the fuse BatchNorms) ----------------------------------------------------
         uniq, seen = [], set()

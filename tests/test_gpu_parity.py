@@ -799,8 +799,8 @@ FLAG_NETS = {       # tests/golden/make_golden_flags.py: (oracle flags, build_ss
     'dcn2_detach': (dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=2, groups_dcn=1, dcn_cat_sab=True),
                     (True, 4, 4, 1, True, True, True, 2, 1, True, True, 1),
                     ['vgg.0.weight', 'vgg.30.weight', 'dcn_list.0.weight', 'dcn_list.1.weight', 'dcn_list.1.conv_offset_mask.weight',
-                     'dcn_list.0.conv_offset_mask.bias', 'self_attn_base_list.0.snconv1x1_g.weight_orig', 'self_attn_base_list.0.sigma',
-                     'loc.0.weight']),
+                     'dcn_list.0.conv_offset_mask.bias', 'self_attn_base_list.0.snconv1x1_g.weight_orig',
+                     'self_attn_base_list.0.snconv1x1_attn.weight_orig', 'loc.0.weight']),
     'dcn_nocat': (dict(num_dcn_layers=1, groups_dcn=4), (True, 4, 4, 1, True, False, False, 1, 4, False, False, 1),
                   ['vgg.0.weight', 'vgg.30.weight', 'dcn_list.0.weight', 'dcn_list.0.bias', 'dcn_list.0.conv_offset_mask.weight',
                    'fuse_11.weight', 'loc.0.weight']),
@@ -864,8 +864,9 @@ def test_constructor_flags(dev, golden, name):
     errs = {k: l2rel(named[k].grad, sg[k]) for k in gkeys}
     print(name, 'HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in errs.items()})
     # (per tensor, relative L2: a handful of ReLU / max-pool decisions flip between two fp32 implementations, see
-    # test_backward_gradients; sigma is one heavily cancelling sum over the whole map -- 6e-2 there at B = 4, B = 2 here)
-    assert all(np.isfinite(v) and v < (1e-1 if k.endswith('sigma') else 2e-2) for k, v in errs.items()), errs
+    # test_backward_gradients -- which also covers the sigma gates: scalars that are one heavily cancelling sum over the whole map,
+    # 1e-1 run-to-run noise at B = 2)
+    assert all(np.isfinite(v) and v < 2e-2 for k, v in errs.items()), errs
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     unused = [k for k, p in named.items() if p.grad is None]
     assert unused == [k for k in unused if sg[k] is None], unused          # exactly the parameters the reference graph leaves out
@@ -946,6 +947,47 @@ def test_backward_gradients(dev, name):
     print('HIP vs ATen backward (L2-relative)', {k: f'{v:.1e}' for k, v in e2.items()})
     assert max(v for k, v in e2.items() if not k.endswith('sigma')) < 2e-2, e2
     assert all(v < 6e-2 for k, v in e2.items() if k.endswith('sigma')), e2
+
+
+def test_backward_branch_streams_equal_single_stream(dev):
+    """gssd/backward.py runs the backward of branch blocks 1 .. 5 on their own streams beside the trunk's; the same step list on one
+    stream (the mode used with a gradient-segment hook / GSSD_BWD_STREAMS=0) must give the same gradients (split-K atomics aside)."""
+    import copy
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssdpp']
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth.synth_state_dict(shapes, seed=1111))
+    net = net.to(dev).train()
+    sd0 = copy.deepcopy(net.state_dict())
+    x = synth.synth_images(4, seed=9).to(dev)
+    rng = np.random.default_rng(0)
+    r1 = torch.from_numpy(rng.normal(size=(4, 8732, 4)).astype(np.float32)).to(dev)
+    r2 = torch.from_numpy(rng.normal(size=(4, 8732, 2)).astype(np.float32)).to(dev)
+
+    def grads(single):
+        net.load_state_dict(sd0)
+        net.zero_grad(set_to_none=True)
+        loc, conf, _ = net(x)
+        bp = net._engine._last_plan.backward_plan()
+        assert bp.hoisted == [6, 5, 4, 3, 2]
+        keep = bp.hoisted
+        if single:
+            bp.hoisted = []
+        try:
+            ((loc * r1).sum() + (conf * r2).sum()).backward()
+        finally:
+            bp.hoisted = keep
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    # Gradients that are mathematically zero (conv biases in front of a train-mode BatchNorm, phi's bias, ...) hold the rounding noise of
+    # atomically accumulated sums and differ between any two runs; so the yardstick per tensor is the difference between two
+    # single-stream runs.  Several rounds: a missing stream dependency shows as a sporadic mismatch.
+    for rep in range(3):
+        ga, gb, gc = grads(False), grads(True), grads(True)
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            d_ms, d_ss, ref = float((ga[k] - gb[k]).norm()), float((gc[k] - gb[k]).norm()), float(gb[k].norm())
+            assert d_ms <= 3.0 * d_ss + 1e-5 * ref, (k, d_ms, d_ss, ref)
 
 
 def test_training_steps_reduce_loss(dev):
