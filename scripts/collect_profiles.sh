@@ -16,4 +16,17 @@ cd $R
 timeout 400 bash scripts/pmc_traffic.sh gssdpp f32 > gpurun_out/${tag}_pmc_f32.log 2>&1
 timeout 400 bash scripts/pmc_traffic.sh gssdpp bf16 > gpurun_out/${tag}_pmc_bf16.log 2>&1
 timeout 400 bash scripts/pmc_traffic.sh gssd f32 > gpurun_out/${tag}_pmc_gssd.log 2>&1
+# layer tables, full training step (bench line + kernel stats), PixelLink++ kernel stats
+python3 scripts/layer_times.py gssdpp f32 > gpurun_out/${tag}_gssdpp_b32_f32_layer_times.txt 2>/dev/null
+python3 scripts/layer_times.py gssdpp bf16 > gpurun_out/${tag}_gssdpp_b32_bf16_layer_times.txt 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > gpurun_out/${tag}_gssdpp_b32_fullstep.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --config gssd --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > gpurun_out/${tag}_gssd_b32_fullstep.json 2>> gpurun_out/${tag}_bench.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_fs -o p -- python3 $R/bench.py --steps 2 --warmup 1 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > /dev/null 2>&1
+f=$(find $R/gpurun_out/${tag}_prof_fs -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $R/gpurun_out/${tag}_gssdpp_b32_fullstep_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_pl -o p -- python3 $R/scripts/prof_pixellink.py > $R/gpurun_out/${tag}_pixellink_b32_bench.json 2>/dev/null
+f=$(find $R/gpurun_out/${tag}_prof_pl -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $R/gpurun_out/${tag}_pixellink_b32_kernel_stats.csv
+cd $R
 tail -3 gpurun_out/${tag}_bench.err
