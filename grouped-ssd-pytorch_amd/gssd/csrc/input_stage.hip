@@ -4,7 +4,8 @@
 // train_lesion_multiphase_v2.py:198).  The resampler restates Pillow's 8-bit path (src/libImaging/Resample.c): double
 // coefficients normalised per output pixel and quantised to 22-bit fixed point ON THE HOST (gssd_resample_coeffs), integer
 // accumulation from 1 << 21, arithmetic shift, clip to [0, 255]; horizontal pass, then vertical, uint8 in between.  Pure
-// byte / integer work: bit-exact against Pillow.  All three kernels are HBM-streaming (100 MB in, 138 MB out at B = 32).
+// byte / integer work: bit-exact against Pillow.  All three kernels are HBM-streaming (100 MB in, 138 MB out at B = 32); the
+// LDS-staged forms further down are the ones the 512 -> 300 path runs, the first two kernels the fallback for odd row lengths.
 // Compiled with -ffp-contract=off: the host coefficient code and the fp32 normalisation must round like the reference.
 #include <math.h>
 
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
         for (int t = 0; t < n; ++t) {
             const int w = k[t];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += (int)src[t * C + c] * w;
+            for (int c = 0; c < C; ++c) acc[c] += __mul24((int)src[t * C + c], w);     // 8-bit x 23-bit: exact in 24-bit multiplies
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) out[i * C + c] = clip8(acc[c]);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict
                 const uint32_t v = src[(long long)t * words];
                 const int w = k[t];
 #pragma unroll
-                for (int e = 0; e < NB; ++e) acc[e] += (int)((v >> (8 * e)) & 255u) * w;
+                for (int e = 0; e < NB; ++e) acc[e] += __mul24((int)((v >> (8 * e)) & 255u), w);
             }
             uint32_t r = 0;
             int c = c0;
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict
         }
     }
     if (mm) {
-        int* m = mm + (img / imgs_per_study) * C * 2;
+        // one workgroup-level result, then at most 2 C atomics by 2 C lanes in parallel: with one (load, atomic) chain per wave and
+        // channel the six round trips to the hot L2 lines at the end of every workgroup were most of this kernel's time (0.34 ms
+        // at B = 32, growing with the number of workgroups: 0.96 ms with 3 rows per workgroup, 0.16 ms with 30)
+        __shared__ int red[4][8];
         for (int q = 0; q < C; ++q) {
             int l = lo[q], h = hi[q];
 #pragma unroll
@@ -125,13 +129,58 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict
                 l = min(l, __shfl_xor(l, o, 64));
                 h = max(h, __shfl_xor(h, o, 64));
             }
-            // few hot addresses: only touch them when this wave would actually move an extremum (a stale read is fine, the
-            // atomic decides)
-            if ((threadIdx.x & 63) == 0 && h >= l) {
-                if (255 - l > __atomic_load_n(m + 2 * q, __ATOMIC_RELAXED)) atomicMax(m + 2 * q, 255 - l);
-                if (h > __atomic_load_n(m + 2 * q + 1, __ATOMIC_RELAXED)) atomicMax(m + 2 * q + 1, h);
+            if ((threadIdx.x & 63) == 0) {
+                red[threadIdx.x >> 6][2 * q] = h >= l ? 255 - l : 0;
+                red[threadIdx.x >> 6][2 * q + 1] = h >= l ? h : 0;
             }
         }
+        __syncthreads();
+        if (threadIdx.x < 2 * C) {
+            int* m = mm + (img / imgs_per_study) * C * 2 + threadIdx.x;
+            const int v = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+            if (v > __atomic_load_n(m, __ATOMIC_RELAXED)) atomicMax(m, v);      // (a stale read is fine, the atomic decides)
+        }
+    }
+}
+
+// The horizontal pass for rows that are whole 32-bit words: a workgroup stages H_ROWS input rows (coalesced words) and the
+// coefficient table in LDS; a thread then produces one 32-bit word of an output row from LDS bytes (0.25 -> 0.18 ms at B = 32).
+// Measured and rejected: one thread per output pixel on the same staging (0.26 ms), and a vertical pass that first gathers a
+// thread's whole input window into its own LDS column with batched independent loads (0.45 - 0.51 ms against 0.34 ms for the plain
+// kernel above: the four workgroups per CU that fit beside the 32 KB column array hide less latency than the eight without it).
+constexpr int H_ROWS = 16;
+
+template <int C>
+__global__ __launch_bounds__(256) void resize_h_lds_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                           long long rows, int Win, int Wout) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hsm[];
+    const int inw = Win * C / 4, outw = Wout * C / 4, tid = threadIdx.x;
+    const uint8_t* rowb = reinterpret_cast<const uint8_t*>(hsm);
+    int* kl = reinterpret_cast<int*>(hsm + H_ROWS * inw);
+    int* bl = kl + Wout * ksize;
+    const long long row0 = (long long)blockIdx.x * H_ROWS;
+    const int nr = (int)(rows - row0 < H_ROWS ? rows - row0 : H_ROWS);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + row0 * Win * C);
+    for (int i = tid; i < nr * inw; i += 256) hsm[i] = src[i];
+    for (int i = tid; i < Wout * ksize; i += 256) kl[i] = kk[i];
+    for (int i = tid; i < 2 * Wout; i += 256) bl[i] = bounds[i];
+    __syncthreads();
+    for (int item = tid; item < nr * outw; item += 256) {                   // one 32-bit word of an output row
+        const int r = item / outw, w = item - r * outw;
+        uint32_t res = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = 4 * w + e;
+            const int xo = b / C, c = b - xo * C;
+            const int x0 = bl[2 * xo], n = bl[2 * xo + 1];
+            const int* k = kl + xo * ksize;
+            const uint8_t* sp = rowb + (size_t)r * Win * C + x0 * C + c;
+            int acc = 1 << (PRECISION_BITS - 1);
+            for (int t = 0; t < n; ++t) acc += __mul24((int)sp[t * C], k[t]);      // 8-bit x 23-bit: exact in the 24-bit multiplier
+            res |= (uint32_t)clip8(acc) << (8 * e);
+        }
+        reinterpret_cast<uint32_t*>(out + (row0 + r) * Wout * C)[w] = res;
     }
 }
 
@@ -213,6 +262,15 @@ extern "C" int gssd_resize_u8_horizontal(const uint8_t* in, uint8_t* out, const 
     const long long rows = (long long)n_img * H;
     long long blocks = (rows * W_out + 255) / 256;
     if (blocks > 65536) blocks = 65536;
+    const size_t lds = (size_t)H_ROWS * W_in * C + (size_t)(W_out * ksize + 2 * W_out) * sizeof(int);
+    if ((W_in * C) % 4 == 0 && (W_out * C) % 4 == 0 && ((uintptr_t)in % 4) == 0 && ((uintptr_t)out % 4) == 0 && lds <= 60 * 1024 &&
+        (rows + H_ROWS - 1) / H_ROWS < (1ll << 31)) {
+        auto kl = C == 1 ? resize_h_lds_kernel<1> : C == 2 ? resize_h_lds_kernel<2> : C == 3 ? resize_h_lds_kernel<3> : resize_h_lds_kernel<4>;
+        hipLaunchKernelGGL(kl, dim3((unsigned)((rows + H_ROWS - 1) / H_ROWS)), dim3(256), lds, as_stream(stream), in, out, bounds, kk, ksize,
+                           rows, W_in, W_out);
+        GSSD_CHECK_LAUNCH();
+        return GSSD_OK;
+    }
     auto kern = C == 1 ? resize_h_kernel<1> : C == 2 ? resize_h_kernel<2> : C == 3 ? resize_h_kernel<3> : resize_h_kernel<4>;
     hipLaunchKernelGGL(kern, dim3((int)blocks), dim3(256), 0, as_stream(stream), in, out, bounds, kk, ksize, rows, W_in, W_out);
     GSSD_CHECK_LAUNCH();

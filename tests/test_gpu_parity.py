@@ -1503,6 +1503,13 @@ def test_input_stage_bit_exact(dev, golden):
         assert np.array_equal(x[i], IO.to_network_input(IO.base_transform(raws[i], 300, mean, True)))
     xl = DeviceInputStage(300, mean, True, filt='bilinear')(torch.from_numpy(raws[:1]).to(dev)).cpu().numpy()
     assert np.array_equal(xl[0], IO.to_network_input(IO.base_transform(raws[0], 300, mean, True, filt='bilinear')))
+    # other geometries of the LDS-staged kernels (whole 32-bit words per row): a small one, and a 5.12 x reduction whose vertical
+    # window (73 input rows for 10 output rows) does not fit the staged column, so every tap is fetched in place
+    for src, size in ((64, 40), (512, 100)):
+        rs = np.stack([synth.synth_study_u8(31 + i, 4, src) for i in range(2)])
+        xs = DeviceInputStage(size, mean, True)(torch.from_numpy(rs).to(dev)).cpu().numpy()
+        for i in range(2):
+            assert np.array_equal(xs[i], IO.to_network_input(IO.base_transform(rs[i], size, mean, True))), (src, size, i)
 
 
 # --------------------------------------------------------------------------------------------------
