@@ -22,9 +22,11 @@
 //     (conv1_2 +48 %: the slices then reach HBM unmerged);
 //   * 16-row patches (half the barriers and load round trips per pixel, 1.27 x instead of 1.41 x halo): -4 .. -7 %;
 //   * the producer BatchNorm constants in registers instead of an LDS table (the table reads were 4 x the patch bytes): conv1_2 -5 %.
-//   conv1_1 194 -> 161 us, conv1_2 231 -> 211 us, conv2_1 142 -> 135 us, conv2_2 176 -> 172 us.  The next step would be whole-line
-//   stores without a workgroup barrier (one wave computing two groups, 64-byte slices); the LDS-output-tile form of that idea was
-//   measured earlier and lost its gain to the extra barrier and LDS pass.
+//   conv1_1 194 -> 161 us, conv1_2 231 -> 211 us, conv2_1 142 -> 135 us, conv2_2 176 -> 172 us.
+//   * measured and rejected after that: a wave owning a PAIR of groups and half the rows, its two 8-byte pieces per pixel rearranged by
+//     v_permlane32_swap + v_permlane16_swap into one 16-byte store of a 64-byte contiguous slice (half the write requests, same
+//     instruction count): conv1_1 214 us, conv1_2 263 us -- wider slices are not what the store path wants either (conv2_1, whose
+//     slices are 64 bytes by construction, sits at the same 2.1 TB/s); as was the LDS output tile (whole 128-byte lines) earlier.
 // Measured and rejected earlier (conv1_1 190 us / conv1_2 232 us / conv2_1 142 us at the time): a second patch stage with the next
 // tile's DMA in flight under the current tile (179 / 303 / 138 us), a persistent grid of 5 instead of 3 workgroups per CU
 // (199 / 237 / 176 us), whole-pixel-vector stores through an LDS output tile (196 / 256 / 152 us).
