@@ -27,15 +27,15 @@ struct BgemmParams {
     float alpha;
 };
 
-// element (row, k) of op(X): X[row*ld + k] (not transposed) or X[k*ld + row] (transposed)
-__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int trans, int row0, int nrows, int k0, int K, float* lds,
-                                          int tid) {
+// element (row, k) of op(X): X[row*ld + k] (not transposed) or X[k*ld + row] (transposed).  A 64 x 16 tile is one 16-byte quad per
+// thread: fetched into a register (fetch_tile) one k-step ahead of the MFMAs that use it, written to LDS (commit_tile) after them.
+__device__ __forceinline__ f32x4 fetch_tile(const float* __restrict__ X, int ld, int trans, int row0, int nrows, int k0, int K, int tid) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!trans) {
         // contiguous along k: thread -> (row = tid / 4, k quad = tid % 4)
         const int row = tid >> 2, kq = (tid & 3) << 2;
         const int gr = row0 + row, gk = k0 + kq;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gr < nrows) {
+        if (gr < nrows && gk < K) {
             const float* p = X + (size_t)gr * ld + gk;
             if (gk + 3 < K && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
             else {
@@ -44,13 +44,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, i
                     if (gk + e < K) v[e] = p[e];
             }
         }
-        *reinterpret_cast<f32x4*>(lds + row * LDS_LD + kq) = v;
     } else {
         // contiguous along the row index: thread -> (k = tid / 16, row quad = tid % 16)
         const int k = tid >> 4, rq = (tid & 15) << 2;
         const int gk = k0 + k, gr = row0 + rq;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gk < K) {
+        if (gk < K && gr < nrows) {
             const float* p = X + (size_t)gk * ld + gr;
             if (gr + 3 < nrows && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
             else {
@@ -59,6 +57,16 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, i
                     if (gr + e < nrows) v[e] = p[e];
             }
         }
+    }
+    return v;
+}
+
+__device__ __forceinline__ void commit_tile(const f32x4 v, int trans, float* lds, int tid) {
+    if (!trans) {
+        const int row = tid >> 2, kq = (tid & 3) << 2;
+        *reinterpret_cast<f32x4*>(lds + row * LDS_LD + kq) = v;
+    } else {
+        const int k = tid >> 4, rq = (tid & 15) << 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) lds[(rq + e) * LDS_LD + k] = v[e];
     }
@@ -80,11 +88,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // op(B)[k][n]: stored B[k*ldb + n] (not transposed) = "row index n is the contiguous one" -> the transposed loader
+    f32x4 ra = fetch_tile(A, p.lda, p.transA, m0, p.M, 0, p.K, tid);
+    f32x4 rb = fetch_tile(B, p.ldb, !p.transB, n0, p.N, 0, p.K, tid);
     for (int k0 = 0; k0 < p.K; k0 += TK) {
-        load_tile(A, p.lda, p.transA, m0, p.M, k0, p.K, As, tid);
-        // op(B)[k][n]: stored B[k*ldb + n] (not transposed) = "row index n is the contiguous one" -> the transposed loader
-        load_tile(B, p.ldb, !p.transB, n0, p.N, k0, p.K, Bs, tid);
+        commit_tile(ra, p.transA, As, tid);
+        commit_tile(rb, !p.transB, Bs, tid);
         __syncthreads();
+        if (k0 + TK < p.K) {                      // the next k-step's quads travel while this one's MFMAs run
+            ra = fetch_tile(A, p.lda, p.transA, m0, p.M, k0 + TK, p.K, tid);
+            rb = fetch_tile(B, p.ldb, !p.transB, n0, p.N, k0 + TK, p.K, tid);
+        }
         f32x4 af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + (wm * 32 + i * 16 + r) * LDS_LD + 4 * kq);
