@@ -85,7 +85,7 @@ SIGNATURES = {
     'gssd_upsample_insert_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_l2norm_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_self_attn_core_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
-    'gssd_self_attn_core_kv_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_self_attn_core_kv_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     'gssd_sa_pool_kv_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_sa_unpool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weights_batched': (c_i, [c_fp, c_i, c_fp]),
@@ -117,6 +117,9 @@ SIGNATURES = {
     'gssd_sn_weight_grad_f32': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     'gssd_scaled_transpose_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     'gssd_dot_f32': (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
+    'gssd_rowdot_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_fp]),
+    'gssd_bgemm_ex_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_f,
+                                c_i, c_fp, c_fp, c_fp]),
     'gssd_axpby_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp]),
     'gssd_scale_cast_f64_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_fp]),
     'gssd_sa_sigma_grad_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp]),

@@ -357,15 +357,26 @@ class BackwardPlan:
         Nk, Nkp, pooled = r['Nk'], r['Nkp'], r['kp'] is not None
         keys, krow, vals = (r['kp'], C8, r['gTp']) if pooled else (tp[0, 0, C8:], C4, gT)
         A = self._buf(B, N, Nkp)
-        d_qk, _, _ = mk(tp, keys, A, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=Nk, out_stride=Nkp, m_per_image=True,
-                        in_batch_stride=N * C4, wgt_batch_stride=Nk * krow, out_batch_stride=N * Nkp, wgt_row_stride=krow)
-        self._add(fn, (C.byref(d_qk),), keep=d_qk)
-        self._add(lib.gssd_softmax_rows_f32, (A.data_ptr(), B * N, Nk, Nkp))
-        # dA = d(ag)' . g ;  dS in place
         dA = self._buf(B, N, Nkp)
-        self._add(lib.gssd_bgemm_f32, (dag.data_ptr(), vals.data_ptr(), dA.data_ptr(), N, Nk, C2, C2, Nkp, Nkp, 0, 0, N * C2, C2 * Nkp,
-                                       N * Nkp, B, 1.0, 0))
-        self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, Nk, Nkp))
+        lse = r.get('lse')
+        if lse is not None:
+            # A = exp(theta . keys^T - lse) and dS = A o (d(ag)' . values - D), D_i = <d(ag)'_i, ag_i> = rowsum(A o dA): both in the
+            # epilogue of the GEMM that produces the logits / dA -- no pass over the [N, Nk] maps for softmax or its backward
+            self._add(lib.gssd_bgemm_ex_f32, (tp.data_ptr(), keys.data_ptr(), A.data_ptr(), N, Nk, C8, C4, krow, Nkp, 0, 1, N * C4, Nk * krow,
+                                              N * Nkp, B, 1.0, 1, lse.data_ptr(), 0))
+            Dv = self._buf(B, N)
+            self._add(lib.gssd_rowdot_f32, (dag.data_ptr(), ag.data_ptr(), Dv.data_ptr(), M, C2))
+            self._add(lib.gssd_bgemm_ex_f32, (dag.data_ptr(), vals.data_ptr(), dA.data_ptr(), N, Nk, C2, C2, Nkp, Nkp, 0, 0, N * C2, C2 * Nkp,
+                                              N * Nkp, B, 1.0, 2, Dv.data_ptr(), A.data_ptr()))
+        else:
+            d_qk, _, _ = mk(tp, keys, A, B=B, H=H, W=H, in_stride=C4, cin_g=C8, Cout=Nk, out_stride=Nkp, m_per_image=True,
+                            in_batch_stride=N * C4, wgt_batch_stride=Nk * krow, out_batch_stride=N * Nkp, wgt_row_stride=krow)
+            self._add(fn, (C.byref(d_qk),), keep=d_qk)
+            self._add(lib.gssd_softmax_rows_f32, (A.data_ptr(), B * N, Nk, Nkp))
+            # dA = d(ag)' . g ;  dS in place
+            self._add(lib.gssd_bgemm_f32, (dag.data_ptr(), vals.data_ptr(), dA.data_ptr(), N, Nk, C2, C2, Nkp, Nkp, 0, 0, N * C2, C2 * Nkp,
+                                           N * Nkp, B, 1.0, 0))
+            self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, Nk, Nkp))
         # [d theta | d phi | d g] token-major, one buffer (the gradient of the merged projection's output)
         dtpg = self._buf(B, N, CT)
         self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), keys.data_ptr(), dtpg.data_ptr(), N, C8, Nk, Nkp, krow, CT, 0, 0, N * Nkp, Nk * krow,

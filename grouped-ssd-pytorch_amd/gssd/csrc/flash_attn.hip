@@ -55,7 +55,8 @@ __device__ __forceinline__ void stage_tile(float* lds, int wave, int lane, RowPt
 template <int D, int C2, int BKV>
 __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ kp,
                                                            const float* __restrict__ gT, float* __restrict__ out, int N, int Nk,
-                                                           int Np, int qtiles, int d_real, int kstride, int out_bf16) {
+                                                           int Np, int qtiles, int d_real, int kstride, int out_bf16,
+                                                           float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                    // [BKV][D]
     float* const Vs = smem + BKV * D;          // [C2][BKV]
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_run;
+    // log-sum-exp of the row's logits: the backward rebuilds the probabilities as exp(s - lse) in a GEMM epilogue (no softmax pass)
+    if (lse != nullptr && q < N && kq == 0) lse[(size_t)b * N + q] = m_run + logf(l_run);
     if (q < N) {
         if (out_bf16) {             // bf16 storage mode (configs[4]): the o conv reads bf16
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
 
 template <int D, int C2, int BKV>
 int launch(const float* tp, const float* kp, const float* gT, float* out, int B, int N, int Nk, int Np, int d_real, int kstride,
-           int out_bf16, hipStream_t stream) {
+           int out_bf16, float* lse, hipStream_t stream) {
     constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
     static bool attr_set[16] = {false};
     int dev = 0;
@@ -199,7 +202,7 @@ int launch(const float* tp, const float* kp, const float* gT, float* out, int B,
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16, lse);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -357,18 +360,18 @@ int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np3
 }  // namespace
 
 extern "C" int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, const float* gT, void* out_v, int B, int N, int Nk, int Nkp,
-                                          int D, int C2, int kstride, int out_bf16, gssd_stream_t stream) {
+                                          int D, int C2, int kstride, int out_bf16, float* lse, gssd_stream_t stream) {
     float* out = reinterpret_cast<float*>(out_v);
     GSSD_CHECK_ARG(tp && kp && gT && out && B > 0 && N > 0 && Nk > 0 && Nkp >= Nk && Nkp % 4 == 0);
     GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)gT % 16) == 0 && ((uintptr_t)out % 16) == 0);
     GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
     hipStream_t s = as_stream(stream);
     GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0 && kstride >= D && kstride % 4 == 0);
-    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
-    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
-    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
-    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);     // small maps (Self_Attn(64): op-level tests)
-    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, s);
+    if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
+    if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
+    if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
+    if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);     // small maps (Self_Attn(64): op-level tests)
+    if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
     gssd_set_error("self-attention core: unsupported (theta/phi channels %d, g channels %d); built: (64,256) (128,512) (32,128) (<=16,32|64)", D, C2);
     return GSSD_EINVAL;
 }
@@ -376,7 +379,7 @@ extern "C" int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, cons
 extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out_v, int B, int N, int Np, int D, int C2,
                                        int out_bf16, gssd_stream_t stream) {
     GSSD_CHECK_ARG(tp && D > 0);
-    return gssd_self_attn_core_kv_f32(tp, tp + D, gT, out_v, B, N, N, Np, D, C2, 2 * D, out_bf16, stream);   // keys = phi of the same tokens
+    return gssd_self_attn_core_kv_f32(tp, tp + D, gT, out_v, B, N, N, Np, D, C2, 2 * D, out_bf16, nullptr, stream);   // keys = phi of the same tokens
 }
 
 extern "C" int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,

@@ -8,8 +8,10 @@
 //                             two launches: a multi-workgroup dot product, then the elementwise update)
 //   gssd_scaled_transpose_f32 Wd[c][n] = W[n][c] * alpha[n]: the data-gradient weights of a spectrally normalised 1x1 conv
 //   gssd_dot_f32              sum a[i] * b[i] into a double (the gradient of Self_Attn's scalar gate sigma)
-// The forward is flash-style and keeps no attention map; the backward re-materialises A per block (QK^T by the conv kernel + row
-// softmax) -- a flash-style backward is the next step.
+//   gssd_bgemm_ex_f32         the same GEMM with an epilogue: exp(acc - lse[m]) rebuilds the probabilities from the forward's
+//                             log-sum-exp (no QK^T conv + softmax pass), aux (acc - D[m]) turns dA into dS where it is produced
+//   gssd_rowdot_f32           D_i = <d(ag)_i, ag_i> = rowsum(A o dA)
+// The forward is flash-style and keeps no attention map, only the rows' log-sum-exp; the backward re-materialises A per block.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -25,6 +27,9 @@ struct BgemmParams {
     int M, N, K, lda, ldb, ldc, transA, transB, accumulate;
     long long sA, sB, sC;
     float alpha;
+    int mode;                 // 0: C = alpha acc;  1: C = exp(alpha acc - rowvec[m]);  2: C = aux[m][n] (alpha acc - rowvec[m])
+    const float* rowvec;      // [batch][M]
+    const float* aux;         // laid out like C
 };
 
 // element (row, k) of op(X): X[row*ld + k] (not transposed) or X[k*ld + row] (transposed).  A 64 x 16 tile is one 16-byte quad per
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
                 const int m = m0 + wm * 32 + i * 16 + kq * 4 + e;
                 if (m >= p.M) continue;
                 float* dst = C + (size_t)m * p.ldc + n;
-                const float v = acc[i][j][e] * p.alpha;
+                float v = acc[i][j][e] * p.alpha;
+                if (p.mode == 1) v = __expf(v - p.rowvec[(size_t)b * p.M + m]);
+                else if (p.mode == 2) v = p.aux[(size_t)b * p.sC + (size_t)m * p.ldc + n] * (v - p.rowvec[(size_t)b * p.M + m]);
                 *dst = p.accumulate ? *dst + v : v;
             }
         }
@@ -143,6 +150,20 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
         s = wave_sum(s);
         for (int c = lane; c < stride; c += 64) d[c] = c < n ? a[c] * (d[c] - s) : 0.f;
     }
+}
+
+// out[row] = sum_c a[row][c] * b[row][c]: D_i = <d(ag)_i, ag_i> = rowsum(A o dA) of the attention backward (one wave per row)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                     long long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const float* pa = a + row * C;
+    const float* pb = b + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += pa[c] * pb[c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
 }
 
 // spectral-norm chain rule in two launches: (1) dot = <scale * dW_eff, W> (grid-stride partial sums, one fp64 atomic per
@@ -252,7 +273,19 @@ extern "C" int gssd_bgemm_f32(const float* A, const float* B, float* C, int M, i
                               gssd_stream_t stream) {
     GSSD_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
     GSSD_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
-    BgemmParams p{A, B, C, M, N, K, lda, ldb, ldc, transA, transB, accumulate, strideA, strideB, strideC, alpha};
+    BgemmParams p{A, B, C, M, N, K, lda, ldb, ldc, transA, transB, accumulate, strideA, strideB, strideC, alpha, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(bgemm_kernel, dim3((M + TM - 1) / TM, (N + TN - 1) / TN, batch), dim3(256), 0, as_stream(stream), p);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bgemm_ex_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                                 int transB, long long strideA, long long strideB, long long strideC, int batch, float alpha, int mode,
+                                 const float* rowvec, const float* aux, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
+    GSSD_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    GSSD_CHECK_ARG((mode == 0) || (mode == 1 && rowvec) || (mode == 2 && rowvec && aux));
+    BgemmParams p{A, B, C, M, N, K, lda, ldb, ldc, transA, transB, 0, strideA, strideB, strideC, alpha, mode, rowvec, aux};
     hipLaunchKernelGGL(bgemm_kernel, dim3((M + TM - 1) / TM, (N + TN - 1) / TN, batch), dim3(256), 0, as_stream(stream), p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -287,6 +320,13 @@ extern "C" int gssd_scaled_transpose_f32(const float* w, const float* alpha, flo
     const long long total = (long long)rows * cols;
     hipLaunchKernelGGL(scaled_transpose_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w, alpha, out, rows, cols);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_rowdot_f32(const float* a, const float* b, float* out, int64_t rows, int C, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(a && b && out && rows > 0 && C > 0 && (rows + 3) / 4 < (1ll << 31));
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), a, b, out, rows, C);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -732,6 +732,8 @@ class _Plan(_PlanBase):
                            out_batch_stride=C2 * Np)
             self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
             self._add(fn, (C.byref(d1b),), keep=d1b)
+        # training keeps the rows' log-sum-exp: the backward rebuilds the probabilities from it in a GEMM epilogue
+        lse = self._buf(B, N) if (self.training and not self.bf16) else None
         # max_pool_factor > 1 (layers/self_attn.py:57-59, 67, 76): keys / values average-pooled to a P x P grid before the core
         P = max(H // int(sa.max_pool_factor), 1)
         pooled = P != H
@@ -743,13 +745,14 @@ class _Plan(_PlanBase):
             kp, gTp = self._buf(B, Nk, C8), self._buf(B, C2, Nkp)
             self._add(lib.gssd_sa_pool_kv_f32, (tp.data_ptr(), gT.data_ptr(), kp.data_ptr(), gTp.data_ptr(), B, H, P, C8, C2, Np, Nkp))
             self._add(lib.gssd_self_attn_core_kv_f32, (tp.data_ptr(), kp.data_ptr(), gTp.data_ptr(), ag.data_ptr(), B, N, Nk, Nkp, C8, C2,
-                                                       C8, 0),
+                                                       C8, 0, lse.data_ptr() if lse is not None else 0),
                       tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * Nk * (C8 + C2), 4.0 * B * (N * C8 + Nk * C8 + C2 * Nkp + N * C2)))
         elif self.bf16:
             self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
                       tag=(f'flash_attn_bf16v<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), B * (4.0 * N * C4 + 2.0 * C2 * Np + 2.0 * N * C2)))
         else:
-            self._add(lib.gssd_self_attn_core_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2, 0),
+            self._add(lib.gssd_self_attn_core_kv_f32, (tp.data_ptr(), tp[0, 0, C8:].data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, N, Np,
+                                                       C8, C2, C4, 0, lse.data_ptr() if lse is not None else 0),
                       tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
         S = None
         if want_map:
@@ -764,7 +767,7 @@ class _Plan(_PlanBase):
         self.attn_maps = getattr(self, 'attn_maps', {})
         self.attn_maps[(lst_name, idx)] = (S, Nk, Nkp)
         self.rec.append(('sa', dict(mod=sa, name=name, x_in=x, out=out, out2=out2, H=H, C=Cc, tp=tp, gT=gT, ag=ag, N=N, Np=Np,
-                                    inv_sigma=(a_tpg, a_o), P=P, Nk=Nk, Nkp=Nkp, kp=kp, gTp=gTp)))
+                                    inv_sigma=(a_tpg, a_o), P=P, Nk=Nk, Nkp=Nkp, kp=kp, gTp=gTp, lse=lse)))
         return out, out2
 
     def _dcn(self, li, x, H, Cin):

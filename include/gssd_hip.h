@@ -249,7 +249,8 @@ int gssd_self_attn_core_f32(const float* tp, const float* gT, void* out, int B, 
  * gssd_self_attn_core_f32 is the case kp = tp + D, Nk = N, kstride = 2 D; Self_Attn with max_pool_factor > 1 passes the pooled
  * phi / g of gssd_sa_pool_kv_f32 (layers/self_attn.py:57-59, 67, 76: Nk = max(H / factor, 1)^2 keys for N = H^2 queries). */
 int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, const float* gT, void* out, int B, int N, int Nk, int Nkp, int D,
-                               int C2, int kstride, int out_bf16, gssd_stream_t stream);
+                               int C2, int kstride, int out_bf16, float* lse, gssd_stream_t stream);
+/* lse (optional, [B][N]): log-sum-exp of every query's logits -- what the training step keeps of the softmax for its backward */
 
 /* F.adaptive_avg_pool2d(phi, P) / (g, P) of Self_Attn (layers/self_attn.py:67, 76) on the projection outputs: tp [B][H*H][2*C8]
  * (theta | phi) -> kp [B][P*P][C8]; gT [B][C2][Np] -> gTp [B][C2][Nkp] (pad columns zero).  Cell o of the P-grid covers rows
@@ -365,6 +366,14 @@ int gssd_input_finish_f32(const uint8_t* img, const int32_t* minmax, float mean0
 int gssd_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                    long long strideA, long long strideB, long long strideC, int batch, float alpha, int accumulate,
                    gssd_stream_t stream);
+/* The same GEMM with an epilogue on alpha * acc: mode 1 -> exp(. - rowvec[b][m]) (the attention probabilities from the forward's
+ * log-sum-exp: torch.softmax of self_attn.py:72 without a pass over the logits), mode 2 -> aux[b][m][n] * (. - rowvec[b][m]) (softmax
+ * backward where dA is produced; aux laid out like C); mode 0 = gssd_bgemm_f32 without accumulation. */
+int gssd_bgemm_ex_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
+                      long long strideA, long long strideB, long long strideC, int batch, float alpha, int mode, const float* rowvec,
+                      const float* aux, gssd_stream_t stream);
+/* out[row] = sum_c a[row][c] * b[row][c]  (rowsum(A o dA) = <d(ag)_i, ag_i> of the attention backward) */
+int gssd_rowdot_f32(const float* a, const float* b, float* out, int64_t rows, int C, gssd_stream_t stream);
 /* Softmax backward over rows, in place: dattn[r][j] <- attn[r][j] * (dattn[r][j] - sum_j attn[r][j]*dattn[r][j]); pad columns zeroed */
 int gssd_softmax_bwd_rows_f32(const float* attn, float* dattn, int64_t rows, int n, int row_stride, gssd_stream_t stream);
 /* Spectral-norm chain rule (layers/spectral_norm.py:83-85 with u, v constants): dW_eff' = scale[0] * dW_eff (scale may be NULL);

@@ -985,9 +985,12 @@ def test_backward_branch_streams_equal_single_stream(dev):
     for rep in range(3):
         ga, gb, gc = grads(False), grads(True), grads(True)
         assert ga.keys() == gb.keys()
+        gmax = max(float(v.norm()) for v in gb.values())
         for k in ga:
             d_ms, d_ss, ref = float((ga[k] - gb[k]).norm()), float((gc[k] - gb[k]).norm()), float(gb[k].norm())
-            assert d_ms <= 3.0 * d_ss + 1e-5 * ref, (k, d_ms, d_ss, ref)
+            # (+ 1e-6 of the largest gradient: tensors that are pure noise -- e.g. theta / phi of the 1 x 1 map's attention block,
+            # whose single-key softmax has no gradient -- are noise on both sides of the comparison)
+            assert d_ms <= 3.0 * d_ss + 1e-5 * ref + 1e-6 * gmax, (k, d_ms, d_ss, ref, gmax)
 
 
 def test_training_steps_reduce_loss(dev):
