@@ -230,15 +230,21 @@ class BackwardPlan:
         pk, ps, pp = (pool[0], pool[1], pool[2]) if pool else (0, 1, 0)
         dz = self._buf(B, Ho, Ho, Cout, zero_each_run=bool(pool and ps < pk))
         sums = self._buf(2 * Cout, dtype=torch.float64, zero_each_run=True)
-        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr(),
+        # without pooling the reduce pass only sums (dz = NULL) and the apply pass re-derives dz from d(out): 5 instead of 6 HBM passes
+        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0,
                                                sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
         ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
         self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
                                                  float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
                                                  self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr()))
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
-        self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
-                                              B * Ho * Ho, Cout, cs.data_ptr()))
+        if pool:
+            self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                                  B * Ho * Ho, Cout, cs.data_ptr()))
+        else:
+            self._add(lib.gssd_bn_bwd_apply_masked_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), int(r['relu']),
+                                                         ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dz.data_ptr(), B * Ho * Ho, Cout,
+                                                         cs.data_ptr()))
         self._bias_from_colsum(cs, conv.bias)
         # weight gradient (the forward descriptor carries the input geometry and the fused input transform)
         cin_g_pad = Cin // groups

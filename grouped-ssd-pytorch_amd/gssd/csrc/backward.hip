@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 f32x4 d;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
-                *reinterpret_cast<f32x4*>(dz + o) = d;
+                if (dz) *reinterpret_cast<f32x4*>(dz + o) = d;      // (sums only: the apply pass re-derives dz from dout)
                 a1 += d;
                 a2 += d * rv;
             } else {
@@ -137,10 +137,14 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double
     coefC[c] = (float)(-g * inv * s1 / count + g * inv * inv * mean * dg / count);
 }
 
+// ``dsrc`` (optional): d(out) of a layer without pooling -- dz is then re-derived here as dsrc * [raw * scale + shift > 0] instead of
+// being written by the reduce pass and read back (one HBM pass less per layer)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB,
                                                            const float* __restrict__ coefC, long long pixels, int C,
-                                                           double* __restrict__ colsum) {
+                                                           double* __restrict__ colsum, const float* __restrict__ dsrc,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int relu) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C4 = C >> 2;
     if (colsum) {
@@ -156,9 +160,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         const f32x4 a = *reinterpret_cast<const f32x4*>(coefA + 4 * c4);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(coefB + 4 * c4);
         const f32x4 cc = *reinterpret_cast<const f32x4*>(coefC + 4 * c4);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (dsrc && scale) {
+            sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
+            sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+        }
         for (long long i = i0; i < total; i += stride) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + i * 4);
             const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + i * 4);
+            f32x4 d;
+            if (dsrc) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dsrc + i * 4);
+                const f32x4 z = rv * sc + sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
+            } else {
+                d = *reinterpret_cast<const f32x4*>(dz + i * 4);
+            }
             const f32x4 o = a * d + bb * rv + cc;
             *reinterpret_cast<f32x4*>(dz + i * 4) = o;
             acc += o;
@@ -286,7 +303,7 @@ inline int nblocks(long long items, int cap = 2048) {
 extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const float* scale, const float* shift, float* dz,
                                       double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
                                       int pool_p, int relu, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(dout && raw && dz && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG(dout && raw && (dz || (pool_k == 0 && sums)) && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
@@ -311,7 +328,18 @@ extern "C" int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* c
                                      const float* coef_c, int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dz && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(pixels * (C / 4))), dim3(256), C * sizeof(float), as_stream(stream),
-                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum);
+                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, nullptr, nullptr, nullptr, 0);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw, const float* scale, const float* shift, int relu,
+                                            const float* coef_a, const float* coef_b, const float* coef_c, float* draw,
+                                            int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dout && draw && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(pixels * (C / 4))), dim3(256), C * sizeof(float), as_stream(stream),
+                       draw, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift, relu);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

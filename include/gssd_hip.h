@@ -221,6 +221,11 @@ int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, const double
                              gssd_stream_t stream);
 int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b, const float* coef_c,
                           int64_t pixels, int C, double* colsum, gssd_stream_t stream);
+/* The same for a layer WITHOUT pooling, straight from d(out): dz = dout * [raw * scale + shift > 0] (relu) is re-derived here, so
+ * gssd_bn_bwd_reduce_f32 may be called with dz = NULL (sums only) -- one HBM pass less per layer than reduce-writes / apply-reads. */
+int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw, const float* scale, const float* shift, int relu,
+                                 const float* coef_a, const float* coef_b, const float* coef_c, float* draw, int64_t pixels, int C,
+                                 double* colsum, gssd_stream_t stream);
 /* out[c] += sum_rows x[row*row_stride + c] (fp64): conv bias gradients. */
 int gssd_colsum_f32(const float* x, int64_t rows, int C, int row_stride, double* out, gssd_stream_t stream);
 int gssd_cast_f64_f32(const double* x, float* y, int n, int accumulate, gssd_stream_t stream);
