@@ -25,6 +25,13 @@ from ._lib import lib
 
 
 BWD_STREAMS = os.environ.get('GSSD_BWD_STREAMS', '1') != '0'
+LEAF_SID = 1000
+
+
+def _leaf_fns():
+    return (lib.gssd_conv2d_wgrad_f32, lib.gssd_unpack_conv_weight_grad, lib.gssd_cast_f64_f32, lib.gssd_colsum_f32,
+            lib.gssd_sn_weight_grad_f32, lib.gssd_scale_cast_f64_f32, lib.gssd_sa_sigma_grad_f32, lib.gssd_dot_f32,
+            lib.gssd_dcn_im2col_f32)
 
 
 class BackwardPlan:
@@ -120,7 +127,12 @@ class BackwardPlan:
     # ------------------------------------------------------------------------------------------------
     def _add(self, fn, args, keep=None):
         self.steps.append((fn, args))
-        self.step_sid.append(self._cur_sid)
+        # launches that only finish parameter gradients (weight gradients and their unpacking, bias column sums, spectral-norm and
+        # sigma gradients, the DCN column matrix for its weight gradient) feed nothing downstream: in the trunk they go to the "leaf"
+        # stream, off the d(activation) chain -- on the small maps the chain's launches no longer queue behind them, and the tails of
+        # the big ones overlap
+        leaf = BWD_STREAMS and self._cur_sid == 0 and fn in _leaf_fns()
+        self.step_sid.append(LEAF_SID if leaf else self._cur_sid)
         if keep is not None:
             self.keep.append(keep)
 
@@ -531,7 +543,7 @@ class BackwardPlan:
             fire = {}
             for k, (lo, hi, ready) in enumerate(self._segs):
                 fire.setdefault(max(ready, 0), []).append(k)
-        if hook is not None or not self.hoisted:
+        if hook is not None or getattr(self, 'single_stream', False) or not (self.hoisted or LEAF_SID in self.step_sid):
             for si, (fn, args) in enumerate(self.steps):
                 self._run_step(fn, args, stream)
                 if hook is not None and si in fire:
@@ -546,12 +558,20 @@ class BackwardPlan:
             st = self.plan._side_stream(100 + sid)
             st.wait_stream(main)
             sides[sid] = st
+        leaf = self.plan._side_stream(LEAF_SID)
+        main_dirty = True                                  # main has launches the leaf stream has not been ordered behind yet
         for si, (fn, args) in enumerate(self.steps):
             for w in self.step_wait.get(si, ()):
                 main.wait_stream(sides[w])
             sid = self.step_sid[si]
             if sid == 0:
                 self._run_step(fn, args, stream)
+                main_dirty = True
+            elif sid == LEAF_SID:
+                if main_dirty:
+                    leaf.wait_stream(main)                 # everything this launch reads was produced by earlier steps
+                    main_dirty = False
+                self._run_step(fn, args, leaf.cuda_stream)
             else:
                 st = sides[sid]
                 if args is None or fn is _pack_dgrad_from_packed:
@@ -561,6 +581,7 @@ class BackwardPlan:
                     self._run_step(fn, args, st.cuda_stream)
         for w in self.step_wait.get(len(self.steps), ()):
             main.wait_stream(sides[w])
+        main.wait_stream(leaf)
         return [self.grads.get(id(p)) for p in self.param_order]
 
     def _run_step(self, fn, args, stream):

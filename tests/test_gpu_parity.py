@@ -950,8 +950,9 @@ def test_backward_gradients(dev, name):
 
 
 def test_backward_branch_streams_equal_single_stream(dev):
-    """gssd/backward.py runs the backward of branch blocks 1 .. 5 on their own streams beside the trunk's; the same step list on one
-    stream (the mode used with a gradient-segment hook / GSSD_BWD_STREAMS=0) must give the same gradients (split-K atomics aside)."""
+    """gssd/backward.py runs the backward of branch blocks 1 .. 5 on their own streams beside the trunk's and the trunk's
+    parameter-gradient launches on a "leaf" stream; the same step list on one stream (the mode used with a gradient-segment hook /
+    GSSD_BWD_STREAMS=0) must give the same gradients (split-K atomics aside)."""
     import copy
     from models.ssd_multiphase_custom_group import build_ssd
     flags, args = NETS['gssdpp']
@@ -971,13 +972,11 @@ def test_backward_branch_streams_equal_single_stream(dev):
         loc, conf, _ = net(x)
         bp = net._engine._last_plan.backward_plan()
         assert bp.hoisted == [6, 5, 4, 3, 2]
-        keep = bp.hoisted
-        if single:
-            bp.hoisted = []
+        bp.single_stream = single
         try:
             ((loc * r1).sum() + (conf * r2).sum()).backward()
         finally:
-            bp.hoisted = keep
+            bp.single_stream = False
         return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
     # Gradients that are mathematically zero (conv biases in front of a train-mode BatchNorm, phi's bias, ...) hold the rounding noise of
     # atomically accumulated sums and differ between any two runs; so the yardstick per tensor is the difference between two
