@@ -26,6 +26,7 @@ from ._lib import lib
 
 BWD_STREAMS = os.environ.get('GSSD_BWD_STREAMS', '1') != '0'
 LEAF_SID = 1000
+HOIST_FROM = int(os.environ.get('GSSD_BWD_HOIST_FROM', '1'))       # first branch stream id whose backward is hoisted (1 = all six)
 N_LEAF = int(os.environ.get('GSSD_BWD_LEAF_STREAMS', '1'))      # leaf streams, taken in turn by the layers (measured: 1 -> 50.3 ms, 2 -> 50.8, 3 -> 51.2, 4 -> 52.1)
 
 
@@ -59,17 +60,17 @@ class BackwardPlan:
         self.dconf = torch.empty(self.B, plan.P, plan.nc, device=self.dev)
         net = plan.eng.net
         self.first_in = plan.rec[0][1]['x_in'].data_ptr()
-        # Branch blocks 1 .. 5 ([SA] -> fuse conv -> loc | conf head on the 19 x 19 .. 1 x 1 maps: dozens of launches of 1 .. 100
-        # workgroups each) depend only on d(loc) / d(conf): their backward is hoisted to the front and tagged with the branch's stream
-        # id, so the five chains run beside each other and beside the trunk's backward; the trunk waits for branch k exactly where the
-        # sequential order had branch k's steps.  (Any order of the contributions to a shared activation gradient is handled: whoever
-        # comes second accumulates.)  Branch 0 -- L2Norm, the 1444-token attention block, fuse_11, head 0 -- is made of chip-filling
-        # launches and stays in line.  The step list in build order is also a valid single-stream order (run() uses it that way
-        # when a gradient-segment hook is installed or GSSD_BWD_STREAMS=0).
+        # The six branch blocks ([SA] -> fuse conv -> loc | conf head; block 0 also L2Norm) depend only on d(loc) / d(conf): their
+        # backward is hoisted to the front and tagged with the branch's stream id, so the chains run beside each other and beside the
+        # trunk's backward (on the 19 x 19 .. 1 x 1 maps a launch has 1 .. 100 workgroups); the trunk waits for branch k where it first
+        # touches a gradient that branch writes.  (Any order of the contributions to a shared activation gradient is handled: whoever
+        # comes second accumulates.)  Measured: blocks 1 .. 5 GSSD++ 56.2 -> 54.8 ms; block 0 as well GSSD 25.5 -> 23.3 ms (GSSD++
+        # unchanged: its block 0 is the 1444-token attention, chip-filling launches).  The step list in build order is also a valid
+        # single-stream order (run() uses it that way when a gradient-segment hook is installed or GSSD_BWD_STREAMS=0).
         self.step_sid = []           # stream id per step
         self.step_wait = {}          # step index -> [stream ids the step's stream waits for first]
         self._cur_sid = 0
-        hoisted = sorted({r.get('sid', 0) for _, r in plan.rec if r.get('sid', 0) >= 2}, reverse=True) if BWD_STREAMS else []
+        hoisted = sorted({r.get('sid', 0) for _, r in plan.rec if r.get('sid', 0) >= HOIST_FROM}, reverse=True) if BWD_STREAMS else []
         for sid in hoisted:
             self._cur_sid = sid
             for kind, r in reversed(plan.rec):
@@ -292,10 +293,12 @@ class BackwardPlan:
         B, H, Cc, Hp = self.B, r['H'], r['C'], r['Hp']
         dout = self._grad_of(r['out'])
         existing = self._grad_of(r['x_in'])
-        assert existing is None, 'pool backward must be the first contribution to its input'
         g = self._buf(B, H, H, Cc, zero_each_run=(r['s'] < r['k']))
         self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), r['x_in'].data_ptr(), 0, 0, g.data_ptr(), 0, B, H, H, Cc, Hp, Hp,
                                                r['k'], r['s'], r['p'], 0))
+        if existing is not None:         # (a hoisted branch hanging off the same activation -- L2Norm on conv4_3 -- wrote first)
+            self._add(lib.gssd_axpby_f32, (existing.data_ptr(), g.data_ptr(), existing.data_ptr(), B * H * H * Cc, 1.0, 1.0))
+            g = existing
         self.gbuf[r['x_in'].data_ptr()] = g
 
     def _l2norm(self, r):
