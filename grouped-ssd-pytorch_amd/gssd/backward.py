@@ -66,7 +66,7 @@ class BackwardPlan:
         # touches a gradient that branch writes.  (Any order of the contributions to a shared activation gradient is handled: whoever
         # comes second accumulates.)  Measured: blocks 1 .. 5 GSSD++ 56.2 -> 54.8 ms; block 0 as well GSSD 25.5 -> 23.3 ms (GSSD++
         # unchanged: its block 0 is the 1444-token attention, chip-filling launches).  The step list in build order is also a valid
-        # single-stream order (run() uses it that way when a gradient-segment hook is installed or GSSD_BWD_STREAMS=0).
+        # single-stream order (run() uses it that way with GSSD_BWD_STREAMS=0; a gradient-segment hook joins the streams where it fires).
         self.step_sid = []           # stream id per step
         self.step_wait = {}          # step index -> [stream ids the step's stream waits for first]
         self._cur_sid = 0
@@ -548,7 +548,7 @@ class BackwardPlan:
             fire = {}
             for k, (lo, hi, ready) in enumerate(self._segs):
                 fire.setdefault(max(ready, 0), []).append(k)
-        if hook is not None or getattr(self, 'single_stream', False) or not (self.hoisted or any(x >= LEAF_SID for x in self.step_sid)):
+        if getattr(self, 'single_stream', False) or not (self.hoisted or any(x >= LEAF_SID for x in self.step_sid)):
             for si, (fn, args) in enumerate(self.steps):
                 self._run_step(fn, args, stream)
                 if hook is not None and si in fire:
@@ -585,6 +585,17 @@ class BackwardPlan:
                         self._run_step(fn, args, st.cuda_stream)
                 else:
                     self._run_step(fn, args, st.cuda_stream)
+            if hook is not None and si in fire:
+                # a range of the flat gradient buffer is final once this step has run: fold every stream that may have written into it
+                # back into the main stream, then hand the range out (the all-reduce is ordered behind the main stream)
+                for st in sides.values():
+                    main.wait_stream(st)
+                for lf in leaves:
+                    main.wait_stream(lf)
+                dirty = [True] * N_LEAF
+                for k in fire[si]:
+                    lo, hi, _ = self._segs[k]
+                    hook(k, self.flat[lo:hi])
         for w in self.step_wait.get(len(self.steps), ()):
             main.wait_stream(sides[w])
         for lf in leaves:

@@ -992,6 +992,40 @@ def test_backward_branch_streams_equal_single_stream(dev):
             assert d_ms <= 3.0 * d_ss + 1e-5 * ref + 1e-6 * gmax, (k, d_ms, d_ss, ref, gmax)
 
 
+def test_gradient_segment_hook_sees_final_ranges(dev):
+    """gssd.dist.OverlappedGradReducer's contract with the multi-stream backward: when the hook fires for a range of the flat gradient
+    buffer, every launch writing into that range -- on the main, branch and leaf streams -- is ordered before work enqueued from the
+    hook.  A fake hook snapshots its range on the current stream; the snapshots must equal the final gradients."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssdpp']
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth.synth_state_dict(shapes, seed=1111))
+    net = net.to(dev).train()
+    x = synth.synth_images(4, seed=9).to(dev)
+    rng = np.random.default_rng(0)
+    r1 = torch.from_numpy(rng.normal(size=(4, 8732, 4)).astype(np.float32)).to(dev)
+    r2 = torch.from_numpy(rng.normal(size=(4, 8732, 2)).astype(np.float32)).to(dev)
+    snaps = {}
+
+    def hook(k, flat_slice):
+        snaps[k] = (flat_slice, flat_slice.clone())
+    net._engine.grad_segment_hook = hook
+    try:
+        for rep in range(3):
+            snaps.clear()
+            net.zero_grad(set_to_none=True)
+            loc, conf, _ = net(x)
+            ((loc * r1).sum() + (conf * r2).sum()).backward()
+            torch.cuda.synchronize()
+            assert sorted(snaps) == [0, 1, 2, 3]
+            assert sum(s[0].numel() for s in snaps.values()) == net._engine._last_plan.backward_plan().flat.numel()
+            for k, (final, snap) in snaps.items():
+                assert torch.equal(final, snap), k
+    finally:
+        net._engine.grad_segment_hook = None
+
+
 def test_training_steps_reduce_loss(dev):
     """The driver's step sequence (train_lesion_multiphase_v2.py:242-253) on a fixed synthetic batch: forward, MultiBoxLoss,
     backward (HIP), SGD(momentum 0.9, wd 5e-4).  The loss must fall, and the weights must track the same steps taken with
