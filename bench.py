@@ -310,9 +310,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary (plain GSSD) measurement')
-    ap.add_argument('--full-step', type=int, default=0, metavar='K',
+    ap.add_argument('--full-step', type=int, default=None, metavar='K',
                     help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
-                         'reported as "full_step" beside the fwd+loss metric (BASELINE config 4)')
+                         'reported as "full_step" beside the fwd+loss metric (BASELINE config 4); default: 8 on one GPU, 0 for N > 1')
     ap.add_argument('--no-input-stage', action='store_true', help='skip the separate timing of the device input stage')
     a = ap.parse_args()
 
@@ -323,6 +323,8 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
                          '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    if a.full_step is None:
+        a.full_step = 8 if (world == 1 and a.dtype == 'f32') else 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)

@@ -8,7 +8,7 @@ python3 bench.py > gpurun_out/${tag}_gssdpp_b32_bench.json 2> gpurun_out/${tag}_
 python3 bench.py --dtype bf16 --cpu-sample 0 > gpurun_out/${tag}_gssdpp_b32_bf16_bench.json 2>> gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 for dt in f32 bf16; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_$dt -o p -- python3 $R/bench.py --cpu-sample 0 --no-input-stage --no-secondary --steps 20 --warmup 5 --steady 0 --dtype $dt > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_$dt -o p -- python3 $R/bench.py --full-step 0 --cpu-sample 0 --no-input-stage --no-secondary --steps 20 --warmup 5 --steady 0 --dtype $dt > /dev/null 2>&1
   f=$(find $R/gpurun_out/${tag}_prof_$dt -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_gssdpp_b32_${dt}_kernel_stats.csv
 done

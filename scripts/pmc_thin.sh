@@ -8,7 +8,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_thin_$i -o p -- python3 $R/bench.py --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --dtype bf16 > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_thin_$i -o p -- python3 $R/bench.py --full-step 0 --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --dtype bf16 > /dev/null 2>&1
   echo "pass $i rc $?"
 done
 python3 - "$R" <<'PY'

@@ -5,7 +5,7 @@ cfg=${1:-gssdpp}
 dtype=${2:-f32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --full-step 0 --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
 done
 key=$cfg; [ "$dtype" != f32 ] && key=${cfg}_$dtype
 python3 - "$GRAFT_REPO_ROOT" "$key" <<'PY'
