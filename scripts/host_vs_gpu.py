@@ -33,3 +33,18 @@ for _ in range(n):
     with torch.no_grad(): crit(out, tg)
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(dtype, 'loss only: enqueue', round((t1 - t0) / n * 1e3, 3), 'total', round((t2 - t0) / n * 1e3, 3))
+if dtype == 'f32':
+    # full training step: forward + loss + backward (multi-stream) + SGD
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    def tstep():
+        opt.zero_grad(set_to_none=True)
+        ll, lc = crit(net(x), tg)
+        (ll + lc).backward()
+        opt.step()
+    for _ in range(3): tstep()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n): tstep()
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(dtype, 'training step: enqueue', round((t1 - t0) / n * 1e3, 3), 'total', round((t2 - t0) / n * 1e3, 3))
