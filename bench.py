@@ -18,9 +18,15 @@ timed region.  Prints ONE JSON line on rank 0.
                  bound by the fp32 matrix/vector peak (157.3 TFLOP/s), not HBM; bf16 runs by HBM.
                  traffic = HBM bytes per launch from the committed PMC passes (profiles/pmc_summary.json: FETCH_SIZE /
                  WRITE_SIZE in separate --pmc runs of this same command, scripts/pmc_traffic.sh).
-  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, fastest thread count of a probe), 1 warm-up
-                 + 3 timed passes over the same 32 images as rank 0's GPU batch, median; rank 0, N = 1 only;
+  cpu_baseline : the oracle (CPU restatement of the reference graph, torch-CPU fp32, fastest thread count of a 2-image probe), 2 timed
+                 passes over the same 32 images as rank 0's GPU batch (~20 s), mean; rank 0, N = 1 only;
                  gpu_vs_cpu_loss_rel = agreement of the two losses on that batch.
+  bf16         : BASELINE configs[4] on the same workload (bf16 storage + bf16 MFMA, fp32 accumulate / BN statistics / loss / NMS);
+                 its `roofline` = HBM roofline of the WHOLE grouped-conv backbone conv1_1 .. conv5_3 (trunk_roofline()).
+  full_step    : BASELINE configs[3]: K training steps (fwd + loss + backward + RCCL gradient all-reduce + SGD), timed last.
+
+N > 1: `python bench.py --gpus N` starts its own N ranks (self_launch(); nothing touches the GPU in the parent); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the launcher's environment.
 """
 import argparse
 import json
@@ -59,7 +65,7 @@ PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline(cfg_name, sample_b, seed):
-    """Oracle forward + loss on the host cores (never the product path): 1 warm-up + 3 timed passes, median."""
+    """Oracle forward + loss on the host cores (never the product path): warm-up probes + 2 timed passes (~20 s)."""
     from oracle import gssd_oracle as O
     from gssd import synth
     from models.ssd_multiphase_custom_group import build_ssd
@@ -88,15 +94,14 @@ def cpu_baseline(cfg_name, sample_b, seed):
             best = (t, nt)
     cores = best[1]
     torch.set_num_threads(cores)
-    one(sample_b, seed)                       # warm-up
-    runs = [one(sample_b, seed) for _ in range(3)]
+    runs = [one(sample_b, seed) for _ in range(2)]          # the probes above were the warm-up
     dts = [r[0] for r in runs]
-    dt, loss = statistics.median(dts), runs[0][1]
+    dt, loss = statistics.mean(dts), runs[0][1]
     return dict(value=round(sample_b / dt, 3), unit='img/s', cores=cores, kind='port', loss=[round(loss[0], 5), round(loss[1], 5)],
                 passes_s=[round(t, 2) for t in dts],
                 sample=f'forward+MultiBoxLoss over the same {sample_b} synthetic images as the GPU batch ({cfg_name}, fp32, '
                        f'train-mode BN, torch-CPU oracle, {cores} of {ncpu} hardware threads = the fastest of a 2-image probe '
-                       f'over thread counts): 1 warm-up + 3 timed passes, median {dt:.1f} s')
+                       f'over thread counts): 2-image warm-up probes + 2 timed passes, mean {dt:.1f} s')
 
 
 class EventList(list):
@@ -112,6 +117,50 @@ def aggregate(evs):
         r[2] += flops
         r[3] += byts
     return agg
+
+
+# the grouped-conv backbone conv1_1 .. conv5_3 (+ pool4) as the engine names its launches (gssd/engine.py::Tag.layer)
+TRUNK = {'vgg.0': 'conv1_1', 'vgg.3': 'conv1_2', 'vgg.7': 'conv2_1', 'vgg.10': 'conv2_2', 'vgg.14': 'conv3_1', 'vgg.17': 'conv3_2',
+         'vgg.20': 'conv3_3', 'vgg.24': 'conv4_1', 'vgg.27': 'conv4_2', 'vgg.30': 'conv4_3', 'vgg.33': 'pool4', 'vgg.34': 'conv5_1',
+         'vgg.37': 'conv5_2', 'vgg.40': 'conv5_3'}
+# SURVEY.md 8(d)'s per-layer accounting (conv in + raw out, BN re-read + activated write), fp32 MB / image, conv1_1 .. conv5_3
+SURVEY_TRUNK_MB_F32 = 73.4 + 74.9 + 40.3 + 37.4 + 20.2 + 23.0 + 18.8 + 10.4 + 11.8 + 11.8 + 3 * 3.0
+
+
+def trunk_roofline(survey, n_pass, B, dtype):
+    """HBM roofline of the whole grouped-conv backbone: sum of the algorithmic bytes of every trunk launch (convs, their BatchNorm /
+    ReLU / pool passes) / sum of their durations, from the eager survey passes (every tagged launch bracketed by HIP events on the
+    launch stream).  Bytes are those of the pass structure AS BUILT (compulsory input + output + weights of each launch): deleting a
+    pass shrinks them, so the fraction cannot be raised by accounting."""
+    lay = {}
+    for tag, e0, e1 in survey:
+        name = TRUNK.get(getattr(tag, 'layer', None))
+        if name is None:
+            continue
+        r = lay.setdefault(name, [0.0, 0.0, 0.0, set()])
+        r[0] += e0.elapsed_time(e1) / n_pass
+        r[1] += tag[2] / n_pass
+        r[2] += tag[1] / n_pass
+        r[3].add(tag[0])
+    if not lay:
+        return None
+    ms = sum(r[0] for r in lay.values())
+    by = sum(r[1] for r in lay.values())
+    fl = sum(r[2] for r in lay.values())
+    per = {k: dict(us=round(1e3 * r[0], 1), alg_mb=round(r[1] / 1e6, 1), gbs=round(r[1] / r[0] / 1e6, 1),
+                   tflops=round(r[2] / r[0] / 1e9, 1), kernels=sorted(r[3])) for k, r in lay.items()}
+    big = {k: v for k, v in per.items() if v['alg_mb'] >= 0.02 * by / 1e6}
+    worst = min(big, key=lambda k: big[k]['gbs'])
+    ach = by / ms / 1e6
+    survey_mb = SURVEY_TRUNK_MB_F32 * (0.5 if dtype == 'bf16' else 1.0)
+    return dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
+                traffic=None, kernel='trunk conv1_1 .. conv5_3 (convs + BN/ReLU/pool passes)', ms_per_step=round(ms, 4),
+                alg_bytes_per_step=round(by), alg_mb_per_img=round(by / B / 1e6, 2), tflops=round(fl / ms / 1e9, 1),
+                survey_accounting=dict(alg_mb_per_img=round(survey_mb, 1), gbs=round(survey_mb * B / ms / 1e3, 1),
+                                       frac=round(survey_mb * B / ms / 1e3 / PEAK_HBM_GBS, 4),
+                                       note='SURVEY 8(d): every layer priced as conv in + raw out + BN re-read + activated write'),
+                worst_layer=dict(layer=worst, **per[worst], frac=round(per[worst]['gbs'] / PEAK_HBM_GBS, 4)), layers=per,
+                note='eager survey passes, every launch bracketed; bytes = compulsory bytes of the pass structure as built')
 
 
 def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
@@ -147,7 +196,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
     # Per-launch HIP events cost ~3 us of GPU idle each.  Two untimed passes bracket EVERY tagged launch (the `kernels`
     # breakdown and the choice of the dominant instance); in the timed region only the dominant instance's launches are
     # bracketed, live, on the launch stream -- that is where `roofline` comes from.
-    sagg, events = None, None
+    sagg, events, trunk = None, None, None
     if not a.no_events:
         survey = EventList()
         net.__dict__['_events'] = survey
@@ -156,6 +205,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
         torch.cuda.synchronize()
         net.__dict__['_events'] = None
         sagg = aggregate(survey)
+        trunk = trunk_roofline(survey, 2, a.batch, dtype)
         events = EventList()
         # the dominant KERNEL: the instance with the most time among those launched at most 12 times per step (a bucket of dozens
         # of small-map launches of one tile shape is not one kernel, and bracketing it would cut the hipGraph into as many pieces)
@@ -179,6 +229,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
     sync()
     dt = time.perf_counter() - t0
     net.__dict__['_events'] = None
+    per_rank = [round(1e3 * t / a.steps, 3) for t in gd.gather_over_ranks(dt, dev)]
     loss = (float(ll), float(lc))
     if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
         raise SystemExit(f'non-finite loss {loss}')
@@ -241,7 +292,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                             traffic=t2, kernel=k, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
                             alg_bytes_per_launch=round(by / n), note='survey passes (eager, every tagged launch bracketed)')
     value = gd.aggregate_rate(world, B, a.steps, dt)
-    res = dict(value=round(value, 2), ms_per_step=round(1e3 * dt / a.steps, 3), loss=[round(loss[0], 5), round(loss[1], 5)],
+    res = dict(value=round(value, 2), ms_per_step=round(1e3 * dt / a.steps, 3), per_rank_ms_per_step=per_rank, loss=[round(loss[0], 5), round(loss[1], 5)],
                steady=(dict(steps=a.steady, ms_per_step=round(1e3 * sdt / a.steady, 3),
                             value=round(gd.aggregate_rate(world, B, a.steady, sdt), 2)) if a.steady > 0 else None),
                workload=WORKLOAD[cfg] + (', bf16 storage / bf16 MFMA / fp32 accumulate + BN statistics + loss' if dtype == 'bf16' else ''),
@@ -251,7 +302,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                                alg_gbs=round(value * mb_img / 1e3, 1),
                                frac_hbm_peak=round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)),
                first_step_loss=[round(first_loss[0], 5), round(first_loss[1], 5)], roofline=roof, roofline_hbm_trunk=roof_hbm,
-               kernels=kernels)
+               trunk=trunk, kernels=kernels)
     return res, net, crit, x, tg, first_loss
 
 
@@ -298,6 +349,92 @@ def measure_pixellink(B, dev, steps=20):
                 workload='pixellink++ cascade_fuse=1 fuseconv=1 bn=1 sa=1 sab=1 dcn=1x4 cat_sab=1, 300x300x12 -> [B,2,75,75] | [B,16,75,75]')
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher: this process touches no GPU (device_count() does not initialise HIP on this
+    image), starts one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- the environment torch.distributed.run would
+    give them -- and exits with their return code.  Rank 0's JSON line is the only thing the children print on stdout."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n and '--launch-probe' not in sys.argv:
+        print(json.dumps({'error': f'--gpus {n} needs {n} visible GPUs, this host has {ndev}', 'n_gpus': n, 'devices_visible': ndev}))
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', GSSD_BENCH_SELF_LAUNCHED='1')
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    c = procs[r].wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for q in pending:                     # one rank died: the others would wait in a collective forever
+                        procs[q].terminate()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def full_step_leg(a, net, crit, x, tg, dev, gd, world, B):
+    """K full training steps (train_lesion_multiphase_v2.py:242-253 with DataParallel :593 replaced by one process per GPU):
+    forward + MultiBoxLoss + backward + gradient all-reduce + SGD.  At world 1 no collective runs."""
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    gd.broadcast_params(net)
+    red = gd.OverlappedGradReducer(world)         # ranges of the flat gradient buffer are all-reduced under the backward
+    ev = []
+
+    def train_step(timed=False):
+        opt.zero_grad(set_to_none=True)
+        ll, lc = crit(net(x), tg)
+        red.arm(net)
+        (ll + lc).backward()
+        if timed and world > 1:
+            # what the all-reduce leaves EXPOSED: the main stream's time between "backward enqueued" and "every range reduced
+            # and scaled" (finish() makes the main stream wait for RCCL's stream, then divides by the world size)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n = red.finish()
+            e1.record()
+            ev.append((e0, e1))
+        else:
+            n = red.finish() if world > 1 else sum(p.grad.numel() for p in params if p.grad is not None)
+        opt.step()
+        return n
+    for _ in range(2):
+        nred = train_step()
+    gd.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.full_step):
+        train_step(True)
+    gd.barrier(dev)
+    fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    exposed = (sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)) if ev else 0.0
+    exposed = gd.max_over_ranks(exposed, dev)
+    return dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
+                ms_per_step=round(1e3 * fdt / a.full_step, 3), grad_elems=int(nred), rccl_ranks=world,
+                allreduce_exposed_ms=round(exposed, 3), allreduce_overlapped=bool(red.overlapped_last),
+                note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (HIP: gssd/backward.py) + '
+                     + (f'RCCL all-reduce of the flat fp32 gradient buffer over {world} ranks in 4 ranges started under the backward '
+                        '(allreduce_exposed_ms = main-stream time from backward-enqueued to all ranges reduced + scaled, max over ranks)'
+                        if world > 1 else 'NO collective (one rank: nothing to reduce)') + ' + SGD')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -312,8 +449,13 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary (plain GSSD) measurement')
     ap.add_argument('--full-step', type=int, default=None, metavar='K',
                     help='additionally time K full training steps (fwd + loss + backward + gradient all-reduce + SGD); '
-                         'reported as "full_step" beside the fwd+loss metric (BASELINE config 4); default: 8 on one GPU, 0 for N > 1')
+                         'reported as "full_step" beside the fwd+loss metric (BASELINE configs[3]); default: 8 in fp32, 0 in bf16')
     ap.add_argument('--no-input-stage', action='store_true', help='skip the separate timing of the device input stage')
+    ap.add_argument('--no-bf16', action='store_true', help='skip the bf16 leg (BASELINE configs[4] on this workload)')
+    ap.add_argument('--full-step-timeout', type=float, default=300.0, help='N > 1: seconds the full-step leg may take')
+    ap.add_argument('--launch-probe', action='store_true',
+                    help='rendezvous check only, no GPU: every rank joins a gloo group, rank 0 prints the ranks it saw '
+                         '(tests/test_host_cpu.py drives the self-launcher with it on the CPU)')
     a = ap.parse_args()
 
     from gssd import dist as gd
@@ -321,53 +463,47 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if a.gpus > 1 and world == 1:
-        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+        sys.exit(self_launch(a.gpus))      # before anything initialises the GPU in this process
+    if a.launch_probe:
+        gd.init('gloo')
+        seen = gd.gather_over_ranks(rank)
+        if os.environ.get('GSSD_PROBE_FAIL_RANK') == str(rank):
+            sys.exit(7)                    # a rank that dies: the launcher must end the others and return its code
+        gd.barrier()
+        if rank == 0:
+            print(json.dumps({'probe': True, 'n_gpus': world, 'ranks': seen, 'rccl_ranks': gd.world_size(),
+                              'launcher': 'self' if os.environ.get('GSSD_BENCH_SELF_LAUNCHED') else 'external'}))
+        gd.finish()
+        return
     if a.full_step is None:
-        a.full_step = 8 if (world == 1 and a.dtype == 'f32') else 0
+        a.full_step = 8 if a.dtype == 'f32' else 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)
 
     from gssd import synth
+    import copy
+    import threading
     B = a.batch
     res, net, crit, x, tg, loss = measure(a.config, a, dev, gd, rank, world, a.dtype)
 
-    full = None
-    if a.full_step > 0:
-        # BASELINE.json configs[3]: forward + loss + backward + RCCL all-reduce of the flat gradient buffer + SGD.
-        # Reported separately; NOT the headline metric (BASELINE.json's metric is forward + loss).
-        params = [p for p in net.parameters() if p.requires_grad]
-        opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=5e-4)
-        gd.broadcast_params(net)
-
-        red = gd.OverlappedGradReducer(world)         # ranges of the flat gradient buffer are all-reduced under the backward
-
-        def train_step():
-            opt.zero_grad(set_to_none=True)
-            ll, lc = crit(net(x), tg)
-            red.arm(net)
-            (ll + lc).backward()
-            n = red.finish() if world > 1 else gd.allreduce_grads(params, world)
-            opt.step()
-            return n
-        for _ in range(2):
-            nred = train_step()
-        gd.barrier(dev)
-        t0 = time.perf_counter()
-        for _ in range(a.full_step):
-            train_step()
-        gd.barrier(dev)
-        fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
-        full = dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
-                    ms_per_step=round(1e3 * fdt / a.full_step, 3), allreduce_elems=int(nred),
-                    note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (HIP: gssd/backward.py) + flat-buffer '
-                         'gradient all-reduce (RCCL) + SGD')
+    # BASELINE.json configs[4] (bf16 storage, bf16 MFMA, fp32 accumulate / BN statistics / loss / NMS) on the same workload: its
+    # `roofline` is the HBM roofline of the WHOLE grouped-conv backbone (north_star's ">= 70 % HBM roofline on the backbone")
+    bf16 = None
+    if a.dtype == 'f32' and not a.no_bf16 and a.config == 'gssdpp':
+        a2 = copy.copy(a)
+        a2.steps, a2.warmup, a2.steady = min(a.steps, 50), min(a.warmup, 5), min(a.steady, 50)
+        bres = measure('gssdpp', a2, dev, gd, rank, world, 'bf16')[0]
+        bf16 = dict(metric='512x512 4-phase CT img/s (fwd+loss)', unit='img/s', dtype='bf16', steps=a2.steps, warmup=a2.warmup,
+                    value=bres['value'], ms_per_step=bres['ms_per_step'], per_rank_ms_per_step=bres['per_rank_ms_per_step'],
+                    steady=bres['steady'], loss=bres['loss'], workload=bres['workload'], whole_path=bres['whole_path'],
+                    roofline=bres['trunk'], dominant_kernel=bres['roofline'], kernels=bres['kernels'])
+        torch.cuda.empty_cache()
 
     # Device-side input stage, timed on its own: raw uint8 [B,4,512,512,3] -> [B,12,300,300] fp32.  The
     # headline keeps the reference's split (resize in the loader, outside the timed region).
     stage_info = None
-    if not a.no_input_stage:
+    if not a.no_input_stage and world == 1:
         import numpy as np
         from gssd.input_stage import DeviceInputStage
         one = synth.synth_study_u8(gd.shard_seed(100, rank), 4, 512)
@@ -388,8 +524,6 @@ def main():
                           note='Pillow-exact 8-bit bicubic 512->300 + mean + min-max + [B,12,300,300] pack')
         del raw, xs
 
-    del net, crit, x, tg
-    torch.cuda.empty_cache()
     secondary = None
     if world == 1 and not a.no_secondary and a.config == 'gssdpp':
         sres = measure('gssd', a, dev, gd, rank, world, a.dtype)[0]
@@ -408,19 +542,49 @@ def main():
             # same inputs and same starting state on both sides: the GPU's first step against the CPU oracle, at the full batch
             cpu['gpu_vs_cpu_loss_rel'] = [round(abs(loss[i] - cpu['loss'][i]) / max(abs(cpu['loss'][i]), 1e-12), 7) for i in (0, 1)]
 
-    if rank == 0:
-        line = {
-            'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': res['value'], 'unit': 'img/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': res['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
-                       'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
-            'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
-            'first_step_loss': res['first_step_loss'],
-            'roofline': res['roofline'], 'roofline_hbm_trunk': res['roofline_hbm_trunk'], 'kernels': res['kernels'], 'cpu_baseline': cpu, 'secondary': secondary, 'pixellink': pixellink,
-            'full_step': full, 'input_stage': stage_info,
-        }
-        print(json.dumps(line))
+    line = {
+        'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': res['value'], 'unit': 'img/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': res['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
+                   'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
+        'rccl_ranks': gd.world_size(), 'per_rank_ms_per_step': res['per_rank_ms_per_step'],
+        'launcher': ('self (python bench.py --gpus N)' if os.environ.get('GSSD_BENCH_SELF_LAUNCHED') else
+                     'torch.distributed.run' if world > 1 else 'single process'),
+        'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
+        'first_step_loss': res['first_step_loss'],
+        'roofline': res['roofline'], 'roofline_hbm_trunk': res['roofline_hbm_trunk'], 'trunk': res['trunk'], 'kernels': res['kernels'],
+        'cpu_baseline': cpu, 'bf16': bf16, 'secondary': secondary, 'pixellink': pixellink,
+        'full_step': None, 'input_stage': stage_info,
+    }
+    printed = threading.Lock()
+
+    def emit(code=None):
+        if printed.acquire(blocking=False):
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            if code is not None:
+                os._exit(code)
+
+    # BASELINE.json configs[3]: K full training steps, LAST (the only leg with a data-path collective).  A collective that hangs
+    # must not cost the line its measured headline: past the deadline every rank's watchdog prints / exits instead.
+    if a.full_step > 0:
+        wd = None
+        if world > 1:
+            def on_timeout():
+                line['full_step'] = {'error': f'full-step leg did not finish within {a.full_step_timeout} s (RCCL all-reduce over '
+                                              f'{world} ranks); the fwd+loss metric above is complete'}
+                emit(0)
+            wd = threading.Timer(a.full_step_timeout, on_timeout)
+            wd.daemon = True
+            wd.start()
+        try:
+            line['full_step'] = full_step_leg(a, net, crit, x, tg, dev, gd, world, B)
+        except Exception as e:                                  # noqa: BLE001 -- reported in the line, never swallowed silently
+            line['full_step'] = {'error': f'{type(e).__name__}: {e}'[:400]}
+        if wd is not None:
+            wd.cancel()
+    emit()
     gd.finish()
 
 

@@ -78,7 +78,6 @@ class GssdTrainFn(torch.autograd.Function):
         if dconf is None:
             dconf = torch.zeros(plan.B, plan.P, plan.nc, device=plan.dev)
         bwd = plan.backward_plan()
-        bwd.segment_hook = getattr(net._engine, 'grad_segment_hook', None)       # gssd.dist.OverlappedGradReducer
         direct = (net.__dict__.get('direct_grad_handout', True)
                   and all(p.is_leaf and not p._backward_hooks for p in params if p.requires_grad)
                   and _will_accumulate_all(ctx, params))
@@ -90,6 +89,15 @@ class GssdTrainFn(torch.autograd.Function):
             for p in params:
                 if p.grad is not None and lo <= p.grad.data_ptr() < hi:
                     p.grad = p.grad.clone()
+        # gssd.dist.OverlappedGradReducer all-reduces ranges of the flat buffer IN PLACE while the backward is still running.
+        # That is only the gradient when every p.grad becomes its slice of that buffer: with accumulation into an existing
+        # p.grad, tensor hooks, torch.autograd.grad or direct_grad_handout=False the slices are copied / added elsewhere
+        # (possibly while RCCL is rewriting them), so the hook is withheld and the reducer told to reduce p.grad afterwards.
+        hook = getattr(net._engine, 'grad_segment_hook', None)
+        if hook is not None and not (direct and all(p.grad is None for p in params if p.requires_grad)):
+            net._engine.grad_segment_skipped = True
+            hook = None
+        bwd.segment_hook = hook
         grads = bwd.run(dloc.contiguous(), dconf.contiguous())
         ctx.lease.release()
         if direct:

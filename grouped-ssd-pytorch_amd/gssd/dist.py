@@ -20,6 +20,11 @@ def init(backend, device=None):
     return world, rank
 
 
+def world_size():
+    """Ranks the process group actually has (1 when no group was initialised: no collective can run)."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def shard_seed(base_seed, rank):
     """Each rank draws its own shard of the global synthetic batch."""
     return base_seed + rank
@@ -39,6 +44,16 @@ def max_over_ranks(seconds, device=None):
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device=None):
+    """Every rank's value, in rank order (a list of length world)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def aggregate_rate(world, per_rank_units, steps, seconds):
@@ -75,18 +90,29 @@ class OverlappedGradReducer:
     the LAST layers first; its flat buffer is cut into ``nseg`` contiguous ranges and each range's all-reduce is started (async, on
     the communication stream RCCL owns) the moment the last kernel writing into it has been enqueued -- the ring all-reduce of the
     heads / extras / fuse ranges then runs under the trunk's backward, and only the first range (conv1_x .. conv3_x gradients,
-    finished last) is exposed.  Usage per step:  ``red.arm(net)`` before ``loss.backward()``, ``red.finish()`` after it."""
+    finished last) is exposed.  Usage per step:  ``red.arm(net)`` before ``loss.backward()``, ``red.finish()`` after it.
+
+    Precondition of the overlapped form: every ``p.grad`` IS its slice of the plan's flat buffer after the backward, i.e. a plain
+    ``loss.backward()`` with ``p.grad is None`` before it (``optimizer.zero_grad(set_to_none=True)``, torch's default), no tensor
+    hooks on parameters, ``net.direct_grad_handout`` left on.  When that does not hold (gradient accumulation into existing
+    ``p.grad``, ``zero_grad(set_to_none=False)``, hooks, ``torch.autograd.grad``) the autograd glue withholds the hook -- nothing is
+    reduced under the backward -- and ``finish()`` falls back to ``allreduce_grads`` over ``p.grad``: still correct, not overlapped.
+    The hook is removed from the engine in ``finish()``; a backward without ``arm()`` never sums across ranks."""
 
     def __init__(self, world=None, nseg=4):
         self.world = world or (dist.get_world_size() if dist.is_initialized() else 1)
         self.nseg = nseg
         self.works, self.ranges = [], []
+        self.net = self.eng = None
+        self.overlapped_last = False      # did the last finish() reduce under the backward (True) or fall back (False)?
 
     def arm(self, net):
         """Install the hook on every backward plan of ``net``'s engine that exists or gets built (cheap: one attribute)."""
         self.works, self.ranges = [], []
-        eng = net._engine if hasattr(net, '_engine') else net.module._engine
-        eng.grad_segment_hook = self._hook if self.world > 1 else None
+        self.net = net
+        self.eng = net._engine if hasattr(net, '_engine') else net.module._engine
+        self.eng.grad_segment_skipped = False
+        self.eng.grad_segment_hook = self._hook if self.world > 1 else None
 
     def _hook(self, k, flat_slice):
         self.ranges.append(flat_slice)
@@ -94,12 +120,24 @@ class OverlappedGradReducer:
 
     def finish(self):
         """Wait for the ranges in flight, scale by 1 / world; returns the number of elements reduced."""
+        eng = self.eng
+        if eng is not None:
+            eng.grad_segment_hook = None
         n = 0
         for w, t in zip(self.works, self.ranges):
             w.wait()
             t.div_(self.world)
             n += t.numel()
+        self.overlapped_last = bool(self.works)
+        skipped = eng is not None and getattr(eng, 'grad_segment_skipped', False)
+        if self.works and skipped:
+            raise RuntimeError('OverlappedGradReducer: one backward of this step reduced the flat gradient buffer in place and '
+                               'another one accumulated into p.grad -- use gssd.dist.allreduce_grads for accumulated gradients')
         self.works, self.ranges = [], []
+        if self.world > 1 and (skipped or not self.overlapped_last) and self.net is not None:
+            n = allreduce_grads([p for p in self.net.parameters() if p.requires_grad], self.world)
+        if eng is not None:
+            eng.grad_segment_skipped = False
         return n
 
 

@@ -41,6 +41,12 @@ USE_BRANCH_STREAMS = os.environ.get('GSSD_NO_BRANCH_STREAMS', '0') != '1'
 SN_STREAM = 9               # stream id of the spectral-norm launch inside a captured graph
 ALL_STREAMS = -1            # _Step.wait value: join every forked stream before this step
 
+class Tag(tuple):
+    """(kernel instance, algorithmic FLOPs, algorithmic bytes) of one launch; ``layer`` names the module it belongs to
+    ('vgg.0' = conv1_1 ... 'vgg.40' = conv5_3) so bench.py can sum the trunk's launches -- convs AND their BatchNorm passes."""
+    layer = None
+
+
 class _Step:
     __slots__ = ('fn', 'args', 'keep', 'tag', 'sid', 'wait')
 
@@ -503,6 +509,9 @@ class _Plan(_PlanBase):
             d = keep[0] if isinstance(keep, tuple) else keep
             tag = conv_tag(d, 3 if (d.cin_g in (4, 8) and d.groups == 4 and d.H == 300) else None,
                            bf16=fn is lib.gssd_conv2d_nhwc_bf16)
+        if tag is not None:
+            tag = Tag(tag)
+            tag.layer = getattr(self, '_layer', None)
         self.steps.append(_Step(fn, args, keep, tag, getattr(self, '_sid', 0), self.__dict__.pop('_pending_wait', None)))
 
     def _abuf(self, *shape):
@@ -556,6 +565,7 @@ class _Plan(_PlanBase):
         whose BN + ReLU this conv applies on the fly; ``defer_bn`` leaves this layer's own BN + ReLU to its consumer and
         returns (raw, H, C, (scale, shift, pad))."""
         B = self.B
+        self._layer = name
         k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         Cout = conv.out_channels
         cin_g = Cin // groups
@@ -585,6 +595,7 @@ class _Plan(_PlanBase):
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                        int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
             rec.update(out=raw, Hp=Ho, xf=(sc, sh, pd))
+            self._layer = None
             return raw, Ho, Cout, (sc, sh, pd)
         if pool:
             pk, ps, pp, ceil = pool
@@ -595,8 +606,11 @@ class _Plan(_PlanBase):
         self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
                   (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
                    bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   float(bn.momentum), float(bn.eps), int(self.training), int(relu)))
+                   float(bn.momentum), float(bn.eps), int(self.training), int(relu)),
+                  tag=('bn_relu_pool_bf16' if self.bf16 else 'bn_relu_pool', 0.0,
+                       (2.0 if self.bf16 else 4.0) * B * Cout * (Ho * Ho + Hp * Hp)))
         rec.update(out=act, Hp=Hp, xf=None)
+        self._layer = None
         return act, Hp, Cout, None
 
     def eng_stat(self, bn):
@@ -607,7 +621,8 @@ class _Plan(_PlanBase):
         Hp = ops.pool_out_size(H, k, s, p, ceil)
         out = self._abuf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
-                  (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0))
+                  (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0),
+                  tag=('bn_relu_pool_bf16' if self.bf16 else 'bn_relu_pool', 0.0, (2.0 if self.bf16 else 4.0) * B * Cc * (H * H + Hp * Hp)))
         self.rec.append(('pool', dict(x_in=x, out=out, H=H, C=Cc, k=k, s=s, p=p, Hp=Hp)))
         return out, Hp
 
@@ -638,7 +653,9 @@ class _Plan(_PlanBase):
         self.rec.append(('l2norm', dict(x_in=x, out=s, H=H, C=Cc, mod=net.L2Norm)))
         self._sid = 0
         src0 = self._branch(s, H, Cc, 0, '11')
+        self._layer = 'vgg.33'                     # pool4: a trunk pass (conv5_1 reads it)
         pooled, Hp = self._pool_only(x, H, Cc, 2, 2, 0)
+        self._layer = None
         return pooled, Hp, Cc, src0
 
     def _branch(self, s, H, Cc, sa_i, fuse):

@@ -106,8 +106,20 @@ def _worker_overlap(rank, world, port, out):
     for k, (lo, hi, ready) in sorted(enumerate(segs), key=lambda kv: kv[1][2]):      # in the order the backward would fire them
         hook(k, bp.flat[lo:hi])
     nred = red.finish()
-    out.put((rank, nred == n, min(float(p.grad.min()) for p in params), float(bp.flat.max()),
-             [float(p.grad.mean()) for p in params][:3]))
+    assert net._engine.grad_segment_hook is None and red.overlapped_last      # finish() disarms the engine
+    res = (rank, nred == n, min(float(p.grad.min()) for p in params), float(bp.flat.max()),
+           [float(p.grad.mean()) for p in params][:3])
+    # the fallback: the autograd glue withheld the hook (accumulation into foreign p.grad tensors): nothing was reduced under
+    # the backward, finish() must average p.grad itself and leave the engine disarmed
+    net.parameters = lambda: iter(params)
+    for p in params:
+        p.grad = torch.full_like(p, float(10 * (rank + 1)))
+    red.arm(net)
+    net._engine.grad_segment_skipped = True                # what GssdTrainFn.backward sets when p.grad is not the flat slice
+    red.finish()
+    assert not red.overlapped_last and net._engine.grad_segment_hook is None
+    assert all(float(p.grad.min()) == float(p.grad.max()) == 15.0 for p in params)
+    out.put(res)
     gd.barrier()
     gd.finish()
 

@@ -1,0 +1,49 @@
+"""Multi-GPU (one process per GPU, RCCL over xGMI) checks.  They need >= 2 MI355X in one box and skip cleanly on the 1-GPU test
+boxes; what CAN run on one GPU (the launcher's refusal) does."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=1500)
+    return r.returncode, [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')], r.stderr[-2000:]
+
+
+def test_bench_gpus_beyond_the_box_is_one_error_line():
+    n = torch.cuda.device_count() + 1
+    rc, lines, _ = _bench('--gpus', str(n))
+    assert rc == 2 and len(lines) == 1 and 'error' in lines[0] and lines[0]['n_gpus'] == n
+
+
+def test_bench_two_gpus_self_launched_rccl():
+    """`python bench.py --gpus 2` (no launcher): two ranks, RCCL barrier + the full-step leg's overlapped gradient all-reduce."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs in one box')
+    rc, lines, err = _bench('--gpus', '2', '--steps', '3', '--warmup', '2', '--steady', '0', '--no-bf16', '--full-step', '2')
+    assert rc == 0 and len(lines) == 1, err
+    ln = lines[0]
+    assert ln['n_gpus'] == 2 and ln['rccl_ranks'] == 2 and len(ln['per_rank_ms_per_step']) == 2 and ln['launcher'].startswith('self')
+    fs = ln['full_step']
+    assert 'error' not in fs and fs['rccl_ranks'] == 2 and fs['allreduce_overlapped'] and fs['grad_elems'] == 18488172
+
+
+def test_overlapped_reducer_equals_flat_allreduce_on_rccl():
+    """OverlappedGradReducer vs allreduce_grads vs the hand-computed mean, on real RCCL ranks, incl. the fallback for
+    accumulated gradients."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs in one box')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29621', os.path.join(ROOT, 'tests', 'multi_gpu_worker.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('[')][-1])
+    for o in res:
+        assert o['flat'] < 1e-6 and o['over'] < 1e-6 and o['acc'] < 1e-6 and not o['acc_overlapped'] and o['differs_from_local'] > 1e-3

@@ -124,3 +124,30 @@ def test_resample_coefficients_match_pillow_restatement():
         IS.resample_tables(0, 300)
     with pytest.raises(Exception):
         IS.DeviceInputStage(300)(torch.zeros(1, 4, 8, 8, 3, dtype=torch.uint8))      # CPU tensor: no fallback
+
+
+def _run_bench(*args, env=None):
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **(env or {})))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r.returncode, [json.loads(ln) for ln in lines]
+
+
+def test_bench_self_launch_refuses_missing_gpus_in_one_line():
+    """`python bench.py --gpus N` on a host with fewer GPUs: one JSON error line, non-zero exit, nothing spawned."""
+    ndev = torch.cuda.device_count()
+    rc, lines = _run_bench('--gpus', str(ndev + 2))
+    assert rc == 2 and len(lines) == 1 and lines[0]['devices_visible'] == ndev and 'error' in lines[0]
+
+
+def test_bench_self_launch_two_ranks_rendezvous():
+    """The self-launcher (no torch.distributed.run): two child ranks find each other on 127.0.0.1, rank 0 alone prints the line,
+    the parent returns their code; a rank that dies ends the job with ITS code instead of hanging the others."""
+    rc, lines = _run_bench('--gpus', '2', '--launch-probe')
+    assert rc == 0 and len(lines) == 1
+    assert lines[0]['ranks'] == [0.0, 1.0] and lines[0]['rccl_ranks'] == 2 and lines[0]['launcher'] == 'self'
+    rc, lines = _run_bench('--gpus', '2', '--launch-probe', env={'GSSD_PROBE_FAIL_RANK': '1'})
+    assert rc == 7 and lines == []
