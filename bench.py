@@ -156,8 +156,8 @@ def trunk_roofline(survey, n_pass, B, dtype):
     return dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
                 traffic=None, kernel='trunk conv1_1 .. conv5_3 (convs + BN/ReLU/pool passes)', ms_per_step=round(ms, 4),
                 alg_bytes_per_step=round(by), alg_mb_per_img=round(by / B / 1e6, 2), tflops=round(fl / ms / 1e9, 1),
-                survey_accounting=dict(alg_mb_per_img=round(survey_mb, 1), gbs=round(survey_mb * B / ms / 1e3, 1),
-                                       frac=round(survey_mb * B / ms / 1e3 / PEAK_HBM_GBS, 4),
+                survey_accounting=dict(alg_mb_per_img=round(survey_mb, 1), gbs=round(survey_mb * B / ms, 1),
+                                       frac=round(survey_mb * B / ms / PEAK_HBM_GBS, 4),
                                        note='SURVEY 8(d): every layer priced as conv in + raw out + BN re-read + activated write'),
                 worst_layer=dict(layer=worst, **per[worst], frac=round(per[worst]['gbs'] / PEAK_HBM_GBS, 4)), layers=per,
                 note='eager survey passes, every launch bracketed; bytes = compulsory bytes of the pass structure as built')

@@ -468,7 +468,7 @@ class BackwardPlan:
         self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, OMC))
         w_main = self._buf(Cout, Kc)
         self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
-        # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- plain GEMMs (rocBLAS)
+        # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- the slot-scheduled TN / NT GEMMs (csrc/wgrad_slot.hip, csrc/gemm_slot.hip; no vendor library)
         dwp = self._buf(Cout, Kc, zero_each_run=True)
         d_c, _, _ = ops.make_conv_desc(cols, None, None, B=B, H=H, W=H, in_stride=Kc, cin_g=Kc, Cout=Cout)
         self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_c), dy.data_ptr(), dwp.data_ptr()), keep=d_c)

@@ -28,14 +28,19 @@ static inline hipStream_t as_stream(gssd_stream_t s) { return reinterpret_cast<h
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: every call site keeps one "done" bit per device id, so a
 // process that touches several GPUs (tests on cuda:1, one-process multi-device callers) never launches a > 48 KB-LDS kernel
-// without it.  Returns true once the attribute is set on the current device.
+// without it.  Launches come from two host threads (the forward from the caller's, the backward from autograd's): the bit is
+// published (gssd_attr_done, release) only AFTER hipFuncSetAttribute has returned success, so a thread that sees it set may
+// launch; two threads racing on an unset bit both set the attribute (idempotent), and a failed call is retried by the next launch.
 static inline bool gssd_attr_needed(unsigned* mask) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return true;
-    if (*mask & (1u << dev)) return false;
-    *mask |= 1u << dev;
-    return true;
+    return (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & (1u << dev)) == 0;
+}
+static inline void gssd_attr_done(unsigned* mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 32) (void)__atomic_fetch_or(mask, 1u << dev, __ATOMIC_RELEASE);
 }
 
 // 64-lane wavefront reductions (gfx950: wave = 64)

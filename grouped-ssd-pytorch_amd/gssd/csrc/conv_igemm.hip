@@ -349,6 +349,7 @@ int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;
     const int mtiles = (M + BM - 1) / BM;

@@ -166,6 +166,7 @@ int launch_patch_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipS
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     static int per_cu = 0;                                // resident workgroups per CU: 2 for the 64-channel variant, up to 4
     if (!per_cu) {                                        // for the small ones (they hide each other's staging latency)

@@ -329,6 +329,7 @@ int launch_thin_impl(const gssd_conv_desc& d, hipStream_t stream) {
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     const int per_cu = smem > 60 * 1024 ? 2 : 3;
     int grid = 256 * per_cu;

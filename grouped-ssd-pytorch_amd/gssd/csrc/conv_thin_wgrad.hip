@@ -172,6 +172,7 @@ int launch_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipSt
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 512;
     if (ntiles < grid) grid = (int)ntiles;

@@ -225,6 +225,7 @@ int launch_thin_wino(const gssd_conv_desc& d, hipStream_t stream) {
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 512;                                       // two resident workgroups per CU (80 KB of LDS, <= 256 VGPRs each)
     if (ntiles < grid) grid = (int)ntiles;

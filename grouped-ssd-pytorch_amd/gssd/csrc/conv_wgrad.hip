@@ -253,6 +253,7 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)tiles), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -387,6 +387,7 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
             return GSSD_ELAUNCH;
         }
     }
+    gssd_attr_done(&attr_mask);
     const int nitems = (p.ntiles + 63) / 64;
     static int per_cu = 0;                                // resident workgroups per CU (registers / LDS decide: 1 or 2)
     if (!per_cu) {

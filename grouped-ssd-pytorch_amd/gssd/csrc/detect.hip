@@ -261,6 +261,7 @@ extern "C" int gssd_detect(const float* loc, const float* conf, const float* pri
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             120 * 1024);
     }
+    gssd_attr_done(&attr_mask);
     hipLaunchKernelGGL(detect_kernel, dim3(B * (C - 1)), dim3(DT), smem, as_stream(stream), loc, conf, priors, P, C,
                        top_k, conf_thresh, nms_thresh, var0, var1, conf_is_logits, loc_is_boxes, out, keep_idx, keep_cnt);
     GSSD_CHECK_LAUNCH();

@@ -351,6 +351,7 @@ int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np3
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
+    gssd_attr_done(&attr_mask);
     const int qtiles = (N + 63) / 64;
     hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles);
     GSSD_CHECK_LAUNCH();

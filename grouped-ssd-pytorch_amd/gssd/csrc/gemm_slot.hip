@@ -366,6 +366,7 @@ static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
+    gssd_attr_done(&attr_mask);
     int blocks;
     if (8 % ntn == 0) {
         const int per = 8 / ntn;

@@ -359,6 +359,7 @@ extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* l
     if (smem > 48 * 1024 && gssd_attr_needed(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hnm_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024);
+        gssd_attr_done(&attr_mask);
     }
     hipLaunchKernelGGL(hnm_loss_kernel, dim3(B), dim3(LT), smem, as_stream(stream), loc, conf, loc_t, conf_t, xmax, xmax_n, P,
                        C, negpos_ratio, sel, partial, loss_c_all);

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void pl_decode_kernel(const float* __restrict
         if (act == 0ull) continue;
         const int id0 = __builtin_amdgcn_readlane(id, __builtin_ctzll(act));
         if (__ballot(id >= 0 && id != id0) == 0ull) {
-            float cnt = id >= 0 ? 1.f : 0.f, ssum = sc;
+            float cnt = id >= 0 ? 1.f : 0.f, ssum = id >= 0 ? sc : 0.f;   // pixels beyond the component table (id reset to -1) add nothing
             float mnx = id >= 0 ? fx : 1e9f, mny = id >= 0 ? fy : 1e9f, mxx = id >= 0 ? fx : -1.f, mxy = id >= 0 ? fy : -1.f;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {

@@ -275,6 +275,7 @@ static int launch_ws(const WsParams& p, int groups, hipStream_t stream) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
+    gssd_attr_done(&attr_mask);
     hipLaunchKernelGGL(kern, dim3(p.ntn * p.mtiles, groups, p.split), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

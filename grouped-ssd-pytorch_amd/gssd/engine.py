@@ -857,7 +857,7 @@ class _Plan(_PlanBase):
 
     def _run_eager(self, x, events, only):
         B, dev = self.B, self.dev
-        # zero-filled: the heads accumulate split-K slices with atomics
+        # every element is written: the head convs store per-slice partial sums, _finish_heads' reduce launches add them in order
         loc = torch.empty(B, self.P, 4, device=dev, dtype=torch.float32)
         conf = torch.empty(B, self.P, self.nc, device=dev, dtype=torch.float32)
         self._set_outputs(loc, conf)

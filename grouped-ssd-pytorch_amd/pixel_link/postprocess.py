@@ -12,6 +12,7 @@ import pixel_link.pixel_link_config as config
 from gssd import _lib
 
 lib = _lib.lib
+STAT_COMPS_MAX = 1024        # csrc/pixellink.hip PL_STAT_COMPS: components with statistics (the label map itself is unlimited)
 
 
 def decode(pixel_mask, link_mask, pixel_thres=None, link_thres=None, max_components=512):
@@ -35,6 +36,14 @@ def mask_to_box(pixel_mask, link_mask, neighbors=8, img_shape=(300, 300), pixel_
     assert neighbors == 8
     B, _, H, W = pixel_mask.shape
     _, comps, ncomp = decode(pixel_mask, link_mask, pixel_thres)
+    nmax = int(ncomp.max())
+    if nmax > comps.shape[1]:
+        # more components than the default statistics table holds (a noisy 75 x 75 map can have > 512): the reference's func()
+        # handles every component, so decode again with the kernel's largest table and refuse to truncate beyond that
+        if nmax > STAT_COMPS_MAX:
+            raise _lib.GssdError(f'pixel_link.postprocess.mask_to_box: {nmax} components in one image; the device keeps statistics '
+                                 f'for at most {STAT_COMPS_MAX} (the label map from decode() is complete, the box table is not)')
+        _, comps, ncomp = decode(pixel_mask, link_mask, pixel_thres, max_components=STAT_COMPS_MAX)
     comps, ncomp = comps.cpu(), ncomp.cpu()
     sx, sy = img_shape[0] / W, img_shape[1] / H
     out = []

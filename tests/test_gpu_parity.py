@@ -12,6 +12,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import gssd_oracle as O          # noqa: E402
 from gssd import synth                       # noqa: E402
@@ -469,6 +470,75 @@ def test_dcn_fused_forward(dev, ops, B, Cc, H, dg, Cout):
     assert rel(nchw(yi)[:, :, 1:H - 2, 3:H - 1], (shifted + bias.view(1, -1, 1, 1))[:, :, 1:H - 2, 3:H - 1]) < TOL
 
 
+@pytest.mark.parametrize('B,Cc,H,dg,Cout,std', [(2, 128, 9, 4, 32, 2.5), (1, 64, 7, 1, 64, 5.0), (3, 128, 13, 2, 96, 1.0)])
+def test_dcn_fused_vs_scalar_restatement(dev, ops, B, Cc, H, dg, Cout, std):
+    """The fused kernel against the SECOND, structurally independent restatement of DCNv2 (oracle/csrc/dcn_scalar.c: scalar loop nest
+    in the published algorithm's order, float64 accumulation) -- offsets of several pixels, samples crossing every border -- and the
+    properties the algorithm must have whatever the convention: linearity in the mask, integer-offset translation equivariance, the
+    (row, column) offset order of utils/show_offset.py:28-32.  DCN stays "parity unpinned" (dcn_v2 is not vendored)."""
+    from oracle import dcn_scalar
+    rng = np.random.default_rng(28)
+    x = rng.normal(size=(B, Cc, H, H)).astype(np.float32)
+    om = rng.normal(0, std, size=(B, 27 * dg, H, H)).astype(np.float32)
+    w = rng.normal(0, 0.1, size=(Cout, Cc, 3, 3)).astype(np.float32)
+    bias = rng.normal(size=(Cout,)).astype(np.float32)
+    sig = lambda v: (1.0 / (1.0 + np.exp(-v.astype(np.float64)))).astype(np.float32)
+    ref = dcn_scalar.dcn_v2_conv(x, om[:, :18 * dg], sig(om[:, 18 * dg:]), w, bias, 1, 1, 1, dg)
+    xd, wd, bd = nhwc(torch.from_numpy(x)).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev)
+    run = lambda o: nchw(ops.dcn_forward(xd, nhwc(torch.from_numpy(o)).to(dev), wd, bd, dg)).cpu().numpy()
+    y = run(om)
+    assert rel(y, ref) < TOL
+    # linearity in the mask: logits chosen so that sigmoid = 0.2 / 0.6 / 0.8 -> y(0.8) - b = (y(0.2) - b) + (y(0.6) - b)
+    logit = lambda p: float(np.log(p / (1 - p)))
+    ys = []
+    for p_ in (0.2, 0.6, 0.8):
+        o = om.copy()
+        o[:, 18 * dg:] = logit(p_)
+        ys.append(run(o) - bias.reshape(1, -1, 1, 1))
+    assert rel(ys[2], ys[0] + ys[1]) < 3e-5
+    # offset order: +1 on channel 2k of every group moves tap k's sample one ROW down (show_offset.py:28-32), +1 on 2k+1 one COLUMN right
+    xt = torch.from_numpy(x)
+    for ch, shift in ((0, (1, 0)), (1, (0, 1))):
+        o = np.zeros_like(om)
+        o[:, 18 * dg:] = 30.0                                             # mask = 1
+        for g in range(dg):
+            o[:, g * 18 + ch:(g + 1) * 18:2] = 1.0
+        xs = torch.zeros_like(xt)
+        if shift == (1, 0):
+            xs[:, :, :H - 1, :] = xt[:, :, 1:, :]                         # xs[y, x] = x[y + 1, x]
+        else:
+            xs[:, :, :, :H - 1] = xt[:, :, :, 1:]
+        want = (torch.nn.functional.conv2d(xs, torch.from_numpy(w), None, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1)).numpy()
+        got = run(o)
+        # rows / columns whose shifted taps would read the zero padding of the ORIGINAL map differ by construction: compare the interior
+        assert rel(got[:, :, 1:H - 2, 1:H - 2], want[:, :, 1:H - 2, 1:H - 2]) < TOL, ch
+    # translation equivariance under integer offsets: shifting the input by (2, -1) and adding (-2, +1) to every offset samples the
+    # same values wherever both sample sets stay inside the map
+    o2 = np.round(om).astype(np.float32)
+    o2[:, 18 * dg:] = om[:, 18 * dg:]
+    xs = torch.zeros_like(xt)
+    xs[:, :, 2:, :H - 1] = xt[:, :, :H - 2, 1:]                           # xs[y, x] = x[y - 2, x + 1]
+    o3 = o2.copy()
+    for g in range(dg):
+        o3[:, g * 18:(g + 1) * 18:2] += 2.0
+        o3[:, g * 18 + 1:(g + 1) * 18:2] -= 1.0
+    a = dcn_scalar.dcn_v2_conv(x, o2[:, :18 * dg], sig(o2[:, 18 * dg:]), w, bias, 1, 1, 1, dg)
+    bq = nchw(ops.dcn_forward(nhwc(xs).to(dev), nhwc(torch.from_numpy(o3)).to(dev), wd, bd, dg)).cpu().numpy()
+    # a sample (Y, X) of the unshifted problem becomes (Y + 2, X - 1) in the shifted one and reads the same value unless it is
+    # inside the map before and outside after the shift: output pixels without such a sample must agree
+    hh, ww = np.meshgrid(np.arange(H), np.arange(H), indexing='ij')
+    ok = np.ones((B, H, H), bool)
+    for g in range(dg):
+        for t in range(9):
+            Y = hh[None] - 1 + t // 3 + o2[:, g * 18 + 2 * t]
+            X = ww[None] - 1 + t % 3 + o2[:, g * 18 + 2 * t + 1]
+            inside = (Y >= 0) & (Y <= H - 1) & (X >= 0) & (X <= H - 1)
+            ok &= ~(inside & ((Y + 2 > H - 1) | (X - 1 < 0)))
+    assert ok.mean() > 0.02
+    sel = np.broadcast_to(ok[:, None], a.shape)
+    assert np.abs(a - bq)[sel].max() / np.abs(a).max() < TOL
+
+
 def test_sa_backward_building_blocks(dev):
     """gssd_bgemm_f32 (all four transpose forms, ragged sizes, batched), the row softmax backward, the spectral-norm chain rule and
     the small helpers of csrc/sa_backward.hip against torch-CPU."""
@@ -766,6 +836,66 @@ def test_end_to_end(dev, golden, name):
     ref = g[f'{name}.det']
     assert np.array_equal(det[..., 0] > 0, ref[..., 0] > 0)
     assert same_detections(det, ref, 5e-5)
+
+
+def _stage_errors(net, taps):
+    """Cumulative HIP-vs-oracle error at every stage both sides expose (plan records vs the oracle's taps): where it jumps is the
+    layer that eats the 1e-4 budget."""
+    plan = net._engine._last_plan
+    out = []
+    for kind, r in plan.rec:
+        if kind == 'convbn' and r['name'].startswith('vgg') and r.get('xf') is None:
+            i = int(r['name'].split('.')[1])
+            key = f'vgg.{i + 3}' if r['pool'] else f'vgg.{i + 2}'
+            if key in taps and tuple(taps[key].shape) == tuple(nchw(r['out']).shape):
+                out.append((r['name'] + ' (act)', rel(nchw(r['out']), taps[key])))
+        elif kind == 'dcn' and 'dcn0.out' in taps:
+            out.append(('dcn0', rel(nchw(r['out']), taps['dcn0.out'])))
+        elif kind == 'l2norm' and 'l2norm' in taps:
+            out.append(('l2norm', rel(nchw(r['out']), taps['l2norm'])))
+    for i, (t, H, Cc) in enumerate(plan.sources):
+        if f'source{i}' in taps:
+            out.append((f'source{i}', rel(nchw(t), taps[f'source{i}'])))
+    return out
+
+
+@pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
+def test_end_to_end_seed_sweep_margin(dev, name):
+    """the 1e-4 gate held with 25 % headroom on ONE seed.  Five weight / image seed pairs, full tensors against the
+    (fixture-pinned) oracle, with the per-stage error table printed (pytest -s) and written to gpurun_out/ so the layer that eats the
+    budget is named.  Winograd F(2x2,3x3) on the trunk + 13 train-mode BatchNorms are the suspects."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    from layers.modules import MultiBoxLoss
+    flags, args = NETS[name]
+    net = build_ssd('train', 300, 2, *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    pri = O.prior_box()
+    lines, worst = [], 0.0
+    for wseed, xseed in ((1111, 11), (2024, 12), (7, 13), (31337, 14), (99, 15)):
+        sd = synth.synth_state_dict(shapes, seed=wseed)
+        net.load_state_dict(sd)
+        x = synth.synth_images(4, seed=xseed)
+        tg = synth.synth_targets(4, seed=xseed)
+        taps = {}
+        with torch.no_grad():
+            loc, conf, _ = net(x.to(dev))
+            ll, lc = crit((loc, conf, torch.from_numpy(pri).to(dev)), tg)
+            lo, co, _ = O.gssd_forward(sd, x, taps=taps, **flags)
+        rl, rc = O.multibox_loss(lo.numpy(), co.numpy(), pri, [t.numpy() for t in tg])[:2]
+        e = dict(loc=rel(loc, lo), conf=rel(conf, co), loss_l=rel(ll, rl), loss_c=rel(lc, rc))
+        st = _stage_errors(net, taps)
+        lines.append(f'{name} weights {wseed} images {xseed}: ' + ' '.join(f'{k} {v:.2e}' for k, v in e.items()))
+        lines += [f'    {k:18s} {v:.2e}' for k, v in st]
+        worst = max(worst, *e.values())
+    lines.append(f'{name}: worst of 5 seeds {worst:.2e} (gate {TOL:.0e})')
+    print('\n'.join(lines))
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, f'parity_margin_{name}.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    assert worst < TOL, lines[-1]
 
 
 FLAG_NETS = {       # tests/golden/make_golden_flags.py: (oracle flags, build_ssd positional args, parameters whose gradients are compared)
