@@ -91,6 +91,8 @@ SIGNATURES = {
     'gssd_sa_unpool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weights_batched': (c_i, [c_fp, c_i, c_fp]),
     'gssd_gemm_slot_takes': (c_i, [c_fp]),
+    'gssd_conv_flat_bf16_takes': (c_i, [c_fp]),
+    'gssd_conv_flat_bf16_tile': (c_i, [c_i]),
     'gssd_heads_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_interp_add_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pixellink_final_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),

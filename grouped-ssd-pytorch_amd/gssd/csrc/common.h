@@ -80,3 +80,5 @@ int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream);
 int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);
 // conv_thin_bf16.hip: bf16 thin trunk layers (conv1_1 .. conv2_2); returns 1 when the descriptor is not one of them
 int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream);
+// conv_flat_bf16.hip: bf16 grouped 3x3 trunk layers with 32 .. 128 channels per group (conv3_1 .. conv6); returns 1 when not one of them
+int gssd_try_conv_flat_bf16(const gssd_conv_desc& d, hipStream_t stream);

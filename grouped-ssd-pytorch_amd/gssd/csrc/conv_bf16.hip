@@ -484,6 +484,10 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
         const int rc = gssd_try_conv_thin_bf16(d, s);      // conv1_1 .. conv2_2: patch-staged HBM-stream kernel
         if (rc != 1) return rc;
     }
+    {
+        const int rc = gssd_try_conv_flat_bf16(d, s);      // conv3_1 .. conv6: flat-window kernel (csrc/conv_flat_bf16.hip)
+        if (rc != 1) return rc;
+    }
     if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 1024 && !d.m_per_image);
     if (cout_g > 64) {
         const long long mt = (M + 127) / 128, z = d.m_per_image ? images : d.split_k;

@@ -82,6 +82,10 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g, d.groups) and not d.m_per_image
           and d.split_k <= 1 and not d.relu):
         name = f'conv_wino<{64 if (cout_g % 64 == 0 or (cout_g % 32 != 0 and cout_g > 32)) else 32}>'   # gssd_try_conv_wino
+    if bf16 and name.startswith('conv_bf16'):
+        bm = lib.gssd_conv_flat_bf16_takes(C.byref(d))      # csrc/conv_flat_bf16.hip: the library's own host rule
+        if bm:
+            name = f'conv_flat_bf16<{d.cin_g},{min(cout_g, 128) if cout_g % 128 == 0 else 64},{bm}>'
     if not bf16 and name.startswith('conv_igemm') and lib.gssd_gemm_slot_takes(C.byref(d)) == 1:
         name = 'gemm_slot<128x128>'                      # gssd_try_gemm_slot (csrc/gemm_slot.hip): the library's own host rule
     M = d.B * d.Ho * d.Wo

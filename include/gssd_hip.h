@@ -271,6 +271,13 @@ int gssd_sa_unpool_f32(const float* dkg, float* dst, int B, int H, int P, int CW
  * 1x1 convolutions / GEMMs), 0 when it stays on the generic implicit-GEMM kernel.  Host logic only. */
 int gssd_gemm_slot_takes(const gssd_conv_desc* d);
 
+/* bf16 mode: pixels per workgroup (128 or 256) when gssd_conv2d_nhwc_bf16 runs this descriptor on the flat-window kernel
+ * (csrc/conv_flat_bf16.hip: grouped 3x3 trunk layers with 32 .. 128 channels per group, conv3_1 .. conv6), 0 when another kernel
+ * takes it.  Host logic only.  gssd_conv_flat_bf16_tile(0 | 128 | 256) overrides the per-shape choice (0 = automatic; ablation and
+ * tests) and returns the previous setting. */
+int gssd_conv_flat_bf16_takes(const gssd_conv_desc* d);
+int gssd_conv_flat_bf16_tile(int pixels_per_workgroup);
+
 /* bf16-storage variant (configs[4]): theta | phi fp32 and the logits on the fp32 matrix cores (a bf16 logit would move its
  * probability by tens of percent), g^T and the probabilities bf16 on v_mfma_f32_16x16x32_bf16 (80 % of the block's FLOPs), out bf16.
  * gT rows are Np32 (multiple of 32) bf16 long with the token order of GSSD_CONV_OUTB_BF16_PERM32. */

@@ -65,7 +65,11 @@ CASES = [
     (1, 80, 64, 128, 3, 1, 1, 1, 4),     # <16,32>
     (1, 77, 128, 128, 3, 1, 1, 1, 4),    # <32,32>
     (2, 77, 128, 256, 3, 1, 1, 1, 4),    # conv3_1 shape on a large map (generic kernel)
-    (2, 75, 256, 256, 3, 1, 1, 1, 4),    # conv3_2 / conv3_3
+    (2, 75, 256, 256, 3, 1, 1, 1, 4),    # conv3_2 / conv3_3: flat-window kernel <64, 64> (csrc/conv_flat_bf16.hip), last tile ragged
+    (3, 38, 256, 512, 3, 1, 1, 1, 4),    # conv4_1: flat <64, 128>
+    (2, 38, 512, 512, 3, 1, 1, 1, 4),    # conv4_2 / conv4_3: flat <128, 128>, two staged channel halves
+    (1, 12, 128, 256, 3, 1, 1, 1, 4),    # flat <32, 64> on a map of 144 pixels: one full tile + 16 pixels, windows mostly outside the image
+    (2, 13, 512, 1024, 3, 1, 3, 3, 4),   # flat, dilation 3, two 128-channel tiles per group
 ]
 
 
@@ -99,6 +103,53 @@ def test_conv_bf16(dev, case):
         n = ref.numel() / Cout
         assert rel(stats[:Cout] / n, ref.double().mean(dim=(0, 2, 3))) < 1e-5
         assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W', [(256, 256, 21, 37), (512, 512, 9, 40), (128, 256, 33, 14), (512, 1024, 17, 23)])
+@pytest.mark.parametrize('xf', [False, True])
+@pytest.mark.parametrize('bm', [128, 256])
+def test_conv_flat_bf16(dev, Cin, Cout, H, W, xf, bm):
+    """csrc/conv_flat_bf16.hip (conv3_1 .. conv6 in bf16 mode): non-square maps (a row / column mix-up in the flat window cannot
+    hide), tiles that start and end mid-row, the sideways-tap masks at both image borders, both staged channel halves, with and
+    without the deferred producer BatchNorm + ReLU (zero padding AFTER the transform), bf16 output + batch statistics."""
+    from gssd import ops, _lib
+    import ctypes as C
+    rng = np.random.default_rng(Cin + 7 * H + W)
+    B, g = 3, 4
+    x = q(torch.from_numpy(rng.normal(0.2, 1.0, size=(B, Cin, H, W)).astype(np.float32)))
+    w = q(torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cin // g, 3, 3)).astype(np.float32)))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    act, sc, sh, pdv = x, None, None, None
+    if xf:
+        scv = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
+        shv = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+        act = q(torch.relu(torch.addcmul(shv.view(1, -1, 1, 1), x, scv.view(1, -1, 1, 1))))     # fma, like the kernel
+        sc, sh = scv.to(dev), shv.to(dev)
+        pdv = torch.zeros(Cin, device=dev, dtype=torch.bfloat16)          # (unused by the flat kernel: it stages zeros and skips them)
+    ref = torch.nn.functional.conv2d(act, w, b, 1, 1, 1, g)
+    wp = ops.pack_weight_bf16(w.to(dev))
+    out = torch.empty(B, H, W, Cout, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    d, _, _ = ops.make_conv_desc(nhwc(x).to(dev).to(torch.bfloat16), wp, out, B=B, H=H, W=W, in_stride=Cin, cin_g=Cin // g, Cout=Cout,
+                                 groups=g, k=3, stride=1, pad=1, bias=b.to(dev), stats=stats, in_scale=sc, in_shift=sh, in_pad=pdv)
+    prev = _lib.lib.gssd_conv_flat_bf16_tile(bm)          # 128 pixels / 256 threads or 256 pixels / 512 threads per workgroup
+    try:
+        took = _lib.lib.gssd_conv_flat_bf16_takes(C.byref(d))
+        assert took == bm                                     # the flat kernel, in the forced form
+        _lib.check(_lib.lib.gssd_conv2d_nhwc_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream))
+    finally:
+        _lib.lib.gssd_conv_flat_bf16_tile(prev)
+    y = nchw(out.float())
+    # without the transform: exact bf16 products, fp32 accumulation, one rounding.  With it an activation can round the other way
+    # (the oracle's fma is the kernel's fma, but ties at the bf16 boundary are hit by ~1e-3 of the elements)
+    if not xf:
+        assert rel(y, ref) < 1.01 * BF_ULP
+        assert float((y.cpu() - q(ref)).abs().max()) <= float(ref.abs().max()) * BF_ULP
+    else:
+        assert rel(y, ref) < 2 * BF_ULP and l2rel(y, ref) < 0.6 * BF_ULP
+    n = ref.numel() / Cout
+    assert rel(stats[:Cout] / n, ref.double().mean(dim=(0, 2, 3))) < (1e-5 if not xf else 2e-3)
+    assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < (1e-5 if not xf else 2e-3)
 
 
 @pytest.mark.parametrize('Cin,Cout,H,k,st,pd', [(64, 64, 40, 3, 1, 1), (128, 128, 40, 3, 1, 1), (512, 512, 19, 3, 1, 1),
