@@ -365,6 +365,105 @@ def test_bf16_end_to_end(dev, name):
     assert rel(l32, lo32) < 1e-4 and rel(c32, co32) < 1e-4
 
 
+def _layer_local_checks_sampled(plan, imgs):
+    """_layer_local_checks on a SAMPLE of the batch (full-size runs): convolutions, L2Norm, the deformable conv and the attention
+    blocks are per-image operations, so the sampled images' stages are recomputed from the HIP path's own stored inputs; the
+    BatchNorm + ReLU (+ pool) pass is checked with the batch statistics the HIP path itself accumulated (fp64 sums of the fp32
+    accumulators), and those sums are checked against the stored raw tensor of the WHOLE batch."""
+    F = torch.nn.functional
+    worst = {}
+    ii = torch.tensor(imgs, device=plan.dev)
+    for kind, r in plan.rec:
+        if kind == 'convbn':
+            conv, bn = r['conv'], r['bn']
+            x = r['x_in'][ii].float().cpu()
+            if r['in_xf'] is not None:
+                sc, sh = r['in_xf'][0].cpu(), r['in_xf'][1].cpu()
+                x = q(torch.relu(x * sc + sh))
+            xin = nchw(x)
+            if conv.weight.shape[1] * r['groups'] != xin.shape[1]:
+                xin = xin.view(xin.shape[0], r['groups'], -1, *xin.shape[2:])[:, :, :conv.weight.shape[1]].reshape(
+                    xin.shape[0], -1, *xin.shape[2:])
+            ref_raw = F.conv2d(xin, q(conv.weight.detach().cpu()), conv.bias.detach().cpu(), r['stride'], r['pad'], r['dil'], r['groups'])
+            raw = nchw(r['raw'][ii].float().cpu())
+            worst[r['name'] + '.raw'] = rel(raw, q(ref_raw))
+            Cc = r['Cout']
+            n = float(r['raw'].shape[0] * r['Ho'] * r['Ho'])
+            st = r['stats'].cpu()
+            mean, var = st[:Cc] / n, st[Cc:] / n - (st[:Cc] / n) ** 2
+            full = r['raw'].float()                                        # whole batch, on the device (checker-side torch math)
+            worst[r['name'] + '.mean'] = float(((full.mean(dim=(0, 1, 2)).double().cpu() - mean).abs() / (var.sqrt() + 1e-6)).max()) / 4
+            if r['xf'] is None:
+                scale = bn.weight.detach().cpu().double() / torch.sqrt(var + bn.eps)
+                shift = bn.bias.detach().cpu().double() - mean * scale
+                y = torch.relu(raw * scale.float().view(1, -1, 1, 1) + shift.float().view(1, -1, 1, 1))
+                if r['pool']:
+                    pk, ps, pp, ceil = r['pool']
+                    y = F.max_pool2d(y, pk, ps, pp, ceil_mode=ceil)
+                worst[r['name'] + '.act'] = rel(nchw(r['out'][ii].float().cpu()), q(y))
+        elif kind == 'l2norm':
+            worst['l2norm'] = rel(nchw(r['out'][ii].float().cpu()), q(O.l2norm(nchw(r['x_in'][ii].float().cpu()), r['mod'].weight.detach().cpu())))
+        elif kind == 'dcn':
+            m, xin = r['mod'], nchw(r['x_in'][ii].float().cpu())
+            om = nchw(r['om'][ii].cpu())[:, :27 * r['dg']]
+            om_ref = F.conv2d(xin, q(m.conv_offset_mask.weight.detach().cpu()), m.conv_offset_mask.bias.detach().cpu(), 1, 1)
+            worst['dcn.om'] = rel(om, om_ref)
+            o1, o2, mk = torch.chunk(om, 3, dim=1)
+            ref = O.dcn_v2_conv(xin, torch.cat((o1, o2), 1), torch.sigmoid(mk), q(m.weight.detach().cpu()), m.bias.detach().cpu(), 1, 1, 1,
+                                r['dg'], col_round=q)
+            worst['dcn.out'] = rel(nchw(r['out'][ii].float().cpu()), q(ref)) / 3
+        elif kind == 'sa':
+            sa, xin = r['mod'], nchw(r['x_in'][ii].float().cpu())
+            sd1 = {'p.' + k: v.detach().cpu() for k, v in sa.state_dict().items()}
+            o_out, o_ag, _ = O.self_attn(xin, sd1, 'p', False, q=q)
+            worst[f"sa{r['H']}.out"] = rel(nchw(r['out'][ii].float().cpu()), o_out) / 2
+    return worst
+
+
+@pytest.mark.parametrize('name', ['gssdpp'])
+def test_full_size_properties_bf16(dev, name):
+    """BASELINE.json configs[4] on one GPU at the BENCHMARKED size (batch 32, bf16 storage): the flat-window / thin / 256-pixel-tile
+    kernels only take their full-size forms here.  Size-independent checks: every stage of two sampled images recomputed from the HIP
+    path's own stored input within one bf16 ulp (layer-local contract of test_bf16_end_to_end), BatchNorm batch sums against the stored
+    raw maps of the whole batch, the loss against the oracle on the same predictions, Detect bit-exact on the path's fp32 outputs,
+    eval-mode image independence (image i of the batch-32 run == the same image in a batch of 2)."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    from layers.modules import MultiBoxLoss
+    from gssd import ops
+    flags, args = NETS[name]
+    net = build_ssd('train', 300, 2, *args)
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+    net = net.to(dev).train()
+    net.compute_dtype = 'bf16'
+    x = synth.synth_images(32, seed=11).to(dev)
+    tg = synth.synth_targets(32, seed=11)
+    crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
+    with torch.no_grad():
+        loc, conf, pri = net(x)
+        ll, lc = crit((loc, conf, pri), tg)
+    assert torch.isfinite(loc).all() and torch.isfinite(conf).all() and loc.dtype == torch.float32
+    plan = net._engine._last_plan
+    names = {st.tag[0] for st in plan.steps if st.tag is not None}
+    assert any(n.startswith('conv_flat_bf16<') for n in names) and any(n.startswith('conv_thin_bf16<') for n in names), names
+    worst = _layer_local_checks_sampled(plan, [7, 31])
+    print(name, 'B=32 layer-local worst:', {k: f'{v:.1e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+    bad = {k: v for k, v in worst.items() if v > 1.01 * BF_ULP_LOW}
+    assert not bad, bad
+    rl, rc = O.multibox_loss(loc.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), [t.numpy() for t in tg])
+    assert rel(ll, rl) < 1e-4 and rel(lc, rc) < 1e-4
+    with torch.no_grad():
+        net.eval()
+        l32, c32, _ = net(x)
+        l2, c2, _ = net(x[5:7])
+    assert l2rel(l32[5:7], l2) < 1e-6 and l2rel(c32[5:7], c2) < 1e-6       # per-image work does not depend on the batch it sits in
+    det, keep, cnt = ops.detect(l32, c32, pri, 2, conf_is_logits=True, want_keep=True)
+    det = det.cpu().numpy()
+    assert (np.diff(det[:, 1, :, 0], axis=1) <= 0).all() and (det[:, 0] == 0).all()
+    b = 3
+    ref = O.detect(2, 0, 200, 0.01, 0.45, l32[b:b + 1].cpu().numpy(), O.softmax_scores(c32[b:b + 1].cpu().numpy()), pri.cpu().numpy())
+    assert np.array_equal(det[b:b + 1], ref)
+
+
 def test_bf16_is_forward_only(dev):
     from models.ssd_multiphase_custom_group import build_ssd
     from gssd._lib import GssdError
