@@ -476,7 +476,7 @@ def main():
         gd.finish()
         return
     if a.full_step is None:
-        a.full_step = 8 if a.dtype == 'f32' else 0
+        a.full_step = 8 if a.dtype == 'f32' else 4
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)
@@ -493,11 +493,22 @@ def main():
     if a.dtype == 'f32' and not a.no_bf16 and a.config == 'gssdpp':
         a2 = copy.copy(a)
         a2.steps, a2.warmup, a2.steady = min(a.steps, 50), min(a.warmup, 5), min(a.steady, 50)
-        bres = measure('gssdpp', a2, dev, gd, rank, world, 'bf16')[0]
+        bres, bnet, bcrit, bx, btg, _ = measure('gssdpp', a2, dev, gd, rank, world, 'bf16')
+        bfull = None
+        if a.full_step > 0 and world == 1:
+            # configs[4] as a training config: bf16 forward + loss, mixed-precision backward (fp32 gradients at the stored bf16
+            # activations, gssd/backward.py::Bf16Shadow), SGD on the fp32 master weights
+            a2.full_step = min(a.full_step, 4)
+            try:
+                bfull = full_step_leg(a2, bnet, bcrit, bx, btg, dev, gd, world, B)
+                bfull['note'] = 'bf16 forward + loss, mixed-precision backward (fp32 backward plan on fp32 copies of the stored bf16 activations), SGD on fp32 masters'
+            except Exception as e:                                  # noqa: BLE001 -- reported in the line
+                bfull = {'error': f'{type(e).__name__}: {e}'[:300]}
+        del bnet, bcrit, bx, btg
         bf16 = dict(metric='512x512 4-phase CT img/s (fwd+loss)', unit='img/s', dtype='bf16', steps=a2.steps, warmup=a2.warmup,
                     value=bres['value'], ms_per_step=bres['ms_per_step'], per_rank_ms_per_step=bres['per_rank_ms_per_step'],
                     steady=bres['steady'], loss=bres['loss'], workload=bres['workload'], whole_path=bres['whole_path'],
-                    roofline=bres['trunk'], dominant_kernel=bres['roofline'], kernels=bres['kernels'])
+                    roofline=bres['trunk'], dominant_kernel=bres['roofline'], full_step=bfull, kernels=bres['kernels'])
         torch.cuda.empty_cache()
 
     # Device-side input stage, timed on its own: raw uint8 [B,4,512,512,3] -> [B,12,300,300] fp32.  The

@@ -36,6 +36,144 @@ def _leaf_fns():
             lib.gssd_dcn_im2col_f32)
 
 
+class _EngView:
+    """What BackwardPlan reads of the engine, with fp32 packed weights for a bf16 forward plan."""
+
+    def __init__(self, eng, packed):
+        self.net, self._packed = eng.net, packed
+
+
+class Bf16Shadow:
+    """fp32 view of a bf16-storage forward plan (BASELINE.json configs[4] as a TRAINING config,
+    train_lesion_multiphase_v2.py:242-253): the backward of the bf16 mode is mixed precision -- the forward computed and STORED its
+    activations in bf16 (bf16 MFMA, fp32 accumulate); the backward runs the fp32 backward plan (fp32 master weights, fp32 gradients,
+    fp32 MFMA) on exact fp32 copies of those stored activations, i.e. it differentiates the fp32 graph AT the rounded activations
+    (straight-through rounding; the oracle's ``bf16='ste'``).  What the bf16 forward does not keep in a form the fp32 backward reads is
+    rebuilt at the start of every backward (``pre`` steps, on the main stream before the branch streams fork):
+      * one gssd_cast_bf16_f32 per stored activation (~2 GB read, ~4 GB written at batch 32);
+      * the pad vectors of the deferred BatchNorms in fp32 (gssd_bn_finalize_f32, mode 2 = no second running-statistics update);
+      * Self_Attn's value projection g^T in fp32 token order (the forward's copy is bf16 in the 32-key order of the bf16 attention
+        core): one fp32 1x1 conv per block from the fp32 copy of the block's input; the attention map is re-materialised by the
+        backward's explicit softmax path (the bf16 core keeps no log-sum-exp);
+      * fp32 packed copies of the weights the backward reads in packed form (merged head rows, merged theta | phi | g rows).
+    bf16 kernels for the backward itself (bf16 dgrad / wgrad operands) are not built: gradients are fp32 end to end."""
+
+    def __init__(self, plan):
+        self.real = plan
+        self.B, self.dev, self.P, self.nc = plan.B, plan.dev, plan.P, plan.nc
+        self.training = plan.training
+        self.pre = []
+        self._keep = []
+        self._s = {}                 # data_ptr of a bf16 forward tensor -> its fp32 shadow
+        self._xf = {}                # data_ptr of a deferred BatchNorm's scale vector -> (scale, shift, pad_fp32)
+        packed = {}
+        self.eng = _EngView(plan.eng, packed)
+        eng, net, B, dev = plan.eng, plan.eng.net, plan.B, plan.dev
+        f32 = torch.float32
+        casts, later = [], []
+
+        def S(t):
+            if t is None or t.dtype == f32:
+                return t
+            k = t.data_ptr()
+            if k not in self._s:
+                sh = torch.empty(t.shape, device=dev, dtype=f32)
+                self._s[k] = sh
+                self._keep.append((t, sh))
+                casts.append((lib.gssd_cast_bf16_f32, (t.data_ptr(), sh.data_ptr(), t.numel())))
+            return self._s[k]
+
+        def XF(xf, bn, stats, count, Cc):
+            if xf is None:
+                return None
+            if xf[0].data_ptr() not in self._xf:
+                sc, sh = xf[0], xf[1]
+                pd = torch.empty(Cc, device=dev, dtype=f32)
+                sc2, sh2 = torch.empty(Cc, device=dev, dtype=f32), torch.empty(Cc, device=dev, dtype=f32)
+                self._keep.append((xf, pd, sc2, sh2))
+                later.append((lib.gssd_bn_finalize_f32, (stats.data_ptr(), float(count), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                         bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
+                                                         float(bn.eps), 2, Cc, sc2.data_ptr(), sh2.data_ptr(), pd.data_ptr())))
+                self._xf[xf[0].data_ptr()] = (sc, sh, pd)  # the forward's own scale / shift (identical values), an fp32 pad
+            return self._xf[xf[0].data_ptr()]
+
+        rec = []
+        for kind, r in plan.rec:
+            q = dict(r)
+            if kind == 'convbn':
+                q['x_in'], q['raw'] = S(r['x_in']), S(r['raw'])
+                q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'])
+                q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'])
+            elif kind == 'head':
+                q['src'] = S(r['src'])
+            elif kind in ('pool', 'l2norm'):
+                q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
+            elif kind == 'slice_cat':
+                q['a'], q['b'], q['out'] = S(r['a']), S(r['b']), S(r['out'])
+            elif kind == 'dcn':
+                q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
+            elif kind == 'sa':
+                q['x_in'], q['out'], q['ag'] = S(r['x_in']), S(r['out']), S(r['ag'])
+                q['out2'] = S(r['out2']) if r['out2'] is not None else None
+            else:
+                raise _lib.GssdError(f'bf16 backward: no fp32 view for a {kind} record')
+            rec.append((kind, q))
+        # second pass: what needs the shadows of OTHER records (a consumer's fused input transform is its producer's xf)
+        for (kind, r), (_, q) in zip(plan.rec, rec):
+            if kind == 'convbn':
+                if r['in_xf'] is not None:
+                    prod = next(rr for kk, rr in plan.rec if kk == 'convbn' and rr.get('xf') is not None and rr['xf'][0] is r['in_xf'][0])
+                    q['in_xf'] = XF(r['in_xf'], prod['bn'], prod['stats'], B * prod['Ho'] * prod['Ho'], prod['Cout'])
+                ix = q['in_xf']
+                d, _, _ = ops.make_conv_desc(q['x_in'], None, q['raw'], B=B, H=r['H'], W=r['H'], in_stride=r['Cin'],
+                                             cin_g=r['Cin'] // r['groups'], Cout=r['Cout'], groups=r['groups'], k=r['k'], stride=r['stride'],
+                                             pad=r['pad'], dil=r['dil'], in_scale=ix[0] if ix else None, in_shift=ix[1] if ix else None,
+                                             in_pad=ix[2] if ix else None)
+                q['desc'] = d
+            elif kind == 'dcn':
+                OMC = r['omc']
+                d, _, _ = ops.make_conv_desc(q['x_in'], None, None, B=B, H=r['H'], W=r['H'], in_stride=r['Cin'], cin_g=r['Cin'], Cout=OMC,
+                                             k=3, pad=1)
+                q['d_om'] = d
+            elif kind == 'sa':
+                sa, name, Cc, H, N = r['mod'], r['name'], r['C'], r['H'], r['N']
+                C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+                Np4 = ops.round_up(N, 4)
+                w32 = torch.empty(C4 + C2, Cc, device=dev, dtype=f32)
+                packed[name + '.tpg.w'] = w32
+
+                def refresh(w32=w32, sa=sa, C8=C8, C4=C4):
+                    ops.copy_into(w32[:C8], sa.snconv1x1_theta.weight_orig)
+                    ops.copy_into(w32[C8:C4], sa.snconv1x1_phi.weight_orig)
+                    ops.copy_into(w32[C4:], sa.snconv1x1_g.weight_orig)
+                later.append((refresh, None))
+                gT = torch.empty(B, C2, Np4, device=dev, dtype=f32)
+                a_tpg = r['inv_sigma'][0]
+                bg = sa.snconv1x1_g.bias.detach()
+                d, _, _ = ops.make_conv_desc(q['x_in'], w32[C4:], gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=bg,
+                                             alpha=a_tpg[C4:], out_mode=_lib.OUT_TRANSPOSED, out_stride=Np4, m_per_image=True,
+                                             in_batch_stride=N * Cc, out_batch_stride=C2 * Np4)
+                self._keep.append((d, gT, w32, bg))
+                later.append((lib.gssd_conv2d_nhwc_f32, (C.byref(d),)))
+                q.update(gT=gT, Np=Np4, Nkp=Np4, lse=None)
+            elif kind == 'head':
+                i, Cs, A = r['i'], r['C'], r['A']
+                nloc = A * 4
+                _, K = ops.packed_k(Cs, 3, 3)
+                hw = torch.empty(nloc + A * plan.nc, K, device=dev, dtype=f32)
+                packed[f'heads.{i}.w'] = hw
+
+                def refresh_h(hw=hw, lw=r['loc'], cw=r['conf'], nloc=nloc):
+                    ops.pack_weight(lw.weight, hw, 0)
+                    ops.pack_weight(cw.weight, hw, nloc)
+                later.append((refresh_h, None))
+        self.rec = rec
+        self.pre = casts + later
+
+    def _side_stream(self, sid):
+        return self.real._side_stream(sid)
+
+
 class BackwardPlan:
     def __init__(self, plan):
         self.plan = plan
@@ -541,6 +679,8 @@ class BackwardPlan:
             for grp in self._zero_groups:
                 torch._foreach_zero_(grp)
         stream = torch.cuda.current_stream().cuda_stream
+        for fn, args in getattr(self.plan, 'pre', ()):          # bf16 forward plan: fp32 copies of what the forward stored (Bf16Shadow)
+            self._run_step(fn, args, stream)
         hook = self.segment_hook
         if hook is not None:
             if getattr(self, '_segs', None) is None:

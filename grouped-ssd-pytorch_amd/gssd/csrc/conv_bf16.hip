@@ -422,7 +422,33 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, u16* __restric
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }
 
+// bf16 -> fp32 (exact), 8 elements per thread
+__global__ void cast_bf16_f32_kernel(const u16* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long n8 = n >> 3;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + 8 * i);
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = (float)v[e];
+            b[e] = (float)v[e + 4];
+        }
+        *reinterpret_cast<f32x4*>(y + 8 * i) = a;
+        *reinterpret_cast<f32x4*>(y + 8 * i + 4) = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[8 * n8 + threadIdx.x] = bf2f(x[8 * n8 + threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" int gssd_cast_bf16_f32(const void* x, float* y, int64_t n, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && n > 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0);
+    const long long thr = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)(thr > 16384 ? 16384 : (thr < 1 ? 1 : thr))), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const u16*>(x), y, (long long)n);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
 
 extern "C" int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad,
                                           int Kpad, gssd_stream_t stream) {

@@ -246,11 +246,10 @@ class _PlanBase:
     _bwd = None
 
     def backward_plan(self):
-        if getattr(self, 'bf16', False):
-            raise _lib.GssdError('bf16 storage mode (net.compute_dtype = "bf16") is forward + loss only; train in fp32')
         if self._bwd is None:
-            from .backward import BackwardPlan
-            self._bwd = BackwardPlan(self)
+            from .backward import BackwardPlan, Bf16Shadow
+            # bf16 storage mode: the fp32 backward plan over fp32 copies of the stored bf16 activations (mixed precision)
+            self._bwd = BackwardPlan(Bf16Shadow(self) if getattr(self, 'bf16', False) else self)
         return self._bwd
 
 

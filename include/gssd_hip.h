@@ -148,6 +148,9 @@ int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,
                                gssd_stream_t stream);
 int gssd_cast_f32_bf16(const float* x, void* y, int64_t n, gssd_stream_t stream);
+/* bf16 -> fp32 array cast (exact; x and y 16-byte aligned): the backward of the bf16 storage mode runs on fp32 copies of the
+ * activations the forward stored (gssd/backward.py::Bf16Shadow) */
+int gssd_cast_bf16_f32(const void* x, float* y, int64_t n, gssd_stream_t stream);
 /* bf16 variants of the HBM-bound passes (fp32 arithmetic, one rounding on store): input pack (3 -> 8 channels per phase),
  * BatchNorm + ReLU + max-pool, BN finalize with a bf16 pad vector, L2Norm */
 int gssd_pack_input_nhwc_bf16(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int groups, gssd_stream_t stream);

@@ -268,6 +268,13 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def bf16_round_ste(t):
+    """bf16_round for gradient checks: the same forward value (in t's own dtype, so float64 graphs stay float64), identity backward
+    (straight-through): the gradient of the bf16 storage mode is the fp32 graph's gradient evaluated at the rounded activations --
+    autograd through ``.to(bfloat16)`` would round the GRADIENT at every storage point instead."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
 def _ident(t):
     return t
 
@@ -497,7 +504,8 @@ def gssd_forward(sd, x, num_classes=2, batch_norm=True, groups_vgg=4, groups_ext
     forward mutates (BN running stats, spectral-norm u/v).  ``taps`` (dict) collects named
     intermediate activations for op-level parity tests."""
     assert batch_norm or not bf16, 'bf16 storage mode is defined for the BatchNorm graph only'
-    q = bf16_round if bf16 else None          # BASELINE.json configs[4]: rounding at every bf16 storage point (see bf16_round)
+    # BASELINE.json configs[4]: rounding at every bf16 storage point (see bf16_round); bf16='ste' = straight-through rounding for autograd
+    q = (bf16_round_ste if bf16 == 'ste' else bf16_round) if bf16 else None
     qq = q or _ident
     x = qq(x)
     updates = {}
