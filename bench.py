@@ -206,6 +206,14 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
         net.__dict__['_events'] = None
         sagg = aggregate(survey)
         trunk = trunk_roofline(survey, 2, a.batch, dtype)
+        if trunk is not None:
+            try:        # HBM bytes of the trunk's kernels per step from the committed PMC passes (scripts/pmc_traffic.sh)
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json'))).get((cfg if dtype == 'f32' else f'{cfg}_{dtype}') + '_trunk')
+                if tr:
+                    trunk['traffic'] = tr['hbm_bytes_per_step']
+                    trunk['traffic_over_alg'] = round(tr['hbm_bytes_per_step'] / trunk['alg_bytes_per_step'], 3)
+            except (OSError, ValueError, KeyError):
+                pass
         events = EventList()
         # the dominant KERNEL: the instance with the most time among those launched at most 12 times per step (a bucket of dozens
         # of small-map launches of one tile shape is not one kernel, and bracketing it would cut the hipGraph into as many pieces)

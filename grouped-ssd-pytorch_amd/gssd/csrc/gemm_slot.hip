@@ -322,24 +322,15 @@ static int slot_shape(const gssd_conv_desc& d) {
     const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
     const int images = d.m_per_image ? d.B : 1;
     const int mtiles = (int)((M + BM - 1) / BM);
-    // The 128 x 256 / one-workgroup-per-CU form (the tiling of dcn_fused, where the gather forces it) is kept for ablation only
-    // (GSSD_GEMM_SLOT256=1): on every shape of scripts/bench_gemm.py the 128 x 128 form with two resident workgroups is as fast or
-    // faster (K = 512, N = 9216: 3.28 vs 3.38 ms; K = 256: 125 vs 127 us) -- the second workgroup's MFMAs cover the ~20 us of prologue
-    // + epilogue a lone workgroup leaves exposed per tile.
-    {
-        static const bool want256 = getenv("GSSD_GEMM_SLOT256") != nullptr;
-        const int ntn = (d.Cout + 255) / 256;
-        const double nfill = (double)d.Cout / (double)(ntn * 256);
-        const double rounds = (double)((long long)mtiles * ntn * images) / 256.0;
-        const double qfill = rounds / (double)(long long)(rounds + 0.999999);
-        if (want256 && d.K >= 512 && nfill >= 0.9 && qfill * nfill >= 0.80) return 256;
-    }
-    static const bool no128 = getenv("GSSD_NO_GEMM_SLOT128") != nullptr;            // ablation switch
+    // (A 128 x 256 / one-workgroup-per-CU form -- the tiling of dcn_fused, where the gather forces it -- was measured on every shape of
+    // scripts/bench_gemm.py and never won: K = 512, N = 9216: 3.38 vs 3.28 ms; K = 256: 127 vs 125 us -- the second resident workgroup's
+    // MFMAs cover the ~20 us of prologue + epilogue a lone workgroup leaves exposed per tile.  Its switch is gone; the BN = 256 template
+    // instance stays compilable for scripts/bench_gemm.py-style experiments.)
     // 128 x 128: any wide enough plain GEMM with at least ~3/8 of a round of workgroups (below that the generic kernel's 128 x 64
     // tiles spread the work over more CUs: M = 3200, N = 512 measures 55 us there, 64 us here)
     const int ntn = (d.Cout + 127) / 128;
     const double nfill = (double)d.Cout / (double)(ntn * 128);
-    if (no128 || nfill < 0.75 || (long long)mtiles * ntn * images < 192) return 0;
+    if (nfill < 0.75 || (long long)mtiles * ntn * images < 192) return 0;
     // Per-image batched projections only: last-round fill against the generic kernel's 128 x 64 tiling (three resident workgroups per
     // CU).  B = 32 x 19 x 19 tokens x 768 columns per image is 576 workgroups = 1.1 rounds of 512 here and 1152 = 1.5 rounds of 768
     // there: measured 252 vs 200 us.  Plain (non-batched) GEMMs are faster here at every fill measured (scripts/bench_gemm.py:

@@ -308,12 +308,11 @@ int gssd_try_wgrad_slot(const gssd_conv_desc& d, const float* dy, float* dw, hip
         return launch_ws<false>(p, 1, stream);
     }
     // convolutions with taps (stride / dilation / padding; the group index is a grid dimension)
-    static const bool no_conv = getenv("GSSD_NO_WGRAD_SLOT_CONV") != nullptr;           // ablation switch
     // Dense layers only (the DCN offset conv: 1.75 -> 1.06 ms).  Measured and rejected for the grouped trunk layers: conv4_2 (4 groups x
     // 128 x 1152 weights, 25 reduction slices so that 500 workgroups fill the chip) runs 765 us here against 484 us on conv_wgrad<4,2,2>
     // (112 TFLOP/s: its 128 x 128 tiles need 22 slices only and two workgroups share a CU) -- with so little output per group the
     // one-workgroup-per-CU stream spends its time in prologues and atomic epilogues.
-    if (no_conv || d.groups != 1 || d.in_scale || d.cin_g % 4 != 0 || cout_g % 4 != 0 || cout_g < 96 || d.K < 192) return 1;
+    if (d.groups != 1 || d.in_scale || d.cin_g % 4 != 0 || cout_g % 4 != 0 || cout_g < 96 || d.K < 192) return 1;
     if ((long long)d.B * d.H * d.W * d.in_stride >= (1ll << 31)) return 1;
     p.Cout = cout_g;
     p.cout_total = d.Cout;

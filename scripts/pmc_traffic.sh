@@ -5,7 +5,7 @@ cfg=${1:-gssdpp}
 dtype=${2:-f32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --full-step 0 --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --full-step 0 --steps 3 --warmup 1 --steady 0 --cpu-sample 0 --no-events --no-secondary --no-bf16 --no-input-stage --config $cfg --dtype $dtype > /dev/null 2>&1
 done
 key=$cfg; [ "$dtype" != f32 ] && key=${cfg}_$dtype
 python3 - "$GRAFT_REPO_ROOT" "$key" <<'PY'
@@ -27,6 +27,8 @@ def short(n):
     if m: return f'conv_wino<{m.group(1)}>'
     m = re.search(r'conv_bf16_kernel<(\d+), (\d+)', n)
     if m: return f'conv_bf16<{m.group(1)}x{m.group(2)}>'
+    m = re.search(r'conv_flat_bf16_kernel<(\d+), (\d+), (?:true|false), (\d+), (\d+)', n)
+    if m: return f'conv_flat_bf16<{m.group(1)},{m.group(2)},{64 * int(m.group(4))}>' + ('' if m.group(3) != '2' else '/ring2')
     m = re.search(r'conv_thin_bf16_kernel<(\d+), (\d+)', n)
     if m: return f'conv_thin_bf16<{m.group(1)},{m.group(2)}>'
     m = re.search(r'flash_attn_mixed_kernel<(\d+), (\d+)', n)
@@ -53,6 +55,14 @@ for k, d in pool.items():
 p = os.path.join(root, 'gpurun_out', 'pmc_summary.json')
 allj = json.load(open(p)) if os.path.exists(p) else {}
 allj[cfg] = out
+# the grouped-conv backbone as one figure: every launch of the trunk's conv kernels (thin / flat-window / Winograd families; the
+# dilated conv6 runs the 2-stage-ring flat instance and is excluded) plus EVERY BatchNorm + ReLU + pool pass of the step (a slight
+# over-count: five of the seventeen passes belong to the fuse convs and extras)
+trunk = [k for k in out if k.startswith(('conv_thin', 'conv_wino', 'conv_flat_bf16')) and not k.endswith('/ring2')] + \
+        [k for k in out if k.startswith('bn_relu_pool')]
+per_step = float(max([out[k]['launches'] for k in out if k.startswith('pack_input')] or [1]))      # the input pack runs once per forward
+allj[cfg + '_trunk'] = dict(kernels=sorted(trunk), hbm_bytes_per_step=round(sum(out[k]['hbm_bytes_per_launch'] * out[k]['launches'] for k in trunk) / per_step),
+                            note='sum over the trunk kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches / steps run')
 json.dump(allj, open(p, 'w'), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
     print(k, v)

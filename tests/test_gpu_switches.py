@@ -1,0 +1,67 @@
+"""Every GSSD_* kernel-selection / scheduling switch the product code still reads (profiles/README.md lists what each one is for) is an
+untested combination unless something runs it: one GSSD++ training step at batch 4 per switch, in a subprocess (the switches are read
+once per process), against the default configuration of the same process family.  The alternative paths compute the same function
+with a different kernel or schedule: fp32 results agree to 1e-4 of the tensor's scale (gradients 2e-2 relative L2: ReLU / max-pool
+decisions flip between fp32 summation orders, tests/test_gpu_parity.py::test_backward_gradients), bf16 results within the bf16
+contract of tests/test_gpu_bf16.py (a few per cent after the trunk, loss 1e-2)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+_cache = {}
+
+
+def run(dtype, env):
+    key = (dtype, tuple(sorted(env.items())))
+    if key not in _cache:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'switch_worker.py'), dtype], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('SWITCHJSON ')][-1]
+        _cache[key] = json.loads(line[len('SWITCHJSON '):])
+    return _cache[key]
+
+
+def l2rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+SWITCHES = [
+    # dtype, environment, what must (not) be in the launched kernel set
+    ('f32', {'GSSD_NO_GRAPH': '1'}, lambda o, base: o['graphs'] == 0 and base['graphs'] > 0),
+    ('f32', {'GSSD_NO_BRANCH_STREAMS': '1'}, lambda o, base: True),
+    ('f32', {'GSSD_BWD_STREAMS': '0'}, lambda o, base: True),
+    ('f32', {'GSSD_NO_WINOGRAD': '1'}, lambda o, base: not any(k.startswith(('conv_wino', 'conv_thin_wino')) for k in o['kernels'])
+     and any(k.startswith('conv_wino') for k in base['kernels'])),
+    ('f32', {'GSSD_NO_GEMM_SLOT': '1'}, lambda o, base: True),
+    ('f32', {'GSSD_NO_WGRAD_SLOT': '1'}, lambda o, base: True),
+    ('bf16', {'GSSD_NO_CONV_FLAT': '1'}, lambda o, base: not any(k.startswith('conv_flat_bf16') for k in o['kernels'])
+     and any(k.startswith('conv_flat_bf16') for k in base['kernels'])),
+    ('bf16', {'GSSD_FLAT_BM': '128'}, lambda o, base: all(k.endswith(',128>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
+    ('bf16', {'GSSD_FLAT_BM': '256'}, lambda o, base: any(k.endswith(',256>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
+    ('bf16', {'GSSD_FLAT_PERSIST': '0'}, lambda o, base: True),
+]
+
+
+@pytest.mark.parametrize('dtype,env,check', SWITCHES, ids=[f"{d}-{'-'.join(f'{k}={v}' for k, v in e.items())}" for d, e, _ in SWITCHES])
+def test_switch_path_agrees_with_default(dtype, env, check):
+    base = run(dtype, {})
+    out = run(dtype, env)
+    assert check(out, base), (out['kernels'], out['graphs'])
+    assert out['graph_replay'] <= (1e-6 if dtype == 'f32' else 0.0) * max(out['loc_max'], 1.0) + 1e-5     # eager == hipGraph replay
+    f32 = dtype == 'f32'
+    assert l2rel(out['loc'], base['loc']) < (1e-4 if f32 else 6e-2)
+    for i in (0, 1):
+        assert abs(out['loss'][i] - base['loss'][i]) <= (1e-4 if f32 else 1e-2) * abs(base['loss'][i])
+    for k, v in out['gnorm'].items():
+        tol = 2e-2 if f32 else 0.6        # bf16: two bf16 forwards' trunk gradients differ by tens of per cent (test_bf16_backward_gradients)
+        assert abs(v - base['gnorm'][k]) <= tol * base['gnorm'][k], (k, v, base['gnorm'][k])
+        if f32:
+            assert l2rel(out['gsample'][k], base['gsample'][k]) < 5e-2, k
