@@ -33,6 +33,14 @@
 // Also measured and rejected: this kernel for the 64-channel groups of conv3_x (weights of a group = 144 / 288 registers per lane, one
 // workgroup per CU, rows in blocks of four): conv3_1 114 us vs 99 us, conv3_2 213 us vs 189 us on the generic conv_bf16 -- one wave
 // per SIMD cannot hide the 92 KB patch load, the transform pass and the fragment reads behind its own MFMAs.
+// Round 3, measured and rejected: a two-tile software pipeline of this kernel (8-row tiles, two patch buffers, the packed bf16
+// outputs of tile t kept in registers and stored at the top of tile t + 1, so that neither the next patch's DMA nor the stores sit
+// directly in front of the vmcnt(0) wait that covers them -- stores and loads share that counter on gfx950): conv1_1 171 us,
+// conv1_2 232 us, conv2_1 149 us against 159 / 210 / 137 us.  The wait was not the limiter: scripts/ubench/store_patterns.hip writes
+// this very store pattern (four waves, one 32-byte slice each of every 128-byte vector) at 5.3 TB/s in isolation, and the per-phase
+// stamps put a conv2_1 tile at ~27 k cycles per workgroup for ~105 KB moved = 7.8 B/cycle per CU with two workgroups resident --
+// the combined load + store rate one CU's memory pipe sustains (a device-wide copy runs 5.2 .. 5.5 TB/s = 9 B/cycle/CU).  What these
+// kernels lose against a copy is phase overlap inside the CU (load -> wait -> MFMA -> store per workgroup), not store efficiency.
 #include <stdlib.h>
 #include "common.h"
 

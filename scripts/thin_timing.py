@@ -3,6 +3,9 @@ lib/libgssd_hip.so on the GPU box): wave 1 of every workgroup accumulates the cy
 import sys, os, ctypes as C
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
+import shutil
+LIBD = os.path.join(ROOT, 'grouped-ssd-pytorch_amd', 'gssd', 'lib')
+shutil.copyfile(os.path.join(LIBD, 'libgssd_hip_tt.so'), os.path.join(LIBD, 'libgssd_hip.so'))     # scratch copy on the GPU box
 import torch
 from gssd import ops, _lib
 dev = torch.device('cuda:0')

@@ -25,6 +25,53 @@ __global__ __launch_bounds__(256) void store_kernel(u32x4* __restrict__ out, lon
     }
 }
 
+// The thin trunk kernels' pattern: the 4 waves of a workgroup each write ONE RUN-byte slice (a phase group's channels) of the same
+// pixels' vectors (pitch = 4 * RUN), 16 pixels x (RUN / 16) pieces per instruction... QUART = true; or each wave writes whole vectors
+// of a quarter of the pixels (QUART = false), same bytes per workgroup.
+template <int RUN, bool QUART>
+__global__ __launch_bounds__(256) void group_store_kernel(u32x4* __restrict__ out, long long rows_per_wg, int iters) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int PPR = RUN / 16, NPIX = 64 / PPR, PITCH16 = 4 * PPR;
+    u32x4 v = {(unsigned)lane, 1u, 2u, 3u};
+    const long long row0 = (long long)blockIdx.x * rows_per_wg;
+    if (QUART) {
+        const int pix = lane % NPIX, piece = lane / NPIX;
+        for (int it = 0; it < iters; ++it) {
+            out[(row0 + (long long)it * NPIX + pix) * PITCH16 + w * PPR + piece] = v;
+            v.x += 64;
+        }
+    } else {
+        // wave w owns rows [w * iters * NPIX / 4 ...): whole vectors, PITCH16 pieces per pixel, 64 / PITCH16 pixels per instruction
+        constexpr int NP2 = 64 / PITCH16;
+        const int pix = lane / PITCH16, piece = lane % PITCH16;
+        for (int it = 0; it < iters; ++it) {
+            out[(row0 + ((long long)w * iters + it) * NP2 + pix) * PITCH16 + piece] = v;
+            v.x += 64;
+        }
+    }
+}
+
+template <int RUN, bool QUART>
+double run_group(u32x4* buf, size_t bytes, int reps) {
+    constexpr int PPR = RUN / 16, NPIX = 64 / PPR;
+    const long long rows = (long long)(bytes / (4 * RUN));
+    const int blocks = 256 * 8;
+    const long long rows_per_wg = rows / blocks / (4 * NPIX) * (4 * NPIX);
+    const int iters = QUART ? (int)(rows_per_wg / NPIX) : (int)(rows_per_wg / (64 / (4 * PPR)) / 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    group_store_kernel<RUN, QUART><<<blocks, 256>>>(buf, rows_per_wg, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) group_store_kernel<RUN, QUART><<<blocks, 256>>>(buf, rows_per_wg, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return (double)blocks * 4 * iters * 1024.0 * reps / (ms * 1e-3) / 1e9;
+}
+
 template <int RUN, bool ADJ>
 double run(u32x4* buf, size_t bytes, long long pitch, int reps) {
     constexpr int NPIX = 64 / (RUN / 16);
@@ -70,5 +117,10 @@ int main() {
     R(32, false, 128)
     R(32, true, 256)
     R(16, false, 128)
+    printf("4 waves of a workgroup covering the same pixel vectors:\n");
+    printf("each wave one 32-B slice of every 128-B vector (thin conv1_x epilogue) %8.0f GB/s\n", run_group<32, true>(buf, bytes, 5));
+    printf("each wave whole 128-B vectors of a quarter of the pixels               %8.0f GB/s\n", run_group<32, false>(buf, bytes, 5));
+    printf("each wave one 64-B slice of every 256-B vector (conv2_x epilogue)      %8.0f GB/s\n", run_group<64, true>(buf, bytes, 5));
+    printf("each wave whole 256-B vectors of a quarter of the pixels               %8.0f GB/s\n", run_group<64, false>(buf, bytes, 5));
     return 0;
 }
