@@ -370,7 +370,7 @@ def self_launch(n):
     give them -- and exits with their return code.  Rank 0's JSON line is the only thing the children print on stdout."""
     import subprocess
     ndev = torch.cuda.device_count()
-    if ndev < n and '--launch-probe' not in sys.argv:
+    if ndev < n and '--launch-probe' not in sys.argv and not os.environ.get('GSSD_DIST_SAME_DEVICE'):
         print(json.dumps({'error': f'--gpus {n} needs {n} visible GPUs, this host has {ndev}', 'n_gpus': n, 'devices_visible': ndev}))
         return 2
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
@@ -485,9 +485,14 @@ def main():
         return
     if a.full_step is None:
         a.full_step = 8 if a.dtype == 'f32' else 4
+    # GSSD_DIST_SAME_DEVICE=1 + GSSD_DIST_BACKEND=gloo: every rank on GPU 0 with gloo collectives -- the N > 1 code path (sharding,
+    # barriers, per-rank gather, overlapped gradient reducer, watchdog) on a one-GPU box; tests/test_gpu_multi.py.  Not a measurement.
+    backend = os.environ.get('GSSD_DIST_BACKEND', 'nccl')
+    if os.environ.get('GSSD_DIST_SAME_DEVICE'):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    gd.init('nccl', dev)          # RCCL over xGMI; used for the timing barrier only (no data-path collective)
+    gd.init(backend, dev)         # 'nccl' = RCCL over xGMI; the fwd+loss metric uses it for the timing barrier only
 
     from gssd import synth
     import copy
@@ -567,7 +572,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
                    'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
-        'rccl_ranks': gd.world_size(), 'per_rank_ms_per_step': res['per_rank_ms_per_step'],
+        'rccl_ranks': gd.world_size(), 'collective_backend': backend if world > 1 else None,
+        'per_rank_ms_per_step': res['per_rank_ms_per_step'],
         'launcher': ('self (python bench.py --gpus N)' if os.environ.get('GSSD_BENCH_SELF_LAUNCHED') else
                      'torch.distributed.run' if world > 1 else 'single process'),
         'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
