@@ -98,8 +98,23 @@ class Bf16Shadow:
             return self._xf[xf[0].data_ptr()]
 
         rec = []
+        first = True
         for kind, r in plan.rec:
             q = dict(r)
+            if kind == 'convbn' and first and r['groups'] == 4 and r['Cin'] == 32 and r['conv'].weight.shape[1] == 3:
+                # conv1_1: the bf16 forward packs 3 -> 8 channels per phase; its weight gradient wants the fp32 layout (3 -> 4, the
+                # patch-staged thin wgrad kernel) -- 2.5 ms per step on the generic kernel otherwise.  Same (bf16-rounded) values,
+                # channels 0 .. 3 of every phase: a strided copy (tensor bookkeeping, like slice_and_cat's gradient split)
+                x8 = r['x_in']
+                x4 = torch.empty(*x8.shape[:3], 16, device=dev, dtype=f32)
+                self._s[x8.data_ptr()] = x4
+                self._keep.append((x8, x4))
+
+                def repack(x8=x8, x4=x4):
+                    x4.view(*x4.shape[:3], 4, 4).copy_(x8.view(*x8.shape[:3], 4, 8)[..., :4])
+                casts.append((repack, None))
+                q['Cin'] = 16
+            first = False
             if kind == 'convbn':
                 q['x_in'], q['raw'] = S(r['x_in']), S(r['raw'])
                 q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'])
@@ -125,8 +140,8 @@ class Bf16Shadow:
                     prod = next(rr for kk, rr in plan.rec if kk == 'convbn' and rr.get('xf') is not None and rr['xf'][0] is r['in_xf'][0])
                     q['in_xf'] = XF(r['in_xf'], prod['bn'], prod['stats'], B * prod['Ho'] * prod['Ho'], prod['Cout'])
                 ix = q['in_xf']
-                d, _, _ = ops.make_conv_desc(q['x_in'], None, q['raw'], B=B, H=r['H'], W=r['H'], in_stride=r['Cin'],
-                                             cin_g=r['Cin'] // r['groups'], Cout=r['Cout'], groups=r['groups'], k=r['k'], stride=r['stride'],
+                d, _, _ = ops.make_conv_desc(q['x_in'], None, q['raw'], B=B, H=r['H'], W=r['H'], in_stride=q['Cin'],
+                                             cin_g=q['Cin'] // r['groups'], Cout=r['Cout'], groups=r['groups'], k=r['k'], stride=r['stride'],
                                              pad=r['pad'], dil=r['dil'], in_scale=ix[0] if ix else None, in_shift=ix[1] if ix else None,
                                              in_pad=ix[2] if ix else None)
                 q['desc'] = d
