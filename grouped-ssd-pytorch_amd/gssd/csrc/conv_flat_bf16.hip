@@ -201,8 +201,13 @@ __global__ __launch_bounds__(WMW * WNW * 64, WMW * WNW == 4 ? 2 : 1) void conv_f
         wait_lds_barrier();
     };
 
-    const int step = (int)(gridDim.x >> 3) * 2;
-    for (int item = (int)(blockIdx.x >> 3) * 2 + (xcd & 1); item < p.total; item += step) {
+    // each XCD of the pair walks its own contiguous half of the group's tiles, consecutive workgroups side by side: neighbouring tiles
+    // (whose windows overlap by 2 W + 2 pixels) run at the same time in the SAME L2 (alternating the two XCDs fetched every halo
+    // twice: PMC 241 MB per conv3_2 launch for 185 MB algorithmic)
+    const int half = (p.total + 1) >> 1;
+    const int item_end = (xcd & 1) ? p.total : half;
+    const int step = (int)(gridDim.x >> 3);
+    for (int item = (xcd & 1) * half + (int)(blockIdx.x >> 3); item < item_end; item += step) {
         // item -> (image, pixel tile, channel tile)
         const int nt = item % p.ntn;
         const int rest = item / p.ntn;
@@ -258,15 +263,20 @@ __global__ __launch_bounds__(WMW * WNW * 64, WMW * WNW == 4 ? 2 : 1) void conv_f
 #pragma unroll
         for (int h = 0; h < NHALF; ++h) {
             wait_lds_barrier();                      // every wave is done with the previous window and ring (previous half / tile)
-            // ---- stage the window (one linear source range, zeros outside the image) ------------------------------------------
-            const int ninstr = (npp + PPI - 1) / PPI;
-            for (int n = wave; n < ninstr; n += NW) {
-                const int pp = n * PPI + lane / UPR;
-                const int q = qstart + pp;
-                const bool ok = pp < npp && (unsigned)q < (unsigned)HW;
-                const int lu = (lane % UPR) ^ swz<UPR>(pp);
-                const u16* src = ok ? in_g + ((size_t)(ok ? q : 0) * p.C + h * CP + lu * 8) : g_zero_flat_h;
-                dma16(src, patch + n * PPI * CP);
+            // ---- stage the window (one linear source range, zeros outside the image).  Instruction n covers window pixels
+            //      n * PPI + lane / UPR: PPI is a multiple of the swizzle period, so a lane's unit permutation is the same for every
+            //      n and its source address advances by PPI pixel vectors per instruction -- one add, one range test, one select ----
+            {
+                const int ninstr = (npp + PPI - 1) / PPI;
+                const int pp0 = lane / UPR;
+                const int lu = (lane % UPR) ^ swz<UPR>(pp0);
+                const u16* src0 = in_g + ((long long)(qstart + pp0) * p.C + h * CP + lu * 8);
+                const long long adv = (long long)PPI * p.C;
+                for (int n = wave; n < ninstr; n += NW) {
+                    const int pp = n * PPI + pp0;
+                    const bool ok = pp < npp && (unsigned)(qstart + pp) < (unsigned)HW;
+                    dma16(ok ? src0 + n * adv : g_zero_flat_h, patch + n * PPI * CP);
+                }
             }
             // ---- ring prologue: slices (= taps) 0 .. NSTG - 2 ---------------------------------------------------------------------
 #pragma unroll

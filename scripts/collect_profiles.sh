@@ -25,6 +25,7 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_fs -o p -- python3 $R/bench.py --steps 2 --warmup 1 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --no-bf16 --no-events --full-step 8 > /dev/null 2>&1
 f=$(find $R/gpurun_out/${tag}_prof_fs -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_gssdpp_b32_fullstep_kernel_stats.csv
+cd $R
 # the bf16 training step (bf16 forward, mixed-precision backward): bench line + kernel stats
 python3 bench.py --dtype bf16 --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > gpurun_out/${tag}_gssdpp_b32_bf16_fullstep.json 2>> gpurun_out/${tag}_bench.err
 cd /tmp
