@@ -86,7 +86,7 @@ def cpu_baseline(cfg_name, sample_b, seed):
     # pick the intra-op thread count that is fastest for this graph on this host (all cores oversubscribes oneDNN's
     # grouped convs on big boxes) with 2-image probes
     best = None
-    for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for nt in sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):      # (all 256 hardware threads: 3x slower than 16)
         torch.set_num_threads(nt)
         one(2, seed + 1)
         t = one(2, seed + 1)[0]
