@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
     _fields_ = [
         ('in_', c_fp), ('wgt', c_fp), ('bias', c_fp), ('out', c_fp), ('out_b', c_fp), ('alpha', c_fp),
         ('gate', c_fp), ('resid', c_fp), ('out2', c_fp), ('in_scale', c_fp), ('in_shift', c_fp), ('in_pad', c_fp),
-        ('stats', c_fp), ('wgt_wino', c_fp),
+        ('stats', c_fp), ('wgt_wino', c_fp), ('pool_sign', c_fp),
         ('B', c_i), ('H', c_i), ('W', c_i), ('in_stride', c_i), ('in_ch_off', c_i), ('Ho', c_i), ('Wo', c_i),
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
@@ -44,7 +44,7 @@ class SnItem(C.Structure):
 
 
 OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
-CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES = 1, 2, 4
+CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES, CONV_POOL2 = 1, 2, 4, 8
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {

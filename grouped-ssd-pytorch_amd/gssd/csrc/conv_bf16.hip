@@ -510,6 +510,10 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
         const int rc = gssd_try_conv_thin_bf16(d, s);      // conv1_1 .. conv2_2: patch-staged HBM-stream kernel
         if (rc != 1) return rc;
     }
+    if (d.flags & GSSD_CONV_POOL2) {
+        gssd_set_error("GSSD_CONV_POOL2: no bf16 kernel with a pooled epilogue takes this descriptor (thin trunk shapes only)");
+        return GSSD_EINVAL;
+    }
     {
         const int rc = gssd_try_conv_flat_bf16(d, s);      // conv3_1 .. conv6: flat-window kernel (csrc/conv_flat_bf16.hip)
         if (rc != 1) return rc;

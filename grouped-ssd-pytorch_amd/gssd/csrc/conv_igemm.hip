@@ -414,6 +414,10 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         const int rc = gssd_try_conv_wino(d, s);      // compute-bound 3x3 trunk layers: Winograd F(2x2,3x3)
         if (rc != 1) return rc;
     }
+    if (d.flags & GSSD_CONV_POOL2) {
+        gssd_set_error("GSSD_CONV_POOL2: no fp32 kernel with a pooled epilogue takes this descriptor (Winograd trunk shapes only)");
+        return GSSD_EINVAL;
+    }
     if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 512 && !d.m_per_image);
     {
         static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr;      // ablation switch (scripts/layer_times.py)

@@ -357,7 +357,7 @@ int gssd_try_conv_thin(const gssd_conv_desc& d, hipStream_t stream) {
                           d.out_stride == d.Cout && d.out_ch_off == 0 && !d.m_per_image && !d.relu && !d.gate &&
                           !d.resid && !d.alpha && d.split_k == 1 && d.wgt_row_stride == 9 * d.cin_g &&
                           d.H * d.W >= 75 * 75 && ((uintptr_t)d.out % 16) == 0;
-    if (!shape_ok) return 1;
+    if (!shape_ok || (d.flags & GSSD_CONV_POOL2)) return 1;      // (no pooled epilogue here: conv1_2 takes the Winograd thin kernel)
     if (d.cin_g == 4 && cout_g == 16) return launch_thin<4, 16>(d, stream);
     if (d.cin_g == 16 && cout_g == 16) return launch_thin<16, 16>(d, stream);
     if (d.cin_g == 16 && cout_g == 32) return launch_thin<16, 32>(d, stream);

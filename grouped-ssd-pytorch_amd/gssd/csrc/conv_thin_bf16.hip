@@ -79,6 +79,7 @@ struct ThinBfParams {
     double* stats;
     const float* in_scale;
     const float* in_shift;
+    const float* pool_sign;   // GSSD_CONV_POOL2: `out` is the 2x2 / stride-2 pooled raw map, max where pool_sign[c] >= 0 else min
     int B, H, W, tiles_y, tiles_x;
 };
 
@@ -216,6 +217,72 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
             }
+            if (p.pool_sign) {
+                // GSSD_CONV_POOL2 (include/gssd_hip.h): rows (i, i + 1) of a lane and columns (r, r ^ 1) of neighbouring lanes form one
+                // pooling window (tile origins are even); batch sums over every pixel as usual, then ONE value per window and channel --
+                // the maximum where the channel's BatchNorm weight is >= 0, the minimum where it is negative -- rounded to bf16 (the
+                // rounding commutes with max / min) and stored by the even lane at the pooled position.  The full map is never written.
+                float sg[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) sg[c] = p.pool_sign[g * COUT_G + cb + c];
+                const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+#pragma unroll
+                for (int i = 0; i < RH; i += 2) {
+                    const int y = y0 + rb + i;
+                    const bool ok0 = y < p.H && x < p.W, ok1 = y + 1 < p.H && x < p.W;
+                    float mx[CPL], mn[CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const float v0 = (CPL == 4 ? acc[i][0][c] : acc[i][c >> 2][c & 3]) + bias[c];
+                        const float v1 = (CPL == 4 ? acc[i + 1][0][c] : acc[i + 1][c >> 2][c & 3]) + bias[c];
+                        // row by row and in the arithmetic form of the unpooled epilogue (CPL 4: select, then add; CPL 8: the guarded
+                        // `ssq += v * v` hipcc contracts into an fma): identical batch sums
+                        if constexpr (CPL == 4) {
+                            ssum[c] += ok0 ? v0 : 0.f;
+                            ssq[c] += ok0 ? v0 * v0 : 0.f;
+                            ssum[c] += ok1 ? v1 : 0.f;
+                            ssq[c] += ok1 ? v1 * v1 : 0.f;
+                        } else {
+                            if (ok0) {
+                                ssum[c] += v0;
+                                ssq[c] += v0 * v0;
+                            }
+                            if (ok1) {
+                                ssum[c] += v1;
+                                ssq[c] += v1 * v1;
+                            }
+                        }
+                        mx[c] = ok1 ? fmaxf(v0, v1) : v0;
+                        mn[c] = ok1 ? fminf(v0, v1) : v0;
+                    }
+                    // neighbouring column = neighbouring lane: DPP quad_perm [1, 0, 3, 2] (one VALU move, no LDS crossbar)
+                    const bool pok = __builtin_amdgcn_mov_dpp((int)ok0, 0xB1, 0xF, 0xF, true) != 0;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const float pmx = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx[c]), 0xB1, 0xF, 0xF, true));
+                        const float pmn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mn[c]), 0xB1, 0xF, 0xF, true));
+                        if (pok) {
+                            mx[c] = fmaxf(mx[c], pmx);
+                            mn[c] = fminf(mn[c], pmn);
+                        }
+                    }
+                    if (ok0 && !(r & 1)) {
+                        u16* dst = p.out + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * COUT + g * COUT_G + cb;
+                        if constexpr (CPL == 4) {
+                            bf16x4 h;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
+                            *reinterpret_cast<bf16x4*>(dst) = h;
+                        } else {
+                            bf16x8 h;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
+                            *reinterpret_cast<bf16x8*>(dst) = h;
+                        }
+                    }
+                }
+                continue;
+            }
             // ---- epilogue: + bias, batch sums, 16-byte NHWC stores (lane: pixel (y0 + rb + i, x0 + r), CPL consecutive channels) -----
             if constexpr (CPL == 4) {
                 // 4 channels = 8 bytes per lane and row: rows are taken in pairs and the kq-even / kq-odd lane rows swap halves
@@ -313,6 +380,7 @@ int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     p.stats = d.stats;
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
+    p.pool_sign = (d.flags & GSSD_CONV_POOL2) ? d.pool_sign : nullptr;
     p.B = d.B;
     p.H = d.H;
     p.W = d.W;
@@ -335,7 +403,7 @@ int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     const bool shape_ok = d.groups == 4 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 &&
                           d.in_stride == 4 * d.cin_g && d.in_ch_off == 0 && d.out_mode == GSSD_OUT_NHWC && d.out_stride == d.Cout &&
                           d.out_ch_off == 0 && !d.m_per_image && !d.relu && !d.gate && !d.resid && !d.alpha && d.split_k == 1 &&
-                          d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && d.flags == 0;
+                          d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && (d.flags == 0 || (d.flags == GSSD_CONV_POOL2 && d.pool_sign));
     if (!shape_ok) return 1;
 #define THIN_CASE(CI, CO)                                                                     \
     if (d.cin_g == CI && cout_g == CO)                                                        \

@@ -32,6 +32,7 @@ struct ThinWinoParams {
     const float* in_scale;
     const float* in_shift;
     const float* in_pad;
+    const float* pool_sign;  // GSSD_CONV_POOL2: `out` is the 2x2 / stride-2 pooled raw map, max where pool_sign[c] >= 0 else min
     int B, H, W, tiles_y, tiles_x;
 };
 
@@ -165,6 +166,50 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
             const int y0 = tyi * TW_TH, x0 = txi * TW_TW;
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
             const int c4 = tid & 15;
+            if (p.pool_sign) {
+                // GSSD_CONV_POOL2: the staged 8 x 16 tile is 4 x 8 pooling windows (tile origins are even): a thread reduces the
+                // four pixels of a window for its 4 channels -- batch sums over ALL pixels as before -- and stores the maximum
+                // where the channel's BatchNorm weight is >= 0, the minimum where it is negative.  The full map is never written.
+                const f32x4 sg = *reinterpret_cast<const f32x4*>(p.pool_sign + c4 * 4);
+                const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+                // batch sums: the same pixels in the same order as the unpooled epilogue (identical statistics), no store
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int px = (tid + 256 * it) >> 4;
+                    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+                    if (y < p.H && x < p.W) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * TW_OLD + c4 * 4);
+                        s4 += v;
+                        q4 += v * v;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int w = (tid + 256 * it) >> 4;              // window 0 .. 31 of the tile: (w >> 3, w & 7)
+                    const int wy = w >> 3, wx = w & 7;
+                    const int y = y0 + 2 * wy, x = x0 + 2 * wx;
+                    if (y >= p.H || x >= p.W) continue;
+                    f32x4 mx, mn;
+                    bool first = true;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            if (y + a >= p.H || x + bb >= p.W) continue;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + ((2 * wy + a) * TW_TW + 2 * wx + bb) * TW_OLD + c4 * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                mx[e] = first ? v[e] : fmaxf(mx[e], v[e]);
+                                mn[e] = first ? v[e] : fminf(mn[e], v[e]);
+                            }
+                            first = false;
+                        }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sg[e] >= 0.f ? mx[e] : mn[e];
+                    *reinterpret_cast<f32x4*>(p.out + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * TW_COUT + c4 * 4) = o;
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int px = (tid + 256 * it) >> 4;
@@ -175,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
                     s4 += v;
                     q4 += v * v;
                 }
+            }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -210,6 +256,7 @@ int launch_thin_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.in_pad = d.in_pad;
+    p.pool_sign = (d.flags & GSSD_CONV_POOL2) ? d.pool_sign : nullptr;
     p.B = d.B;
     p.H = d.H;
     p.W = d.W;

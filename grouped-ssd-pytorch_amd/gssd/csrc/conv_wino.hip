@@ -38,6 +38,7 @@ struct WinoParams {
     const float* in_scale;
     const float* in_shift;
     const float* in_pad;
+    const float* pool_sign;  // GSSD_CONV_POOL2: `out` is the 2x2 / stride-2 (ceil) pooled raw map, max where pool_sign[c] >= 0 else min
     double* stats;
     int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, cout_pad, out_stride, out_ch_off;
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
@@ -242,6 +243,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                         s[1][j] = acc[1 * 4 + j][nb][e] - acc[2 * 4 + j][nb][e] - acc[3 * 4 + j][nb][e];
                     }
                     const float bia = p.bias ? p.bias[g * p.cout_g + n0 + nb * 16 + r] : 0.f;
+                    if (p.pool_sign) {
+                        // GSSD_CONV_POOL2: a Winograd tile IS a pooling window (2 x 2 outputs at even coordinates): the lane reduces its
+                        // four outputs (those that exist, ceil mode) and stores one value at the pooled position (ty, tx)
+                        const int ch = g * p.cout_g + n0 + nb * 16 + r;
+                        const float v00 = s[0][0] + s[0][1] + s[0][2] + bia, v01 = s[0][1] - s[0][2] - s[0][3] + bia;
+                        const float v10 = s[1][0] + s[1][1] + s[1][2] + bia, v11 = s[1][1] - s[1][2] - s[1][3] + bia;
+                        // (the batch sums take the four outputs in the order the unpooled epilogue adds them: identical statistics)
+                        float mx = v00, mn = v00;
+                        ssum[nb] += v00;
+                        ssq[nb] = __builtin_fmaf(v00, v00, ssq[nb]);
+                        if (x1) {
+                            mx = fmaxf(mx, v01), mn = fminf(mn, v01);
+                            ssum[nb] += v01;
+                            ssq[nb] = __builtin_fmaf(v01, v01, ssq[nb]);
+                        }
+                        if (y1) {
+                            mx = fmaxf(mx, v10), mn = fminf(mn, v10);
+                            ssum[nb] += v10;
+                            ssq[nb] = __builtin_fmaf(v10, v10, ssq[nb]);
+                            if (x1) {
+                                mx = fmaxf(mx, v11), mn = fminf(mn, v11);
+                                ssum[nb] += v11;
+                                ssq[nb] = __builtin_fmaf(v11, v11, ssq[nb]);
+                            }
+                        }
+                        p.out[((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch] = p.pool_sign[ch] >= 0.f ? mx : mn;
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         if (a == 1 && !y1) continue;
@@ -254,11 +284,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                         }
                         p.out[o] = v0;
                         ssum[nb] += v0;
-                        ssq[nb] += v0 * v0;
+                        ssq[nb] = __builtin_fmaf(v0, v0, ssq[nb]);
                         if (x1) {
                             p.out[o + p.out_stride] = v1;
                             ssum[nb] += v1;
-                            ssq[nb] += v1 * v1;
+                            ssq[nb] = __builtin_fmaf(v1, v1, ssq[nb]);
                         }
                     }
                     // keep the accumulator read-out in small groups: the next item's prefetched patch is live here, so hoisting
@@ -362,6 +392,7 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.in_pad = d.in_pad;
+    p.pool_sign = (d.flags & GSSD_CONV_POOL2) ? d.pool_sign : nullptr;
     p.stats = d.stats;
     p.B = d.B;
     p.H = d.H;
@@ -415,6 +446,7 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
                     d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
     if (!ok) return 1;
+    if ((d.flags & GSSD_CONV_POOL2) && (d.resid || !d.pool_sign)) return 1;
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
     // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent.  (Round 2: the persistent NB = 32
     // variant forced onto the 64 / 128-channel layers measures 15-30 % slower -- conv3_2 489 vs 415 us, conv4_2 436 vs 336 us: it

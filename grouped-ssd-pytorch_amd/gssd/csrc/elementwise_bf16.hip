@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bf16_kernel(
             mean = (double)running_mean[c];
             var = (double)running_var[c];
         }
-        const double inv = 1.0 / sqrt(var + (double)eps);
-        const double sc = (double)gamma[c] * inv;
+        // gamma / sqrt(var + eps) exactly as gssd_bn_finalize_* computes it: a layer gives the same activations whether its
+        // BatchNorm runs in this pass or deferred in its consumer (pooled and unpooled plans agree bit for bit)
+        const double sc = (double)gamma[c] / sqrt(var + (double)eps);
         s_scale[c] = (float)sc;
         s_shift[c] = (float)((double)beta[c] - mean * sc);
     }

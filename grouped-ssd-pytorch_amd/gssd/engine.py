@@ -72,8 +72,9 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if bf16:
         if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
-                and (d.cin_g, cout_g) in ((8, 16), (16, 16), (16, 32), (32, 32)) and not d.m_per_image and d.split_k == 1 and d.flags == 0):
-            name = f'conv_thin_bf16<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin_bf16 (csrc/conv_thin_bf16.hip)
+                and (d.cin_g, cout_g) in ((8, 16), (16, 16), (16, 32), (32, 32)) and not d.m_per_image and d.split_k == 1
+                and d.flags in (0, _lib.CONV_POOL2)):
+            name = f'conv_thin_bf16<{d.cin_g},{cout_g}>' + ('/pool2' if d.flags & _lib.CONV_POOL2 else '')   # gssd_try_conv_thin_bf16
     elif (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
@@ -92,7 +93,8 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     cin_g = real_cin_g if real_cin_g is not None else d.cin_g
     flops = 2.0 * M * d.Cout * d.KH * d.KW * cin_g
     esz = 2.0 if bf16 else 4.0
-    byts = esz * (d.B * d.H * d.W * cin_g * d.groups + M * d.Cout + d.Cout * d.KH * d.KW * cin_g)
+    out_elems = M * d.Cout // 4 if (d.flags & _lib.CONV_POOL2) else M * d.Cout       # pooled raw output: a quarter of the map
+    byts = esz * (d.B * d.H * d.W * cin_g * d.groups + out_elems + d.Cout * d.KH * d.KW * cin_g)
     return (name, flops, byts)
 
 
@@ -140,7 +142,7 @@ class GssdEngine:
     # ------------------------------------------------------------------------------------------
     MAX_PLANS_IN_FLIGHT = 4
 
-    def forward_plan(self, x, training, events=None, want_maps=False):
+    def forward_plan(self, x, training, events=None, want_maps=False, need_backward=True):
         """Run one forward; returns (loc, conf, plan).  A plan whose last grad-enabled forward still awaits its backward is busy
         (gssd/autograd.py) and is never reused: the call takes (or builds) another instance with its own buffers."""
         net = self.net
@@ -159,14 +161,17 @@ class GssdEngine:
         if tuple(x.shape[1:]) != (cin, 300, 300):
             raise _lib.GssdError(f'expected input [B,{cin},300,300], got {tuple(x.shape)}')
         bn_cfg = tuple((m.momentum, m.eps) for m in self._bn_list)
-        key = (B, bool(training), x.device.index, hash(bn_cfg), bool(want_maps), getattr(net, 'compute_dtype', 'f32'))
+        # a forward no backward will follow (torch.no_grad(): evaluation, the fwd + loss metric) takes a plan whose pooled trunk layers
+        # never write their full-resolution raw maps (GSSD_CONV_POOL2, _Plan._conv_bn); net.pooled_raw = False keeps one plan form
+        nograd = (not need_backward) and bool(getattr(net, 'pooled_raw', True))
+        key = (B, bool(training), x.device.index, hash(bn_cfg), bool(want_maps), getattr(net, 'compute_dtype', 'f32'), nograd)
         plans = self._plans.setdefault(key, [])
         plan = next((pl for pl in plans if not pl.busy), None)
         if plan is None:
             if len(plans) >= self.MAX_PLANS_IN_FLIGHT:
                 raise _lib.GssdError(f'{len(plans)} forwards of batch {B} are still waiting for their backward; free their '
                                      f'outputs (or call backward) before running more')
-            plan = self._build(B, bool(training), x.device, bool(want_maps))
+            plan = self._build(B, bool(training), x.device, bool(want_maps), nograd)
             plans.append(plan)
             vers, ptrs = self._state()
         self._ptrs = ptrs
@@ -178,7 +183,7 @@ class GssdEngine:
         return loc, conf, plan
 
     def forward(self, x, training, events=None, want_maps=False):
-        loc, conf, _ = self.forward_plan(x, training, events, want_maps)
+        loc, conf, _ = self.forward_plan(x, training, events, want_maps, need_backward=False)
         return loc, conf
 
     # ------------------------------------------------------------------------------------------
@@ -221,10 +226,10 @@ class GssdEngine:
         for job in rest:
             job()
 
-    def _build(self, B, training, dev, want_maps=False):
+    def _build(self, B, training, dev, want_maps=False, nograd=False):
         if getattr(self.net, 'vanilla', False):
             return _PlanVanilla(self, B, training, dev)
-        return _Plan(self, B, training, dev, want_maps)
+        return _Plan(self, B, training, dev, want_maps, nograd)
 
 
 class _RecList(list):
@@ -246,6 +251,8 @@ class _PlanBase:
     _bwd = None
 
     def backward_plan(self):
+        if getattr(self, 'nograd', False):
+            raise _lib.GssdError('this forward plan was built for a forward without backward (its pooled layers kept no raw maps)')
         if self._bwd is None:
             from .backward import BackwardPlan, Bf16Shadow
             # bf16 storage mode: the fp32 backward plan over fp32 copies of the stored bf16 activations (mixed precision)
@@ -254,8 +261,9 @@ class _PlanBase:
 
 
 class _Plan(_PlanBase):
-    def __init__(self, eng, B, training, dev, want_maps=False):
+    def __init__(self, eng, B, training, dev, want_maps=False, nograd=False):
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
+        self.nograd = nograd                       # no backward will read this plan's activations
         self.want_maps = want_maps                 # visualize=True: also materialise the attention maps
         # BASELINE.json configs[4]: bf16 NHWC activations + bf16 packed weights + bf16 MFMA, fp32 accumulation / BatchNorm
         # statistics / softmax / offsets / loc + conf / loss / NMS (net.compute_dtype = 'bf16'; parameters stay fp32 masters)
@@ -579,8 +587,37 @@ class _Plan(_PlanBase):
                 return ops.winograd_weight(self.eng._packed[key], groups, cin_g, out)
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
-        raw = self._abuf(B, Ho, Ho, Cout)
         st = self.eng_stat(bn)
+        # Pooled trunk layers of a no-backward forward (conv1_2, conv2_2, conv3_3): max-pooling commutes with the monotone BatchNorm +
+        # ReLU, and the direction of monotonicity is the sign of the BatchNorm weight, known before the launch.  The conv's epilogue
+        # writes max- (gamma >= 0) or min- (gamma < 0) pooled RAW outputs, a quarter of the map, with the batch sums of the full map;
+        # the separate BatchNorm + ReLU + pool pass disappears and the next conv applies the deferred BatchNorm + ReLU to the pooled
+        # raw map on read: bit-identical activations (include/gssd_hip.h: GSSD_CONV_POOL2), the full-resolution raw map is never
+        # written or re-read (conv1_2 in bf16: 369 MB written + 369 MB re-read + 92 MB written become 92 MB written).
+        cout_g = Cout // groups
+        pooled = (self.nograd and relu and pool is not None and pool[:3] == (2, 2, 0) and (pool[3] or Ho % 2 == 0) and k == 3 and s == 1
+                  and p == 1 and dl == 1 and groups == 4 and
+                  ((U is not None) if not self.bf16 else ((cin_g, cout_g) in ((16, 16), (32, 32)) and Ho % 2 == 0 and Ho * Ho >= 75 * 75)))
+        if pooled:
+            Hp = ops.pool_out_size(Ho, 2, 2, 0, pool[3])
+            raw = self._abuf(B, Hp, Hp, Cout)
+            d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
+                                         stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
+                                         stats=st if self.training else None,
+                                         in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
+                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2, pool_sign=bn.weight.detach())
+            self._add(self.conv_fn, (C.byref(d),), keep=d)
+            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._abuf(Cout)
+            self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
+                      (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
+            self.rec.append(('convbn', dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho,
+                                            Cout=Cout, desc=d, stats=st, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl, out=raw,
+                                            Hp=Hp, xf=(sc, sh, pd), pooled=True)))
+            self._layer = None
+            return raw, Hp, Cout, (sc, sh, pd)
+        raw = self._abuf(B, Ho, Ho, Cout)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                      stats=st if self.training else None,

@@ -162,7 +162,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0):
+                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -178,6 +178,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.split_k = split_k
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.wgt_wino = _p(wgt_wino)
+    d.pool_sign = _p(pool_sign)
     d.out_b_stride = out_b_stride
     d.flags = flags
     d.in_batch_stride, d.wgt_batch_stride = in_batch_stride, wgt_batch_stride

@@ -20,7 +20,7 @@ _TRUNK = (('conv1_1', 'conv1_2'), ('conv2_1', 'conv2_2'), ('conv3_1', 'conv3_2',
 
 
 class PixelLinkEngine(GssdEngine):
-    def _build(self, B, training, dev, want_maps=False):
+    def _build(self, B, training, dev, want_maps=False, nograd=False):
         return _PlanPixelLink(self, B, training, dev)
 
     def forward(self, x, training, events=None):

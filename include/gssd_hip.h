@@ -105,6 +105,8 @@ typedef struct gssd_conv_desc {
                            accumulated with fp64 atomics (BatchNorm batch statistics), or NULL */
     const float* wgt_wino; /* optional Winograd F(2x2,3x3) form of `wgt` (gssd_winograd_weight_f32): 3x3 / stride 1 / pad 1
                               convs of a Winograd shape (see gssd_winograd_weight_f32) then take the Winograd kernel; NULL = never */
+    const float* pool_sign; /* flags & GSSD_CONV_POOL2 only: per-output-channel BatchNorm weight (gamma) of the layer's own BatchNorm;
+                               only its SIGN is read (see GSSD_CONV_POOL2) */
     int B, H, W;        /* input geometry */
     int in_stride;      /* floats between consecutive input pixels */
     int in_ch_off;      /* first input channel used */
@@ -143,6 +145,15 @@ int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
  * with plain stores to out + k * B * out_batch_stride (and out_b + k * B * outb_batch_stride); gssd_heads_reduce_f32 then adds
  * the slices in order: run-to-run identical loc / conf */
 #define GSSD_CONV_HEADS_SLICES 4
+/* Both entry points; trunk layers that are followed by BatchNorm + ReLU + a 2x2 / stride-2 max-pool (conv1_2, conv2_2, conv3_3) when
+ * no backward will read the raw map: `out` is the POOLED raw map [B][ceil(Ho/2)][ceil(Wo/2)][Cout] -- per channel the maximum of the
+ * 2x2 window's raw outputs where pool_sign[c] >= 0, the minimum where it is negative (ceil mode: windows cut by the border take
+ * what exists).  Max-pooling commutes with a monotone map, and y -> max(y * scale + shift, 0) is non-decreasing for scale >= 0 and
+ * non-increasing for scale < 0, sign(scale) = sign(gamma): the consumer's deferred BatchNorm + ReLU of this pooled map is BIT-IDENTICAL
+ * to BatchNorm + ReLU + max-pool of the full map, which is then never written or re-read (the BatchNorm batch sums in `stats` are
+ * still those of the full map).  Only the kernels that support it accept the flag (fp32: the Winograd trunk kernels; bf16: the thin
+ * kernels with 16 / 32 output channels per group); everything else returns GSSD_EINVAL. */
+#define GSSD_CONV_POOL2 8
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,

@@ -152,6 +152,54 @@ def test_conv_flat_bf16(dev, Cin, Cout, H, W, xf, bm):
     assert rel(stats[Cout:] / n, (ref.double() ** 2).mean(dim=(0, 2, 3))) < (1e-5 if not xf else 2e-3)
 
 
+@pytest.mark.parametrize('Cin,Cout,H', [(64, 64, 84), (128, 128, 78)])
+@pytest.mark.parametrize('xf', [False, True])
+def test_conv_thin_bf16_pooled_epilogue(dev, Cin, Cout, H, xf):
+    """GSSD_CONV_POOL2 on the thin bf16 kernels (conv1_2 / conv2_2 of a no-backward forward): the launch stores the 2x2 max-pooled raw map
+    where the BatchNorm weight is >= 0 and the min-pooled one where it is negative, with the batch sums of the FULL map; the consumer's
+    deferred BatchNorm + ReLU of that map equals BatchNorm + ReLU + max-pool of the full map bit for bit (checked here on the stored
+    values with both signs of gamma, ragged tiles, an odd-column border)."""
+    from gssd import ops, _lib
+    import ctypes as C
+    rng = np.random.default_rng(Cin + H)
+    B, g = 2, 4
+    x = q(torch.from_numpy(rng.normal(0.2, 1.0, size=(B, Cin, H, H)).astype(np.float32)))
+    w = q(torch.from_numpy(rng.normal(0, 0.08, size=(Cout, Cin // g, 3, 3)).astype(np.float32)))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    gamma = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))              # both signs
+    gamma[3] = 0.0
+    act, sc, sh, pdv = x, None, None, None
+    if xf:
+        scv = torch.from_numpy(rng.uniform(-1.5, 1.5, size=Cin).astype(np.float32))
+        shv = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+        act = q(torch.relu(torch.addcmul(shv.view(1, -1, 1, 1), x, scv.view(1, -1, 1, 1))))
+        sc, sh, pdv = scv.to(dev), shv.to(dev), torch.zeros(Cin, device=dev, dtype=torch.bfloat16)
+    ref = torch.nn.functional.conv2d(act, w, b, 1, 1, 1, g)
+    wp = ops.pack_weight_bf16(w.to(dev))
+    Hp = (H + 1) // 2
+    out = torch.full((B, Hp, Hp, Cout), float('nan'), device=dev, dtype=torch.bfloat16)
+    full = torch.empty(B, H, H, Cout, device=dev, dtype=torch.bfloat16)
+    stats, stats_full = torch.zeros(2 * Cout, dtype=torch.float64, device=dev), torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    gd_ = gamma.to(dev)
+    kw = dict(B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g, k=3, stride=1, pad=1, bias=b.to(dev), in_scale=sc,
+              in_shift=sh, in_pad=pdv)
+    d, _, _ = ops.make_conv_desc(nhwc(x).to(dev).to(torch.bfloat16), wp, out, stats=stats, flags=_lib.CONV_POOL2, pool_sign=gd_, **kw)
+    d0, _, _ = ops.make_conv_desc(nhwc(x).to(dev).to(torch.bfloat16), wp, full, stats=stats_full, **kw)
+    st_ = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib.gssd_conv2d_nhwc_bf16(C.byref(d), st_))
+    _lib.check(_lib.lib.gssd_conv2d_nhwc_bf16(C.byref(d0), st_))
+    # exactly the pooled image of what the plain launch stores, and the same batch sums
+    want = pool_by_sign(nchw(full.float().cpu()), gamma)
+    assert torch.equal(nchw(out.float().cpu()), want)
+    assert rel(stats, stats_full) < 1e-13                                  # the same fp32 additions in the same order (fp64 atomics: last bits)
+    assert rel(nchw(out.float()), q(pool_by_sign(ref, gamma))) < (1.01 if not xf else 2.0) * BF_ULP
+    # the identity the trick rests on: deferred BatchNorm + ReLU of the pooled map == max-pool(BatchNorm + ReLU(full map))
+    scale = gamma * 0.7
+    shift = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    f = lambda t: torch.relu(torch.addcmul(shift.view(1, -1, 1, 1), t, scale.view(1, -1, 1, 1)))
+    assert torch.equal(f(want), torch.nn.functional.max_pool2d(f(nchw(full.float().cpu())), 2, 2, 0, ceil_mode=True))
+
+
 @pytest.mark.parametrize('Cin,Cout,H,k,st,pd', [(64, 64, 40, 3, 1, 1), (128, 128, 40, 3, 1, 1), (512, 512, 19, 3, 1, 1),
                                                (1024, 1024, 19, 1, 1, 0), (256, 512, 19, 3, 2, 1), (256, 256, 77, 3, 1, 1)])
 def test_conv_bf16_fused_input_bn_relu(dev, Cin, Cout, H, k, st, pd):
@@ -255,6 +303,14 @@ NETS = {
 }
 
 
+def pool_by_sign(raw, gamma):
+    """What a GSSD_CONV_POOL2 launch stores: 2x2 / stride-2 ceil-mode max-pool of the raw map where gamma >= 0, min-pool elsewhere."""
+    F = torch.nn.functional
+    mx = F.max_pool2d(raw, 2, 2, 0, ceil_mode=True)
+    mn = -F.max_pool2d(-raw, 2, 2, 0, ceil_mode=True)
+    return torch.where(gamma.view(1, -1, 1, 1) >= 0, mx, mn)
+
+
 def _layer_local_checks(plan, net, name):
     """Teacher-forced parity at full network scale: every stage of the HIP bf16 plan is recomputed on the CPU FROM THE HIP PATH'S OWN
     STORED INPUT of that stage (so rounding flips do not cascade) and must agree within one bf16 ulp (a few for the sampled /
@@ -274,6 +330,8 @@ def _layer_local_checks(plan, net, name):
                     xin.shape[0], -1, *xin.shape[2:])
             ref_raw = F.conv2d(xin, q(conv.weight.detach().cpu()), conv.bias.detach().cpu(), r['stride'], r['pad'], r['dil'], r['groups'])
             raw = nchw(r['raw'].float().cpu())
+            if r.get('pooled'):          # GSSD_CONV_POOL2: max- / min-pooled raw map (by the sign of the BatchNorm weight), ceil mode
+                ref_raw = pool_by_sign(ref_raw, bn.weight.detach().cpu())
             worst[r['name'] + '.raw'] = rel(raw, q(ref_raw))
             if r['xf'] is None:
                 mean = ref_raw.mean(dim=(0, 2, 3))
@@ -386,6 +444,9 @@ def _layer_local_checks_sampled(plan, imgs):
                     xin.shape[0], -1, *xin.shape[2:])
             ref_raw = F.conv2d(xin, q(conv.weight.detach().cpu()), conv.bias.detach().cpu(), r['stride'], r['pad'], r['dil'], r['groups'])
             raw = nchw(r['raw'][ii].float().cpu())
+            if r.get('pooled'):
+                worst[r['name'] + '.raw'] = rel(raw, q(pool_by_sign(ref_raw, bn.weight.detach().cpu())))
+                continue
             worst[r['name'] + '.raw'] = rel(raw, q(ref_raw))
             Cc = r['Cout']
             n = float(r['raw'].shape[0] * r['Ho'] * r['Ho'])

@@ -539,6 +539,61 @@ def test_dcn_fused_vs_scalar_restatement(dev, ops, B, Cc, H, dg, Cout, std):
     assert np.abs(a - bq)[sel].max() / np.abs(a).max() < TOL
 
 
+@pytest.mark.parametrize('Cin,Cout,H,W', [(64, 64, 84, 84), (128, 128, 78, 78), (256, 256, 75, 75), (256, 256, 21, 37)])
+@pytest.mark.parametrize('xf', [False, True])
+def test_conv_winograd_pooled_epilogue(dev, ops, Cin, Cout, H, W, xf):
+    """GSSD_CONV_POOL2 on the fp32 Winograd trunk kernels (conv1_2: conv_thin_wino, conv2_2: conv_wino<32>, conv3_3: conv_wino<64> with
+    its ceil-mode 75 -> 38 pool; a non-square map): the launch stores max- / min-pooled raw outputs by the sign of the BatchNorm weight
+    with the batch sums of the full map -- exactly the pooled image of what the plain launch stores -- and the deferred BatchNorm +
+    ReLU of that map equals BatchNorm + ReLU + max-pool of the full map bit for bit."""
+    import ctypes as C
+    from gssd import _lib
+    F = torch.nn.functional
+    rng = np.random.default_rng(Cin + H)
+    B, g = 2, 4
+    x = torch.from_numpy(rng.normal(0.2, 1.0, size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.08, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    gamma = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    gamma[5] = 0.0
+    act, sc, sh, pdv = x, None, None, None
+    if xf:
+        scv = torch.from_numpy(rng.uniform(0.2, 1.5, size=Cin).astype(np.float32)) * torch.from_numpy(rng.choice([-1.0, 1.0], size=Cin).astype(np.float32))
+        shv = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+        act = torch.relu(x * scv.view(1, -1, 1, 1) + shv.view(1, -1, 1, 1))
+        sc, sh = scv.to(dev), shv.to(dev)
+        pdv = torch.where(sc > 0, torch.full_like(sc, -3.0e38), torch.full_like(sc, 3.0e38))
+    ref = F.conv2d(act, w, b, 1, 1, 1, g)
+    wp = ops.pack_weight(w.to(dev))
+    U = ops.winograd_weight(wp, g, Cin // g)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    out = torch.full((B, Hp, Wp, Cout), float('nan'), device=dev)
+    full = torch.empty(B, H, W, Cout, device=dev)
+    stats, stats_full = torch.zeros(2 * Cout, dtype=torch.float64, device=dev), torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    gd_ = gamma.to(dev)
+    kw = dict(B=B, H=H, W=W, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g, k=3, stride=1, pad=1, bias=b.to(dev), wgt_wino=U,
+              in_scale=sc, in_shift=sh, in_pad=pdv)
+    d, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, out, stats=stats, flags=_lib.CONV_POOL2, pool_sign=gd_, **kw)
+    d0, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, full, stats=stats_full, **kw)
+    st_ = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib.gssd_conv2d_nhwc_f32(C.byref(d), st_))
+    _lib.check(_lib.lib.gssd_conv2d_nhwc_f32(C.byref(d0), st_))
+
+    def pool_by_sign(raw):
+        mx, mn = F.max_pool2d(raw, 2, 2, 0, ceil_mode=True), -F.max_pool2d(-raw, 2, 2, 0, ceil_mode=True)
+        return torch.where(gamma.view(1, -1, 1, 1) >= 0, mx, mn)
+    want = pool_by_sign(nchw(full.cpu()))
+    assert torch.equal(nchw(out.cpu()), want)                               # the pooled image of the plain launch's output, bit for bit
+    assert rel(stats, stats_full) < 1e-13                                  # the same fp32 additions in the same order (fp64 atomics: last bits)
+    assert rel(nchw(out), pool_by_sign(ref)) < TOL                          # (Winograd F(2x2, 3x3) vs direct: 1e-4 of the tensor's scale)
+    scale, shift = gamma * 0.7, torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    f = lambda t: torch.relu(torch.addcmul(shift.view(1, -1, 1, 1), t, scale.view(1, -1, 1, 1)))
+    assert torch.equal(f(want), F.max_pool2d(f(nchw(full.cpu())), 2, 2, 0, ceil_mode=True))
+    # a shape no pooled epilogue exists for is refused loudly, not computed unpooled
+    d1, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, out, flags=_lib.CONV_POOL2, pool_sign=gd_, **{**kw, 'wgt_wino': None})
+    assert _lib.lib.gssd_conv2d_nhwc_f32(C.byref(d1), st_) == -1
+
+
 def test_sa_backward_building_blocks(dev):
     """gssd_bgemm_f32 (all four transpose forms, ragged sizes, batched), the row softmax backward, the spectral-norm chain rule and
     the small helpers of csrc/sa_backward.hip against torch-CPU."""
@@ -896,6 +951,46 @@ def test_end_to_end_seed_sweep_margin(dev, name):
         with open(os.path.join(d, f'parity_margin_{name}.txt'), 'w') as f:
             f.write('\n'.join(lines) + '\n')
     assert worst < TOL, lines[-1]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_pooled_raw_plans_are_bit_identical(dev, dtype):
+    """A forward that no backward follows (torch.no_grad()) runs a plan whose pooled trunk layers store max- / min-pooled RAW maps (by the
+    sign of the BatchNorm weight, GSSD_CONV_POOL2) and skip the BatchNorm + ReLU + pool pass; `net.pooled_raw = False` keeps the
+    ordinary plan.  Max-pooling commutes with the monotone BatchNorm + ReLU, so the two plans must agree BIT FOR BIT -- outputs and
+    the running statistics they update -- with positive, negative and zero BatchNorm weights on the pooled layers."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    flags, args = NETS['gssdpp']
+    net = build_ssd('train', 300, 2, *args)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
+    for k in ('vgg.4.weight', 'vgg.11.weight', 'vgg.21.weight'):           # BatchNorms of conv1_2, conv2_2, conv3_3
+        g = sd[k].clone()
+        g[1::3] *= -1.0
+        g[5] = 0.0
+        sd[k] = g
+    x = synth.synth_images(4, seed=5).to(dev)
+    outs = {}
+    for pooled in (True, False):
+        net.load_state_dict(sd)
+        net = net.to(dev).train()
+        net.compute_dtype = dtype
+        net.pooled_raw = pooled
+        with torch.no_grad():
+            loc, conf, _ = net(x)
+        plan = net._engine._last_plan
+        npool = sum(1 for kind, r in plan.rec if kind == 'convbn' and r.get('pooled'))
+        assert npool == ((3 if dtype == 'f32' else 2) if pooled else 0), npool
+        outs[pooled] = (loc.clone(), conf.clone(), {k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+    print('pooled vs unpooled plan: max |d loc|', float((outs[True][0] - outs[False][0]).abs().max()), 'max |d conf|',
+          float((outs[True][1] - outs[False][1]).abs().max()))
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for k, v in outs[True][2].items():
+        assert torch.equal(v, outs[False][2][k]), k
+    # and a grad-enabled forward never takes the pooled plan (its backward needs the raw maps)
+    net.pooled_raw = True
+    net.compute_dtype = 'f32'
+    loc, conf, _ = net(x)
+    assert loc.requires_grad and not any(r.get('pooled') for kind, r in net._engine._last_plan.rec if kind == 'convbn')
 
 
 FLAG_NETS = {       # tests/golden/make_golden_flags.py: (oracle flags, build_ssd positional args, parameters whose gradients are compared)
