@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bf16_kernel(
             mean = (double)running_mean[c];
             var = (double)running_var[c];
         }
-        // gamma / sqrt(var + eps) exactly as gssd_bn_finalize_* computes it: a layer gives the same activations whether its
+        // gamma * (1 / sqrt(var + eps)) exactly as gssd_bn_finalize_* computes it: a layer gives the same activations whether its
         // BatchNorm runs in this pass or deferred in its consumer (pooled and unpooled plans agree bit for bit)
-        const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+        const double inv = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[c] * inv;
         s_scale[c] = (float)sc;
         s_shift[c] = (float)((double)beta[c] - mean * sc);
     }
@@ -129,7 +130,7 @@ __global__ void bn_finalize_bf16_kernel(const double* __restrict__ stats, double
         mean = (double)running_mean[c];
         var = (double)running_var[c];
     }
-    double sc = (double)gamma[c] / sqrt(var + (double)eps);
+    double sc = (double)gamma[c] * (1.0 / sqrt(var + (double)eps));      // (the pool pass's form)
     const float sh = (float)((double)beta[c] - mean * sc);
     float scf = (float)sc;
     if (scf == 0.f) scf = 1e-30f;

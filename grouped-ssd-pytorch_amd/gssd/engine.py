@@ -595,7 +595,7 @@ class _Plan(_PlanBase):
         # raw map on read: bit-identical activations (include/gssd_hip.h: GSSD_CONV_POOL2), the full-resolution raw map is never
         # written or re-read (conv1_2 in bf16: 369 MB written + 369 MB re-read + 92 MB written become 92 MB written).
         cout_g = Cout // groups
-        pooled = (self.nograd and relu and pool is not None and pool[:3] == (2, 2, 0) and (pool[3] or Ho % 2 == 0) and k == 3 and s == 1
+        pooled = (getattr(self, 'nograd', False) and relu and pool is not None and pool[:3] == (2, 2, 0) and (pool[3] or Ho % 2 == 0) and k == 3 and s == 1
                   and p == 1 and dl == 1 and groups == 4 and
                   ((U is not None) if not self.bf16 else ((cin_g, cout_g) in ((16, 16), (32, 32)) and Ho % 2 == 0 and Ho * Ho >= 75 * 75)))
         if pooled:

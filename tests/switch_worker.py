@@ -29,6 +29,8 @@ def main():
         for _ in range(3):                      # the third forward replays from hipGraphs (unless GSSD_NO_GRAPH)
             net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
             loc0, conf0, _ = net(x)
+    graphs = len(getattr(net._engine._last_plan, '_graphs', {}) or {})      # the no-backward plan of the three forwards above
+    kernels0 = sorted({st.tag[0] for st in net._engine._last_plan.steps if st.tag is not None})
     net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
     loc, conf, pri = net(x)
     ll, lc = crit((loc, conf, pri), tg)
@@ -44,8 +46,7 @@ def main():
                loss=[float(ll), float(lc)],
                gnorm={k: float(named[k].grad.norm()) for k in keys},
                gsample={k: named[k].grad.reshape(-1)[:64].cpu().tolist() for k in keys},
-               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None}),
-               graphs=len(getattr(plan, '_graphs', {}) or {}))
+               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None} | set(kernels0)), graphs=graphs)
     print('SWITCHJSON ' + json.dumps(out))
 
 
