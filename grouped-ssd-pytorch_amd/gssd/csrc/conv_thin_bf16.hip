@@ -41,6 +41,9 @@
 // stamps put a conv2_1 tile at ~27 k cycles per workgroup for ~105 KB moved = 7.8 B/cycle per CU with two workgroups resident --
 // the combined load + store rate one CU's memory pipe sustains (a device-wide copy runs 5.2 .. 5.5 TB/s = 9 B/cycle/CU).  What these
 // kernels lose against a copy is phase overlap inside the CU (load -> wait -> MFMA -> store per workgroup), not store efficiency.
+// Also rejected: a per-lane table of the staging instructions' patch offsets (one add + select per DMA instead of the division by the
+// patch width, the swizzle and the bounds arithmetic; a wave-uniform interior-tile fast path): conv1_2 234 us, conv2_2 226 us against
+// 217 / 192 us -- its 2 x 11 registers cost more (three workgroups per CU leave 170 VGPRs) than the ~300 VALU instructions per tile save.
 #include <stdlib.h>
 #include "common.h"
 
