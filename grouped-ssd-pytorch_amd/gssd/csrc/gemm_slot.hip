@@ -50,7 +50,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // BN = 256: one workgroup per CU (96 KB of LDS, 128 accumulator registers per lane);  BN = 128: two per CU (64 KB, 64 registers) --
 // the second one's MFMAs cover the first one's prologue / epilogue, which is what short reductions (K <= 512) and grids of about one
 // round need.
-template <int BN>
+// SWAP (NHWC outputs): the MFMA takes the weight fragment as its first operand, so the accumulator tile is [channel 4 kq + e][pixel r]
+// -- a lane holds FOUR CONSECUTIVE CHANNELS of one pixel and the epilogue moves 16 bytes per instruction (bias, 1/sigma, gated
+// residual, second output, statistics): the pixel-major form spends 3 x 64 four-byte memory instructions per wave on the Self_Attn
+// output conv (K = 256: its 8 chunks of MFMAs were a third of the tile's time).  The transposed outputs keep the pixel-major form
+// (there four consecutive PIXELS of one channel are the 16-byte unit).
+template <int BN, bool SWAP>
 __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles) {
     constexpr int WTN = BN / 2, NT = WTN / 16, B_STAGE = BN * BK, NBP = BN / 32;     // NBP: B DMA pieces per wave per chunk
     constexpr int SL = MT * NT * 8;                                                  // MFMAs (slots) per chunk
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const
         constexpr int KK = decltype(kc)::value;
         constexpr bool stage = decltype(stage_c)::value;
         constexpr int ks = KK / (SL / 2), s = (KK / (MT * NT)) & 3, i = (KK / NT) & 3, j = KK % NT;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
+        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ks][j][s], af[ks][i][s], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][i][s], bf[ks][j][s], acc[i][j], 0, 0, 0);
         if constexpr (KK < MT) af[1][KK] = *reinterpret_cast<const f32x4*>(Ab + KK * 16 * BK + fo1);
         if constexpr (KK >= MT && KK < MT + NT) bf[1][KK - MT] = *reinterpret_cast<const f32x4*>(Bb + (KK - MT) * 16 * BK + fo1);
         if constexpr (stage) {
@@ -189,6 +195,83 @@ __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const
 
     // ---- epilogue (conv_igemm's, groups == 1, no split-K, no head layout).  One workgroup per CU: nothing overlaps this phase, so the
     //      common store path is kept to one FMA + one store per element (row pointers hoisted, statistics only when asked for) ------
+    if constexpr (SWAP) {
+        // acc[i][j][e]: channel n0 + wn*WTN + 16 j + 4 kq + e, pixel m0 + wm*WTM + 16 i + r   (NHWC outputs only)
+        const float gate = p.gate ? *p.gate : 0.f;
+        const bool want_stats = p.stats != nullptr;
+        float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + 4 * kq;
+            if (n >= p.Cout) continue;                             // (Cout is a multiple of 4 on this path: slot_shape)
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, alpha4 = {1.f, 1.f, 1.f, 1.f};
+            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.alpha) alpha4 = *reinterpret_cast<const f32x4*>(p.alpha + n);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + r;
+                if (m >= M) continue;
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(acc[i][j][e], alpha4[e], bias4[e]);
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ssum[j][e] += t[e];
+                        ssq[j][e] = __builtin_fmaf(t[e], t[e], ssq[j][e]);
+                    }
+                }
+                const size_t o = (size_t)img * p.out_batch_stride + (size_t)m * p.out_stride + p.out_ch_off + n;
+                if (p.gate) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= gate;
+                    if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + o) = t;
+                }
+                if (p.resid) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.resid + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] += rv[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(p.out + o) = t;
+            }
+        }
+        if (p.stats) {
+            // per-channel sums over this tile's rows: the 16 lanes sharing kq hold 16 pixels of the same channels
+            __syncthreads();
+            float* red = smem;  // [2][BN][2]
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = ssum[j][e], qv = ssq[j][e];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        sv += __shfl_xor(sv, o, 64);
+                        qv += __shfl_xor(qv, o, 64);
+                    }
+                    if (r == 0) {
+                        red[(wm * BN + wn * WTN + j * 16 + 4 * kq + e) * 2 + 0] = sv;
+                        red[(wm * BN + wn * WTN + j * 16 + 4 * kq + e) * 2 + 1] = qv;
+                    }
+                }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Cout) {
+                const double sv = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
+                const double qv = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+                unsafeAtomicAdd(p.stats + n0 + tid, sv);
+                unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, qv);
+            }
+        }
+        return;
+    }
     const float gate = p.gate ? *p.gate : 0.f;
     const bool want_stats = p.stats != nullptr;
     const bool plain = p.out_mode == GSSD_OUT_NHWC && !p.gate && !p.resid;
@@ -345,7 +428,7 @@ static int slot_shape(const gssd_conv_desc& d) {
 
 extern "C" int gssd_gemm_slot_takes(const gssd_conv_desc* d) { return d && slot_shape(*d) ? 1 : 0; }
 
-template <int BN>
+template <int BN, bool SWAP>
 static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
     const long long M = (long long)(d.m_per_image ? 1 : d.B) * d.Ho * d.Wo;
     const int images = d.m_per_image ? d.B : 1;
@@ -353,7 +436,7 @@ static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
     static unsigned attr_mask = 0;
     constexpr int smem = 2 * (A_STAGE + BN * BK) * (int)sizeof(float);
     if (gssd_attr_needed(&attr_mask) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel<BN, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
         return GSSD_ELAUNCH;
     }
@@ -365,7 +448,7 @@ static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
     } else {
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
-    hipLaunchKernelGGL(gemm_slot_kernel<BN>, dim3(blocks, 1, images), dim3(256), smem, stream, d, (int)M, ntn, mtiles);
+    hipLaunchKernelGGL((gemm_slot_kernel<BN, SWAP>), dim3(blocks, 1, images), dim3(256), smem, stream, d, (int)M, ntn, mtiles);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -373,7 +456,15 @@ static int launch_slot(const gssd_conv_desc& d, hipStream_t stream) {
 // returns 1 when the descriptor is not a plain 1x1 / GEMM shape worth a slot stream (the caller falls through to conv_igemm)
 int gssd_try_gemm_slot(const gssd_conv_desc& d, hipStream_t stream) {
     const int cls = slot_shape(d);
-    if (cls == 256) return launch_slot<256>(d, stream);
-    if (cls == 128) return launch_slot<128>(d, stream);
+    // channel-major accumulators (16-byte epilogue accesses) for NHWC outputs with 16-byte aligned channel vectors; GSSD_GEMM_SLOT_SWAP=0
+    // keeps the pixel-major form everywhere (ablation)
+    static const bool no_swap = getenv("GSSD_GEMM_SLOT_SWAP") != nullptr && atoi(getenv("GSSD_GEMM_SLOT_SWAP")) == 0;
+    // (measured: gated residual epilogues -- the Self_Attn output convs at 38 x 38 -- 223 -> 170 us and 195 -> 144 us; plain NHWC epilogues
+    // with statistics -- the fuse convs -- 208 -> 231 us and 205 -> 214 us: those keep the pixel-major form)
+    const bool swap = !no_swap && d.out_mode == GSSD_OUT_NHWC && (d.gate || d.resid) && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
+                      ((uintptr_t)d.out % 16) == 0 && (!d.resid || ((uintptr_t)d.resid % 16) == 0) && (!d.out2 || ((uintptr_t)d.out2 % 16) == 0) &&
+                      (!d.bias || ((uintptr_t)d.bias % 16) == 0) && (!d.alpha || ((uintptr_t)d.alpha % 16) == 0) && d.out_batch_stride % 4 == 0;
+    if (cls == 256) return swap ? launch_slot<256, true>(d, stream) : launch_slot<256, false>(d, stream);
+    if (cls == 128) return swap ? launch_slot<128, true>(d, stream) : launch_slot<128, false>(d, stream);
     return 1;
 }

@@ -42,6 +42,7 @@ SWITCHES = [
      and any(k.startswith('conv_wino') for k in base['kernels'])),
     ('f32', {'GSSD_NO_GEMM_SLOT': '1'}, lambda o, base: True),
     ('f32', {'GSSD_NO_WGRAD_SLOT': '1'}, lambda o, base: True),
+    ('f32', {'GSSD_GEMM_SLOT_SWAP': '0'}, lambda o, base: True),
     ('bf16', {'GSSD_NO_CONV_FLAT': '1'}, lambda o, base: not any(k.startswith('conv_flat_bf16') for k in o['kernels'])
      and any(k.startswith('conv_flat_bf16') for k in base['kernels'])),
     ('bf16', {'GSSD_FLAT_BM': '128'}, lambda o, base: all(k.endswith(',128>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
