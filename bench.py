@@ -128,10 +128,10 @@ SURVEY_TRUNK_MB_F32 = 73.4 + 74.9 + 40.3 + 37.4 + 20.2 + 23.0 + 18.8 + 10.4 + 11
 
 
 def trunk_roofline(survey, n_pass, B, dtype):
-    """HBM roofline of the whole grouped-conv backbone: sum of the algorithmic bytes of every trunk launch (convs, their BatchNorm /
-    ReLU / pool passes) / sum of their durations, from the eager survey passes (every tagged launch bracketed by HIP events on the
-    launch stream).  Bytes are those of the pass structure AS BUILT (compulsory input + output + weights of each launch): deleting a
-    pass shrinks them, so the fraction cannot be raised by accounting."""
+    """HBM roofline of the whole grouped-conv backbone conv1_1 .. conv5_3: `achieved` = SURVEY.md 8(d)'s algorithmic bytes per image x
+    images / the summed durations of every trunk launch (convs AND their BatchNorm / ReLU / pool passes; HIP events around every launch
+    in the eager survey passes).  `as_built` gives the same with the compulsory bytes of the pass structure as built (input + output +
+    weights of each launch that still exists): deleting a pass shrinks those, so that fraction cannot be raised by accounting."""
     lay = {}
     for tag, e0, e1 in survey:
         name = TRUNK.get(getattr(tag, 'layer', None))
@@ -151,16 +151,20 @@ def trunk_roofline(survey, n_pass, B, dtype):
                    tflops=round(r[2] / r[0] / 1e9, 1), kernels=sorted(r[3])) for k, r in lay.items()}
     big = {k: v for k, v in per.items() if v['alg_mb'] >= 0.02 * by / 1e6}
     worst = min(big, key=lambda k: big[k]['gbs'])
-    ach = by / ms / 1e6
     survey_mb = SURVEY_TRUNK_MB_F32 * (0.5 if dtype == 'bf16' else 1.0)
+    ach = survey_mb * B / ms                          # MB / ms = GB/s
+    built = by / ms / 1e6
     return dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
                 traffic=None, kernel='trunk conv1_1 .. conv5_3 (convs + BN/ReLU/pool passes)', ms_per_step=round(ms, 4),
-                alg_bytes_per_step=round(by), alg_mb_per_img=round(by / B / 1e6, 2), tflops=round(fl / ms / 1e9, 1),
-                survey_accounting=dict(alg_mb_per_img=round(survey_mb, 1), gbs=round(survey_mb * B / ms, 1),
-                                       frac=round(survey_mb * B / ms / PEAK_HBM_GBS, 4),
-                                       note='SURVEY 8(d): every layer priced as conv in + raw out + BN re-read + activated write'),
+                alg_mb_per_img=round(survey_mb, 1), alg_bytes_per_step=round(survey_mb * 1e6 * B), tflops=round(fl / ms / 1e9, 1),
+                accounting='achieved = SURVEY.md 8(d)\'s algorithmic bytes of the trunk (every layer priced as conv in + raw out + BatchNorm '
+                           're-read + activated write; bf16 = half the fp32 figure) x images / measured trunk time: an EFFECTIVE rate, like '
+                           'direct-conv FLOPs for the Winograd kernels -- passes this build deleted (deferred BatchNorms, pooled raw maps) '
+                           'count as moved.  `as_built` prices only the bytes the pass structure as built still moves',
+                as_built=dict(alg_mb_per_img=round(by / B / 1e6, 2), alg_bytes_per_step=round(by), gbs=round(built, 1),
+                              frac=round(built / PEAK_HBM_GBS, 4)),
                 worst_layer=dict(layer=worst, **per[worst], frac=round(per[worst]['gbs'] / PEAK_HBM_GBS, 4)), layers=per,
-                note='eager survey passes, every launch bracketed; bytes = compulsory bytes of the pass structure as built')
+                note='eager survey passes, every trunk launch bracketed by HIP events on the launch stream')
 
 
 def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
@@ -211,7 +215,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                 tr = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json'))).get((cfg if dtype == 'f32' else f'{cfg}_{dtype}') + '_trunk')
                 if tr:
                     trunk['traffic'] = tr['hbm_bytes_per_step']
-                    trunk['traffic_over_alg'] = round(tr['hbm_bytes_per_step'] / trunk['alg_bytes_per_step'], 3)
+                    trunk['as_built']['traffic_over_bytes'] = round(tr['hbm_bytes_per_step'] / trunk['as_built']['alg_bytes_per_step'], 3)
             except (OSError, ValueError, KeyError):
                 pass
         events = EventList()
