@@ -20,6 +20,20 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef WINO_TIMING
+// debug build (scripts/wino_timing.py): wave 0 of every workgroup accumulates the shader clocks between its phase boundaries
+__device__ unsigned long long g_wino_timing[8];
+extern "C" int gssd_wino_timing_read(unsigned long long* out8) {
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wino_timing), 64);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_wino_timing), z, 64);
+    return 0;
+}
+#define WSTAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; }
+#else
+#define WSTAMP(k)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(16))) float g_zero_page_wino[4] = {0.f, 0.f, 0.f, 0.f};
@@ -42,9 +56,10 @@ struct WinoParams {
     double* stats;
     int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, cout_pad, out_stride, out_ch_off;
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
+    int vec_ok;                        // bias / resid / out / pool_sign pointers are 16-byte aligned
 };
 
-template <int NB, bool XF, bool PERSIST>
+template <int NB, bool XF, bool PERSIST, int EPI>      // EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     constexpr int NBT = NB / 16;                  // 16-wide output-channel tiles per wave
     constexpr int STAGE = 16 * NB * 16;           // floats per U stage: [xi][n][16 ci]
@@ -112,9 +127,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
         for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ssum[NBT], ssq[NBT];
+    f32x4 ssum[NBT], ssq[NBT];              // per-lane batch sums of channels n0 + nb*16 + 4*kq + j over the lane's tiles
 #pragma unroll
-    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 16-byte bias / residual / output accesses (every channel quad starts on a 16-byte boundary)
+    const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
 
     const int nchunks = p.cin_g >> 4;
     f32x4 raw[16];
@@ -135,6 +152,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         dma16(src, smem + buf * STAGE + pc * 256);
     };
 
+#ifdef WINO_TIMING
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     unsigned in_cur, valid_cur;
     decode(item, in_cur, valid_cur);
 #pragma unroll
@@ -154,6 +174,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         if (have_next) decode(item_next, in_next, valid_next);
         for (int c = 0; c < nchunks; ++c) {
             // ---- lane permutation + input transform of chunk c (registers) ---------------------------------------------------
+#ifdef WINO_TIMING
+            WSTAMP(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WSTAMP(1)
+#endif
             f32x4 V[16];
             {
                 f32x4 sc, sh, padq = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -187,8 +212,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);            // raw[] is dead from here on: the next step's loads reuse its registers
+#ifdef WINO_TIMING
+            asm volatile("s_nop 0" ::"v"(V[0][0]), "v"(V[15][3]));
+            WSTAMP(2)
+#endif
             __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): this wave's DMA pieces of the current stage have landed
             __syncthreads();                              // ... everyone's have; the other buffer is free again
+            WSTAMP(3)
             const bool last = c + 1 == nchunks;
             const bool more = !last || have_next;
             const unsigned ld_in = last ? in_next : in_cur;
@@ -217,79 +247,109 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int nb = 0; nb < NBT; ++nb)
-                        acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi][j], bf[xi & 1][nb][j], acc[xi][nb], 0, 0, 0);
+                        acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[xi & 1][nb][j], V[xi][j], acc[xi][nb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             buf ^= 1;
+#ifdef WINO_TIMING
+            asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[15][NBT - 1][3]));      // the MFMAs have retired
+#endif
+            WSTAMP(4)
         }
 
-        // ---- output transform + epilogue: lane holds M[tile 4*kq + e][co n0 + nb*16 + r] for all 16 xi -------------------------
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = (item * 4 + wv) * 16 + kq * 4 + e;
+        // ---- output transform + epilogue: lane (r, kq) holds M[co n0 + nb*16 + 4*kq + j][tile r] for all 16 xi (the MFMAs run with
+        // U as the A operand: four CONSECUTIVE output channels of ONE tile per accumulator quad -> one tile decode per lane, 16-byte
+        // bias / residual loads and stores; round 3: 64 four-byte stores and four tile decodes per lane before) ----------------------
+        {
+            const int t = (item * 4 + wv) * 16 + r;
             if (t < p.ntiles) {
                 const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
                 const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
                 const int y = 2 * ty, x = 2 * tx;
                 const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
-                const size_t o00 = ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + g * p.cout_g + n0 + r;
+                const int ch0 = g * p.cout_g + n0 + kq * 4;
+                const size_t o00 = EPI == 2 ? ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch0
+                                            : ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + ch0;
 #pragma unroll
                 for (int nb = 0; nb < NBT; ++nb) {
-                    if (n0 + nb * 16 + r >= p.cout_g) continue;       // padded output channels (cout_g not a multiple of NB)
-                    float s[2][4];
+                    const int nrem = p.cout_g - (n0 + nb * 16 + kq * 4);      // channels of this quad that exist (padded rows of U beyond)
+                    if (nrem <= 0) continue;
+                    f32x4 s0[4], s1[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {             // A^T M
-                        s[0][j] = acc[0 * 4 + j][nb][e] + acc[1 * 4 + j][nb][e] + acc[2 * 4 + j][nb][e];
-                        s[1][j] = acc[1 * 4 + j][nb][e] - acc[2 * 4 + j][nb][e] - acc[3 * 4 + j][nb][e];
+                    for (int j = 0; j < 4; ++j) {             // A^T M, four channels at a time
+                        s0[j] = acc[0 * 4 + j][nb] + acc[1 * 4 + j][nb] + acc[2 * 4 + j][nb];
+                        s1[j] = acc[1 * 4 + j][nb] - acc[2 * 4 + j][nb] - acc[3 * 4 + j][nb];
                     }
-                    const float bia = p.bias ? p.bias[g * p.cout_g + n0 + nb * 16 + r] : 0.f;
-                    if (p.pool_sign) {
+                    f32x4 bia = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) {
+                        if (vec && nrem >= 4) bia = *reinterpret_cast<const f32x4*>(p.bias + ch0 + nb * 16);
+                        else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) bia[j] = p.bias[ch0 + nb * 16 + j];
+                    }
+                    f32x4 v[2][2];
+                    v[0][0] = s0[0] + s0[1] + s0[2] + bia;
+                    v[0][1] = s0[1] - s0[2] - s0[3] + bia;
+                    v[1][0] = s1[0] + s1[1] + s1[2] + bia;
+                    v[1][1] = s1[1] - s1[2] - s1[3] + bia;
+                    auto put = [&](size_t o, const f32x4& val) {
+                        if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
+                        else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) p.out[o + j] = val[j];
+                    };
+                    if (EPI == 2) {
                         // GSSD_CONV_POOL2: a Winograd tile IS a pooling window (2 x 2 outputs at even coordinates): the lane reduces its
-                        // four outputs (those that exist, ceil mode) and stores one value at the pooled position (ty, tx)
-                        const int ch = g * p.cout_g + n0 + nb * 16 + r;
-                        const float v00 = s[0][0] + s[0][1] + s[0][2] + bia, v01 = s[0][1] - s[0][2] - s[0][3] + bia;
-                        const float v10 = s[1][0] + s[1][1] + s[1][2] + bia, v11 = s[1][1] - s[1][2] - s[1][3] + bia;
-                        // (the batch sums take the four outputs in the order the unpooled epilogue adds them: identical statistics)
-                        float mx = v00, mn = v00;
-                        ssum[nb] += v00;
-                        ssq[nb] = __builtin_fmaf(v00, v00, ssq[nb]);
-                        if (x1) {
-                            mx = fmaxf(mx, v01), mn = fminf(mn, v01);
-                            ssum[nb] += v01;
-                            ssq[nb] = __builtin_fmaf(v01, v01, ssq[nb]);
-                        }
-                        if (y1) {
-                            mx = fmaxf(mx, v10), mn = fminf(mn, v10);
-                            ssum[nb] += v10;
-                            ssq[nb] = __builtin_fmaf(v10, v10, ssq[nb]);
-                            if (x1) {
-                                mx = fmaxf(mx, v11), mn = fminf(mn, v11);
-                                ssum[nb] += v11;
-                                ssq[nb] = __builtin_fmaf(v11, v11, ssq[nb]);
-                            }
-                        }
-                        p.out[((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch] = p.pool_sign[ch] >= 0.f ? mx : mn;
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
+                        // four outputs (those that exist, ceil mode) and stores one value at the pooled position (ty, tx).  The batch
+                        // sums take the outputs in the order the unpooled epilogue adds them: identical statistics.
+                        f32x4 mx = v[0][0], mn = v[0][0];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if (a == 1 && !y1) continue;
-                        float v0 = s[a][0] + s[a][1] + s[a][2] + bia;
-                        float v1 = s[a][1] - s[a][2] - s[a][3] + bia;
-                        const size_t o = o00 + nb * 16 + (size_t)a * p.W * p.out_stride;
-                        if (p.resid) {
-                            v0 += p.resid[o];
-                            if (x1) v1 += p.resid[o + p.out_stride];
-                        }
-                        p.out[o] = v0;
-                        ssum[nb] += v0;
-                        ssq[nb] = __builtin_fmaf(v0, v0, ssq[nb]);
-                        if (x1) {
-                            p.out[o + p.out_stride] = v1;
-                            ssum[nb] += v1;
-                            ssq[nb] = __builtin_fmaf(v1, v1, ssq[nb]);
-                        }
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    mx[j] = fmaxf(mx[j], v[a][c2][j]);
+                                    mn[j] = fminf(mn[j], v[a][c2][j]);
+                                    ssum[nb][j] += v[a][c2][j];
+                                    ssq[nb][j] = __builtin_fmaf(v[a][c2][j], v[a][c2][j], ssq[nb][j]);
+                                }
+                            }
+                        f32x4 sg = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (vec && nrem >= 4) sg = *reinterpret_cast<const f32x4*>(p.pool_sign + ch0 + nb * 16);
+                        else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) sg[j] = p.pool_sign[ch0 + nb * 16 + j];
+                        f32x4 res;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) res[j] = sg[j] >= 0.f ? mx[j] : mn[j];
+                        put(o00 + nb * 16, res);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+                                const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
+                                f32x4 val = v[a][c2];
+                                if (EPI == 1) {
+                                    if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
+                                    else
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            if (j < nrem) val[j] += p.resid[o + j];
+                                }
+                                put(o, val);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    ssum[nb][j] += val[j];
+                                    ssq[nb][j] = __builtin_fmaf(val[j], val[j], ssq[nb][j]);
+                                }
+                            }
                     }
                     // keep the accumulator read-out in small groups: the next item's prefetched patch is live here, so hoisting
                     // all reads out of the AGPR file at once would not fit the 256 architectural VGPRs
@@ -297,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 }
             }
         }
+        WSTAMP(5)
         if (!have_next) break;
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi)
@@ -307,21 +368,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         valid_cur = valid_next;
     }
 
-    if (p.stats) {                                        // one flush per workgroup: lanes sharing r -> LDS over waves -> fp64 atomics
+    if (p.stats) {                                        // one flush per workgroup: the 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
         __syncthreads();                                  // all waves are done with the U stages
         float* red = smem;                                // [4 waves][NB][2]
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            float s = ssum[nb], q = ssq[nb];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (kq == 0) {
-                red[(wv * NB + nb * 16 + r) * 2 + 0] = s;
-                red[(wv * NB + nb * 16 + r) * 2 + 1] = q;
+        for (int nb = 0; nb < NBT; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = ssum[nb][j], q = ssq[nb][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (r == 0) {
+                    red[(wv * NB + nb * 16 + kq * 4 + j) * 2 + 0] = s;
+                    red[(wv * NB + nb * 16 + kq * 4 + j) * 2 + 1] = q;
+                }
             }
-        }
         __syncthreads();
         if (tid < NB && n0 + tid < p.cout_g) {
             double s = 0.0, q = 0.0;
@@ -335,6 +399,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
             unsafeAtomicAdd(p.stats + p.Cout + n, q);
         }
     }
+#ifdef WINO_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(6)
+    if (tid == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_wino_timing[k], tacc[k]);
+        atomicAdd(&g_wino_timing[7], 1ull);
+    }
+#endif
 }
 
 // packed K-major weights [Cout][tap * cin_g + ci] (row stride `ws`) -> U[g][xi][co][ci] = (G g G^T)_xi; rows cout_g..cout_pad-1
@@ -381,7 +453,7 @@ inline int wino_u_rows(int cout_g, int groups) {
     return cout_g % 16 == 0 ? cout_g : 0;
 }
 
-template <int NB, bool XF, bool PERSIST>
+template <int NB, bool XF, bool PERSIST, int EPI>
 int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     WinoParams p;
     p.in = d.in;
@@ -409,7 +481,8 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.tiles_x = (d.W + 1) / 2;
     p.ntiles = d.B * p.tiles_y * p.tiles_x;
     constexpr size_t smem = 2 * (size_t)16 * NB * 16 * sizeof(float);
-    auto kern = conv_wino_kernel<NB, XF, PERSIST>;
+    p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
+    auto kern = conv_wino_kernel<NB, XF, PERSIST, EPI>;
     static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
@@ -451,8 +524,15 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
     // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent.  (Round 2: the persistent NB = 32
     // variant forced onto the 64 / 128-channel layers measures 15-30 % slower -- conv3_2 489 vs 415 us, conv4_2 436 vs 336 us: it
     // transforms every input tile once per 32-channel block.)
-    if (wino_nb(cout_g, d.groups) == 64) return d.in_scale ? launch_wino<64, true, false>(d, stream) : launch_wino<64, false, false>(d, stream);
-    return d.in_scale ? launch_wino<32, true, true>(d, stream) : launch_wino<32, false, true>(d, stream);
+    const int epi = (d.flags & GSSD_CONV_POOL2) ? 2 : d.resid ? 1 : 0;
+#define WINO_GO(NB_, P_)                                                                                              \
+    (d.in_scale ? (epi == 2 ? launch_wino<NB_, true, P_, 2>(d, stream)                                               \
+                            : epi == 1 ? launch_wino<NB_, true, P_, 1>(d, stream) : launch_wino<NB_, true, P_, 0>(d, stream))   \
+                : (epi == 2 ? launch_wino<NB_, false, P_, 2>(d, stream)                                              \
+                            : epi == 1 ? launch_wino<NB_, false, P_, 1>(d, stream) : launch_wino<NB_, false, P_, 0>(d, stream)))
+    if (wino_nb(cout_g, d.groups) == 64) return WINO_GO(64, false);
+    return WINO_GO(32, true);
+#undef WINO_GO
 }
 
 extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g) {
