@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef WINO_TIMING
 // debug build (scripts/wino_timing.py): wave 0 of every workgroup accumulates the shader clocks between its phase boundaries
@@ -142,14 +143,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     };
     // U stage: 16 * NBT pieces of 1 KB; piece (xi, nb) = 16 rows (n) x 64 B; lane -> row lane >> 2, quad lane & 3.  Wave w
     // moves pieces w, w + 4, ...: slot s (0 .. 4*NBT-1) -> piece 4*s + w.
+    const unsigned u_lane = (unsigned)((((lane >> 2) * p.cin_g) + (((lane & 3) ^ ((lane >> 4) & 1)) << 2)) * 4);
     auto stage_U1 = [&](int c, int buf, int s4) {
         const int pc = 4 * s4 + wv;
         const int xi = pc / NBT, nb = pc - xi * NBT;
         // quads of row n sit at position quad ^ ((n >> 2) & 1): the eight lanes a ds_read_b128 serves per cycle (rows r..r+7,
         // 64 B apart) then cover all 64 banks instead of hitting 32 of them twice
-        const int row = lane >> 2;
-        const float* src = Ug + ((size_t)xi * p.cout_pad + nb * 16 + row) * p.cin_g + c * 16 + (((lane & 3) ^ ((row >> 2) & 1)) << 2);
-        dma16(src, smem + buf * STAGE + pc * 256);
+        // (uniform base + one 32-bit lane offset: no 64-bit VGPR address arithmetic per piece)
+        const unsigned off = u_lane + (unsigned)((((xi * p.cout_pad + nb * 16) * p.cin_g) + c * 16) * 4);
+        dma16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ug) + off), smem + buf * STAGE + pc * 256);
     };
 
 #ifdef WINO_TIMING
@@ -187,14 +189,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                     sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_mf + c * 16);
                     padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + c * 16);
                 }
+                // all 64 lane exchanges first, in place (one exposure of the LDS crossbar's latency per chunk instead of four), then the
+                // arithmetic one channel at a time (32 transient registers).  Round 3 measured the packed form (v_pk_add_f32 on channel
+                // pairs): 29.7k instead of 24.9k cycles per 8 chunks -- packed fp32 is no gain beside fp32 MFMAs, nor is dealing this
+                // work out between the MFMAs (the fp32 MFMA shares the vector ALU's fp32 lanes: a just-in-time transform inside the MFMA
+                // loop ran 13.1k cycles per chunk against 9.3k + 3.1k here)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {             // one channel at a time keeps the transient registers at 32
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) raw[q][e] = __shfl((valid_cur >> q) & 1 ? raw[q][e] : padq[e], perm_addr >> 2, 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
                     float d[16], t[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = __shfl((valid_cur >> q) & 1 ? raw[q][e] : padq[e], perm_addr >> 2, 64);
-                        d[q] = XF ? fmaxf(v * sc[e] + sh[e], 0.f) : v;
-                    }
+                    for (int q = 0; q < 16; ++q) d[q] = XF ? fmaxf(raw[q][e] * sc[e] + sh[e], 0.f) : raw[q][e];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {         // B^T d
                         t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
@@ -371,21 +379,38 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     if (p.stats) {                                        // one flush per workgroup: the 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
         __syncthreads();                                  // all waves are done with the U stages
         float* red = smem;                                // [4 waves][NB][2]
+        // the 4 * NBT sums of a lane are folded over its 16 tile lanes by a halving exchange (lane keeps the half its r bit selects and
+        // adds the partner's): 4 * NBT - 1 lane exchanges per quantity instead of 4 per value; lane r ends with value index r
+        // (NBT = 4: channel n0 + 16 * (r >> 2) + 4 * kq + (r & 3); NBT = 2: lanes r and r ^ 8 hold the same value)
+        float fs[16], fq[16];
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb)
+        for (int i = 0; i < 16; ++i) {
+            fs[i] = ssum[(i >> 2) % NBT][i & 3];
+            fq[i] = ssq[(i >> 2) % NBT][i & 3];
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float s = ssum[nb][j], q = ssq[nb][j];
+        for (int w = 8; w >= 1; w >>= 1) {
+            if (4 * NBT <= w) continue;                   // (NBT = 2: only 8 values, the top exchange is skipped)
+            const bool up = (r & w) != 0;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                if (r == 0) {
-                    red[(wv * NB + nb * 16 + kq * 4 + j) * 2 + 0] = s;
-                    red[(wv * NB + nb * 16 + kq * 4 + j) * 2 + 1] = q;
-                }
+            for (int i = 0; i < w; ++i) {
+                const float ks = up ? fs[i + w] : fs[i], gs = up ? fs[i] : fs[i + w];
+                const float kq2 = up ? fq[i + w] : fq[i], gq = up ? fq[i] : fq[i + w];
+                fs[i] = ks + __shfl_xor(gs, w, 64);
+                fq[i] = kq2 + __shfl_xor(gq, w, 64);
             }
+        }
+        if (4 * NBT == 8) {                               // fold the two tile-lane halves that both hold value index r & 7
+            fs[0] += __shfl_xor(fs[0], 8, 64);
+            fq[0] += __shfl_xor(fq[0], 8, 64);
+        }
+        {
+            const int vi = r & (4 * NBT - 1);             // value index held by this lane
+            if (r < 4 * NBT) {
+                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 0] = fs[0];
+                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 1] = fq[0];
+            }
+        }
         __syncthreads();
         if (tid < NB && n0 + tid < p.cout_g) {
             double s = 0.0, q = 0.0;
