@@ -356,8 +356,30 @@ def measure_pixellink(B, dev, steps=20):
         pl, ll = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # training step of the row (train loop of ssd_liverdet/pixel_link: forward, PixelLinkLoss, loss.backward(), SGD): HIP forward plan,
+    # HIP loss backward, HIP backward plan (gssd/backward.py::PixelLinkBackwardPlan)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9)
+    tsteps = max(2, steps // 4)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        o1, o2 = net(x)
+        pp, pn = crit.pixel_loss(o1, pix_t, neg_t, posw_t, link=(o2, link_t))
+        lp, ln = crit.link_loss(o2, link_t)
+        (pp + pn + lp + ln).backward()
+        opt.step()
+    for _ in range(2):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(tsteps):
+        train_step()
+    torch.cuda.synchronize()
+    dtt = time.perf_counter() - t0
     return dict(metric='512x512 4-phase CT img/s (PixelLink++ fwd + loss + link decoding)', value=round(B * steps / dt, 2), unit='img/s',
                 steps=steps, ms_per_step=round(1e3 * dt / steps, 3), batch=B, dtype='f32', loss=[round(float(pl), 5), round(float(ll), 5)],
+                full_step=dict(metric='PixelLink++ training step (forward + PixelLinkLoss + backward + SGD)', steps=tsteps,
+                               ms_per_step=round(1e3 * dtt / tsteps, 3), value=round(B * tsteps / dtt, 2), unit='img/s'),
                 workload='pixellink++ cascade_fuse=1 fuseconv=1 bn=1 sa=1 sab=1 dcn=1x4 cat_sab=1, 300x300x12 -> [B,2,75,75] | [B,16,75,75]')
 
 

@@ -110,3 +110,35 @@ class GssdTrainFn(torch.autograd.Function):
                     p.grad.add_(g)
             return (None, None) + (None,) * len(params)
         return (None, None) + tuple(g if (g is not None and p.requires_grad) else None for p, g in zip(params, grads))
+
+
+class PixelLinkTrainFn(torch.autograd.Function):
+    """PixelLink++ (pixel_link/model.py): HIP forward plan + gssd/backward.py::PixelLinkBackwardPlan.  Same contract as GssdTrainFn;
+    the parameter gradients are returned to autograd (no direct hand-out: the PixelLink++ row has no data-parallel reducer)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        if x.requires_grad:
+            raise _lib.GssdError('the HIP path provides no gradient with respect to the input images '
+                                 '(x.requires_grad=True); detach the input')
+        out_1, out_2, plan = net._engine.forward_plan(x, True, net.__dict__.get('_events'))
+        ctx.net, ctx.params = net, params
+        ctx.plan, ctx.gen = plan, plan.generation
+        ctx.lease = _Lease(plan)
+        ctx.set_materialize_grads(False)
+        return out_1, out_2
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        params, plan = ctx.params, ctx.plan
+        if plan.generation != ctx.gen:
+            raise _lib.GssdError('PixelLink++ HIP backward: the forward plan ran again after the forward this backward belongs to')
+        Ho = plan.H_out
+        if d1 is None:
+            d1 = torch.zeros(plan.B, 2, Ho, Ho, device=plan.dev)
+        if d2 is None:
+            d2 = torch.zeros(plan.B, 16, Ho, Ho, device=plan.dev)
+        grads = plan.backward_plan().run(d1.contiguous().float(), d2.contiguous().float())
+        ctx.lease.release()
+        # the slices alias the plan's flat buffer, which the next backward of this plan overwrites: hand out copies
+        return (None, None) + tuple(g.clone() if (g is not None and p.requires_grad) else None for p, g in zip(params, grads))

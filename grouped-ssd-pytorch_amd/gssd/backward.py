@@ -275,6 +275,14 @@ class BackwardPlan:
             self._slice_cat(r)
         elif kind == 'dcn':
             self._dcn(r)
+        elif kind == 'relupool':
+            self._relupool(r)
+        elif kind == 'plhead':
+            self._plhead(r)
+        elif kind == 'interp':
+            self._interp(r)
+        elif kind == 'plfinal':
+            self._plfinal(r)
         else:
             raise _lib.GssdError(f'no HIP backward for {kind}')
         while len(self.step_sid) < len(self.steps):          # (handlers also append host-side steps directly)
@@ -429,9 +437,12 @@ class BackwardPlan:
         dout = self._grad_of(out)
         if dout is None:
             raise _lib.GssdError(f"no gradient reaches {r['name']}")
-        dz = self._buf(B, Ho, Ho, Cout)
-        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), out.data_ptr(), 0, 0, dz.data_ptr(), 0, B, Ho, Ho, Cout, Ho, Ho,
-                                               0, 1, 0, 1))
+        if r.get('relu', True):
+            dz = self._buf(B, Ho, Ho, Cout)
+            self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), out.data_ptr(), 0, 0, dz.data_ptr(), 0, B, Ho, Ho, Cout, Ho, Ho,
+                                                   0, 1, 0, 1))
+        else:
+            dz = dout                    # conv + bias only (PixelLink++ fuse conv without BatchNorm): no mask
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dz.data_ptr(), B * Ho * Ho, Cout, Cout, cs.data_ptr()))
         self._bias_from_colsum(cs, conv.bias)
@@ -465,6 +476,90 @@ class BackwardPlan:
                                             float(mod.eps)))
         self._bias_from_colsum(dw, mod.weight)
         self.gbuf[r['x_in'].data_ptr()] = g
+
+    # ---- PixelLink++ tail (gssd/pixellink.py records; csrc/pixellink.hip) -------------------------------------------------------------
+    PL_LD = 20          # channel stride of the gradient maps of the 18-channel score maps (whole 16-byte quads for the conv kernels)
+
+    def _relupool(self, r):
+        """ReLU and / or max-pool pass of the PixelLink++ trunk (identity-affine bn_relu_pool launch): first-maximum routing, ReLU mask."""
+        B, H, Cc, Hp = self.B, r['H'], r['C'], r['Hp']
+        dout = self._grad_of(r['out'])
+        if dout is None:
+            raise _lib.GssdError('no gradient reaches a ReLU / pool pass of the PixelLink++ trunk')
+        existing = self._grad_of(r['x_in'])
+        g = self._buf(B, H, H, Cc, zero_each_run=bool(r['k'] and r['s'] < r['k']))
+        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), r['x_in'].data_ptr(), 0, 0, g.data_ptr(), 0, B, H, H, Cc, Hp, Hp,
+                                               r['k'], r['s'], r['p'], int(r['relu'])))
+        if existing is not None:
+            self._add(lib.gssd_axpby_f32, (existing.data_ptr(), g.data_ptr(), existing.data_ptr(), B * H * H * Cc, 1.0, 1.0))
+            g = existing
+        self.gbuf[r['x_in'].data_ptr()] = g
+
+    def _pl_grad(self, t, H):
+        """Gradient map (channel stride PL_LD, zeroed every run: the cascade accumulates into it) of an 18-channel score map."""
+        g = self.gbuf.get(t.data_ptr())
+        if g is None:
+            g = self._buf(self.B, H, H, self.PL_LD, zero_each_run=True)
+            self.gbuf[t.data_ptr()] = g
+        return g
+
+    def _plfinal(self, r):
+        """final_1 / final_2 (model.py:360,386 / 396,411): d(features), weight and bias gradients; the roots d(out_1), d(out_2)."""
+        B, H, feats, f1, f2 = self.B, r['H'], r['feats'], r['final_1'], r['final_2']
+        nf = len(feats)
+        gs = [self._pl_grad(f, H) for f in feats]
+        dw1 = self._buf(2 * 2 * nf + 2, dtype=torch.float64, zero_each_run=True)
+        dw2 = self._buf(16 * 16 * nf + 16, dtype=torch.float64, zero_each_run=True)
+        w1, w2 = f1.weight.detach().view(2, -1), f2.weight.detach().view(16, -1)
+        fp = [f.data_ptr() for f in feats] + [0] * (4 - nf)
+        gp = [g.data_ptr() for g in gs] + [0] * (4 - nf)
+        self._add(lib.gssd_pixellink_final_bwd_f32, (self.d_out1.data_ptr(), self.d_out2.data_ptr(), *fp, nf, w1.data_ptr(), w2.data_ptr(),
+                                                     *gp, 0, dw1.data_ptr(), dw2.data_ptr(), B, H * H, self.PL_LD), keep=(w1, w2))
+        for dw, mod, nw in ((dw1, f1, 4 * nf), (dw2, f2, 256 * nf)):
+            self._add(lib.gssd_cast_f64_f32, (dw.data_ptr(), self._pgrad(mod.weight).data_ptr(), nw, 0))
+            self._add(lib.gssd_cast_f64_f32, (dw[nw:].data_ptr(), self._pgrad(mod.bias).data_ptr(), mod.bias.numel(), 0))
+
+    def _interp(self, r):
+        """out = interp(src) [, out2 = out + addend]: d(src) += interp^T(d(out) + d(out2)), d(addend) += d(out2)."""
+        B, Hs, Hd = self.B, r['Hs'], r['Hd']
+        go = self.gbuf.get(r['out'].data_ptr())
+        go2 = self.gbuf.get(r['out2'].data_ptr()) if r['out2'] is not None else None
+        if go is None and go2 is None:
+            return
+        gsrc = self._pl_grad(r['src'], Hs)
+        gadd = self._pl_grad(r['addend'], Hd) if (r['addend'] is not None and go2 is not None) else None
+        self._add(lib.gssd_interp_add_bwd_f32, (go.data_ptr() if go is not None else 0, go2.data_ptr() if go2 is not None else 0,
+                                                gsrc.data_ptr(), gadd.data_ptr() if gadd is not None else 0, B, Hs, Hs, Hd, Hd, 18,
+                                                self.PL_LD))
+
+    def _plhead(self, r):
+        """The merged 1x1 score heads out{k}_1 | out{k}_2 (18 channels, run on PL_LD = 20 in the backward: rows 18, 19 are zero)."""
+        B, H, Cs, LD = self.B, r['H'], r['C'], self.PL_LD
+        o1, o2, src = r['o1'], r['o2'], r['src']
+        dy = self.gbuf.get(r['out'].data_ptr())
+        if dy is None:
+            raise _lib.GssdError(f"no gradient reaches the score heads of stage {r['k']}")
+        fdesc, _, _ = ops.make_conv_desc(src, None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=LD, k=1)
+        dwp, K = self._wgrad(fdesc, dy, None, Cs, Cs, 1, LD)
+        self._unpack(dwp, K, 0, o1.weight, Cs, Cs, 1)
+        self._unpack(dwp, K, 2, o2.weight, Cs, Cs, 1)
+        cs = self._buf(LD, dtype=torch.float64, zero_each_run=True)
+        self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, LD, LD, cs.data_ptr()))
+        self._bias_from_colsum(cs, o1.bias, 0)
+        self._bias_from_colsum(cs, o2.bias, 2)
+        # d(src) = dy . W  (1x1 conv over dy with the transposed merged weight [Cs][LD], refreshed every run)
+        wd = torch.zeros(Cs, LD, device=self.dev)
+        self.keep.append(wd)
+
+        def refresh(wd=wd, o1=o1, o2=o2, Cs=Cs):
+            wd[:, :2].copy_(o1.weight.detach().view(2, Cs).t())
+            wd[:, 2:18].copy_(o2.weight.detach().view(16, Cs).t())
+        self.steps.append((refresh, None))
+        existing = self._grad_of(src)
+        g = existing if existing is not None else self._buf(B, H, H, Cs)
+        d, _, _ = ops.make_conv_desc(dy, wd, g, B=B, H=H, W=H, in_stride=LD, cin_g=LD, Cout=Cs, k=1, resid=existing)
+        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        self.gbuf[src.data_ptr()] = g
 
     # ---- GSSD++ blocks ---------------------------------------------------------------------------------------------------------
     def _reserve(self, t, shape):
@@ -684,6 +779,9 @@ class BackwardPlan:
     def run(self, dloc, dconf):
         self.dloc.copy_(dloc)
         self.dconf.copy_(dconf)
+        return self._execute()
+
+    def _execute(self):
         if self.zero_list:
             # one multi-tensor launch per dtype (a mixed fp32 / fp64 list takes _foreach_zero_'s slow path: ~180 fill launches a step)
             if getattr(self, '_zero_groups', None) is None or sum(len(g) for g in self._zero_groups) != len(self.zero_list):
@@ -766,6 +864,22 @@ class BackwardPlan:
             rc = fn(*args, stream)
             if rc != 0:
                 _lib.check(rc)
+
+
+class PixelLinkBackwardPlan(BackwardPlan):
+    """HIP backward of the PixelLink++ launch plan (gssd/pixellink.py): the same record walk, rooted at d(out_1) [B,2,H,W] and
+    d(out_2) [B,16,H,W] (what PixelLinkLoss's backward hands over) instead of d(loc), d(conf)."""
+
+    def __init__(self, plan):
+        Ho = plan.H_out
+        self.d_out1 = torch.zeros(plan.B, 2, Ho, Ho, device=plan.dev)
+        self.d_out2 = torch.zeros(plan.B, 16, Ho, Ho, device=plan.dev)
+        super().__init__(plan)
+
+    def run(self, d_out1, d_out2):
+        self.d_out1.copy_(d_out1)
+        self.d_out2.copy_(d_out2)
+        return self._execute()
 
 
 class _PaddedWeight:

@@ -206,6 +206,189 @@ __global__ __launch_bounds__(1024) void pl_loss_kernel(const float* __restrict__
     }
 }
 
+// ---- backward of the tail (training: ssd_liverdet/pixel_link train loop = forward, PixelLinkLoss, loss.backward()) ------
+// Gradient maps of the 18-channel score maps carry a channel stride `ld` >= 18 (20 in the plan: the conv kernels that continue the chain
+// want rows of whole 16-byte quads; channels 18 .. ld-1 stay zero).
+
+// d(interp_add): g = d(out) [+ d(out2)] scattered to the four source corners with the forward's weights (atomics: d(src) accumulates);
+// d(addend) += d(out2).  dout / dout2 may be NULL (no gradient reached that output).
+__global__ __launch_bounds__(256) void interp_add_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dout2,
+                                                             float* __restrict__ dsrc, float* __restrict__ daddend, int B, int Hs, int Ws,
+                                                             int Hd, int Wd, int C, int ld) {
+    const long long total = (long long)B * Hd * Wd * C;
+    const float sh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+    const float sw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const size_t po = (size_t)t * ld + c;
+        const int x = (int)(t % Wd);
+        t /= Wd;
+        const int y = (int)(t % Hd);
+        const int b = (int)(t / Hd);
+        const float g2 = dout2 ? dout2[po] : 0.f;
+        const float g = (dout ? dout[po] : 0.f) + g2;
+        if (daddend && dout2) daddend[po] += g2;
+        if (g == 0.f) continue;
+        const float fy = sh * (float)y, fx = sw * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+        float* sb = dsrc + (size_t)b * Hs * Ws * ld + c;
+        unsafeAtomicAdd(sb + (size_t)(y0 * Ws + x0) * ld, g * h0 * w0);
+        unsafeAtomicAdd(sb + (size_t)(y0 * Ws + x1) * ld, g * h0 * w1);
+        unsafeAtomicAdd(sb + (size_t)(y1 * Ws + x0) * ld, g * h1 * w0);
+        unsafeAtomicAdd(sb + (size_t)(y1 * Ws + x1) * ld, g * h1 * w1);
+    }
+}
+
+// d(final_1 / final_2) w.r.t. the cascade features: df[k][p][c] (+)= sum_o w1[o][2k + c] d1[b][o][pix] (c < 2), sum_o w2[o][16k + c-2] d2[b][o][pix]
+// (c >= 2).  acc[k] != 0: the map already holds another contribution (a feature that also feeds the next cascade step).
+__global__ __launch_bounds__(256) void pl_final_bwd_kernel(const float* __restrict__ d1, const float* __restrict__ d2, int nf,
+                                                           const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ g0,
+                                                           float* __restrict__ g1, float* __restrict__ g2, float* __restrict__ g3, int acc_mask,
+                                                           int B, int HW, int ld) {
+    __shared__ float sw1[2 * 8], sw2[16 * 64];
+    for (int i = threadIdx.x; i < 2 * 2 * nf; i += 256) sw1[i] = w1[i];
+    for (int i = threadIdx.x; i < 16 * 16 * nf; i += 256) sw2[i] = w2[i];
+    __syncthreads();
+    float* gs[4] = {g0, g1, g2, g3};
+    const long long total = (long long)B * HW;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW), pix = (int)(p - (long long)b * HW);
+        float a1[2], a2[16];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) a1[o] = d1[((size_t)b * 2 + o) * HW + pix];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) a2[o] = d2[((size_t)b * 16 + o) * HW + pix];
+        for (int k = 0; k < nf; ++k) {
+            float* gp = gs[k] + (size_t)p * ld;
+            const bool acc = (acc_mask >> k) & 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int o = 0; o < 2; ++o) v = __builtin_fmaf(sw1[o * 2 * nf + k * 2 + c], a1[o], v);
+                gp[c] = acc ? gp[c] + v : v;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) v = __builtin_fmaf(sw2[o * 16 * nf + k * 16 + c], a2[o], v);
+                gp[2 + c] = acc ? gp[2 + c] + v : v;
+            }
+        }
+    }
+}
+
+// weight / bias gradients of final_1 / final_2: dw1[o][2k + c] = sum_p d1[o][p] f[k][p][c], db1[o] = sum_p d1[o][p] (same for final_2);
+// a workgroup reduces 256 pixels through LDS (thread -> one output row o of final_2 and a 4-wide column block, the 16 + 2 leftovers
+// on the first threads), then fp64 atomics.  dw layout = the conv weights' [O][nf * c] rows; db follow at dw + O * nf * c.
+__global__ __launch_bounds__(256) void pl_final_wgrad_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                             const float* __restrict__ f0, const float* __restrict__ f1,
+                                                             const float* __restrict__ f2, const float* __restrict__ f3, int nf,
+                                                             double* __restrict__ dw1, double* __restrict__ dw2, int B, int HW) {
+    constexpr int TP = 128;                 // pixels per pass (47 KB of LDS)
+    __shared__ float sd[TP][18 + 1];        // d1 (2) | d2 (16) of the pass's pixels
+    __shared__ float sf[TP][72 + 1];        // features: k * 18 + c
+    const float* fs[4] = {f0, f1, f2, f3};
+    const long long total = (long long)B * HW;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int o2 = threadIdx.x >> 4, cb = (threadIdx.x & 15) * 4;        // final_2: row o2, columns cb .. cb + 3 of [16][16 nf]
+    const int lp = threadIdx.x & (TP - 1), half = threadIdx.x >> 7;      // loader: pixel lp of the pass; half 0 = d + f0, f1, half 1 = f2, f3
+    for (long long base = (long long)blockIdx.x * TP; base < total; base += (long long)gridDim.x * TP) {
+        const long long p = base + lp;
+        __syncthreads();
+        const bool ok = p < total;
+        const int b = ok ? (int)(p / HW) : 0, pix = ok ? (int)(p - (long long)b * HW) : 0;
+        if (half == 0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) sd[lp][o] = ok ? d1[((size_t)b * 2 + o) * HW + pix] : 0.f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) sd[lp][2 + o] = ok ? d2[((size_t)b * 16 + o) * HW + pix] : 0.f;
+        }
+        for (int k = 2 * half; k < 2 * half + 2 && k < nf; ++k)
+#pragma unroll
+            for (int c = 0; c < 18; ++c) sf[lp][k * 18 + c] = ok ? fs[k][p * 18 + c] : 0.f;
+        __syncthreads();
+        for (int q = 0; q < TP; ++q) {
+            const float g = sd[q][2 + o2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cb + j;                        // = k * 16 + c  (c < 16) of final_2's input
+                if (col < 16 * nf) acc[j] = __builtin_fmaf(g, sf[q][(col >> 4) * 18 + 2 + (col & 15)], acc[j]);
+            }
+            // leftovers on threads 0 .. 4 nf + 17: final_1's 2 x 2 nf weights, then the 2 + 16 biases
+            const int t = threadIdx.x;
+            if (t < 4 * nf) {
+                const int o = t / (2 * nf), col = t - o * 2 * nf;
+                acc[4] = __builtin_fmaf(sd[q][o], sf[q][(col >> 1) * 18 + (col & 1)], acc[4]);
+            } else if (t < 4 * nf + 18) {
+                acc[4] += sd[q][t - 4 * nf];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (cb + j < 16 * nf) unsafeAtomicAdd(dw2 + o2 * 16 * nf + cb + j, (double)acc[j]);
+    const int t = threadIdx.x;
+    if (t < 4 * nf) unsafeAtomicAdd(dw1 + t, (double)acc[4]);
+    else if (t < 4 * nf + 2) unsafeAtomicAdd(dw1 + 4 * nf + (t - 4 * nf), (double)acc[4]);               // db1
+    else if (t < 4 * nf + 18) unsafeAtomicAdd(dw2 + 16 * 16 * nf + (t - 4 * nf - 2), (double)acc[4]);     // db2
+}
+
+// d(PixelLinkLoss) w.r.t. the two score maps (criterion.py:24-104 under autograd: the mined-negative mask, the areas and the link weight
+// sums are constants of the step).  g[4] = upstream gradients of the four returned means (pixel pos, pixel neg, link pos, link neg);
+// neg_w = the mined mask the forward launch wrote; per_image = its [B][6] result (area, neg_area in columns 4, 5).
+__global__ __launch_bounds__(1024) void pl_loss_bwd_kernel(const float* __restrict__ out1, const float* __restrict__ out2,
+                                                           const long long* __restrict__ pixel_t, const float* __restrict__ neg_w,
+                                                           const float* __restrict__ pos_w, const long long* __restrict__ link_t,
+                                                           const double* __restrict__ res, const float* __restrict__ g,
+                                                           float* __restrict__ d1, float* __restrict__ d2, int B, int HW) {
+    __shared__ double red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double den = res[b * 6 + 4] + res[b * 6 + 5];
+    const float inv_den = den > 0.0 ? (float)(1.0 / (den * (double)B)) : 0.f;
+    const float gp = g[0], gn = g[1], glp = g[2], gln = g[3];
+    const float* l0 = out1 + (size_t)b * 2 * HW;
+    const float* l1 = l0 + HW;
+    for (int i = tid; i < HW; i += 1024) {
+        const float a = l0[i], c = l1[i];
+        const float m = fmaxf(a, c);
+        const float e0 = expf(a - m), e1 = expf(c - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        const long long t = pixel_t[(size_t)b * HW + i];
+        const float wgt = (gp * pos_w[(size_t)b * HW + i] + gn * neg_w[(size_t)b * HW + i]) * inv_den;
+        d1[((size_t)b * 2) * HW + i] = wgt * (p0 - (t ? 0.f : 1.f));
+        d1[((size_t)b * 2 + 1) * HW + i] = wgt * (p1 - (t ? 1.f : 0.f));
+    }
+    double wp = 0.0, wn = 0.0;
+    for (int i = tid; i < 8 * HW; i += 1024) {
+        const int n = i / HW, pix = i - n * HW;
+        const long long t = link_t[((size_t)b * 8 + n) * HW + pix];
+        const float w = pos_w[(size_t)b * HW + pix];
+        if (t == 1) wp += (double)w;
+        else if (t == 0) wn += (double)w;
+    }
+    wp = block_sum(wp, red);
+    wn = block_sum(wn, red);
+    const float cp = wp == 0.0 ? 0.f : (float)((double)glp / (wp * (double)B));
+    const float cn = wn == 0.0 ? 0.f : (float)((double)gln / (wn * (double)B));
+    for (int i = tid; i < 8 * HW; i += 1024) {
+        const int n = i / HW, pix = i - n * HW;
+        const size_t oa = ((size_t)b * 16 + 2 * n) * HW + pix, oc = oa + HW;
+        const float a = out2[oa], c = out2[oc];
+        const float m = fmaxf(a, c);
+        const float e0 = expf(a - m), e1 = expf(c - m);
+        const float pa = e0 / (e0 + e1), pc = e1 / (e0 + e1);
+        const long long t = link_t[((size_t)b * 8 + n) * HW + pix];
+        const float coef = pos_w[(size_t)b * HW + pix] * (t == 1 ? cp : t == 0 ? cn : 0.f);
+        d2[oa] = coef * (pa - (t == 0 ? 1.f : 0.f));
+        d2[oc] = coef * (pc - (t == 1 ? 1.f : 0.f));
+    }
+}
+
 // ---- link decoding ------------------------------------------------------------------------------------------------------------------
 // postprocess.py:104-121 thresholds + `func` (:178-234).  neighbour order (get_neighbors :166-176): (-1,-1) (-1,0) (-1,+1) (0,+1)
 // (+1,+1) (+1,0) (+1,-1) (0,-1).  Two positive pixels p, q are joined when link i of p towards q is on (either direction suffices:
@@ -425,6 +608,46 @@ extern "C" int gssd_pixellink_loss_f32(const float* out1, const float* out2, con
     GSSD_CHECK_ARG(B > 0 && H > 0 && W > 0 && H * W <= PL_SORT && neg_pos_ratio > 0);
     hipLaunchKernelGGL(pl_loss_kernel, dim3(B), dim3(1024), 0, as_stream(stream), out1, out2, pixel_target, neg_pixel_mask,
                        pixel_pos_weight, link_target, per_image, neg_weight_out, H * W, neg_pos_ratio);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_interp_add_bwd_f32(const float* dout, const float* dout2, float* dsrc, float* daddend, int B, int Hs, int Ws, int Hd,
+                                       int Wd, int C, int ld, gssd_stream_t stream) {
+    GSSD_CHECK_ARG((dout || dout2) && dsrc && B > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && ld >= C);
+    const long long total = (long long)B * Hd * Wd * C;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(interp_add_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dout, dout2, dsrc, daddend, B, Hs, Ws, Hd, Wd,
+                       C, ld);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pixellink_final_bwd_f32(const float* d_out1, const float* d_out2, const float* f0, const float* f1, const float* f2,
+                                            const float* f3, int nf, const float* w1, const float* w2, float* g0, float* g1, float* g2,
+                                            float* g3, int accumulate_mask, double* dw1, double* dw2, int B, int HW, int ld,
+                                            gssd_stream_t stream) {
+    GSSD_CHECK_ARG(d_out1 && d_out2 && f0 && w1 && w2 && g0 && dw1 && dw2 && B > 0 && HW > 0 && nf >= 1 && nf <= 4 && ld >= 18);
+    GSSD_CHECK_ARG((nf < 2 || (f1 && g1)) && (nf < 3 || (f2 && g2)) && (nf < 4 || (f3 && g3)));
+    const long long total = (long long)B * HW;
+    hipLaunchKernelGGL(pl_final_bwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, as_stream(stream), d_out1, d_out2, nf, w1, w2,
+                       g0, g1, g2, g3, accumulate_mask, B, HW, ld);
+    GSSD_CHECK_LAUNCH();
+    const int blocks = (int)((total + 127) / 128 > 1024 ? 1024 : (total + 127) / 128);
+    hipLaunchKernelGGL(pl_final_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_out1, d_out2, f0, f1, f2, f3, nf, dw1, dw2,
+                       B, HW);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_pixellink_loss_bwd_f32(const float* out1, const float* out2, const long long* pixel_target, const float* neg_weight,
+                                           const float* pixel_pos_weight, const long long* link_target, const double* per_image,
+                                           const float* upstream4, float* d_out1, float* d_out2, int B, int H, int W,
+                                           gssd_stream_t stream) {
+    GSSD_CHECK_ARG(out1 && out2 && pixel_target && neg_weight && pixel_pos_weight && link_target && per_image && upstream4 && d_out1 &&
+                   d_out2 && B > 0 && H > 0 && W > 0);
+    hipLaunchKernelGGL(pl_loss_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), out1, out2, pixel_target, neg_weight,
+                       pixel_pos_weight, link_target, per_image, upstream4, d_out1, d_out2, B, H * W);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -4,14 +4,15 @@ Nothing here is a new convolution: the grouped VGG trunk (conv + bias, ReLU appl
 the pool pass), the Self_Attn blocks (merged projection + flash core + gated output conv), the slice_and_cat + fused deformable
 conv at the 75 x 75 stage, the 1x1 fuse conv + BatchNorm and the 1x1 score heads (pixel 2 + link 16 channels as ONE 18-channel
 conv per stage) are launches of the kernels the detector uses.  New are the upsample-add cascade and the final 1x1 convs
-(csrc/pixellink.hip).  Forward only; fp32.
+(csrc/pixellink.hip).  fp32.  Every launch leaves a record (``rec``); a grad-enabled forward is followed by the HIP backward plan
+of gssd/backward.py::PixelLinkBackwardPlan (SURVEY.md 8f row 4 as a TRAINING row).
 """
 import ctypes as C
 
 import torch
 
 from . import _lib, ops
-from .engine import GssdEngine, _Plan, USE_WINOGRAD
+from .engine import GssdEngine, _Plan, _RecList, USE_WINOGRAD
 
 lib = _lib.lib
 
@@ -29,12 +30,20 @@ class PixelLinkEngine(GssdEngine):
 
 
 class _PlanPixelLink(_Plan):
+    def backward_plan(self):
+        if self._bwd is None:
+            from .backward import PixelLinkBackwardPlan
+            self._bwd = PixelLinkBackwardPlan(self)
+        return self._bwd
+
     def __init__(self, eng, B, training, dev):   # noqa: _Plan.__init__ builds the detector graph; not called on purpose
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         self.want_maps = False
         self.bf16, self.adt, self.conv_fn, self.cpad = False, torch.float32, lib.gssd_conv2d_nhwc_f32, 4
         net = eng.net
-        self.steps, self.bufs, self.rec, self.head_descs = [], [], [], []  # (forward only: plain record list)
+        self.steps, self.bufs, self.head_descs = [], [], []
+        self.rec = _RecList(self)         # forward graph records, walked in reverse by gssd/backward.py::PixelLinkBackwardPlan
+        self.P, self.nc = 0, 0            # (no prior boxes: the roots of the backward are d(out_1), d(out_2))
         g = net.vgg_groups
         # ---- batch-stat arena (the fuse BatchNorms) ----------------------------------------------------
         uniq, seen = [], set()
@@ -92,6 +101,7 @@ class _PlanPixelLink(_Plan):
         ptrs = [f.data_ptr() for f in feats] + [0] * (4 - len(feats))
         self._add(lib.gssd_pixellink_final_f32, ptrs + [len(feats), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0, 0, B,
                                                         H2 * H2], keep=(w1, b1, w2, b2, feats))
+        self.rec.append(('plfinal', dict(feats=feats, H=H2, final_1=net.final_1, final_2=net.final_2)))
 
     # ------------------------------------------------------------------------------------------------
     def _identity_relu(self, Cc):
@@ -103,7 +113,9 @@ class _PlanPixelLink(_Plan):
             self._relu_xf[Cc] = (one, zero, torch.zeros(Cc, device=self.dev))
         return self._relu_xf[Cc]
 
-    def _conv_raw(self, name, conv, x, H, Cin, groups, in_xf):
+    def _conv_raw(self, name, conv, x, H, Cin, groups, in_xf, relu_after=True):
+        """conv + bias; ``relu_after``: the ReLU that follows in the graph is applied by the consumer (fused input transform) or by the
+        next _relu_pool pass -- the backward masks this layer's output gradient with [raw > 0]."""
         B = self.B
         k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         Cout = conv.out_channels
@@ -121,6 +133,8 @@ class _PlanPixelLink(_Plan):
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None)
         self._add(self.conv_fn, (C.byref(d),), keep=(d, in_xf))
+        self.rec.append(('convrelu', dict(name=name, conv=conv, x_in=x, out=raw, H=H, Cin=Cin, Ho=Ho, Cout=Cout, desc=d, k=k, stride=s,
+                                          pad=p, dil=dl, groups=groups, relu=bool(relu_after))))
         return raw, Ho, Cout
 
     def _relu_pool(self, x, H, Cc, pool, relu=True):
@@ -134,6 +148,7 @@ class _PlanPixelLink(_Plan):
         out = self._buf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_f32, (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, pk, ps, pp, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5,
                                               0, int(relu)))
+        self.rec.append(('relupool', dict(x_in=x, out=out, H=H, C=Cc, k=pk, s=ps, p=pp, Hp=Hp, relu=bool(relu))))
         return out, Hp
 
     def _stage(self, x, H, Cc, si):
@@ -150,6 +165,8 @@ class _PlanPixelLink(_Plan):
             if net.dcn_cat_sab:
                 xc = self._buf(B, H, H, 2 * Cc)
                 self._add(lib.gssd_slice_and_cat_f32, (x.data_ptr(), attn_g.data_ptr(), xc.data_ptr(), B * H * H, Cc, Cc, net.vgg_groups))
+                self.rec.append(('slice_cat', dict(a=x, b=attn_g, out=xc, H=H, Ca=Cc, Cb=Cc, groups=net.vgg_groups,
+                                                   detach_b=bool(net.detach_sab))))
                 xin, Cin = xc, 2 * Cc
             for li in range(net.num_dcn_layers):
                 xin, Cin = self._dcn(li, xin, H, Cin)
@@ -163,7 +180,7 @@ class _PlanPixelLink(_Plan):
             if net.batch_norm:
                 s, _, _, _ = self._conv_bn(f'fuse{k}', conv, getattr(net, f'bn_fuse{k}'), s, H, Cc, 1, relu=False)
             else:
-                s, _, _ = self._conv_raw(f'fuse{k}', conv, s, H, Cc, 1, None)
+                s, _, _ = self._conv_raw(f'fuse{k}', conv, s, H, Cc, 1, None, relu_after=False)
         o1, o2 = getattr(net, f'out{k}_1'), getattr(net, f'out{k}_2')
 
         def build_w(out, o1=o1, o2=o2, Cc=Cc):
@@ -184,6 +201,7 @@ class _PlanPixelLink(_Plan):
         l = self._buf(B, H, H, 18)
         d, _, _ = ops.make_conv_desc(s, w, l, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=18, bias=bb)
         self._add(self.conv_fn, (C.byref(d),), keep=(d, w, bb))
+        self.rec.append(('plhead', dict(src=s, out=l, H=H, C=Cc, k=k, o1=o1, o2=o2)))
         self.l[k] = (l, H)
         return x, Cc
 
@@ -193,6 +211,7 @@ class _PlanPixelLink(_Plan):
         out2 = self._buf(B, Hd, Hd, 18) if addend is not None else None
         self._add(lib.gssd_interp_add_f32, (src.data_ptr(), addend.data_ptr() if addend is not None else 0, out.data_ptr(),
                                             out2.data_ptr() if out2 is not None else 0, B, Hs, Hs, Hd, Hd, 18))
+        self.rec.append(('interp', dict(src=src, addend=addend, out=out, out2=out2, Hs=Hs, Hd=Hd)))
         return out, out2
 
     # ------------------------------------------------------------------------------------------------

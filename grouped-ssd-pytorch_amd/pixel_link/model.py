@@ -1,6 +1,6 @@
 """``PixelLink`` (drop-in for ssd_liverdet/pixel_link/model.py:20-188: same constructor, attribute names and state-dict keys --
 including the ``modules_except_dcn`` aliases -- so reference checkpoints load); ``forward`` runs the HIP launch plan of
-gssd/pixellink.py and returns ``[out_1 [B,2,75,75], out_2 [B,16,75,75]]`` like model.py:413."""
+gssd/pixellink.py (a grad-enabled call is differentiable: the HIP backward plan follows) and returns ``[out_1 [B,2,75,75], out_2 [B,16,75,75]]`` like model.py:413."""
 import os
 
 import torch
@@ -99,8 +99,12 @@ class PixelLink(nn.Module):
             from gssd.pixellink import PixelLinkEngine
             self.__dict__['_engine'] = PixelLinkEngine(self)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise _lib.GssdError('PixelLink++ on the HIP path is forward + loss + decoding only (no backward yet): call it under '
-                                 'torch.no_grad()')
+            from gssd.autograd import PixelLinkTrainFn             # HIP forward plan + HIP backward plan (gssd/backward.py)
+            if not self.training:
+                raise _lib.GssdError('a grad-enabled PixelLink++ forward needs train mode (the backward differentiates the batch-statistics '
+                                     'BatchNorm); call .train() or torch.no_grad()')
+            out_1, out_2 = PixelLinkTrainFn.apply(self, x, *self.parameters())
+            return [out_1, out_2]
         out_1, out_2 = self.__dict__['_engine'].forward(x, self.training)
         return [out_1, out_2]
 

@@ -507,6 +507,23 @@ int gssd_pixellink_loss_f32(const float* out1, const float* out2, const long lon
                             const float* pixel_pos_weight, const long long* link_target, double* per_image, float* neg_weight_out,
                             int B, int H, int W, int neg_pos_ratio, gssd_stream_t stream);
 
+/* Backward of the tail (training: forward -> PixelLinkLoss -> loss.backward()).  Gradient maps of the 18-channel score maps are NHWC
+ * with a channel stride ld >= 18 (channels 18 .. ld-1 are never written: the caller zeroes them once).
+ * gssd_interp_add_bwd_f32: d(src) += interp^T(d(out) + d(out2)) (atomics: zero d(src) first or let it hold another contribution),
+ * d(addend) += d(out2); d_out or d_out2 may be NULL.
+ * gssd_pixellink_final_bwd_f32: g[k] (= or += per bit k of accumulate_mask) the gradient of feature k; dw1 fp64 [2*2*nf + 2] = final_1's
+ * weight rows then its bias, dw2 fp64 [16*16*nf + 16] likewise (accumulated with atomics: zero them first).
+ * gssd_pixellink_loss_bwd_f32: d(out1), d(out2) of sum_k upstream4[k] * loss_k for the four means gssd_pixellink_loss_f32 defines; neg_weight
+ * and per_image are that launch's outputs (the mined-negative mask, areas and link weight sums are constants under autograd). */
+int gssd_interp_add_bwd_f32(const float* d_out, const float* d_out2, float* d_src, float* d_addend, int B, int Hs, int Ws, int Hd, int Wd,
+                            int C, int ld, gssd_stream_t stream);
+int gssd_pixellink_final_bwd_f32(const float* d_out1, const float* d_out2, const float* f0, const float* f1, const float* f2,
+                                 const float* f3, int nf, const float* w1, const float* w2, float* g0, float* g1, float* g2, float* g3,
+                                 int accumulate_mask, double* dw1, double* dw2, int B, int HW, int ld, gssd_stream_t stream);
+int gssd_pixellink_loss_bwd_f32(const float* out1, const float* out2, const long long* pixel_target, const float* neg_weight,
+                                const float* pixel_pos_weight, const long long* link_target, const double* per_image,
+                                const float* upstream4, float* d_out1, float* d_out2, int B, int H, int W, gssd_stream_t stream);
+
 /* Link decoding (pixel_link/postprocess.py:104-121 thresholds, :178-234 `func`): labels [B][H][W] int32 = 0 for background, else
  * 1 + rank of the pixel's connected component by its first pixel in raster order (the reference's root_map numbering; the reference
  * stores it as uint8 and wraps beyond 255 components, this does not).  comps [B][max_comp][6] = {pixel count, min x, min y, max x,

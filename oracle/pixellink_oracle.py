@@ -114,11 +114,14 @@ def pixellink_forward(sd, x, cascade_fuse=True, use_fuseconv=True, batch_norm=Tr
     return outs[0], outs[1], updates
 
 
-def pixel_link_loss(out_1, out_2, pixel_masks, neg_pixel_masks, pixel_pos_weights, link_masks, neg_pos_ratio=NEG_POS_RATIO):
-    """criterion.py:24-104.  Returns (pixel_pos, pixel_neg, link_pos, link_neg) as python floats + the mined-negative mask."""
+def pixel_link_loss(out_1, out_2, pixel_masks, neg_pixel_masks, pixel_pos_weights, link_masks, neg_pos_ratio=NEG_POS_RATIO,
+                    as_tensors=False):
+    """criterion.py:24-104.  Returns (pixel_pos, pixel_neg, link_pos, link_neg) as python floats + the mined-negative mask;
+    ``as_tensors``: the four means as fp64 tensors that carry the autograd graph (the mined mask, areas and weight sums enter as
+    constants, as in the reference: topk indices and comparisons have no gradient)."""
     out_1, out_2 = out_1.float(), out_2.float()
     B = out_1.shape[0]
-    p0 = torch.softmax(out_1, dim=1)[:, 0]
+    p0 = torch.softmax(out_1, dim=1)[:, 0].detach()
     ce = F.cross_entropy(out_1, pixel_masks, reduction='none')
     area = pixel_masks.view(B, -1).sum(1)
     neg_w = torch.zeros_like(pixel_pos_weights, dtype=torch.bool)
@@ -141,6 +144,8 @@ def pixel_link_loss(out_1, out_2, pixel_masks, neg_pixel_masks, pixel_pos_weight
     swp, swn = wp.view(B, -1).double().sum(1), wn.view(B, -1).double().sum(1)
     lp = torch.where(swp == 0, torch.zeros_like(swp), (wp * lce).view(B, -1).double().sum(1) / swp.clamp_min(1e-300))
     ln = torch.where(swn == 0, torch.zeros_like(swn), (wn * lce).view(B, -1).double().sum(1) / swn.clamp_min(1e-300))
+    if as_tensors:
+        return pos, neg, lp.mean(), ln.mean(), neg_w
     return float(pos), float(neg), float(lp.mean()), float(ln.mean()), neg_w
 
 

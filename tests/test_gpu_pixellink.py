@@ -85,14 +85,172 @@ def test_model_vs_oracle_batch(dev, training, tag):
         assert torch.isfinite(f1).all() and torch.isfinite(f2).all() and torch.equal(f1, g1) and torch.equal(f2, g2)
 
 
-def test_forward_needs_no_grad(dev):
+def test_forward_error_behaviour(dev):
     from gssd import _lib
     net = build(PLAIN).to(dev)
     with pytest.raises(_lib.GssdError):
-        net(synth.synth_images(1, seed=1).to(dev))
-    with pytest.raises(_lib.GssdError):
         with torch.no_grad():
             net(synth.synth_images(1, seed=1))           # CPU input: no fallback
+    net.eval()
+    with pytest.raises(_lib.GssdError):
+        net(synth.synth_images(1, seed=1).to(dev))       # grad-enabled forward in eval mode: the backward differentiates batch statistics
+    net.train()
+    o1, o2 = net(synth.synth_images(1, seed=1).to(dev))
+    assert o1.requires_grad and o2.requires_grad
+
+
+@pytest.mark.parametrize('Hs,Hd', [(19, 19), (19, 38), (38, 75), (19, 75)])
+def test_interp_add_backward(dev, Hs, Hd):
+    """gssd_interp_add_bwd_f32 (channel stride 20) vs autograd through F.interpolate + the lateral add."""
+    from gssd import _lib
+    g = torch.Generator().manual_seed(Hs * 7 + Hd)
+    B, C, LD = 2, 18, 20
+    src = torch.randn(B, C, Hs, Hs, generator=g, dtype=torch.float64, requires_grad=True)
+    add = torch.randn(B, C, Hd, Hd, generator=g, dtype=torch.float64, requires_grad=True)
+    go, go2 = torch.randn(B, C, Hd, Hd, generator=g, dtype=torch.float64), torch.randn(B, C, Hd, Hd, generator=g, dtype=torch.float64)
+    up = F.interpolate(src, size=(Hd, Hd), mode='bilinear', align_corners=True)
+    ((up * go).sum() + ((up + add) * go2).sum()).backward()
+
+    def pad(t):                                            # NCHW fp64 -> NHWC fp32 with channel stride LD
+        out = torch.zeros(B, t.shape[2], t.shape[3], LD)
+        out[..., :C] = t.permute(0, 2, 3, 1).float()
+        return out.to(dev)
+    d_o, d_o2 = pad(go), pad(go2)
+    d_src = torch.zeros(B, Hs, Hs, LD, device=dev)
+    d_add = torch.ones(B, Hd, Hd, LD, device=dev)          # holds another contribution already: accumulated into
+    _lib.check(_lib.lib.gssd_interp_add_bwd_f32(d_o.data_ptr(), d_o2.data_ptr(), d_src.data_ptr(), d_add.data_ptr(), B, Hs, Hs, Hd, Hd, C,
+                                                LD, torch.cuda.current_stream().cuda_stream))
+    assert rel(d_src[..., :C].permute(0, 3, 1, 2).cpu(), src.grad) < 2e-6
+    assert rel(d_add[..., :C].permute(0, 3, 1, 2).cpu() - 1.0, add.grad) < 2e-6
+    assert float(d_src[..., C:].abs().max()) == 0.0 and float((d_add[..., C:] - 1.0).abs().max()) == 0.0
+
+
+def _loss_inputs(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    o1, o2 = torch.randn(B, 2, 75, 75, generator=g), torch.randn(B, 16, 75, 75, generator=g)
+    pix = (torch.rand(B, 75, 75, generator=g) < 0.08).long()
+    neg = ((torch.rand(B, 75, 75, generator=g) < 0.9) & (pix == 0)).to(torch.uint8)
+    posw = torch.rand(B, 75, 75, generator=g) * pix.float()
+    link = (torch.rand(B, 8, 75, 75, generator=g) < 0.5).long() * pix[:, None]
+    return o1, o2, pix, neg, posw, link
+
+
+def test_loss_backward_vs_oracle_autograd(dev):
+    """d(PixelLinkLoss) on the HIP kernel vs autograd through the oracle restatement (the mined mask, areas and link weight sums are
+    constants in both), for a weighted sum of the four returned means; both calling patterns of the reference driver."""
+    from pixel_link.criterion import PixelLinkLoss
+    o1, o2, pix, neg, posw, link = _loss_inputs(3, 77)
+    wts = (1.0, 0.7, 2.0, 0.3)
+    a1, a2 = o1.clone().requires_grad_(), o2.clone().requires_grad_()
+    terms = PO.pixel_link_loss(a1, a2, pix, neg, posw, link, as_tensors=True)[:4]
+    sum(w * t for w, t in zip(wts, terms)).backward()
+    for fused in (True, False):
+        h1, h2 = o1.to(dev).requires_grad_(), o2.to(dev).requires_grad_()
+        crit = PixelLinkLoss()
+        pp, pn = crit.pixel_loss(h1, pix.to(dev), neg.to(dev), posw.to(dev), link=(h2, link.to(dev)) if fused else None)
+        lp, ln = crit.link_loss(h2, link.to(dev))
+        (wts[0] * pp + wts[1] * pn + wts[2] * lp + wts[3] * ln).backward()
+        assert rel([float(pp), float(pn), float(lp), float(ln)], [float(t) for t in terms]) < 1e-5
+        assert rel(h1.grad.cpu(), a1.grad) < 1e-5 and rel(h2.grad.cpu(), a2.grad) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['full', 'plain'])
+def test_backward_gradients_vs_oracle(dev, tag):
+    """Training step of the PixelLink++ row: HIP forward -> PixelLinkLoss -> loss.backward() (HIP loss backward + HIP backward plan)
+    against CPU autograd through the oracle graph and the oracle loss, B = 2, relative L2 error per parameter tensor.  The bounds are
+    those of the detector's gradient test (tests/test_gpu_parity.py::test_backward_gradients): ReLU / max-pool decisions at |z| ~ 1e-6
+    flip between two fp32 implementations and move single entries by ~1 %; parameters with no decision downstream match to 1e-4."""
+    from pixel_link.criterion import PixelLinkLoss
+    kw = FULL if tag == 'full' else PLAIN
+    net = build(kw)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    B = 2
+    x = synth.synth_images(B, seed=311)
+    _, _, pix, neg, posw, link = _loss_inputs(B, 5)
+    wts = (1.0, 1.0, 0.5, 0.5)
+    skip = ('running_mean', 'running_var', 'weight_u', 'weight_v', 'num_batches_tracked')
+    sdg = {k: (v.clone().requires_grad_() if (v.is_floating_point() and not k.endswith(skip)) else v) for k, v in sd.items()}
+    r1, r2, _ = PO.pixellink_forward(sdg, x, training=True, **kw)
+    terms = PO.pixel_link_loss(r1, r2, pix, neg, posw, link, as_tensors=True)[:4]
+    sum(w * t for w, t in zip(wts, terms)).backward()
+    net = net.to(dev).train()
+    o1, o2 = net(x.to(dev))
+    crit = PixelLinkLoss()
+    pp, pn = crit.pixel_loss(o1, pix.to(dev), neg.to(dev), posw.to(dev), link=(o2, link.to(dev)))
+    lp, ln = crit.link_loss(o2, link.to(dev))
+    (wts[0] * pp + wts[1] * pn + wts[2] * lp + wts[3] * ln).backward()
+    assert rel([float(pp), float(pn), float(lp), float(ln)], [float(t) for t in terms]) < 1e-4
+    named = dict(net.named_parameters(remove_duplicate=False))     # (modules_except_dcn aliases most modules: keep every name)
+
+    def l2rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+    keys = ['conv1_1.weight', 'conv2_2.weight', 'conv3_3.bias', 'conv4_2.weight', 'conv5_3.weight', 'conv6.weight', 'conv7.bias',
+            'fuse2.weight', 'bn_fuse3.weight', 'bn_fuse5.bias', 'out2_1.weight', 'out3_2.weight', 'out5_2.bias', 'final_1.weight',
+            'final_2.weight', 'final_2.bias']
+    if tag == 'full':
+        keys += ['self_attn_list.0.snconv1x1_theta.weight_orig', 'self_attn_base_list.0.sigma', 'self_attn_base_list.3.snconv1x1_g.bias',
+                 'dcn_list.0.weight', 'dcn_list.0.conv_offset_mask.weight']
+    missing = [k for k in keys if named[k].grad is None]
+    assert not missing, missing
+    errs = {k: l2rel(named[k].grad, sdg[k].grad) for k in keys}
+    print(tag, 'PixelLink++ gradient L2-relative errors vs CPU autograd', {k: f'{v:.1e}' for k, v in errs.items()})
+    assert errs['final_1.weight'] < 1e-4 and errs['final_2.weight'] < 1e-4 and errs['final_2.bias'] < 1e-4
+    assert max(v for k, v in errs.items() if not k.endswith('sigma')) < 2e-2, errs
+    assert all(v < 6e-2 for k, v in errs.items() if k.endswith('sigma')), errs
+    # every parameter the oracle graph differentiates received a gradient, and nothing else did
+    for k, p in named.items():
+        if not k.startswith('modules_except_dcn.') and p.grad is None:
+            assert sdg[k].grad is None or float(sdg[k].grad.abs().max()) == 0.0, k
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    # a second step through the same plan (buffers re-zeroed, gradients accumulate into .grad like autograd's)
+    g0 = named['final_2.weight'].grad.clone()
+    o1, o2 = net(x.to(dev))
+    pp, pn = crit.pixel_loss(o1, pix.to(dev), neg.to(dev), posw.to(dev), link=(o2, link.to(dev)))
+    lp, ln = crit.link_loss(o2, link.to(dev))
+    (wts[0] * pp + wts[1] * pn + wts[2] * lp + wts[3] * ln).backward()
+    # plain graph: the same step again, exactly twice the gradient (split-K atomics aside); full graph: the spectral-norm u / v moved one
+    # power iteration on between the two forwards (sigma changes by several per cent on the synthetic weights)
+    assert l2rel(named['final_2.weight'].grad, 2 * g0) < (5e-3 if tag == 'plain' else 0.3)
+
+
+def test_training_steps_reduce_loss(dev):
+    """Five SGD steps of the full PixelLink++ graph on one batch (HIP forward, loss, backward; torch.optim.SGD on the parameters):
+    the loss falls, every parameter with a non-zero gradient moved, nothing is NaN."""
+    from pixel_link.criterion import PixelLinkLoss
+    net = build(FULL).to(dev).train()
+    B = 2
+    x = synth.synth_images(B, seed=312).to(dev)
+    _, _, pix, neg, posw, link = _loss_inputs(B, 6)
+    pix, neg, posw, link = pix.to(dev), neg.to(dev), posw.to(dev), link.to(dev)
+    crit = PixelLinkLoss()
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    losses, opt = [], None
+    for _ in range(5):
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+        o1, o2 = net(x)
+        pp, pn = crit.pixel_loss(o1, pix, neg, posw, link=(o2, link))
+        lp, ln = crit.link_loss(o2, link)
+        loss = pp + pn + lp + ln
+        loss.backward()
+        if opt is None:
+            # step size from the first gradient: a first-order decrease of 2 % of the loss per step (the synthetic weights put the
+            # activations at 1e2 .. 1e4, a fixed learning rate would be a guess)
+            g2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters() if p.grad is not None)
+            opt = torch.optim.SGD(net.parameters(), lr=0.02 * float(loss) / g2)
+        opt.step()
+        losses.append(float(loss))
+    print('PixelLink++ training losses', [round(v, 4) for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # every weight moved.  Biases whose gradient is zero by construction stay bit-identical (rounding noise times a 1e-7 step): a conv
+    # bias in front of a train-mode BatchNorm (the fuse convs; in the side-branch Self_Attn blocks also the g and output-conv biases,
+    # which reach the fuse BatchNorm as per-channel constants) and the phi bias of every Self_Attn block (it shifts all logits of a query
+    # row alike); a sigma gate (one scalar, gradient = a cancelling sum over the map) may move by less than its ulp
+    still = sorted(k for k, v in net.named_parameters() if torch.equal(v.detach(), before[k]))
+    print('unmoved', still)
+    assert all(k.endswith(('.bias', '.sigma')) for k in still), still
+    assert sum(k.endswith('.sigma') for k in still) <= 2 and len(still) < 0.2 * len(before)
 
 
 def test_loss_vs_reference_fixture(dev, golden):
