@@ -918,7 +918,16 @@ def _stage_errors(net, taps):
 def test_end_to_end_seed_sweep_margin(dev, name):
     """the 1e-4 gate held with 25 % headroom on ONE seed.  Five weight / image seed pairs, full tensors against the
     (fixture-pinned) oracle, with the per-stage error table printed (pytest -s) and written to gpurun_out/ so the layer that eats the
-    budget is named.  Winograd F(2x2,3x3) on the trunk + 13 train-mode BatchNorms are the suspects."""
+    budget is named.
+
+    What the sweep shows (round 3, scripts/dbg_fwd64.py): the error is NOT the Winograd trunk's (GSSD_NO_WINOGRAD=1 gives the same 5 -
+    7e-5) -- it is fp32 rounding noise amplified by the train-mode BatchNorms of the extras chain, whose statistics at this test's
+    batch of 4 run over 4 x 9 values on the 3 x 3 map and over FOUR values on the 1 x 1 map.  The worst entries always sit on the four
+    priors of the 1 x 1 map (8728 .. 8731).  There the fp32 REFERENCE is itself only defined to ~5e-5: against the same graph in
+    float64 the CPU fp32 oracle is off by 4 - 5e-5 and the HIP path by 5 - 7e-5, and when the two errors have opposite signs their
+    difference touches 1e-4 (seed 31337: 1.04e-4; before the Winograd epilogue of round 3 changed the order of the batch sums: 9.9e-5).
+    Gates: priors 0 .. 8727 and both losses against the fp32 oracle at 1e-4 (north_star); the four 1 x 1-map priors against FLOAT64 at
+    1e-4, and no worse than twice the fp32 oracle's own distance from float64 (+ 2e-5)."""
     from models.ssd_multiphase_custom_group import build_ssd
     from layers.modules import MultiBoxLoss
     flags, args = NETS[name]
@@ -927,7 +936,12 @@ def test_end_to_end_seed_sweep_margin(dev, name):
     net = net.to(dev).train()
     crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
     pri = O.prior_box()
-    lines, worst = [], 0.0
+    lines, worst, worst_tail = [], 0.0, 0.0
+    NT = 8728                                   # priors of the 1 x 1 map start here
+
+    def part(a, b, lo_, hi_):                   # max error over a prior range, relative to the whole reference tensor's max
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a[:, lo_:hi_] - b[:, lo_:hi_]).abs().max() / b.abs().max())
     for wseed, xseed in ((1111, 11), (2024, 12), (7, 13), (31337, 14), (99, 15)):
         sd = synth.synth_state_dict(shapes, seed=wseed)
         net.load_state_dict(sd)
@@ -938,13 +952,23 @@ def test_end_to_end_seed_sweep_margin(dev, name):
             loc, conf, _ = net(x.to(dev))
             ll, lc = crit((loc, conf, torch.from_numpy(pri).to(dev)), tg)
             lo, co, _ = O.gssd_forward(sd, x, taps=taps, **flags)
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+            l64, c64, _ = O.gssd_forward(sd64, x.double(), **flags)
         rl, rc = O.multibox_loss(lo.numpy(), co.numpy(), pri, [t.numpy() for t in tg])[:2]
-        e = dict(loc=rel(loc, lo), conf=rel(conf, co), loss_l=rel(ll, rl), loss_c=rel(lc, rc))
+        e = dict(loc=part(loc, lo, 0, NT), conf=part(conf, co, 0, NT), loss_l=rel(ll, rl), loss_c=rel(lc, rc))
+        tail = dict(hip_ref=max(part(loc, lo, NT, None), part(conf, co, NT, None)),
+                    hip_f64=max(part(loc, l64, NT, None), part(conf, c64, NT, None)),
+                    ref_f64=max(part(lo, l64, NT, None), part(co, c64, NT, None)))
         st = _stage_errors(net, taps)
-        lines.append(f'{name} weights {wseed} images {xseed}: ' + ' '.join(f'{k} {v:.2e}' for k, v in e.items()))
+        lines.append(f'{name} weights {wseed} images {xseed}: ' + ' '.join(f'{k} {v:.2e}' for k, v in e.items()) +
+                     '  | 1x1-map priors: HIP-oracle %.2e HIP-float64 %.2e oracle-float64 %.2e' % (tail['hip_ref'], tail['hip_f64'],
+                                                                                                   tail['ref_f64']))
         lines += [f'    {k:18s} {v:.2e}' for k, v in st]
         worst = max(worst, *e.values())
-    lines.append(f'{name}: worst of 5 seeds {worst:.2e} (gate {TOL:.0e})')
+        worst_tail = max(worst_tail, tail['hip_f64'])
+        assert tail['hip_f64'] < TOL and tail['hip_f64'] <= 2.0 * tail['ref_f64'] + 2e-5, lines[-len(st) - 1]
+    lines.append(f'{name}: worst of 5 seeds {worst:.2e} vs the fp32 oracle on priors 0..8727 and the losses, {worst_tail:.2e} vs float64 on '
+                 f'the 1x1-map priors (gate {TOL:.0e})')
     print('\n'.join(lines))
     d = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(d):
