@@ -18,17 +18,24 @@ inline int ew_blocks(long long work_items, int per_block = EW_THREADS, int cap =
 
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 
-// NCHW fp32 -> NHWC bf16 with each group's channels padded from cpg_in to 8 (zeros): one 16-byte store per (pixel, group)
+// NCHW fp32 -> NHWC bf16 with each group's channels padded from cpg_in to a multiple of 8 (zeros): one 16-byte store per (pixel, group,
+// 8-channel piece) -- one piece for 4 and 2 groups (3 and 6 channels), two for the ungrouped 12-channel input
 __global__ void pack_input_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, int B, int C, int HW, int groups, int cpg_in) {
-    const long long total = (long long)B * HW * groups;
+    const int pieces = (cpg_in + 7) >> 3;
+    const long long total = (long long)B * HW * groups * pieces;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const long long bp = i / groups;
+        const int pc = (int)(i % pieces);
+        const long long ig = i / pieces;
+        const int g = (int)(ig % groups);
+        const long long bp = ig / groups;
         const int pix = (int)(bp % HW);
         const int b = (int)(bp / HW);
         bf16x8 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (__bf16)((c < cpg_in) ? x[((long long)b * C + g * cpg_in + c) * HW + pix] : 0.f);
+        for (int c = 0; c < 8; ++c) {
+            const int cc = pc * 8 + c;
+            o[c] = (__bf16)((cc < cpg_in) ? x[((long long)b * C + g * cpg_in + cc) * HW + pix] : 0.f);
+        }
         *reinterpret_cast<bf16x8*>(y + i * 8) = o;
     }
 }
@@ -171,8 +178,8 @@ __global__ __launch_bounds__(256) void l2norm_bf16_kernel(const u16* __restrict_
 
 extern "C" int gssd_pack_input_nhwc_bf16(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int groups,
                                          gssd_stream_t stream) {
-    GSSD_CHECK_ARG(x_nchw && y_nhwc && B > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0 && C / groups <= 8);
-    hipLaunchKernelGGL(pack_input_bf16_kernel, dim3(ew_blocks((long long)B * H * W * groups)), dim3(EW_THREADS), 0, as_stream(stream),
+    GSSD_CHECK_ARG(x_nchw && y_nhwc && B > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0);
+    hipLaunchKernelGGL(pack_input_bf16_kernel, dim3(ew_blocks((long long)B * H * W * groups * ((C / groups + 7) / 8))), dim3(EW_THREADS), 0, as_stream(stream),
                        x_nchw, reinterpret_cast<u16*>(y_nhwc), B, C, H * W, groups, C / groups);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -270,7 +270,9 @@ class _Plan(_PlanBase):
         self.bf16 = getattr(eng.net, 'compute_dtype', 'f32') == 'bf16'
         self.adt = torch.bfloat16 if self.bf16 else torch.float32
         self.conv_fn = lib.gssd_conv2d_nhwc_bf16 if self.bf16 else lib.gssd_conv2d_nhwc_f32
-        self.cpad = 8 if self.bf16 else 4          # channels per phase of the packed input (3 real)
+        # channels per group of the packed input: 12 / groups_vgg real ones (3 per CT phase at the default 4 groups), zero-padded to whole
+        # 16-byte pieces (fp32: 4 channels, bf16: 8)
+        self.cpad = ops.round_up(12 // eng.net.groups_vgg, 8 if self.bf16 else 4)
         net = eng.net
         self.steps = []
         self.bufs = []
@@ -313,7 +315,7 @@ class _Plan(_PlanBase):
         if self.bf16:
             self._add(lib.gssd_pack_input_nhwc_bf16, [0, x16.data_ptr(), B, 12, 300, 300, g])
         else:
-            self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, 4])
+            self._add(lib.gssd_pack_input_nhwc, [0, x16.data_ptr(), B, 12, 300, 300, g, self.cpad])
 
         if not net.batch_norm:
             if self.bf16:
@@ -580,6 +582,9 @@ class _Plan(_PlanBase):
         k, s, p, dl = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         Cout = conv.out_channels
         cin_g = Cin // groups
+        if defer_bn and Cout // groups > 512:
+            defer_bn = False        # the consumer (same group count) would read more than 512 channels per group: the conv kernels' fused
+            #                         input transform keeps at most 512 scale / shift pairs (ungrouped conv6 -> conv7 at groups_vgg = 1)
         wp = self._packed_conv(name, conv)
         U = None
         if not self.bf16 and USE_WINOGRAD and ops.winograd_eligible(k, s, p, dl, cin_g, Cout // groups, groups):

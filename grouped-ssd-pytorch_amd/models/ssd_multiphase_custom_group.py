@@ -36,8 +36,9 @@ class SSD(nn.Module):
                  use_fuseconv, use_self_attention, use_self_attention_base, num_dcn_layers, groups_dcn, dcn_cat_sab,
                  detach_sab, max_pool_factor):
         super().__init__()
-        if groups_vgg != 4 or groups_extra != 4:
-            raise NotImplementedError('the HIP path is laid out for 4 phases (groups_vgg = groups_extra = 4)')
+        if groups_vgg not in (1, 2, 4) or groups_extra not in (1, 2, 4):
+            raise ValueError('groups_vgg / groups_extra must divide the 12 input channels and every layer width: 1, 2 or 4 '
+                             '(4 = one group per CT phase is what the tuned kernels are laid out for; 1 and 2 run the generic ones)')
         self.phase = phase
         self.num_classes = num_classes
         self.batch_norm = batch_norm

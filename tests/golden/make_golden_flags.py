@@ -2,6 +2,7 @@
 142-145): ``--use_fuseconv False``, ``--batch_norm False``, ``--max_pool_factor 2 / 3``, ``--feature_scale 2`` (every channel width doubled).
 
     python tests/golden/make_golden_flags.py     # rewrites tests/golden/flags.npz  (build container only: imports /root/reference)
+    python tests/golden/make_golden_flags.py g1 g2pp g4e1     # computes only the named nets and merges them into flags.npz
 """
 import os
 import sys
@@ -24,6 +25,10 @@ FLAG_NETS = {
     'fs2': (True, 4, 4, 2, True, False, False, 0, 1, False, False, 1),
     'dcn2_detach': (True, 4, 4, 1, True, True, True, 2, 1, True, True, 1),      # two DCN layers, one deformable group, detached SAB
     'dcn_nocat': (True, 4, 4, 1, True, False, False, 1, 4, False, False, 1),     # DCN on the plain conv4_3 map (512 -> 512)
+    # round 3: --groups_vgg / --groups_extra other than 4 (train_lesion_multiphase_v2.py:47-48)
+    'g1': (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1),            # ungrouped trunk and extras on the 12-channel input
+    'g2pp': (True, 2, 2, 1, True, True, True, 1, 4, True, False, 1),             # GSSD++ with two groups (slice_and_cat over 2 groups)
+    'g4e1': (True, 4, 1, 1, True, False, False, 0, 1, False, False, 1),          # grouped trunk, ungrouped extras
 }
 EB = 2
 
@@ -35,7 +40,13 @@ def main():
     x = synth.synth_images(EB, seed=5)
     tg = synth.synth_targets(EB, seed=5)
     d = {}
+    only = sys.argv[1:]
+    if only:                                     # keep every other entry of the existing file byte for byte
+        with np.load(os.path.join(HERE, 'flags.npz'), allow_pickle=False) as old:
+            d = {k: old[k] for k in old.files}
     for name, args in FLAG_NETS.items():
+        if only and name not in only:
+            continue
         net = R.mg.build_ssd('train', 300, 2, *args)
         shapes = {k: v.shape for k, v in net.state_dict().items()}
         sd = synth.synth_state_dict(shapes, seed=1111)

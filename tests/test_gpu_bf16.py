@@ -640,3 +640,28 @@ def test_self_attn_core_bf16_values(dev, N, D, C2):
     got = out.float().cpu().double()
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max() / ref.abs().max()) <= BF_ULP_LOW
+
+
+@pytest.mark.parametrize('name,flags,args', [
+    ('g1', dict(groups_vgg=1, groups_extra=1), (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1)),
+    ('g2pp', dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                  dcn_cat_sab=True), (True, 2, 2, 1, True, True, True, 1, 4, True, False, 1))])
+def test_bf16_group_counts(dev, name, flags, args):
+    """--groups_vgg / --groups_extra 1 and 2 in the bf16 storage mode (the input pack writes 12 -> 16 / 6 -> 8 channels per group; every
+    layer runs the generic bf16 kernels).  End to end at B = 2 the bf16 graph is far from the fp32 one (ill-conditioned small-batch
+    BatchNorms, tests above): the HIP result must sit well inside that gap around the bf16 oracle."""
+    from models.ssd_multiphase_custom_group import build_ssd
+    net = build_ssd('train', 300, 2, *args)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    net.compute_dtype = 'bf16'
+    x = synth.synth_images(2, seed=5)
+    with torch.no_grad():
+        loc, conf, _ = net(x.to(dev))
+        lo, co, _ = O.gssd_forward(sd, x, bf16=True, **flags)
+        lo32, co32, _ = O.gssd_forward(sd, x, **flags)
+    assert torch.isfinite(loc).all() and torch.isfinite(conf).all()
+    e, gap = max(rel(loc, lo), rel(conf, co)), max(rel(lo, lo32), rel(co, co32))
+    print(name, f'bf16 HIP vs bf16 oracle {e:.3f}; bf16 oracle vs fp32 oracle {gap:.3f}')
+    assert e < 0.6 * gap, (e, gap)

@@ -1053,6 +1053,17 @@ FLAG_NETS = {       # tests/golden/make_golden_flags.py: (oracle flags, build_ss
     'dcn_nocat': (dict(num_dcn_layers=1, groups_dcn=4), (True, 4, 4, 1, True, False, False, 1, 4, False, False, 1),
                   ['vgg.0.weight', 'vgg.30.weight', 'dcn_list.0.weight', 'dcn_list.0.bias', 'dcn_list.0.conv_offset_mask.weight',
                    'fuse_11.weight', 'loc.0.weight']),
+    # round 3: --groups_vgg / --groups_extra 1 and 2 (train_lesion_multiphase_v2.py:47-48): the generic kernels, same plan code
+    'g1': (dict(groups_vgg=1, groups_extra=1), (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1),
+           ['vgg.0.weight', 'vgg.14.weight', 'vgg.31.weight', 'vgg.44.weight', 'extras.2.weight', 'extras.8.weight', 'fuse_21.weight',
+            'loc.0.weight', 'conf.3.bias']),
+    'g2pp': (dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                  dcn_cat_sab=True), (True, 2, 2, 1, True, True, True, 1, 4, True, False, 1),
+             ['vgg.0.weight', 'vgg.24.weight', 'vgg.40.weight', 'extras.4.weight', 'fuse_11.weight', 'loc.0.weight', 'dcn_list.0.weight',
+              'dcn_list.0.conv_offset_mask.weight', 'self_attn_base_list.0.snconv1x1_g.weight_orig',
+              'self_attn_list.1.snconv1x1_theta.weight_orig']),
+    'g4e1': (dict(groups_extra=1), (True, 4, 1, 1, True, False, False, 0, 1, False, False, 1),
+             ['vgg.0.weight', 'vgg.44.weight', 'extras.0.weight', 'extras.6.weight', 'fuse_41.weight', 'loc.4.weight', 'conf.4.bias']),
 }
 
 

@@ -228,12 +228,17 @@ FLAG_NETS = {       # tests/golden/make_golden_flags.py: the driver-reachable no
     'fs2': dict(feature_scale=2),
     'dcn2_detach': dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=2, groups_dcn=1, dcn_cat_sab=True),
     'dcn_nocat': dict(num_dcn_layers=1, groups_dcn=4),
+    'g1': dict(groups_vgg=1, groups_extra=1),
+    'g2pp': dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
+                 dcn_cat_sab=True),
+    'g4e1': dict(groups_extra=1),
 }
 
 
-@pytest.mark.parametrize('name', ['nofuse', 'nobn', 'nobn_plain', 'mpf2', 'mpf3_sa', 'fs2', 'dcn2_detach', 'dcn_nocat'])
+@pytest.mark.parametrize('name', ['nofuse', 'nobn', 'nobn_plain', 'mpf2', 'mpf3_sa', 'fs2', 'dcn2_detach', 'dcn_nocat', 'g1', 'g2pp', 'g4e1'])
 def test_constructor_flags_vs_reference(golden, name):
-    """--use_fuseconv False / --batch_norm False / --max_pool_factor / --feature_scale (train_lesion_multiphase_v2.py:49-77):
+    """--use_fuseconv False / --batch_norm False / --max_pool_factor / --feature_scale / --groups_vgg, --groups_extra 1, 2
+    (train_lesion_multiphase_v2.py:47-77):
     the oracle graph against what the imported reference computed (flags.npz)."""
     g = golden('flags')
     keys = [str(k) for k in g[f'{name}.keys']]
