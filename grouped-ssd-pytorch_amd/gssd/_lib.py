@@ -109,6 +109,7 @@ SIGNATURES = {
     'gssd_dcn_im2col_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_packed_weight_elems': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    'gssd_dcn_streamk': (c_i, [c_i]),
     'gssd_dcn_forward_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_resample_ksize': (c_i, [c_i, c_i, c_i]),
     'gssd_resample_coeffs': (c_i, [c_i, c_i, c_i, c_fp, c_fp]),

@@ -27,6 +27,8 @@
 // the slots (ablations in round 2: one per slot / one per four slots / wave-staggered slots all measure the same; an LDS read costs
 // ~4, an LDS-DMA piece less than a load -- hence the weight tile by LDS-DMA).  Next step: stage the x window of a channel chunk in
 // LDS once per 9 taps (10x fewer vector-memory instructions) and gather from LDS.
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -63,10 +65,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // wp: [n_tiles][chunks][BN][32] (slot-swizzled rows), chunk = (d * cpg/32 + c32) * 9 + tap
+//
+// SK ("stream-K"): the grid is one persistent workgroup per CU; the (tile, chunk) iteration space of an XCD's tiles is cut into equal
+// contiguous spans, one per workgroup of that XCD, so 722 tiles on 256 CUs cost 2.82 tile times instead of 3 rounds.  A tile that
+// straddles a span boundary is computed by two workgroups of the SAME XCD (same L2): the one that owns its last chunks meets it first
+// and stores its partial sums to the tile's place in `out`, raises the tile's flag; the owner of its first chunks meets it last, waits
+// for the flag (long set), adds its own sums and the bias, resets the flag.  Spans are handed out in DEcreasing workgroup id, so a
+// waiter always has a higher id than the workgroup it waits for: with in-order dispatch the provider is resident or done whenever a
+// waiter spins, whatever share of the CUs other streams occupy.  Two partial sums added in either order give the same bits.
+template <bool SK>
 __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg,
-                                                          int om_stride, int Cout, int ntn, int mtiles) {
+                                                          int om_stride, int Cout, int ntn, int mtiles, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                                   // [2][BM][32]
     float* const Bs = smem + 2 * A_STAGE;                     // [2][BN][32]
@@ -78,32 +89,41 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, kq = lane >> 4;
     // XCD-aware tile order: workgroup id L runs on XCD L & 7; an XCD streams ONE weight slab (N tile) when the N-tile count
-    // divides 8, and walks consecutive M tiles (shared halo rows of x stay in that L2)
-    int mt, nt;
-    {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // divides 8, and walks consecutive M tiles (shared halo rows of x stay in that L2).  Tile (slot, xcd) <-> id L = slot * 8 + xcd.
+    const int xcd = blockIdx.x & 7;
+    auto tile_of = [&](int slot, int& mt_, int& nt_) {
         if (8 % ntn == 0) {
-            nt = xcd % ntn;
-            mt = slot * (8 / ntn) + xcd / ntn;
+            nt_ = xcd % ntn;
+            mt_ = slot * (8 / ntn) + xcd / ntn;
         } else {
             const int id = slot * 8 + xcd;
-            nt = id % ntn;
-            mt = id / ntn;
+            nt_ = id % ntn;
+            mt_ = id / ntn;
         }
-    }
-    if (mt >= mtiles) return;
-    const int m0 = mt * BM;
+    };
     const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;       // chunks of channels per deformable group
     const int nchunks = dg * cpc * 9;
-    const float* wslab = wp + (size_t)nt * nchunks * B_STAGE;
+    // this workgroup's span of its XCD's (slot, chunk) space
+    long long sk_pos = 0, sk_hi = 0;
+    if (SK) {
+        const int R = gridDim.x >> 3, rank = R - 1 - (int)(blockIdx.x >> 3);
+        const int nx = 8 % ntn == 0 ? (mtiles - xcd / ntn + (8 / ntn) - 1) / (8 / ntn) : (mtiles * ntn - xcd + 7) / 8;
+        const long long tot = (long long)(nx > 0 ? nx : 0) * nchunks;
+        sk_pos = tot * rank / R;
+        sk_hi = tot * (rank + 1) / R;
+        if (sk_pos >= sk_hi) return;
+    }
+    int mt = 0, nt = 0, m0 = 0, c_begin = 0, c_end = nchunks, tile_id = 0;
+    if (!SK) {
+        tile_of((int)(blockIdx.x >> 3), mt, nt);
+        if (mt >= mtiles) return;
+        m0 = mt * BM;
+    }
+    const float* wslab = wp;
     const char* xbytes = reinterpret_cast<const char*>(x);
 
     f32x4 acc[MT][NT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
 
     // gather roles: thread -> (pixel row pl = (tid >> 3) + 32*j, 4-channel quad q = tid & 7), j = 0..3
     const int gq = tid & 7, gp = tid >> 3;
@@ -170,26 +190,7 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
         ch_d += wc ? 1 : 0;
     };
 
-    // ---- prologue: chunk 0, unscheduled ----------------------------------------------------------------------------------
-    setups(0);
-    __syncthreads();
-    {
-        cb = (unsigned)(gq * 4) * 4u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = gp + 32 * j;
-            const f32x4 w4 = setw[e];
-            const u32x4 o = seto[e];
-            f32x4 v = zero4;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v += *reinterpret_cast<const f32x4*>(xbytes + (o[k] + cb)) * w4[k];
-            *reinterpret_cast<f32x4*>(As + a_wr0 + j * 32 * BKC) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dma16(wslab + (j * 4 + wave) * 256 + lane * 4, Bs + (j * 4 + wave) * 256);
-    }
-    advance();
-    __syncthreads();
+    // (the segment loop follows the definition of the slot stream below)
 
     // One chunk = 256 MFMAs per wave (8192 matrix-pipe cycles).  Slot k = MFMA k followed by at most a few staging instructions of
     // chunk ch+1 that issue in that MFMA's 32-cycle shadow; a scheduling fence after every slot keeps hipcc from regrouping them:
@@ -248,54 +249,117 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // fragments k 0..15 of chunk 0
-    {
-        const float* Ab = As + wm * WTM * BKC;
-        const float* Bb = Bs + wn * WTN * BKC;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * BKC + fo0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 16 * BKC + fo0);
-    }
-    for (int ch = 0; ch < nchunks - 1; ++ch) {
-        const int buf = ch & 1;
-        if (ch_tap == 0 && ch_c == 0) {          // the next chunk opens a new deformable group: new sampling table
-            setups(ch_d);
-            __syncthreads();
+    // ---- segments: one tile (all chunks) per workgroup, or the pieces of this workgroup's stream-K span ---------------------------
+    for (;;) {
+        if (SK) {
+            if (sk_pos >= sk_hi) break;
+            const int slot_i = (int)(sk_pos / nchunks);
+            c_begin = (int)(sk_pos - (long long)slot_i * nchunks);
+            const long long left = sk_hi - sk_pos;
+            c_end = (nchunks - c_begin) < left ? nchunks : c_begin + (int)left;
+            sk_pos += c_end - c_begin;
+            tile_of(slot_i, mt, nt);
+            m0 = mt * BM;
+            tile_id = slot_i * 8 + xcd;
         }
-        cb = (unsigned)(ch_d * cpg + ch_c * BKC + gq * 4) * 4u;
-        stage_src = wslab + (size_t)(ch + 1) * B_STAGE + wave * 256 + lane * 4;
-        stage_dst = Bs + (buf ^ 1) * B_STAGE + wave * 256 + lane * 4;
-        stage_dst_w = Bs + (buf ^ 1) * B_STAGE + wave * 256;
-        a_dst = As + (buf ^ 1) * A_STAGE + a_wr0;
-        const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
-        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
-        const float* Abn = As + (buf ^ 1) * A_STAGE + wm * WTM * BKC;
-        const float* Bbn = Bs + (buf ^ 1) * B_STAGE + wn * WTN * BKC;
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 256>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
+        wslab = wp + (size_t)nt * nchunks * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
+        // ---- prologue: chunk c_begin, unscheduled ------------------------------------------------------------------------------
+        ch_tap = c_begin % 9;
+        ch_c = (c_begin / 9) % cpc;
+        ch_d = c_begin / (9 * cpc);
+        setups(ch_d);
+        __syncthreads();
+        {
+            cb = (unsigned)(ch_d * cpg + ch_c * BKC + gq * 4) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = ch_tap * BM + gp + 32 * j;
+                const f32x4 w4 = setw[e];
+                const u32x4 o = seto[e];
+                f32x4 v = zero4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v += *reinterpret_cast<const f32x4*>(xbytes + (o[k] + cb)) * w4[k];
+                *reinterpret_cast<f32x4*>(As + a_wr0 + j * 32 * BKC) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dma16(wslab + (size_t)c_begin * B_STAGE + (j * 4 + wave) * 256 + lane * 4, Bs + (j * 4 + wave) * 256);
+        }
         advance();
-    }
-    {
-        const int buf = (nchunks - 1) & 1;
-        const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
-        const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
-        static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
-    }
-
-    // ---- epilogue: + bias, NHWC store ------------------------------------------------------------------------------------
+        __syncthreads();
+        // fragments k 0..15 of the first chunk
+        {
+            const float* Ab = As + wm * WTM * BKC;
+            const float* Bb = Bs + wn * WTN * BKC;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = nt * BN + wn * WTN + j * 16 + r;
-        if (n >= Cout) continue;
-        const float bv = bias ? bias[n] : 0.f;
+            for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * BKC + fo0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mb = m0 + wm * WTM + i * 16 + kq * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (mb + e < M) out[(size_t)(mb + e) * Cout + n] = acc[i][j][e] + bv;
+            for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 16 * BKC + fo0);
         }
+        for (int ch = c_begin; ch < c_end - 1; ++ch) {
+            const int buf = (ch - c_begin) & 1;
+            if (ch_tap == 0 && ch_c == 0) {          // the next chunk opens a new deformable group: new sampling table
+                setups(ch_d);
+                __syncthreads();
+            }
+            cb = (unsigned)(ch_d * cpg + ch_c * BKC + gq * 4) * 4u;
+            stage_src = wslab + (size_t)(ch + 1) * B_STAGE + wave * 256 + lane * 4;
+            stage_dst = Bs + (buf ^ 1) * B_STAGE + wave * 256 + lane * 4;
+            stage_dst_w = Bs + (buf ^ 1) * B_STAGE + wave * 256;
+            a_dst = As + (buf ^ 1) * A_STAGE + a_wr0;
+            const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
+            const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
+            const float* Abn = As + (buf ^ 1) * A_STAGE + wm * WTM * BKC;
+            const float* Bbn = Bs + (buf ^ 1) * B_STAGE + wn * WTN * BKC;
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 256>([&](auto kc) { slot(kc, std::true_type{}, Ab, Bb, Abn, Bbn); });
+            advance();
+        }
+        {
+            const int buf = (c_end - 1 - c_begin) & 1;
+            const float* Ab = As + buf * A_STAGE + wm * WTM * BKC;
+            const float* Bb = Bs + buf * B_STAGE + wn * WTN * BKC;
+            static_for<0, 256>([&](auto kc) { slot(kc, std::false_type{}, Ab, Bb, Ab, Bb); });
+        }
+
+        // ---- epilogue: + bias, NHWC store; a stream-K piece that owns only part of the tile's chunks hands over / picks up partial sums
+        const bool head = c_begin == 0, tail = c_end == nchunks;
+        if (SK && head && !tail) {
+            if (tid == 0) {
+                while (__hip_atomic_load(flags + tile_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nt * BN + wn * WTN + j * 16 + r;
+            if (n >= Cout) continue;
+            const float bv = (bias && head) ? bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mb = m0 + wm * WTM + i * 16 + kq * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (mb + e < M) {
+                        float v = acc[i][j][e] + bv;
+                        if (SK && head && !tail) v += out[(size_t)(mb + e) * Cout + n];
+                        out[(size_t)(mb + e) * Cout + n] = v;
+                    }
+            }
+        }
+        if (SK && tail && !head) {                   // partial sums of the tile's last chunks are in place: raise its flag
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + tile_id, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (SK && head && !tail && tid == 0) __hip_atomic_store(flags + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!SK) break;
+        __syncthreads();                             // LDS (tiles, sampling table) is free for the next piece
     }
 }
 
@@ -333,6 +397,13 @@ extern "C" int gssd_dcn_pack_weight_f32(const float* w_oihw, float* w_packed, in
     return GSSD_OK;
 }
 
+static int g_dcn_sk_force = -1;     // -1: GSSD_DCN_STREAMK decides (default on), 0 / 1: forced (tests, ablation)
+extern "C" int gssd_dcn_streamk(int mode) {
+    const int prev = g_dcn_sk_force;
+    g_dcn_sk_force = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
+
 extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B,
                                     int H, int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && om && w_packed && out && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0 && Cout > 0);
@@ -347,8 +418,10 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     (void)hipGetDevice(&dev);
     constexpr int smem = LDS_FLOATS * (int)sizeof(float);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+                hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
             return GSSD_ELAUNCH;
         }
@@ -362,8 +435,44 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     } else {
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
-    hipLaunchKernelGGL(dcn_fused_kernel, dim3(blocks), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H, W, C, dg,
-                       om_stride, Cout, ntn, mtiles);
+    // Stream-K form (one persistent workgroup per CU, equal spans of the (tile, chunk) space): taken when every XCD has at least as
+    // many tiles as workgroups (a tile then straddles at most one span boundary) and the tile count does not already fill whole rounds.
+    // The per-tile flags live in a per-device buffer (8 regions taken in turn, so launches in flight on different streams do not
+    // share flags); it is allocated on the first launch outside a stream capture.  GSSD_DCN_STREAMK=0 keeps one tile per workgroup.
+    static const bool sk_off = []() { const char* e = getenv("GSSD_DCN_STREAMK"); return e && e[0] == '0'; }();
+    constexpr int SK_REGIONS = 8, SK_REGION_INTS = 1 << 16;
+    static int* sk_flags[16] = {nullptr};
+    static int sk_cus[16] = {0};
+    static std::atomic<unsigned> sk_turn{0};
+    bool sk = (g_dcn_sk_force < 0 ? !sk_off : g_dcn_sk_force == 1) && dev >= 0 && dev < 16 && blocks <= SK_REGION_INTS;
+    if (sk && !sk_cus[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        sk_cus[dev] = cus > 0 ? cus : -1;
+    }
+    if (sk) {
+        const int cus = sk_cus[dev];
+        const int nslots = blocks / 8;                       // tiles of the fullest XCD; the emptiest has nslots - 1 or nslots
+        sk = cus >= 8 && cus % 8 == 0 && nslots - 1 >= cus / 8 && blocks > cus && blocks % cus != 0;
+    }
+    if (sk && !sk_flags[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(as_stream(stream), &cap);
+        int* p = nullptr;
+        if (cap == hipStreamCaptureStatusNone && hipMalloc(&p, (size_t)SK_REGIONS * SK_REGION_INTS * sizeof(int)) == hipSuccess &&
+            hipMemset(p, 0, (size_t)SK_REGIONS * SK_REGION_INTS * sizeof(int)) == hipSuccess)
+            sk_flags[dev] = p;
+        else
+            sk = false;
+    }
+    if (sk) {
+        int* fl = sk_flags[dev] + (size_t)(sk_turn.fetch_add(1) % SK_REGIONS) * SK_REGION_INTS;
+        hipLaunchKernelGGL(dcn_fused_kernel<true>, dim3(sk_cus[dev]), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M,
+                           H, W, C, dg, om_stride, Cout, ntn, mtiles, fl);
+    } else {
+        hipLaunchKernelGGL(dcn_fused_kernel<false>, dim3(blocks), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H,
+                           W, C, dg, om_stride, Cout, ntn, mtiles, (int*)nullptr);
+    }
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
