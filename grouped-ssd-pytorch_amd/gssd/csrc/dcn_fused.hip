@@ -66,13 +66,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // wp: [n_tiles][chunks][BN][32] (slot-swizzled rows), chunk = (d * cpg/32 + c32) * 9 + tap
 //
-// SK ("stream-K"): the grid is one persistent workgroup per CU; the (tile, chunk) iteration space of an XCD's tiles is cut into equal
-// contiguous spans, one per workgroup of that XCD, so 722 tiles on 256 CUs cost 2.82 tile times instead of 3 rounds.  A tile that
-// straddles a span boundary is computed by two workgroups of the SAME XCD (same L2): the one that owns its last chunks meets it first
-// and stores its partial sums to the tile's place in `out`, raises the tile's flag; the owner of its first chunks meets it last, waits
-// for the flag (long set), adds its own sums and the bias, resets the flag.  Spans are handed out in DEcreasing workgroup id, so a
-// waiter always has a higher id than the workgroup it waits for: with in-order dispatch the provider is resident or done whenever a
-// waiter spins, whatever share of the CUs other streams occupy.  Two partial sums added in either order give the same bits.
+// SK ("stream-K"): the grid is one persistent workgroup per CU.  722 tiles on 256 CUs cost 3 rounds for 2.82 rounds of work (542 tiles at
+// batch 24: 3 rounds for 2.1); here every workgroup computes floor(tiles / workgroups) whole tiles of its XCD round by round, then an
+// equal contiguous span of the (tile, chunk) space of the XCD's remaining tiles.  A remaining tile is cut into pieces owned by
+// consecutive ranks of the SAME XCD (same L2); the piece with the tile's LAST chunks is met first (start of its owner's span), the piece
+// with the first chunks last.  Partial sums travel through the tile's place in `out`: every piece but the last waits until the tile's
+// flag says "the sums of chunks c_end .. are in place", adds its own, every piece but the first publishes the longer suffix, the first
+// adds the bias and resets the flag.  Spans are handed out in DEcreasing workgroup id, so a waiter always has a higher id than the
+// workgroup it waits for: with in-order dispatch the provider is resident or done whenever a waiter spins, whatever share of the CUs
+// other streams occupy.  The order of the additions is fixed by the chain: results are deterministic.
 template <bool SK>
 __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
@@ -103,15 +105,20 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     };
     const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;       // chunks of channels per deformable group
     const int nchunks = dg * cpc * 9;
-    // this workgroup's span of its XCD's (slot, chunk) space
+    // Stream-K, phase-aligned: every workgroup first computes `sk_full` whole tiles (round i: slot i * R + rank, like the rounds of the
+    // one-tile grid -- all workgroups of an XCD then stream the same weight chunk at the same time, which is what keeps the 9.4 MB weight
+    // slab an L2 hit), then its span of the (slot, chunk) space of the XCD's remaining tiles (fewer than R)
     long long sk_pos = 0, sk_hi = 0;
+    int sk_full = 0, sk_round = 0, sk_R = 1, sk_rank = 0;
     if (SK) {
-        const int R = gridDim.x >> 3, rank = R - 1 - (int)(blockIdx.x >> 3);
+        sk_R = gridDim.x >> 3;
+        sk_rank = sk_R - 1 - (int)(blockIdx.x >> 3);
         const int nx = 8 % ntn == 0 ? (mtiles - xcd / ntn + (8 / ntn) - 1) / (8 / ntn) : (mtiles * ntn - xcd + 7) / 8;
-        const long long tot = (long long)(nx > 0 ? nx : 0) * nchunks;
-        sk_pos = tot * rank / R;
-        sk_hi = tot * (rank + 1) / R;
-        if (sk_pos >= sk_hi) return;
+        sk_full = (nx > 0 ? nx : 0) / sk_R;
+        const long long tot = (long long)((nx > 0 ? nx : 0) - sk_full * sk_R) * nchunks;
+        sk_pos = tot * sk_rank / sk_R;
+        sk_hi = tot * (sk_rank + 1) / sk_R;
+        if (sk_full == 0 && sk_pos >= sk_hi) return;
     }
     int mt = 0, nt = 0, m0 = 0, c_begin = 0, c_end = nchunks, tile_id = 0;
     if (!SK) {
@@ -252,12 +259,21 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     // ---- segments: one tile (all chunks) per workgroup, or the pieces of this workgroup's stream-K span ---------------------------
     for (;;) {
         if (SK) {
-            if (sk_pos >= sk_hi) break;
-            const int slot_i = (int)(sk_pos / nchunks);
-            c_begin = (int)(sk_pos - (long long)slot_i * nchunks);
-            const long long left = sk_hi - sk_pos;
-            c_end = (nchunks - c_begin) < left ? nchunks : c_begin + (int)left;
-            sk_pos += c_end - c_begin;
+            int slot_i;
+            if (sk_round < sk_full) {
+                slot_i = sk_round * sk_R + sk_rank;
+                ++sk_round;
+                c_begin = 0;
+                c_end = nchunks;
+            } else {
+                if (sk_pos >= sk_hi) break;
+                const int rs = (int)(sk_pos / nchunks);
+                slot_i = sk_full * sk_R + rs;
+                c_begin = (int)(sk_pos - (long long)rs * nchunks);
+                const long long left = sk_hi - sk_pos;
+                c_end = (nchunks - c_begin) < left ? nchunks : c_begin + (int)left;
+                sk_pos += c_end - c_begin;
+            }
             tile_of(slot_i, mt, nt);
             m0 = mt * BM;
             tile_id = slot_i * 8 + xcd;
@@ -327,13 +343,20 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
         }
 
         // ---- epilogue: + bias, NHWC store; a stream-K piece that owns only part of the tile's chunks hands over / picks up partial sums
+        // A tile cut into pieces (consecutive ranks of one XCD, the piece with the LAST chunks is met first): every piece but the last
+        // waits until the tile's flag says "the sums of chunks c_end .. nchunks-1 are in `out`" (flag = their count), adds its own, and
+        // every piece but the first publishes the longer suffix the same way; the first piece adds the bias and resets the flag.
         const bool head = c_begin == 0, tail = c_end == nchunks;
-        if (SK && head && !tail) {
+        // No fences: an agent-scope release / acquire on gfx950 writes back / invalidates the XCD's whole L2 (measured: 0.6 - 1.6 ms per
+        // launch once tiles are cut into many pieces, and the evicted weight slab slows every other workgroup).  Provider and consumer
+        // share ONE L2, so it is enough that (a) the provider's stores have been acknowledged by L2 before its flag store issues
+        // (vmcnt(0) + barrier; vector stores are write-through) and (b) the consumer reads flag and partial sums past its L1
+        // (relaxed agent-scope atomic loads).
+        if (SK && !tail) {
             if (tid == 0) {
-                while (__hip_atomic_load(flags + tile_id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                while (__hip_atomic_load(flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchunks - c_end) __builtin_amdgcn_s_sleep(4);
             }
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -347,15 +370,15 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
                 for (int e = 0; e < 4; ++e)
                     if (mb + e < M) {
                         float v = acc[i][j][e] + bv;
-                        if (SK && head && !tail) v += out[(size_t)(mb + e) * Cout + n];
+                        if (SK && !tail) v += __hip_atomic_load(out + (size_t)(mb + e) * Cout + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         out[(size_t)(mb + e) * Cout + n] = v;
                     }
             }
         }
-        if (SK && tail && !head) {                   // partial sums of the tile's last chunks are in place: raise its flag
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (SK && !head) {                           // the sums of chunks c_begin .. nchunks-1 are in place
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + tile_id, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(flags + tile_id, nchunks - c_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (SK && head && !tail && tid == 0) __hip_atomic_store(flags + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!SK) break;
@@ -453,7 +476,7 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     if (sk) {
         const int cus = sk_cus[dev];
         const int nslots = blocks / 8;                       // tiles of the fullest XCD; the emptiest has nslots - 1 or nslots
-        sk = cus >= 8 && cus % 8 == 0 && nslots - 1 >= cus / 8 && blocks > cus && blocks % cus != 0;
+        sk = cus >= 8 && cus % 8 == 0 && nslots >= 1 && blocks > cus && blocks % cus != 0;
     }
     if (sk && !sk_flags[dev]) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

@@ -341,10 +341,11 @@ long long gssd_dcn_packed_weight_elems(int Cout, int C);
 int gssd_dcn_pack_weight_f32(const float* w_oihw, float* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
 int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B, int H,
                          int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream);
-/* Work split of gssd_dcn_forward_f32: 1 = stream-K (one persistent workgroup per CU, equal spans of the (tile, K-chunk) space; taken
- * when the tile count neither fills whole rounds of workgroups nor is smaller than the CU count), 0 = one tile per workgroup, -1 = the
+/* Work split of gssd_dcn_forward_f32: 1 = stream-K (one persistent workgroup per CU: whole tiles round by round, then equal spans of the
+ * (tile, K-chunk) space of the tiles that do not fill a round; taken when the tile count neither fills whole rounds nor is below the CU count), 0 = one tile per workgroup, -1 = the
  * default (stream-K unless GSSD_DCN_STREAMK=0).  Returns the previous setting.  Both forms compute every output from the same
- * products; a tile split between two workgroups adds two partial sums (results differ from the unsplit form by fp32 rounding only). */
+ * products; a tile cut into pieces adds their partial sums in a fixed order (results differ from the unsplit form by fp32 rounding only and
+ * are the same from run to run).  The bf16 kernel keeps one tile per workgroup (its stream-K form measured slower: DESIGN.md, section 9). */
 int gssd_dcn_streamk(int mode);
 
 /* bf16 storage variant (configs[4]): x, w_packed, out bf16; om, bias fp32; fp32 blend and accumulation */

@@ -665,3 +665,4 @@ def test_bf16_group_counts(dev, name, flags, args):
     e, gap = max(rel(loc, lo), rel(conf, co)), max(rel(lo, lo32), rel(co, co32))
     print(name, f'bf16 HIP vs bf16 oracle {e:.3f}; bf16 oracle vs fp32 oracle {gap:.3f}')
     assert e < 0.6 * gap, (e, gap)
+

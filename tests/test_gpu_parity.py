@@ -1931,13 +1931,15 @@ def test_gemm_slot(dev, ops, case):
         assert float((out.view(-1, os_)[:, :32] - 7.0).abs().max()) == 0.0 and float((out.view(-1, os_)[:, 32 + N:] - 7.0).abs().max()) == 0.0
 
 
-def test_dcn_fused_streamk(dev, ops):
-    """gssd_dcn_forward_f32 at the GSSD++ shape (B = 32, 38 x 38, 1024 -> 512, 4 deformable groups: 722 tiles for 256 CUs) in its
-    stream-K form against the one-tile-per-workgroup form: the same products, tiles that straddle a span boundary add two partial sums
-    (fp32 rounding only); stream-K runs agree bit for bit (two partial sums added in either order give the same bits) and the
-    per-tile flags are back to zero afterwards (a second launch would hang or read stale partials otherwise)."""
+@pytest.mark.parametrize('B', [32, 24, 12])
+def test_dcn_fused_streamk(dev, ops, B):
+    """gssd_dcn_forward_f32 at the GSSD++ shape (38 x 38, 1024 -> 512, 4 deformable groups) in its stream-K form against the
+    one-tile-per-workgroup form, at batch 32 (722 tiles for 256 CUs: two whole tiles per workgroup, the remaining 26 - 27 tiles of an XCD
+    cut into 0.82-tile spans), 24 (542 tiles: remaining tiles cut into ~8 pieces each) and 12 (272 tiles: ~16 pieces each): the same
+    products, cut tiles add their pieces' partial sums in a fixed chain (fp32 rounding only); stream-K runs agree bit for bit and the
+    per-tile flags are back to zero afterwards (a later launch would hang or read stale partials otherwise)."""
     from gssd._lib import lib, check
-    B, H, Cc, Cout, dg = 32, 38, 1024, 512, 4
+    H, Cc, Cout, dg = 38, 1024, 512, 4
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, H, H, Cc, generator=g).to(dev)
     om = (torch.randn(B, H, H, 27 * dg, generator=g) * 0.8).to(dev)
@@ -1946,11 +1948,12 @@ def test_dcn_fused_streamk(dev, ops):
     wp = ops.dcn_pack_weight(w, dg)
     st = torch.cuda.current_stream().cuda_stream
 
-    def run(mode):
+    def run(mode, xx=x, oo=om):
         prev = lib.gssd_dcn_streamk(mode)
-        out = torch.full((B, H, H, Cout), float('nan'), device=dev)
+        n = xx.shape[0]
+        out = torch.full((n, H, H, Cout), float('nan'), device=dev)
         try:
-            check(lib.gssd_dcn_forward_f32(x.data_ptr(), om.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, Cc, dg,
+            check(lib.gssd_dcn_forward_f32(xx.data_ptr(), oo.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), n, H, H, Cc, dg,
                                            27 * dg, Cout, st))
             torch.cuda.synchronize()
         finally:
@@ -1958,19 +1961,11 @@ def test_dcn_fused_streamk(dev, ops):
         return out
     plain, sk1, sk2, sk3 = run(0), run(1), run(1), run(1)
     assert torch.isfinite(sk1).all()
-    assert rel(sk1, plain) < 2e-6
+    assert rel(sk1, plain) < 3e-6
     assert torch.equal(sk1, sk2) and torch.equal(sk1, sk3)
     frac = float((sk1 != plain).float().mean())
-    print(f'stream-K: {100 * frac:.1f} % of the outputs differ from the unsplit form (split tiles), max rel {rel(sk1, plain):.1e}')
+    print(f'stream-K B={B}: {100 * frac:.1f} % of the outputs differ from the unsplit form (cut tiles), max rel {rel(sk1, plain):.1e}')
     assert 0.0 < frac < 0.6
     # a shape whose tile count is below the CU count keeps the one-tile form whatever the setting
-    xs, oms = x[:2].contiguous(), om[:2].contiguous()
-    a = torch.empty(2, H, H, Cout, device=dev)
-    b = torch.empty_like(a)
-    for mode, o in ((0, a), (1, b)):
-        prev = lib.gssd_dcn_streamk(mode)
-        check(lib.gssd_dcn_forward_f32(xs.data_ptr(), oms.data_ptr(), wp.data_ptr(), bias.data_ptr(), o.data_ptr(), 2, H, H, Cc, dg, 27 * dg,
-                                       Cout, st))
-        lib.gssd_dcn_streamk(prev)
-    torch.cuda.synchronize()
+    a, b = run(0, x[:2].contiguous(), om[:2].contiguous()), run(1, x[:2].contiguous(), om[:2].contiguous())
     assert torch.equal(a, b)
