@@ -28,6 +28,7 @@
 // ~4, an LDS-DMA piece less than a load -- hence the weight tile by LDS-DMA).  Next step: stage the x window of a channel chunk in
 // LDS once per 9 taps (10x fewer vector-memory instructions) and gather from LDS.
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -478,6 +479,8 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
         const int nslots = blocks / 8;                       // tiles of the fullest XCD; the emptiest has nslots - 1 or nslots
         sk = cus >= 8 && cus % 8 == 0 && nslots >= 1 && blocks > cus && blocks % cus != 0;
     }
+    static std::mutex sk_mu;                                 // (first launches may come from two host threads)
+    std::lock_guard<std::mutex> sk_lock(sk_mu);
     if (sk && !sk_flags[dev]) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(as_stream(stream), &cap);
