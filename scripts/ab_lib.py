@@ -5,7 +5,7 @@ shapes with HIP events; the table shows the mean over rounds."""
 import sys, os, subprocess, json, shutil
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 LIBD = os.path.join(ROOT, 'grouped-ssd-pytorch_amd', 'gssd', 'lib')
-SHAPES = ((150, 128, 128, True), (75, 128, 256, False), (75, 256, 256, True), (38, 256, 512, False), (38, 512, 512, True), (19, 512, 512, True))
+SHAPES = ((300, 64, 64, True), (150, 128, 128, True), (75, 128, 256, False), (75, 256, 256, True), (38, 256, 512, False), (38, 512, 512, True), (19, 512, 512, True))
 
 
 def worker(libname):
