@@ -1931,15 +1931,16 @@ def test_gemm_slot(dev, ops, case):
         assert float((out.view(-1, os_)[:, :32] - 7.0).abs().max()) == 0.0 and float((out.view(-1, os_)[:, 32 + N:] - 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('B', [32, 24, 12])
-def test_dcn_fused_streamk(dev, ops, B):
+@pytest.mark.parametrize('B,Cc,Cout,dg', [(32, 1024, 512, 4), (24, 1024, 512, 4), (12, 1024, 512, 4), (16, 256, 640, 1), (20, 128, 300, 2)])
+def test_dcn_fused_streamk(dev, ops, B, Cc, Cout, dg):
     """gssd_dcn_forward_f32 at the GSSD++ shape (38 x 38, 1024 -> 512, 4 deformable groups) in its stream-K form against the
     one-tile-per-workgroup form, at batch 32 (722 tiles for 256 CUs: two whole tiles per workgroup, the remaining 26 - 27 tiles of an XCD
-    cut into 0.82-tile spans), 24 (542 tiles: remaining tiles cut into ~8 pieces each) and 12 (272 tiles: ~16 pieces each): the same
-    products, cut tiles add their pieces' partial sums in a fixed chain (fp32 rounding only); stream-K runs agree bit for bit and the
+    cut into 0.82-tile spans), 24 (542 tiles: remaining tiles cut into ~8 pieces each) and 12 (272 tiles: ~16 pieces each), and on two
+    other shapes (three N tiles -- the tile order that does not divide the 8 XCDs --, a partial last N tile, one / two deformable groups,
+    M not a multiple of 128): the same products, cut tiles add their pieces' partial sums in a fixed chain (fp32 rounding only); stream-K runs agree bit for bit and the
     per-tile flags are back to zero afterwards (a later launch would hang or read stale partials otherwise)."""
     from gssd._lib import lib, check
-    H, Cc, Cout, dg = 38, 1024, 512, 4
+    H = 38
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, H, H, Cc, generator=g).to(dev)
     om = (torch.randn(B, H, H, 27 * dg, generator=g) * 0.8).to(dev)
@@ -1965,7 +1966,7 @@ def test_dcn_fused_streamk(dev, ops, B):
     assert torch.equal(sk1, sk2) and torch.equal(sk1, sk3)
     frac = float((sk1 != plain).float().mean())
     print(f'stream-K B={B}: {100 * frac:.1f} % of the outputs differ from the unsplit form (cut tiles), max rel {rel(sk1, plain):.1e}')
-    assert 0.0 < frac < 0.6
+    assert 0.0 < frac < 0.7
     # a shape whose tile count is below the CU count keeps the one-tile form whatever the setting
     a, b = run(0, x[:2].contiguous(), om[:2].contiguous()), run(1, x[:2].contiguous(), om[:2].contiguous())
     assert torch.equal(a, b)
