@@ -94,19 +94,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     }
     if (item >= item_end) return;
 
-    // Loading lane l fetches quad (l & 3) of tile (l >> 2): four consecutive lanes read one 64-byte segment, so the memory
-    // pipe sees 16 requests per instruction instead of 64.  The MFMA wants lane (r, kq) to hold quad kq of tile r: a fixed
-    // lane permutation (ds_bpermute, LDS crossbar only) after the data has landed.
-    const int ld_quad = lane & 3;
-    const int perm_addr = ((r << 2) | kq) << 2;
+    // Lane (r, kq) fetches quad kq of tile r -- the MFMA's own layout.  (Rounds 1-2 loaded quad (l & 3) of tile (l >> 2), four
+    // consecutive lanes per 64-byte segment, and permuted with 64 ds_bpermute per chunk: beside fp32 MFMAs those cost ~800 cycles per
+    // chunk in full (profiles/r03_mfma_valu_overlap.txt), the four-times-higher line count per load instruction costs nothing that shows:
+    // same-box A/B conv2_2 450 -> 401 us, conv4_2 305 -> 290, conv5_x 103 -> 98, conv3_1 224 -> 231.)
+    const int ld_quad = kq;
     const int cb_ld = p.in_ch_off + g * p.cin_g + ld_quad * 4;       // + chunk * 16   (loading lanes)
     const int cb_mf = p.in_ch_off + g * p.cin_g + kq * 4;            //                (MFMA lanes: BN scale / shift)
     const float* Ug = p.U + ((size_t)g * 16 * p.cout_pad + n0) * p.cin_g;     // + (xi * cout_pad + n) * cin_g + ci
 
     // Per item a loading lane keeps just the byte offset of its tile's patch origin and a 16-bit validity mask; out-of-image
-    // positions are fetched from offset 0 (always mapped) and replaced by the padding value before the permutation.
+    // positions are fetched from offset 0 (always mapped) and replaced by the padding value before the transform.
     auto decode = [&](int it, unsigned& pix_off, unsigned& valid) {
-        const int t = (it * 4 + wv) * 16 + (lane >> 2);
+        const int t = (it * 4 + wv) * 16 + r;
         valid = 0;
         int pix0 = 0;
         if (t < p.ntiles) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         unsigned in_next = in_cur, valid_next = 0;
         if (have_next) decode(item_next, in_next, valid_next);
         for (int c = 0; c < nchunks; ++c) {
-            // ---- lane permutation + input transform of chunk c (registers) ---------------------------------------------------
+            // ---- padding select + input transform of chunk c (registers) -----------------------------------------------------
 #ifdef WINO_TIMING
             WSTAMP(0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                     sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_mf + c * 16);
                     padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + c * 16);
                 }
-                // all 64 lane exchanges first, in place (one exposure of the LDS crossbar's latency per chunk instead of four), then the
-                // arithmetic one channel at a time (32 transient registers).  Round 3 measured the packed form (v_pk_add_f32 on channel
+                // padding select in place, then the arithmetic one channel at a time (32 transient registers).  Round 3 measured the
+                // packed form (v_pk_add_f32 on channel
                 // pairs): 29.7k instead of 24.9k cycles per 8 chunks -- packed fp32 is no gain beside fp32 MFMAs, nor is dealing this
                 // work out between the MFMAs (the fp32 MFMA shares the vector ALU's fp32 lanes: a just-in-time transform inside the MFMA
                 // loop ran 13.1k cycles per chunk against 9.3k + 3.1k here)
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) raw[q][e] = __shfl((valid_cur >> q) & 1 ? raw[q][e] : padq[e], perm_addr >> 2, 64);
+                    for (int e = 0; e < 4; ++e) raw[q][e] = (valid_cur >> q) & 1 ? raw[q][e] : padq[e];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float d[16], t[16];
