@@ -58,6 +58,8 @@ struct WinoParams {
     int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, cout_pad, out_stride, out_ch_off;
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
     int vec_ok;                        // bias / resid / out / pool_sign pointers are 16-byte aligned
+    unsigned pad_off;                  // != 0: the padding vector lies pad_off bytes behind `in` (32-bit reachable): out-of-image patch
+                                       // positions LOAD their padding value (address select) instead of a per-element select afterwards
 };
 
 template <int NB, bool XF, bool PERSIST, int EPI>      // EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     f32x4 raw[16];
     auto load_raw1 = [&](unsigned pix_off, unsigned valid, int c, int q) {
         const int i = q >> 2, j = q & 3;
-        const unsigned off = (valid >> q) & 1 ? pix_off + (unsigned)(((i * p.W + j) * p.in_stride + c * 16) * 4) : 0u;
+        const unsigned off = (valid >> q) & 1 ? pix_off + (unsigned)(((i * p.W + j) * p.in_stride + c * 16) * 4)
+                                              : (p.pad_off ? p.pad_off + (unsigned)((cb_ld + c * 16) * 4) : 0u);
         raw[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
     };
     // U stage: 16 * NBT pieces of 1 KB; piece (xi, nb) = 16 rows (n) x 64 B; lane -> row lane >> 2, quad lane & 3.  Wave w
@@ -194,10 +197,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 // pairs): 29.7k instead of 24.9k cycles per 8 chunks -- packed fp32 is no gain beside fp32 MFMAs, nor is dealing this
                 // work out between the MFMAs (the fp32 MFMA shares the vector ALU's fp32 lanes: a just-in-time transform inside the MFMA
                 // loop ran 13.1k cycles per chunk against 9.3k + 3.1k here)
+                if (!p.pad_off) {                              // (64 selects of 8.4 cycles each beside fp32 MFMAs: skipped when the loads did it)
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
+                    for (int q = 0; q < 16; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) raw[q][e] = (valid_cur >> q) & 1 ? raw[q][e] : padq[e];
+                        for (int e = 0; e < 4; ++e) raw[q][e] = (valid_cur >> q) & 1 ? raw[q][e] : padq[e];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float d[16], t[16];
@@ -507,6 +512,14 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.ntiles = d.B * p.tiles_y * p.tiles_x;
     constexpr size_t smem = 2 * (size_t)16 * NB * 16 * sizeof(float);
     p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
+    p.pad_off = 0;
+    if (XF && d.in_pad && (uintptr_t)d.in_pad > (uintptr_t)d.in) {
+        const unsigned long long diff = (unsigned long long)((uintptr_t)d.in_pad - (uintptr_t)d.in);
+        // only the layout the engine builds: the vector directly behind the dense map (so the 32-bit offsets of the kernel reach it)
+        if (diff == (unsigned long long)d.B * d.H * d.W * d.in_stride * sizeof(float) && diff + (unsigned long long)d.in_stride * 4 < (1ull << 32) &&
+            (diff & 15) == 0)
+            p.pad_off = (unsigned)diff;
+    }
     auto kern = conv_wino_kernel<NB, XF, PERSIST, EPI>;
     static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     if (gssd_attr_needed(&attr_mask)) {
@@ -542,7 +555,7 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
     const bool ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.cin_g % 16 == 0 && wino_nb(cout_g, d.groups) != 0 &&
                     d.out_mode == GSSD_OUT_NHWC && !d.alpha && !d.gate && !d.out2 && !d.relu && d.split_k <= 1 && !d.m_per_image &&
                     d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
-                    (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31);
+                    (long long)d.B * d.H * d.W * d.in_stride < (1ll << 30);     // 32-bit BYTE offsets into the input
     if (!ok) return 1;
     if ((d.flags & GSSD_CONV_POOL2) && (d.resid || !d.pool_sign)) return 1;
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item

@@ -538,6 +538,18 @@ class _Plan(_PlanBase):
         self.bufs.append(t)
         return t
 
+    def _abuf_tail(self, tail, *shape):
+        """Activation buffer with ``tail`` more elements stored right behind it (one allocation): a raw conv output whose deferred
+        BatchNorm's padding vector sits at ``map + numel`` -- the fp32 Winograd kernel then fetches the padding value of an out-of-image
+        patch position through the load ADDRESS (32-bit offset from the map) instead of selecting it per loaded element
+        (include/gssd_hip.h: in_pad).  Returns (map, tail view)."""
+        n = 1
+        for v in shape:
+            n *= v
+        flat = torch.empty(n + tail, device=self.dev, dtype=getattr(self, 'adt', torch.float32))
+        self.bufs.append(flat)
+        return flat[:n].view(*shape), flat[n:]
+
     def _setup_spectral_norm(self, lists):
         """layers/spectral_norm.py:74-89 for every Self_Attn conv of ``lists`` = [(list name, ModuleList)]: ONE launch that
         (training) runs the power iteration in place and writes 1/sigma per output channel (the convs' ``alpha`` vectors)."""
@@ -605,14 +617,14 @@ class _Plan(_PlanBase):
                   ((U is not None) if not self.bf16 else ((cin_g, cout_g) in ((16, 16), (32, 32)) and Ho % 2 == 0 and Ho * Ho >= 75 * 75)))
         if pooled:
             Hp = ops.pool_out_size(Ho, 2, 2, 0, pool[3])
-            raw = self._abuf(B, Hp, Hp, Cout)
+            raw, pd = self._abuf_tail(Cout, B, Hp, Hp, Cout)
             d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                          stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                          stats=st if self.training else None,
                                          in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                          in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2, pool_sign=bn.weight.detach())
             self._add(self.conv_fn, (C.byref(d),), keep=d)
-            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._abuf(Cout)
+            sc, sh = self._buf(Cout), self._buf(Cout)
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
@@ -622,7 +634,7 @@ class _Plan(_PlanBase):
                                             Hp=Hp, xf=(sc, sh, pd), pooled=True)))
             self._layer = None
             return raw, Hp, Cout, (sc, sh, pd)
-        raw = self._abuf(B, Ho, Ho, Cout)
+        raw, pd_tail = self._abuf_tail(Cout, B, Ho, Ho, Cout) if defer_bn else (self._abuf(B, Ho, Ho, Cout), None)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                      stats=st if self.training else None,
@@ -634,7 +646,7 @@ class _Plan(_PlanBase):
         self.rec.append(('convbn', rec))
         if defer_bn:
             assert pool is None and relu
-            sc, sh, pd = self._buf(Cout), self._buf(Cout), self._abuf(Cout)
+            sc, sh, pd = self._buf(Cout), self._buf(Cout), pd_tail
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),

@@ -100,7 +100,9 @@ typedef struct gssd_conv_desc {
     float* out2;        /* receives gate*(acc*alpha+bias) when gate != NULL and out2 != NULL */
     const float* in_scale; /* fused producer BatchNorm+ReLU: the input is read as max(x*in_scale[c] + in_shift[c], 0) */
     const float* in_shift; /* (per input channel, from gssd_bn_finalize_f32); NULL = plain input.  Zero padding applies */
-    const float* in_pad;   /* AFTER the transform: out-of-image taps read in_pad[c], a value the transform maps to 0 */
+    const float* in_pad;   /* AFTER the transform: out-of-image taps read in_pad[c], a value the transform maps to 0.  Layout hint (no
+                            * change of meaning): when in_pad == in + B*H*W*in_stride (the vector stored directly behind a dense map) the
+                            * fp32 Winograd kernel loads the padding value through the tap's address instead of selecting it per element */
     double* stats;      /* [2*Cout]: per-channel sum / sum of squares of the pre-activation output
                            accumulated with fp64 atomics (BatchNorm batch statistics), or NULL */
     const float* wgt_wino; /* optional Winograd F(2x2,3x3) form of `wgt` (gssd_winograd_weight_f32): 3x3 / stride 1 / pad 1
