@@ -543,6 +543,8 @@ class _Plan(_PlanBase):
         BatchNorm's padding vector sits at ``map + numel`` -- the fp32 Winograd kernel then fetches the padding value of an out-of-image
         patch position through the load ADDRESS (32-bit offset from the map) instead of selecting it per loaded element
         (include/gssd_hip.h: in_pad).  Returns (map, tail view)."""
+        if getattr(self, 'bf16', False):
+            return self._abuf(*shape), self._abuf(tail)          # (only the fp32 Winograd kernel uses the layout)
         n = 1
         for v in shape:
             n *= v
