@@ -152,17 +152,25 @@ def trunk_roofline(survey, n_pass, B, dtype):
     big = {k: v for k, v in per.items() if v['alg_mb'] >= 0.02 * by / 1e6}
     worst = min(big, key=lambda k: big[k]['gbs'])
     survey_mb = SURVEY_TRUNK_MB_F32 * (0.5 if dtype == 'bf16' else 1.0)
-    ach = survey_mb * B / ms                          # MB / ms = GB/s
+    eff = survey_mb * B / ms                          # MB / ms = GB/s
     built = by / ms / 1e6
-    return dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
+    # `achieved` / `frac` are the bytes the pass structure AS BUILT moves (input + output + weights of every launch that still
+    # exists) -- deleting a pass shrinks them, so the fraction cannot be raised by accounting.  The figure under SURVEY.md 8(d)'s
+    # accounting (the reference's pass structure, deleted passes counted as moved) is kept beside it under its own name.
+    return dict(bound='hbm', achieved=round(built, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(built / PEAK_HBM_GBS, 4),
                 traffic=None, kernel='trunk conv1_1 .. conv5_3 (convs + BN/ReLU/pool passes)', ms_per_step=round(ms, 4),
-                alg_mb_per_img=round(survey_mb, 1), alg_bytes_per_step=round(survey_mb * 1e6 * B), tflops=round(fl / ms / 1e9, 1),
-                accounting='achieved = SURVEY.md 8(d)\'s algorithmic bytes of the trunk (every layer priced as conv in + raw out + BatchNorm '
-                           're-read + activated write; bf16 = half the fp32 figure) x images / measured trunk time: an EFFECTIVE rate, like '
-                           'direct-conv FLOPs for the Winograd kernels -- passes this build deleted (deferred BatchNorms, pooled raw maps) '
-                           'count as moved.  `as_built` prices only the bytes the pass structure as built still moves',
+                plan='nograd (torch.no_grad() forward: pooled trunk layers keep no full-resolution raw maps; a training step cannot use it)',
+                alg_mb_per_img=round(by / B / 1e6, 2), alg_bytes_per_step=round(by), tflops=round(fl / ms / 1e9, 1),
+                accounting='achieved = compulsory bytes of the launches as built (input + output + weights per launch) x images / '
+                           'measured trunk time (every trunk launch -- convs AND BatchNorm / ReLU / pool passes -- bracketed by HIP events '
+                           'in the eager survey passes)',
                 as_built=dict(alg_mb_per_img=round(by / B / 1e6, 2), alg_bytes_per_step=round(by), gbs=round(built, 1),
                               frac=round(built / PEAK_HBM_GBS, 4)),
+                effective_vs_reference_passes=dict(
+                    alg_mb_per_img=round(survey_mb, 1), alg_bytes_per_step=round(survey_mb * 1e6 * B), gbs=round(eff, 1),
+                    frac=round(eff / PEAK_HBM_GBS, 4),
+                    note="SURVEY.md 8(d)'s accounting: every layer priced as conv in + raw out + BatchNorm re-read + activated write (bf16 = "
+                         'half the fp32 figure); passes this build deleted count as moved -- an effective rate, NOT HBM utilisation'),
                 worst_layer=dict(layer=worst, **per[worst], frac=round(per[worst]['gbs'] / PEAK_HBM_GBS, 4)), layers=per,
                 note='eager survey passes, every trunk launch bracketed by HIP events on the launch stream')
 
@@ -256,6 +264,17 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
         sync()
         sdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # host side of a step: wall time this rank's Python needs to ENQUEUE a step (graph replays + loss launches), nothing waited for.
+    # With 8 ranks on one host this -- not the GPU -- is what weak scaling can lose; max / per-rank values are reported.
+    sync()
+    nh = max(1, min(a.steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(nh):
+        step()
+    host_ms = 1e3 * (time.perf_counter() - t0) / nh
+    sync()
+    host_per_rank = [round(t, 3) for t in gd.gather_over_ranks(host_ms, dev)]
+
     roof, kernels = None, {}
     peak_t = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
     if events:
@@ -274,17 +293,22 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             except Exception:
                 traffic = None
         ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        wino = dom.startswith('conv_wino') or dom.startswith('conv_thin_wino')
         if ach_b / PEAK_HBM_GBS > ach_t / peak_t:
             roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
+        elif wino:
+            # Winograd F(2x2,3x3) issues 2.25x fewer MFMA FLOPs than the direct convolution it computes: `achieved` / `frac` are the ISSUED
+            # FLOPs against the matrix pipe (what a roofline fraction means); the direct-convolution rate is reported under its own name
+            roof = dict(bound='mfma', achieved=round(ach_t / 2.25, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / 2.25 / peak_t, 4),
+                        direct_conv_tflops=round(ach_t, 2), direct_conv_over_peak=round(ach_t / peak_t, 4))
         else:
             roof = dict(bound='mfma', achieved=round(ach_t, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / peak_t, 4))
         roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
                     alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
                     note=('fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
                           else 'bf16 MFMA, fp32 accumulate')
-                         + ('; achieved = ALGORITHMIC (direct-convolution) FLOPs per second: the Winograd F(2x2,3x3) kernel '
-                            'issues 2.25x fewer MFMA FLOPs than that, so its MFMA-pipe utilisation is achieved/2.25/peak'
-                            if dom.startswith('conv_wino') else ''))
+                         + ('; Winograd F(2x2,3x3): achieved / frac = ISSUED MFMA FLOPs (direct-convolution FLOPs / 2.25) against the '
+                            'matrix pipe; direct_conv_tflops = the algorithmic (direct-convolution) rate' if wino else ''))
     # the HBM-side companion of `roofline`: the heaviest of the byte-bound trunk layers (the patch-staged thin kernels of conv1_1 ..
     # conv2_2: arithmetic intensity below the ridge in both storage modes), from the untimed survey passes' per-launch HIP events
     roof_hbm = None
@@ -313,6 +337,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                                frac_mfma_peak=round(value * gflop_img / 1e3 / (peak_t * world), 4),
                                alg_gbs=round(value * mb_img / 1e3, 1),
                                frac_hbm_peak=round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)),
+               host_enqueue_ms_per_step=host_per_rank,
                first_step_loss=[round(first_loss[0], 5), round(first_loss[1], 5)], roofline=roof, roofline_hbm_trunk=roof_hbm,
                trunk=trunk, kernels=kernels)
     return res, net, crit, x, tg, first_loss
@@ -401,8 +426,18 @@ def self_launch(n):
         return 2
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY='0', GSSD_BENCH_SELF_LAUNCHED='1')
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    # each rank gets its own block of host cores (its Python enqueue thread, torch's intra-op pool and RCCL's proxy thread stay off the
+    # other ranks' cores); GSSD_BENCH_NO_PIN=1 leaves the affinity alone
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = []
+    per = len(cores) // n if not os.environ.get('GSSD_BENCH_NO_PIN') else 0
+
+    def pin(r):
+        return (lambda: os.sched_setaffinity(0, cores[r * per:(r + 1) * per])) if per >= 1 else None
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], preexec_fn=pin(r),
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GSSD_BENCH_CORES=str(per))) for r in range(n)]
     rc = 0
     try:
         pending = set(range(n))
@@ -456,12 +491,14 @@ def full_step_leg(a, net, crit, x, tg, dev, gd, world, B):
     t0 = time.perf_counter()
     for _ in range(a.full_step):
         train_step(True)
+    host = time.perf_counter() - t0                 # every step enqueued, nothing waited for (beyond what the steps themselves wait for)
     gd.barrier(dev)
     fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    host_per_rank = [round(1e3 * t / a.full_step, 3) for t in gd.gather_over_ranks(host, dev)]
     exposed = (sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)) if ev else 0.0
     exposed = gd.max_over_ranks(exposed, dev)
     return dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
-                ms_per_step=round(1e3 * fdt / a.full_step, 3), grad_elems=int(nred), rccl_ranks=world,
+                ms_per_step=round(1e3 * fdt / a.full_step, 3), host_enqueue_ms_per_step=host_per_rank, grad_elems=int(nred), rccl_ranks=world,
                 allreduce_exposed_ms=round(exposed, 3), allreduce_overlapped=bool(red.overlapped_last),
                 note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (HIP: gssd/backward.py) + '
                      + (f'RCCL all-reduce of the flat fp32 gradient buffer over {world} ranks in 4 ranges started under the backward '
@@ -599,7 +636,7 @@ def main():
         'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
                    'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
         'rccl_ranks': gd.world_size(), 'collective_backend': backend if world > 1 else None,
-        'per_rank_ms_per_step': res['per_rank_ms_per_step'],
+        'per_rank_ms_per_step': res['per_rank_ms_per_step'], 'host_enqueue_ms_per_step': res['host_enqueue_ms_per_step'],
         'launcher': ('self (python bench.py --gpus N)' if os.environ.get('GSSD_BENCH_SELF_LAUNCHED') else
                      'torch.distributed.run' if world > 1 else 'single process'),
         'whole_path': res['whole_path'], 'steady': res['steady'], 'loss': res['loss'],
@@ -610,31 +647,37 @@ def main():
     }
     printed = threading.Lock()
 
-    def emit(code=None):
+    def emit(code=None, full_step=None):
+        """Print the line once.  `full_step` (the watchdog's error object) is stored under the same lock that guards the print, so
+        the main thread and the watchdog cannot overwrite each other's result."""
         if printed.acquire(blocking=False):
+            if full_step is not None:
+                line['full_step'] = full_step
             if rank == 0:
                 print(json.dumps(line), flush=True)
             if code is not None:
                 os._exit(code)
 
     # BASELINE.json configs[3]: K full training steps, LAST (the only leg with a data-path collective).  A collective that hangs
-    # must not cost the line its measured headline: past the deadline every rank's watchdog prints / exits instead.
+    # must not cost the line its measured headline: past the deadline every rank's watchdog prints the line (with the error in
+    # `full_step`) and exits NON-ZERO (3), which self_launch() / the launcher propagate -- a hung collective is not a success.
     if a.full_step > 0:
         wd = None
         if world > 1:
             def on_timeout():
-                line['full_step'] = {'error': f'full-step leg did not finish within {a.full_step_timeout} s (RCCL all-reduce over '
-                                              f'{world} ranks); the fwd+loss metric above is complete'}
-                emit(0)
+                emit(3, {'error': f'full-step leg did not finish within {a.full_step_timeout} s (RCCL all-reduce over '
+                                  f'{world} ranks); the fwd+loss metric above is complete; exit code 3'})
             wd = threading.Timer(a.full_step_timeout, on_timeout)
             wd.daemon = True
             wd.start()
         try:
-            line['full_step'] = full_step_leg(a, net, crit, x, tg, dev, gd, world, B)
+            fs = full_step_leg(a, net, crit, x, tg, dev, gd, world, B)
         except Exception as e:                                  # noqa: BLE001 -- reported in the line, never swallowed silently
-            line['full_step'] = {'error': f'{type(e).__name__}: {e}'[:400]}
+            fs = {'error': f'{type(e).__name__}: {e}'[:400]}
         if wd is not None:
             wd.cancel()
+        with printed:                                           # (the watchdog may be printing right now: then it also exits)
+            line['full_step'] = fs
     emit()
     gd.finish()
 

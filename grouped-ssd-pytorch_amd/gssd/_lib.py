@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgssd_hip.so')
+# GSSD_LIB_PATH: an alternate build of the SAME library (debug / timing / A-B builds of scripts/*_timing.py, scripts/ab_lib.py)
+LIB_PATH = os.environ.get('GSSD_LIB_PATH') or os.path.join(_HERE, 'lib', 'libgssd_hip.so')
 
 c_fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 c_i = C.c_int
@@ -110,6 +111,8 @@ SIGNATURES = {
     'gssd_dcn_packed_weight_elems': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_streamk': (c_i, [c_i]),
+    'gssd_dcn_streamk_status': (c_i, [c_fp]),
+    'gssd_dcn_streamk_reset': (c_i, [c_fp]),
     'gssd_dcn_forward_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_resample_ksize': (c_i, [c_i, c_i, c_i]),
     'gssd_resample_coeffs': (c_i, [c_i, c_i, c_i, c_fp, c_fp]),

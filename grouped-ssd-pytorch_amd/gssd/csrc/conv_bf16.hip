@@ -382,19 +382,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
-    static bool attr_set[16] = {false};
+    static unsigned attr_mask = 0;
     constexpr size_t smem_base = 2 * (size_t)(BM + BN) * BK * sizeof(u16);
     const size_t smem = smem_base + (d.in_scale ? 2 * (size_t)d.cin_g * sizeof(float) : 0);
     auto kern = conv_bf16_kernel<BM, BN, WM, WN>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(smem_base + 8192)) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", smem_base + 8192);
             return GSSD_ELAUNCH;
         }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        gssd_attr_done(&attr_mask);
     }
     const int cout_g = d.Cout / d.groups;
     const int tiles = (cout_g + BN - 1) / BN;

@@ -268,16 +268,14 @@ extern "C" int gssd_dcn_forward_bf16(const void* x, const float* om, const void*
     GSSD_CHECK_ARG(Mll < (1ll << 30) && Mll * C < (1ll << 32));          // 30-bit pixel index + 2 flag bits; 32-bit element offsets
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    static unsigned attr_mask = 0;
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", LDS_BYTES);
             return GSSD_ELAUNCH;
         }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        gssd_attr_done(&attr_mask);
     }
     int blocks;
     if (8 % ntn == 0) {

@@ -80,7 +80,8 @@ template <bool SK>
 __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg,
-                                                          int om_stride, int Cout, int ntn, int mtiles, int* __restrict__ flags) {
+                                                          int om_stride, int Cout, int ntn, int mtiles, int* __restrict__ flags, unsigned xcc_map,
+                                                          unsigned* __restrict__ sk_err) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                                   // [2][BM][32]
     float* const Bs = smem + 2 * A_STAGE;                     // [2][BN][32]
@@ -112,6 +113,14 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     long long sk_pos = 0, sk_hi = 0;
     int sk_full = 0, sk_round = 0, sk_R = 1, sk_rank = 0;
     if (SK) {
+        // The fence-free hand-over below is only valid between workgroups behind ONE L2.  `xcc_map` is the XCC id the launcher's probe
+        // saw for each residue of the workgroup id (4 bits each); a workgroup that finds itself elsewhere (CU-masked stream, another
+        // partition mode, a driver that places differently) reports it in the host-visible error word: the launcher then fails loudly and
+        // stops using this form.  (One s_getreg per workgroup.)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        if (xcc != ((xcc_map >> ((blockIdx.x & 7) * 4)) & 15u) && tid == 0)
+            __hip_atomic_fetch_or(sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sk_R = gridDim.x >> 3;
         sk_rank = sk_R - 1 - (int)(blockIdx.x >> 3);
         const int nx = 8 % ntn == 0 ? (mtiles - xcd / ntn + (8 / ntn) - 1) / (8 / ntn) : (mtiles * ntn - xcd + 7) / 8;
@@ -355,7 +364,15 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
         // (relaxed agent-scope atomic loads).
         if (SK && !tail) {
             if (tid == 0) {
-                while (__hip_atomic_load(flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchunks - c_end) __builtin_amdgcn_s_sleep(4);
+                // bounded: a provider that never arrives (aborted launch, stale flag behind another L2) costs ~1 s and an error, not a hang
+                int spins = 0;
+                while (__hip_atomic_load(flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchunks - c_end) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1 << 21)) {
+                        __hip_atomic_fetch_or(sk_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -428,6 +445,129 @@ extern "C" int gssd_dcn_streamk(int mode) {
     return prev;
 }
 
+namespace {
+
+// ---- host state of the stream-K form, per device ---------------------------------------------------------------------------------
+// The fence-free partial-sum hand-over is valid only between workgroups behind ONE L2, i.e. if workgroup id & 7 decides the XCD.  That is
+// the observed SPX placement, not a HIP guarantee, so it is PROBED once per device (every workgroup of a CU-count grid reads
+// HW_REG_XCC_ID; the XCC id must be a function of id & 7 and differ between residues), re-checked by every stream-K workgroup of every
+// launch against the probed map, and a violation lands in a host-visible error word the launcher reads before each launch.
+// Flags: one int per tile, in a region that belongs to the launch's OUTPUT buffer (two launches that may be in flight together -- two
+// plans, two captured graphs, more than one stream -- write different outputs, so they never share flags).
+constexpr int SK_POOL_INTS = 1 << 19;                   // 2 MB: 700+ regions of the GSSD++ shape
+constexpr int SK_MAX_REGIONS = 1024;
+struct SkRegion { const void* out; int off, ints; };
+struct SkDev {
+    int cus = 0;                 // 0: not looked at, -1: unusable
+    int status = 0;              // GSSD_DCN_SK_* bits
+    unsigned xcc_map = 0;        // 4 bits per residue of workgroup id & 7
+    int* pool = nullptr;
+    int used = 0;
+    unsigned* err_host = nullptr;   // pinned + mapped; bit 0: a workgroup ran on another XCD than probed, bit 1: a wait timed out
+    unsigned* err_dev = nullptr;
+    SkRegion regions[SK_MAX_REGIONS];
+    int nregions = 0;
+};
+SkDev g_sk[16];
+std::mutex g_sk_mu;              // (first launches may come from two host threads: forward on the caller's, backward on autograd's)
+
+__global__ void sk_probe_kernel(unsigned* __restrict__ xcc_of_block) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (threadIdx.x == 0) xcc_of_block[blockIdx.x] = xcc;
+    // stay resident long enough for the whole grid to be dispatched side by side (placement of a grid that fills the chip)
+    __builtin_amdgcn_s_sleep(127);
+}
+
+// one-time set-up outside stream capture: CU count, placement probe, flag pool (zeroed and SYNCHRONISED before first use), error word
+void sk_init(SkDev& s, int dev) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    s.cus = -1;
+    if (cus < 8 || cus % 8 != 0 || cus > 1024) { s.status |= GSSD_DCN_SK_UNSUPPORTED; return; }
+    unsigned* probe = nullptr;
+    unsigned host[1024];
+    bool ok = hipMalloc(&probe, cus * sizeof(unsigned)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sk_probe_kernel, dim3(cus), dim3(256), 0, nullptr, probe);
+        ok = hipMemcpy(host, probe, cus * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(probe);
+    }
+    if (!ok) { s.status |= GSSD_DCN_SK_UNSUPPORTED; (void)hipGetLastError(); return; }
+    unsigned map = 0, seen = 0;
+    bool good = true;
+    for (int r = 0; r < 8 && good; ++r) {
+        const unsigned id = host[r];
+        for (int b = r; b < cus; b += 8) good = good && host[b] == id;
+        good = good && id < 16 && !(seen & (1u << id));
+        seen |= 1u << id;
+        map |= (id & 15u) << (4 * r);
+    }
+    if (!good) { s.status |= GSSD_DCN_SK_MAPPING; return; }
+    s.xcc_map = map;
+    int* p = nullptr;
+    unsigned* eh = nullptr;
+    void* ed = nullptr;
+    if (hipMalloc(&p, (size_t)SK_POOL_INTS * sizeof(int)) != hipSuccess || hipMemset(p, 0, (size_t)SK_POOL_INTS * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&eh, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        s.status |= GSSD_DCN_SK_UNSUPPORTED;
+        return;
+    }
+    *eh = 0;
+    if (hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {   // memset ordered before ANY stream's first use
+        (void)hipGetLastError();
+        s.status |= GSSD_DCN_SK_UNSUPPORTED;
+        return;
+    }
+    s.pool = p;
+    s.err_host = eh;
+    s.err_dev = reinterpret_cast<unsigned*>(ed);
+    s.cus = cus;
+}
+
+int* sk_region(SkDev& s, const void* out, int ints) {
+    for (int i = 0; i < s.nregions; ++i)
+        if (s.regions[i].out == out && s.regions[i].ints >= ints) return s.pool + s.regions[i].off;
+    if (s.nregions == SK_MAX_REGIONS || s.used + ints > SK_POOL_INTS) return nullptr;
+    s.regions[s.nregions++] = SkRegion{out, s.used, ints};
+    const int off = s.used;
+    s.used += (ints + 31) & ~31;                         // whole 128-byte lines per region
+    return s.pool + off;
+}
+
+}  // namespace
+
+extern "C" int gssd_dcn_streamk_status(unsigned* xcc_map) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) return GSSD_DCN_SK_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    SkDev& s = g_sk[dev];
+    if (s.cus == 0) sk_init(s, dev);                     // (not to be called while a stream of this thread is capturing)
+    if (s.err_host) {
+        const unsigned e = __atomic_load_n(s.err_host, __ATOMIC_ACQUIRE);
+        if (e & 1u) s.status |= GSSD_DCN_SK_MAPPING;
+        if (e & 2u) s.status |= GSSD_DCN_SK_TIMEOUT;
+    }
+    if (xcc_map) *xcc_map = s.xcc_map;
+    return s.status;
+}
+
+extern "C" int gssd_dcn_streamk_reset(gssd_stream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) return GSSD_OK;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    SkDev& s = g_sk[dev];
+    if (!s.pool || s.used == 0) return GSSD_OK;
+    if (hipMemsetAsync(s.pool, 0, (size_t)s.used * sizeof(int), as_stream(stream)) != hipSuccess) {
+        gssd_set_error("gssd_dcn_streamk_reset: hipMemsetAsync failed");
+        return GSSD_ELAUNCH;
+    }
+    return GSSD_OK;
+}
+
 extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B,
                                     int H, int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && om && w_packed && out && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0 && Cout > 0);
@@ -437,11 +577,11 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     GSSD_CHECK_ARG(Mll < (1ll << 31) && Mll * C < (1ll << 30));          // 32-bit byte offsets into x
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
-    static bool attr_set[16] = {false};
+    static unsigned attr_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     constexpr int smem = LDS_FLOATS * (int)sizeof(float);
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
                 hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
@@ -449,7 +589,7 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
             return GSSD_ELAUNCH;
         }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        gssd_attr_done(&attr_mask);
     }
     // grid: ids round-robin over the 8 XCDs; slots cover ceil(mtiles / (8 / ntn)) groups when ntn divides 8
     int blocks;
@@ -461,43 +601,41 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     }
     // Stream-K form (one persistent workgroup per CU, equal spans of the (tile, chunk) space): taken when every XCD has at least as
     // many tiles as workgroups (a tile then straddles at most one span boundary) and the tile count does not already fill whole rounds.
-    // The per-tile flags live in a per-device buffer (8 regions taken in turn, so launches in flight on different streams do not
-    // share flags); it is allocated on the first launch outside a stream capture.  GSSD_DCN_STREAMK=0 keeps one tile per workgroup.
+    // GSSD_DCN_STREAMK=0 keeps one tile per workgroup.  Per-device state (placement probe, flag pool, error word): SkDev above.
     static const bool sk_off = []() { const char* e = getenv("GSSD_DCN_STREAMK"); return e && e[0] == '0'; }();
-    constexpr int SK_REGIONS = 8, SK_REGION_INTS = 1 << 16;
-    static int* sk_flags[16] = {nullptr};
-    static int sk_cus[16] = {0};
-    static std::atomic<unsigned> sk_turn{0};
-    bool sk = (g_dcn_sk_force < 0 ? !sk_off : g_dcn_sk_force == 1) && dev >= 0 && dev < 16 && blocks <= SK_REGION_INTS;
-    if (sk && !sk_cus[dev]) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        sk_cus[dev] = cus > 0 ? cus : -1;
-    }
+    bool sk = (g_dcn_sk_force < 0 ? !sk_off : g_dcn_sk_force == 1) && dev >= 0 && dev < 16;
+    int* fl = nullptr;
     if (sk) {
-        const int cus = sk_cus[dev];
+        std::lock_guard<std::mutex> sk_lock(g_sk_mu);
+        SkDev& s = g_sk[dev];
+        if (s.cus == 0) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(as_stream(stream), &cap);
+            if (cap == hipStreamCaptureStatusNone) sk_init(s, dev);          // (a first launch inside a capture takes the one-tile form)
+        }
+        if (s.err_host && !(s.status & (GSSD_DCN_SK_MAPPING | GSSD_DCN_SK_TIMEOUT))) {
+            const unsigned e = __atomic_load_n(s.err_host, __ATOMIC_ACQUIRE);
+            if (e) {
+                s.status |= (e & 1u ? GSSD_DCN_SK_MAPPING : 0) | (e & 2u ? GSSD_DCN_SK_TIMEOUT : 0);
+                gssd_set_error("gssd_dcn_forward_f32: an earlier stream-K launch %s%s; its output is not trustworthy -- stream-K is now off "
+                               "on device %d (GSSD_DCN_STREAMK=0 avoids it from the start)",
+                               e & 1u ? "ran workgroups on another XCD than the placement probe saw" : "",
+                               e & 2u ? " timed out waiting for a partial sum" : "", dev);
+                return GSSD_ELAUNCH;
+            }
+        }
         const int nslots = blocks / 8;                       // tiles of the fullest XCD; the emptiest has nslots - 1 or nslots
-        sk = cus >= 8 && cus % 8 == 0 && nslots >= 1 && blocks > cus && blocks % cus != 0;
+        sk = s.cus > 0 && s.status == 0 && nslots >= 1 && blocks > s.cus && blocks % s.cus != 0;
+        if (sk) fl = sk_region(s, out, blocks);
+        sk = sk && fl;
+        if (sk) {
+            hipLaunchKernelGGL(dcn_fused_kernel<true>, dim3(s.cus), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H, W,
+                               C, dg, om_stride, Cout, ntn, mtiles, fl, s.xcc_map, s.err_dev);
+        }
     }
-    static std::mutex sk_mu;                                 // (first launches may come from two host threads)
-    std::lock_guard<std::mutex> sk_lock(sk_mu);
-    if (sk && !sk_flags[dev]) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(as_stream(stream), &cap);
-        int* p = nullptr;
-        if (cap == hipStreamCaptureStatusNone && hipMalloc(&p, (size_t)SK_REGIONS * SK_REGION_INTS * sizeof(int)) == hipSuccess &&
-            hipMemset(p, 0, (size_t)SK_REGIONS * SK_REGION_INTS * sizeof(int)) == hipSuccess)
-            sk_flags[dev] = p;
-        else
-            sk = false;
-    }
-    if (sk) {
-        int* fl = sk_flags[dev] + (size_t)(sk_turn.fetch_add(1) % SK_REGIONS) * SK_REGION_INTS;
-        hipLaunchKernelGGL(dcn_fused_kernel<true>, dim3(sk_cus[dev]), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M,
-                           H, W, C, dg, om_stride, Cout, ntn, mtiles, fl);
-    } else {
+    if (!sk) {
         hipLaunchKernelGGL(dcn_fused_kernel<false>, dim3(blocks), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H,
-                           W, C, dg, om_stride, Cout, ntn, mtiles, (int*)nullptr);
+                           W, C, dg, om_stride, Cout, ntn, mtiles, (int*)nullptr, 0u, (unsigned*)nullptr);
     }
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -190,16 +190,14 @@ template <int D, int C2, int BKV>
 int launch(const float* tp, const float* kp, const float* gT, float* out, int B, int N, int Nk, int Np, int d_real, int kstride,
            int out_bf16, float* lse, hipStream_t stream) {
     constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;
     auto kern = flash_attn_kernel<D, C2, BKV>;
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
             return GSSD_ELAUNCH;
         }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        gssd_attr_done(&attr_mask);
     }
     const int qtiles = (N + 63) / 64;
     hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16, lse);

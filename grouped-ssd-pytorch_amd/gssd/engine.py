@@ -982,6 +982,9 @@ class _Plan(_PlanBase):
                 cur.append(st)
         groups.append(('graph', cur))
         torch.cuda.synchronize(dev)
+        # the stream-K deformable conv keeps per-tile flags that every launch leaves at zero; a launch that was aborted would not:
+        # start every captured plan from zeroed flags (include/gssd_hip.h: gssd_dcn_streamk_reset)
+        _lib.check(lib.gssd_dcn_streamk_reset(torch.cuda.current_stream().cuda_stream))
         pool = torch.cuda.graph_pool_handle()
         segs, n_graph = [], sum(1 for k, _ in groups if k == 'graph')
         gi = 0

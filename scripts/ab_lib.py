@@ -1,6 +1,6 @@
 """A/B of two builds of libgssd_hip.so on the same box, alternating (the clock of a box drifts by several per cent between runs and
 boxes): python3 scripts/ab_lib.py libgssd_hip_old.so libgssd_hip_new.so [rounds].  Each round starts one worker process per library
-(the worker copies the library over the box's scratch copy of lib/libgssd_hip.so before loading it) that times the fp32 Winograd trunk
+(the worker loads its library through GSSD_LIB_PATH) that times the fp32 Winograd trunk
 shapes with HIP events; the table shows the mean over rounds."""
 import sys, os, subprocess, json, shutil
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -9,7 +9,7 @@ SHAPES = ((300, 64, 64, True), (150, 128, 128, True), (75, 128, 256, False), (75
 
 
 def worker(libname):
-    shutil.copyfile(os.path.join(LIBD, libname), os.path.join(LIBD, 'libgssd_hip.so'))
+    os.environ['GSSD_LIB_PATH'] = os.path.join(LIBD, libname)      # gssd/_lib.py loads this build; lib/libgssd_hip.so is never touched
     sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
     import ctypes as C
     import torch

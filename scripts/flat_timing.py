@@ -1,11 +1,10 @@
 """Per-phase shader-clock breakdown of conv_flat_bf16 (debug build: conv_flat_bf16.o compiled with -DFLAT_TIMING and linked with the
-other objects into lib/libgssd_hip_ft.so by `make -C grouped-ssd-pytorch_amd/gssd/csrc flat_timing`; this script copies it over the
-box's scratch copy of lib/libgssd_hip.so before loading it).  Wave 0 of every workgroup accumulates the cycles between its phase
+other objects into lib/libgssd_hip_ft.so by `make -C grouped-ssd-pytorch_amd/gssd/csrc flat_timing`; this script loads it through GSSD_LIB_PATH).  Wave 0 of every workgroup accumulates the cycles between its phase
 boundaries."""
 import sys, os, shutil, ctypes as C
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 LIBD = os.path.join(ROOT, 'grouped-ssd-pytorch_amd', 'gssd', 'lib')
-shutil.copyfile(os.path.join(LIBD, 'libgssd_hip_ft.so'), os.path.join(LIBD, 'libgssd_hip.so'))
+os.environ['GSSD_LIB_PATH'] = os.path.join(LIBD, 'libgssd_hip_ft.so')      # gssd/_lib.py loads this build; lib/libgssd_hip.so is never touched
 sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
 import torch
 from gssd import ops, _lib

@@ -1,11 +1,10 @@
-"""Per-phase shader-clock breakdown of conv_thin_bf16 (debug build with -DTHIN_TIMING, a -DTHIN_TIMING build of conv_thin_bf16.o linked into a copy of the library and copied over
-lib/libgssd_hip.so on the GPU box): wave 1 of every workgroup accumulates the cycles between the phase boundaries of its tiles."""
+"""Per-phase shader-clock breakdown of conv_thin_bf16 (debug build with -DTHIN_TIMING, a -DTHIN_TIMING build of conv_thin_bf16.o linked into a copy of the library, loaded through GSSD_LIB_PATH): wave 1 of every workgroup accumulates the cycles between the phase boundaries of its tiles."""
 import sys, os, ctypes as C
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
 import shutil
 LIBD = os.path.join(ROOT, 'grouped-ssd-pytorch_amd', 'gssd', 'lib')
-shutil.copyfile(os.path.join(LIBD, 'libgssd_hip_tt.so'), os.path.join(LIBD, 'libgssd_hip.so'))     # scratch copy on the GPU box
+os.environ['GSSD_LIB_PATH'] = os.path.join(LIBD, 'libgssd_hip_tt.so')      # gssd/_lib.py loads this build; lib/libgssd_hip.so is never touched
 import torch
 from gssd import ops, _lib
 dev = torch.device('cuda:0')

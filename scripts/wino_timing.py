@@ -1,11 +1,10 @@
 """Per-phase shader-clock breakdown of conv_wino (debug build: conv_wino.o compiled with -DWINO_TIMING and linked with the other
-objects into lib/libgssd_hip_wt.so by `make -C grouped-ssd-pytorch_amd/gssd/csrc wino_timing`; this script copies it over the box's
-scratch copy of lib/libgssd_hip.so before loading it).  Wave 0 of every workgroup accumulates the cycles between its phase
+objects into lib/libgssd_hip_wt.so by `make -C grouped-ssd-pytorch_amd/gssd/csrc wino_timing`; this script loads it through GSSD_LIB_PATH).  Wave 0 of every workgroup accumulates the cycles between its phase
 boundaries (the debug build also drains vmcnt before the transform to separate waiting from arithmetic)."""
 import sys, os, shutil, ctypes as C
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 LIBD = os.path.join(ROOT, 'grouped-ssd-pytorch_amd', 'gssd', 'lib')
-shutil.copyfile(os.path.join(LIBD, 'libgssd_hip_wt.so'), os.path.join(LIBD, 'libgssd_hip.so'))
+os.environ['GSSD_LIB_PATH'] = os.path.join(LIBD, 'libgssd_hip_wt.so')      # gssd/_lib.py loads this build; lib/libgssd_hip.so is never touched
 sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd'))
 import torch
 from gssd import ops, _lib

@@ -41,6 +41,37 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert fs['rccl_ranks'] == 2 and fs['allreduce_overlapped'] and 18488172 <= fs['grad_elems'] <= 18488172 + 4 * 400 and fs['allreduce_exposed_ms'] >= 0
 
 
+def test_bench_eight_ranks_code_path_on_one_gpu():
+    """BASELINE configs[3]'s launch shape -- EIGHT ranks -- on the one-GPU box: `python bench.py --gpus 8` starts its own
+    eight processes, all on GPU 0 with gloo collectives (GSSD_DIST_SAME_DEVICE=1), batch 4 per rank.  Proves that eight ranks rendezvous,
+    shard (eight different image shards), gather per-rank timings, broadcast the weights and reduce the 18.5 M gradients through the
+    overlapped reducer inside a real backward; and measures what a rank's HOST side costs per step while seven other Python processes do
+    the same on this host (host_enqueue_ms_per_step: fwd + loss graph replay, and the eager full training step) -- the quantity that
+    bounds weak scaling on one node, since the data path has no collective (train_lesion_multiphase_v2.py:593's DataParallel replaced by
+    one process per GPU).  Not a throughput measurement: the eight ranks share one GPU."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '2', '--steady', '0',
+                        '--no-bf16', '--no-events', '--full-step', '2', '--batch', '4'], capture_output=True, text=True, timeout=2400,
+                       env=dict(os.environ, GSSD_DIST_SAME_DEVICE='1', GSSD_DIST_BACKEND='gloo'))
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    ln = lines[0]
+    assert ln['n_gpus'] == 8 and ln['rccl_ranks'] == 8 and ln['collective_backend'] == 'gloo' and len(ln['per_rank_ms_per_step']) == 8
+    assert ln['config']['global_batch'] == 32 and ln['launcher'].startswith('self')
+    assert len(ln['host_enqueue_ms_per_step']) == 8 and all(0 < t < 1e3 for t in ln['host_enqueue_ms_per_step'])
+    fs = ln['full_step']
+    assert 'error' not in fs, fs
+    assert fs['rccl_ranks'] == 8 and fs['allreduce_overlapped'] and 18488172 <= fs['grad_elems'] <= 18488172 + 4 * 400
+    assert len(fs['host_enqueue_ms_per_step']) == 8
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'eight_ranks_one_gpu.json'), 'w') as f:
+            json.dump(dict(note='8 self-launched ranks of bench.py on ONE GPU over gloo, batch 4 per rank: code path + host-side cost per '
+                                'rank with 8 concurrent Python processes; NOT a throughput measurement', host_cpus=os.cpu_count(),
+                           fwd_loss_host_enqueue_ms_per_step=ln['host_enqueue_ms_per_step'], fwd_loss_ms_per_step=ln['per_rank_ms_per_step'],
+                           full_step_host_enqueue_ms_per_step=fs['host_enqueue_ms_per_step'], full_step_ms_per_step=fs['ms_per_step'],
+                           loss=ln['loss']), f, indent=1)
+
+
 def test_bench_two_gpus_self_launched_rccl():
     """`python bench.py --gpus 2` (no launcher): two ranks, RCCL barrier + the full-step leg's overlapped gradient all-reduce."""
     if torch.cuda.device_count() < 2:
