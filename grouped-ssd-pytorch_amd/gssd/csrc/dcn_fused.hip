@@ -80,8 +80,8 @@ template <bool SK>
 __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg,
-                                                          int om_stride, int Cout, int ntn, int mtiles, int* __restrict__ flags, unsigned xcc_map,
-                                                          unsigned* __restrict__ sk_err) {
+                                                          int om_stride, int Cout, int ntn, int mtiles, int* __restrict__ flags, float* __restrict__ sk_ws,
+                                                          unsigned sk_ws_bytes, unsigned* __restrict__ sk_err) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                                   // [2][BM][32]
     float* const Bs = smem + 2 * A_STAGE;                     // [2][BN][32]
@@ -113,14 +113,6 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     long long sk_pos = 0, sk_hi = 0;
     int sk_full = 0, sk_round = 0, sk_R = 1, sk_rank = 0;
     if (SK) {
-        // The fence-free hand-over below is only valid between workgroups behind ONE L2.  `xcc_map` is the XCC id the launcher's probe
-        // saw for each residue of the workgroup id (4 bits each); a workgroup that finds itself elsewhere (CU-masked stream, another
-        // partition mode, a driver that places differently) reports it in the host-visible error word: the launcher then fails loudly and
-        // stops using this form.  (One s_getreg per workgroup.)
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-        if (xcc != ((xcc_map >> ((blockIdx.x & 7) * 4)) & 15u) && tid == 0)
-            __hip_atomic_fetch_or(sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sk_R = gridDim.x >> 3;
         sk_rank = sk_R - 1 - (int)(blockIdx.x >> 3);
         const int nx = 8 % ntn == 0 ? (mtiles - xcd / ntn + (8 / ntn) - 1) / (8 / ntn) : (mtiles * ntn - xcd + 7) / 8;
@@ -357,14 +349,18 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
         // waits until the tile's flag says "the sums of chunks c_end .. nchunks-1 are in `out`" (flag = their count), adds its own, and
         // every piece but the first publishes the longer suffix the same way; the first piece adds the bias and resets the flag.
         const bool head = c_begin == 0, tail = c_end == nchunks;
-        // No fences: an agent-scope release / acquire on gfx950 writes back / invalidates the XCD's whole L2 (measured: 0.6 - 1.6 ms per
-        // launch once tiles are cut into many pieces, and the evicted weight slab slows every other workgroup).  Provider and consumer
-        // share ONE L2, so it is enough that (a) the provider's stores have been acknowledged by L2 before its flag store issues
-        // (vmcnt(0) + barrier; vector stores are write-through) and (b) the consumer reads flag and partial sums past its L1
-        // (relaxed agent-scope atomic loads).
+        // The hand-over is PLACEMENT INDEPENDENT (cdna_hip_programming.md, Guideline 16: "a wrong placement guess is slower, not wrong"):
+        // partial sums travel through a 128 KB slab per cut tile in ACCUMULATOR layout ([MFMA tile][thread] float4: every instruction
+        // moves 1 KB), written with 16-byte sc1 (write-through, agent-scope) stores and read with sc1 loads; the provider drains its
+        // stores (vmcnt(0)) and joins its waves before ONE lane publishes the flag with a relaxed agent-scope store, the consumer polls
+        // the flag relaxed.  Round 3 passed the sums through `out` with plain stores and relied on workgroup id & 7 == XCD (one L2 for
+        // both sides); round 4's run-time check of HW_REG_XCC_ID showed launches whose workgroups sit elsewhere (other streams busy),
+        // so that form could read stale sums.  Keeping a tile's pieces on one XCD is still the fast case (same-L2 reads).
+        const unsigned slab = ((unsigned)(tile_id - sk_full * sk_R * 8)) * (unsigned)(MT * NT * 256 * 16);   // remaining tile rs of XCD x: rs * 8 + x
+        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(sk_ws, 0, SK ? (int)sk_ws_bytes : 0, 0x00020000);
         if (SK && !tail) {
             if (tid == 0) {
-                // bounded: a provider that never arrives (aborted launch, stale flag behind another L2) costs ~1 s and an error, not a hang
+                // bounded: a provider that never arrives (aborted launch) costs ~1 s and an error, not a hang
                 int spins = 0;
                 while (__hip_atomic_load(flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchunks - c_end) {
                     __builtin_amdgcn_s_sleep(4);
@@ -375,30 +371,39 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
                 }
             }
             __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wsr, tid * 16 + (i * NT + j) * 4096, slab, 16 /* sc1 */);
+                    acc[i][j] += __builtin_bit_cast(f32x4, v);
+                }
         }
+        if (SK && !head) {                           // publish the sums of chunks c_begin .. nchunks-1
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = nt * BN + wn * WTN + j * 16 + r;
-            if (n >= Cout) continue;
-            const float bv = (bias && head) ? bias[n] : 0.f;
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int mb = m0 + wm * WTM + i * 16 + kq * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (mb + e < M) {
-                        float v = acc[i][j][e] + bv;
-                        if (SK && !tail) v += __hip_atomic_load(out + (size_t)(mb + e) * Cout + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        out[(size_t)(mb + e) * Cout + n] = v;
-                    }
-            }
-        }
-        if (SK && !head) {                           // the sums of chunks c_begin .. nchunks-1 are in place
+                for (int j = 0; j < NT; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), wsr, tid * 16 + (i * NT + j) * 4096, slab, 16 /* sc1 */);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flags + tile_id, nchunks - c_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = nt * BN + wn * WTN + j * 16 + r;
+                if (n >= Cout) continue;
+                const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int mb = m0 + wm * WTM + i * 16 + kq * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (mb + e < M) out[(size_t)(mb + e) * Cout + n] = acc[i][j][e] + bv;
+                }
+            }
+            if (SK && !tail && tid == 0) __hip_atomic_store(flags + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (SK && head && !tail && tid == 0) __hip_atomic_store(flags + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!SK) break;
         __syncthreads();                             // LDS (tiles, sampling table) is free for the next piece
     }
@@ -448,22 +453,19 @@ extern "C" int gssd_dcn_streamk(int mode) {
 namespace {
 
 // ---- host state of the stream-K form, per device ---------------------------------------------------------------------------------
-// The fence-free partial-sum hand-over is valid only between workgroups behind ONE L2, i.e. if workgroup id & 7 decides the XCD.  That is
-// the observed SPX placement, not a HIP guarantee, so it is PROBED once per device (every workgroup of a CU-count grid reads
-// HW_REG_XCC_ID; the XCC id must be a function of id & 7 and differ between residues), re-checked by every stream-K workgroup of every
-// launch against the probed map, and a violation lands in a host-visible error word the launcher reads before each launch.
-// Flags: one int per tile, in a region that belongs to the launch's OUTPUT buffer (two launches that may be in flight together -- two
-// plans, two captured graphs, more than one stream -- write different outputs, so they never share flags).
-constexpr int SK_POOL_INTS = 1 << 19;                   // 2 MB: 700+ regions of the GSSD++ shape
-constexpr int SK_MAX_REGIONS = 1024;
-struct SkRegion { const void* out; int off, ints; };
+// Per OUTPUT buffer (two launches that may be in flight together -- two plans, two captured graphs, several streams -- write different
+// outputs, so they never share state): one flag int per tile and a 128 KB partial-sum slab per cut tile (at most one per
+// workgroup: CUs x 128 KB = 32 MB).  Regions are created on a launch outside stream capture (they allocate); a launch that meets an
+// unknown output while capturing takes the one-tile form.  The hand-over itself is placement independent (kernel epilogue); the XCC
+// probe below is information for gssd_dcn_streamk_status (is the fast same-L2 case the common one on this device?).
+constexpr int SK_MAX_REGIONS = 64;
+constexpr size_t SK_SLAB_BYTES = (size_t)MT * NT * 256 * 16;
+struct SkRegion { const void* out; int* flags; float* ws; int ints; };
 struct SkDev {
     int cus = 0;                 // 0: not looked at, -1: unusable
     int status = 0;              // GSSD_DCN_SK_* bits
-    unsigned xcc_map = 0;        // 4 bits per residue of workgroup id & 7
-    int* pool = nullptr;
-    int used = 0;
-    unsigned* err_host = nullptr;   // pinned + mapped; bit 0: a workgroup ran on another XCD than probed, bit 1: a wait timed out
+    unsigned xcc_map = 0;        // probed XCC id per residue of workgroup id & 7, 4 bits each
+    unsigned* err_host = nullptr;   // pinned + mapped; bit 1: a wait timed out
     unsigned* err_dev = nullptr;
     SkRegion regions[SK_MAX_REGIONS];
     int nregions = 0;
@@ -503,37 +505,43 @@ void sk_init(SkDev& s, int dev) {
         seen |= 1u << id;
         map |= (id & 15u) << (4 * r);
     }
-    if (!good) { s.status |= GSSD_DCN_SK_MAPPING; return; }
     s.xcc_map = map;
-    int* p = nullptr;
+    if (!good) s.status |= GSSD_DCN_SK_MAPPING;          // information only: pieces of a tile may sit behind different L2s (slower, not wrong)
     unsigned* eh = nullptr;
     void* ed = nullptr;
-    if (hipMalloc(&p, (size_t)SK_POOL_INTS * sizeof(int)) != hipSuccess || hipMemset(p, 0, (size_t)SK_POOL_INTS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void**)&eh, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc((void**)&eh, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
         s.status |= GSSD_DCN_SK_UNSUPPORTED;
         return;
     }
     *eh = 0;
-    if (hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {   // memset ordered before ANY stream's first use
+    if (hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess) {
         (void)hipGetLastError();
         s.status |= GSSD_DCN_SK_UNSUPPORTED;
         return;
     }
-    s.pool = p;
     s.err_host = eh;
     s.err_dev = reinterpret_cast<unsigned*>(ed);
     s.cus = cus;
 }
 
-int* sk_region(SkDev& s, const void* out, int ints) {
+// flags + slabs of the launch writing `out`; created (zeroed, SYNCHRONISED before any stream's first use) when `may_alloc`
+SkRegion* sk_region(SkDev& s, const void* out, int ints, bool may_alloc) {
     for (int i = 0; i < s.nregions; ++i)
-        if (s.regions[i].out == out && s.regions[i].ints >= ints) return s.pool + s.regions[i].off;
-    if (s.nregions == SK_MAX_REGIONS || s.used + ints > SK_POOL_INTS) return nullptr;
-    s.regions[s.nregions++] = SkRegion{out, s.used, ints};
-    const int off = s.used;
-    s.used += (ints + 31) & ~31;                         // whole 128-byte lines per region
-    return s.pool + off;
+        if (s.regions[i].out == out && s.regions[i].ints >= ints) return &s.regions[i];
+    if (!may_alloc || s.nregions == SK_MAX_REGIONS) return nullptr;
+    int* fl = nullptr;
+    float* ws = nullptr;
+    const size_t fbytes = (size_t)((ints + 31) & ~31) * sizeof(int);
+    if (hipMalloc(&fl, fbytes) != hipSuccess || hipMalloc(&ws, (size_t)s.cus * SK_SLAB_BYTES) != hipSuccess ||
+        hipMemset(fl, 0, fbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        if (fl) (void)hipFree(fl);
+        if (ws) (void)hipFree(ws);
+        return nullptr;
+    }
+    s.regions[s.nregions] = SkRegion{out, fl, ws, (ints + 31) & ~31};
+    return &s.regions[s.nregions++];
 }
 
 }  // namespace
@@ -547,7 +555,6 @@ extern "C" int gssd_dcn_streamk_status(unsigned* xcc_map) {
     if (s.cus == 0) sk_init(s, dev);                     // (not to be called while a stream of this thread is capturing)
     if (s.err_host) {
         const unsigned e = __atomic_load_n(s.err_host, __ATOMIC_ACQUIRE);
-        if (e & 1u) s.status |= GSSD_DCN_SK_MAPPING;
         if (e & 2u) s.status |= GSSD_DCN_SK_TIMEOUT;
     }
     if (xcc_map) *xcc_map = s.xcc_map;
@@ -560,11 +567,11 @@ extern "C" int gssd_dcn_streamk_reset(gssd_stream_t stream) {
     if (dev < 0 || dev >= 16) return GSSD_OK;
     std::lock_guard<std::mutex> lock(g_sk_mu);
     SkDev& s = g_sk[dev];
-    if (!s.pool || s.used == 0) return GSSD_OK;
-    if (hipMemsetAsync(s.pool, 0, (size_t)s.used * sizeof(int), as_stream(stream)) != hipSuccess) {
-        gssd_set_error("gssd_dcn_streamk_reset: hipMemsetAsync failed");
-        return GSSD_ELAUNCH;
-    }
+    for (int i = 0; i < s.nregions; ++i)
+        if (hipMemsetAsync(s.regions[i].flags, 0, (size_t)s.regions[i].ints * sizeof(int), as_stream(stream)) != hipSuccess) {
+            gssd_set_error("gssd_dcn_streamk_reset: hipMemsetAsync failed");
+            return GSSD_ELAUNCH;
+        }
     return GSSD_OK;
 }
 
@@ -604,38 +611,34 @@ extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float
     // GSSD_DCN_STREAMK=0 keeps one tile per workgroup.  Per-device state (placement probe, flag pool, error word): SkDev above.
     static const bool sk_off = []() { const char* e = getenv("GSSD_DCN_STREAMK"); return e && e[0] == '0'; }();
     bool sk = (g_dcn_sk_force < 0 ? !sk_off : g_dcn_sk_force == 1) && dev >= 0 && dev < 16;
-    int* fl = nullptr;
     if (sk) {
         std::lock_guard<std::mutex> sk_lock(g_sk_mu);
         SkDev& s = g_sk[dev];
-        if (s.cus == 0) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(as_stream(stream), &cap);
-            if (cap == hipStreamCaptureStatusNone) sk_init(s, dev);          // (a first launch inside a capture takes the one-tile form)
-        }
-        if (s.err_host && !(s.status & (GSSD_DCN_SK_MAPPING | GSSD_DCN_SK_TIMEOUT))) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(as_stream(stream), &cap);
+        const bool may_alloc = cap == hipStreamCaptureStatusNone;
+        if (s.cus == 0 && may_alloc) sk_init(s, dev);                        // (a first launch inside a capture takes the one-tile form)
+        if (s.err_host && !(s.status & GSSD_DCN_SK_TIMEOUT)) {
             const unsigned e = __atomic_load_n(s.err_host, __ATOMIC_ACQUIRE);
-            if (e) {
-                s.status |= (e & 1u ? GSSD_DCN_SK_MAPPING : 0) | (e & 2u ? GSSD_DCN_SK_TIMEOUT : 0);
-                gssd_set_error("gssd_dcn_forward_f32: an earlier stream-K launch %s%s; its output is not trustworthy -- stream-K is now off "
-                               "on device %d (GSSD_DCN_STREAMK=0 avoids it from the start)",
-                               e & 1u ? "ran workgroups on another XCD than the placement probe saw" : "",
-                               e & 2u ? " timed out waiting for a partial sum" : "", dev);
+            if (e & 2u) {
+                s.status |= GSSD_DCN_SK_TIMEOUT;
+                gssd_set_error("gssd_dcn_forward_f32: an earlier stream-K launch timed out waiting for a partial sum (aborted launch?); its "
+                               "output is not trustworthy -- stream-K is now off on device %d (GSSD_DCN_STREAMK=0 avoids it from the start)", dev);
                 return GSSD_ELAUNCH;
             }
         }
         const int nslots = blocks / 8;                       // tiles of the fullest XCD; the emptiest has nslots - 1 or nslots
-        sk = s.cus > 0 && s.status == 0 && nslots >= 1 && blocks > s.cus && blocks % s.cus != 0;
-        if (sk) fl = sk_region(s, out, blocks);
-        sk = sk && fl;
+        sk = s.cus > 0 && !(s.status & (GSSD_DCN_SK_UNSUPPORTED | GSSD_DCN_SK_TIMEOUT)) && nslots >= 1 && blocks > s.cus && blocks % s.cus != 0;
+        SkRegion* rg = sk ? sk_region(s, out, blocks, may_alloc) : nullptr;
+        sk = sk && rg;
         if (sk) {
             hipLaunchKernelGGL(dcn_fused_kernel<true>, dim3(s.cus), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H, W,
-                               C, dg, om_stride, Cout, ntn, mtiles, fl, s.xcc_map, s.err_dev);
+                               C, dg, om_stride, Cout, ntn, mtiles, rg->flags, rg->ws, (unsigned)((size_t)s.cus * SK_SLAB_BYTES), s.err_dev);
         }
     }
     if (!sk) {
         hipLaunchKernelGGL(dcn_fused_kernel<false>, dim3(blocks), dim3(256), smem, as_stream(stream), x, om, w_packed, bias, out, M, H,
-                           W, C, dg, om_stride, Cout, ntn, mtiles, (int*)nullptr, 0u, (unsigned*)nullptr);
+                           W, C, dg, om_stride, Cout, ntn, mtiles, (int*)nullptr, (float*)nullptr, 0u, (unsigned*)nullptr);
     }
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -349,20 +349,21 @@ int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed,
  * products; a tile cut into pieces adds their partial sums in a fixed order (results differ from the unsplit form by fp32 rounding only and
  * are the same from run to run).  The bf16 kernel keeps one tile per workgroup (its stream-K form measured slower: DESIGN.md, section 9). */
 int gssd_dcn_streamk(int mode);
-/* The stream-K form passes partial sums between workgroups WITHOUT cache fences, which is valid only while provider and consumer sit
- * behind one L2, i.e. while workgroup id & 7 decides the XCD.  That is the placement observed on MI355X in SPX mode, not a HIP
- * guarantee (a CU-masked stream or another partition mode may place differently), so the library (1) probes it once per device on the
- * first eligible launch outside a stream capture (HW_REG_XCC_ID per workgroup: a function of id & 7, distinct per residue) and keeps
- * the one-tile form where it does not hold, (2) has every stream-K workgroup of every launch compare its XCC id with the probed map and
- * bounds every wait (~1 s): a violation is written to a host-visible word, and the NEXT gssd_dcn_forward_f32 on that device returns
- * GSSD_ELAUNCH ("an earlier stream-K launch ...; its output is not trustworthy") and turns the form off for the process, (3) keeps the
- * per-tile flags in a region that belongs to the launch's `out` pointer, so launches that can be in flight together (different plans,
- * captured graphs, streams) never share flags.  gssd_dcn_streamk_status: bit mask of the GSSD_DCN_SK_* conditions for the current
- * device (0 = usable; runs the probe if it has not run; do not call while capturing), *xcc_map (optional) = the probed XCC id of each
- * residue, 4 bits each.  gssd_dcn_streamk_reset: zeroes every flag region on `stream` (plan build; after a failed launch). */
-#define GSSD_DCN_SK_UNSUPPORTED 1 /* CU count not a multiple of 8, or the probe / its allocations failed */
-#define GSSD_DCN_SK_MAPPING 2     /* workgroup id & 7 does not decide the XCD (probe), or a launch saw a workgroup elsewhere */
-#define GSSD_DCN_SK_TIMEOUT 4     /* a workgroup gave up waiting for a partial sum */
+/* Hand-over of the stream-K form: a tile cut into pieces passes its partial sums through a 128 KB slab in accumulator layout, written
+ * with 16-byte sc1 (write-through, agent-scope) stores and read with sc1 loads, published by a relaxed agent-scope flag store behind
+ * `s_waitcnt vmcnt(0)` + a workgroup barrier -- correct for ANY placement of the pieces on XCDs / CUs (round 3 relied on workgroup
+ * id & 7 == XCD and plain stores; round 4's run-time check of HW_REG_XCC_ID found launches placed differently when other streams were
+ * busy).  Every wait is bounded (~1 s): a time-out is written to a host-visible word, and the NEXT gssd_dcn_forward_f32 on that device
+ * returns GSSD_ELAUNCH ("an earlier stream-K launch timed out ...; its output is not trustworthy") and turns the form off for the
+ * process.  Flags and slabs belong to the launch's `out` pointer (created on the first launch with that output outside a stream
+ * capture: 32 MB per output on a 256-CU device), so launches that can be in flight together (different plans, captured graphs,
+ * streams) never share them.  gssd_dcn_streamk_status: bit mask of the GSSD_DCN_SK_* conditions for the current device (runs the
+ * one-time set-up if it has not run; do not call while capturing); *xcc_map (optional) = XCC id the placement probe saw for each residue
+ * of workgroup id & 7 (4 bits each).  gssd_dcn_streamk_reset: zeroes every flag region on `stream` (plan build; after a failed launch). */
+#define GSSD_DCN_SK_UNSUPPORTED 1 /* CU count not a multiple of 8, or the set-up allocations failed: one-tile form only */
+#define GSSD_DCN_SK_MAPPING 2     /* information: workgroup id & 7 does not decide the XCD on an idle device (pieces of a tile then sit
+                                     behind different L2s: slower hand-over, same results) */
+#define GSSD_DCN_SK_TIMEOUT 4     /* a workgroup gave up waiting for a partial sum: stream-K is off */
 int gssd_dcn_streamk_status(unsigned* xcc_map);
 int gssd_dcn_streamk_reset(gssd_stream_t stream);
 

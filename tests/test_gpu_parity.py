@@ -2017,24 +2017,25 @@ def test_dcn_fused_streamk(dev, ops, B, Cc, Cout, dg):
     # a shape whose tile count is below the CU count keeps the one-tile form whatever the setting
     a, b = run(0, x[:2].contiguous(), om[:2].contiguous()), run(1, x[:2].contiguous(), om[:2].contiguous())
     assert torch.equal(a, b)
-    # no workgroup ran on another XCD than the placement probe saw, no wait timed out
-    assert lib.gssd_dcn_streamk_status(None) == 0
+    # usable, no wait timed out (bit 2 = "id & 7 is not the XCD here" is information: the hand-over is placement independent)
+    assert lib.gssd_dcn_streamk_status(None) & ~2 == 0
 
 
-def test_dcn_streamk_placement_assumption_holds_here(dev, ops):
-    """VERDICT r3 item 5 / ADVICE r3: the stream-K hand-over of csrc/dcn_fused.hip passes partial sums between workgroups without cache
-    fences, valid only while workgroup id & 7 decides the XCD (one L2 for provider and consumer).  The library probes that per device
-    (HW_REG_XCC_ID per workgroup) and re-checks it in every stream-K workgroup of every launch; this test asserts the probe's verdict ON
-    THIS BOX -- status 0, eight distinct XCC ids --, that launches on several streams at once (each output has its own flag region) agree
-    bit for bit with a serial launch, and that gssd_dcn_streamk_reset leaves a usable state."""
+def test_dcn_streamk_is_placement_independent(dev, ops):
+    """VERDICT r3 item 5 / ADVICE r3.  Round 3's stream-K hand-over of csrc/dcn_fused.hip passed partial sums through plain stores and was
+    valid only while workgroup id & 7 decides the XCD.  Round 4 first added a run-time check of HW_REG_XCC_ID in every stream-K workgroup --
+    and it FIRED on this pool as soon as several launches were in flight on different streams (this test's 12-launch case, and the
+    captured forward of test_full_size_properties[gssdpp]).  The hand-over is now placement independent (sc1 slabs + drained flag,
+    cdna_hip_programming.md Guideline 16); this test prints the idle-device placement probe (information), runs 12 launches on 4 streams
+    at once -- each output has its own flags and slabs -- and demands bit-equality with a serial launch, and checks that
+    gssd_dcn_streamk_reset leaves a usable state and that no wait timed out."""
     import ctypes
     from gssd._lib import lib, check
     xm = ctypes.c_uint(0)
     st = lib.gssd_dcn_streamk_status(ctypes.cast(ctypes.pointer(xm), ctypes.c_void_p))
     ids = [(xm.value >> (4 * r)) & 15 for r in range(8)]
-    print(f'stream-K placement probe: status {st}, XCC id of workgroup id & 7 = 0..7: {ids}')
-    assert st == 0, f'status {st}: the fence-free stream-K form is off on this device (mapping {ids})'
-    assert sorted(ids) == list(range(8))
+    print(f'stream-K: status {st}; idle-device placement probe: XCC id of workgroup id & 7 = 0..7: {ids}')
+    assert st & ~2 == 0, f'status {st}: stream-K is unusable on this device'
     B, H, Cc, Cout, dg = 12, 38, 1024, 512, 4
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, H, H, Cc, generator=g).to(dev)
@@ -2064,4 +2065,4 @@ def test_dcn_streamk_placement_assumption_holds_here(dev, ops):
         assert torch.equal(again, ref)
     finally:
         lib.gssd_dcn_streamk(prev)
-    assert lib.gssd_dcn_streamk_status(None) == 0
+    assert lib.gssd_dcn_streamk_status(None) & ~2 == 0
