@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
         ('out_mode', c_i), ('relu', c_i), ('m_per_image', c_i), ('split_n', c_i), ('split_k', c_i),
-        ('out_b_stride', c_i), ('flags', c_i),
+        ('out_b_stride', c_i), ('flags', c_i), ('stats_rep', c_i),
         ('in_batch_stride', c_i64), ('wgt_batch_stride', c_i64), ('out_batch_stride', c_i64),
         ('outb_batch_stride', c_i64), ('out_off', c_i64), ('outb_off', c_i64),
     ]
@@ -63,8 +63,8 @@ SIGNATURES = {
     'gssd_cast_bf16_f32': (c_i, [c_fp, c_fp, c_i64, c_fp]),
     'gssd_pack_input_nhwc_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_relu_pool_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
-                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
-    'gssd_bn_finalize_bf16': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+                                     c_fp, c_fp, c_f, c_f, c_i, c_i, c_i, c_fp]),
+    'gssd_bn_finalize_bf16': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     'gssd_l2norm_bf16': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_f, c_fp]),
     'gssd_dcn_packed_weight_elems_bf16': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
@@ -75,10 +75,10 @@ SIGNATURES = {
     'gssd_unpack_conv_weight_grad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weight_dgrad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,
-                                    c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp]),
-    'gssd_bn_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+                                    c_fp, c_fp, c_f, c_f, c_i, c_i, c_i, c_fp]),
+    'gssd_bn_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     'gssd_bn_bwd_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
-    'gssd_bn_bwd_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'gssd_bn_bwd_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp]),
     'gssd_bn_bwd_apply_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_fp]),
     'gssd_bn_bwd_apply_masked_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_fp]),
     'gssd_colsum_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp, c_fp]),

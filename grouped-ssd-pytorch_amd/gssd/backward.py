@@ -83,7 +83,7 @@ class Bf16Shadow:
                 casts.append((lib.gssd_cast_bf16_f32, (t.data_ptr(), sh.data_ptr(), t.numel())))
             return self._s[k]
 
-        def XF(xf, bn, stats, count, Cc):
+        def XF(xf, bn, stats, count, Cc, srep=0):
             if xf is None:
                 return None
             if xf[0].data_ptr() not in self._xf:
@@ -93,7 +93,7 @@ class Bf16Shadow:
                 self._keep.append((xf, pd, sc2, sh2))
                 later.append((lib.gssd_bn_finalize_f32, (stats.data_ptr(), float(count), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
-                                                         float(bn.eps), 2, Cc, sc2.data_ptr(), sh2.data_ptr(), pd.data_ptr())))
+                                                         float(bn.eps), 2, Cc, sc2.data_ptr(), sh2.data_ptr(), pd.data_ptr(), srep)))
                 self._xf[xf[0].data_ptr()] = (sc, sh, pd)  # the forward's own scale / shift (identical values), an fp32 pad
             return self._xf[xf[0].data_ptr()]
 
@@ -118,7 +118,7 @@ class Bf16Shadow:
             if kind == 'convbn':
                 q['x_in'], q['raw'] = S(r['x_in']), S(r['raw'])
                 q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'])
-                q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'])
+                q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'], r.get('stats_rep', 0))
             elif kind == 'head':
                 q['src'] = S(r['src'])
             elif kind in ('pool', 'l2norm'):
@@ -138,7 +138,7 @@ class Bf16Shadow:
             if kind == 'convbn':
                 if r['in_xf'] is not None:
                     prod = next(rr for kk, rr in plan.rec if kk == 'convbn' and rr.get('xf') is not None and rr['xf'][0] is r['in_xf'][0])
-                    q['in_xf'] = XF(r['in_xf'], prod['bn'], prod['stats'], B * prod['Ho'] * prod['Ho'], prod['Cout'])
+                    q['in_xf'] = XF(r['in_xf'], prod['bn'], prod['stats'], B * prod['Ho'] * prod['Ho'], prod['Cout'], prod.get('stats_rep', 0))
                 ix = q['in_xf']
                 d, _, _ = ops.make_conv_desc(q['x_in'], None, q['raw'], B=B, H=r['H'], W=r['H'], in_stride=q['Cin'],
                                              cin_g=q['Cin'] // r['groups'], Cout=r['Cout'], groups=r['groups'], k=r['k'], stride=r['stride'],
@@ -401,7 +401,7 @@ class BackwardPlan:
             self._add(lib.gssd_bn_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(),
                                                  bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                                  float(bn.momentum), float(bn.eps), 2, Cout, sc.data_ptr(), sh.data_ptr(),
-                                                 pd_.data_ptr()))
+                                                 pd_.data_ptr(), r.get('stats_rep', 0)))
         pool = r['pool']
         pk, ps, pp = (pool[0], pool[1], pool[2]) if pool else (0, 1, 0)
         dz = self._buf(B, Ho, Ho, Cout, zero_each_run=bool(pool and ps < pk))
@@ -412,7 +412,7 @@ class BackwardPlan:
         ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
         self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
                                                  float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
-                                                 self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr()))
+                                                 self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr(), r.get('stats_rep', 0)))
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         if pool:
             self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),

@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double count, const double* __restrict__ bsums,
                                        const float* __restrict__ gamma, float eps, int C, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+                                       float* __restrict__ dbeta, int srep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = fstats[c] / count;
-    double var = fstats[C + c] / count - mean * mean;
+    const double mean = gssd_stats_sum(fstats, c, 2 * C, srep) / count;
+    double var = gssd_stats_sum(fstats, C + c, 2 * C, srep) / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double inv = 1.0 / sqrt(var + (double)eps);
     const double s1 = bsums[c], s2 = bsums[C + c];
@@ -316,10 +316,10 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
 
 extern "C" int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, const double* bwd_sums, const float* gamma,
                                         float eps, int C, float* coef_a, float* coef_b, float* coef_c, float* dgamma,
-                                        float* dbeta, gssd_stream_t stream) {
+                                        float* dbeta, int stats_rep, gssd_stream_t stream) {
     GSSD_CHECK_ARG(fwd_stats && bwd_sums && gamma && coef_a && coef_b && coef_c && dgamma && dbeta && C > 0 && count > 0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), fwd_stats, count,
-                       bwd_sums, gamma, eps, C, coef_a, coef_b, coef_c, dgamma, dbeta);
+                       bwd_sums, gamma, eps, C, coef_a, coef_b, coef_c, dgamma, dbeta, stats_rep);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -43,6 +43,20 @@ static inline void gssd_attr_done(unsigned* mask) {
     if (dev >= 0 && dev < 32) (void)__atomic_fetch_or(mask, 1u << dev, __ATOMIC_RELEASE);
 }
 
+// BatchNorm batch sums (gssd_conv_desc::stats) may be kept in `rep` replicas of [2 * Cout] doubles: a workgroup adds into replica
+// (workgroup id mod rep), the consumers (gssd_bn_finalize_*, gssd_bn_relu_pool_*, gssd_bn_bwd_finalize_f32) add the replicas up in a
+// fixed order.  Why: device-scope fp64 atomics on one cache line are served one after the other (~8 ns each, measured round 4); the
+// persistent trunk kernels flush all their workgroups' sums at the END of the launch -- 131 k atomics on 16 lines = a 60 us serial
+// tail on a 140 us kernel (profiles/r04_thin_knockout.txt).  16 - 32 replicas make the tail 2 - 4 us.
+__device__ __forceinline__ double* gssd_stats_replica(double* stats, int rep, int cout) {
+    return rep > 1 ? stats + (size_t)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) % (unsigned)rep) * (2 * (size_t)cout) : stats;
+}
+__device__ __forceinline__ double gssd_stats_sum(const double* stats, int idx, int two_c, int rep) {
+    double s = stats[idx];
+    for (int r = 1; r < rep; ++r) s += stats[idx + (size_t)r * two_c];
+    return s;
+}
+
 // 64-lane wavefront reductions (gfx950: wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

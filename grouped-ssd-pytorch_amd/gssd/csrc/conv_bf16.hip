@@ -374,8 +374,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
                 q += (double)red[(w * BN + tid) * 2 + 1];
             }
             const int n = g * cout_g + n0g + tid;
-            unsafeAtomicAdd(p.stats + n, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n, q);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n, s);
+            unsafeAtomicAdd(st + p.Cout + n, q);
         }
     }
 }

@@ -82,6 +82,7 @@ struct FlatParams {
     const float* bias;
     u16* out;
     double* stats;
+    int stats_rep;
     const float* in_scale;
     const float* in_shift;
     int B, H, W, HW, C, Cout, dil, mtiles, ntn, npp, wrow, total;
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(WMW * WNW * 64, WMW * WNW == 4 ? 2 : 1) void conv_f
                 q += (double)red[(w * COUT_T + tid) * 2 + 1];
             }
             const int n = g * cout_g + nt * COUT_T + tid;
-            unsafeAtomicAdd(p.stats + n, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n, q);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n, s);
+            unsafeAtomicAdd(st + p.Cout + n, q);
         }
         wait_lds_barrier();
     };
@@ -415,6 +417,7 @@ int launch_flat(const gssd_conv_desc& d, hipStream_t stream) {
     p.bias = d.bias;
     p.out = reinterpret_cast<u16*>(d.out);
     p.stats = d.stats;
+    p.stats_rep = d.stats_rep;
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.B = d.B;

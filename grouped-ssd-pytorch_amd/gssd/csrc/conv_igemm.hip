@@ -330,8 +330,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
                 q += (double)red[(w * BN + tid) * 2 + 1];
             }
             const int n = g * cout_g + n0g + tid;
-            unsafeAtomicAdd(p.stats + n, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n, q);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n, s);
+            unsafeAtomicAdd(st + p.Cout + n, q);
         }
     }
 }

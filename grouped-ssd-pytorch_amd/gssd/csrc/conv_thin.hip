@@ -37,6 +37,7 @@ struct ThinParams {
     const float* bias;
     float* out;
     double* stats;
+    int stats_rep;
     const float* in_scale;   // fused producer BN+ReLU (NULL = none)
     const float* in_shift;
     const float* in_pad;
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_kernel(c
     }
 
     if (p.stats && tid < COUT) {
-        unsafeAtomicAdd(p.stats + tid, lacc[tid]);
-        unsafeAtomicAdd(p.stats + COUT + tid, lacc[COUT + tid]);
+        double* st = gssd_stats_replica(p.stats, p.stats_rep, COUT);
+        unsafeAtomicAdd(st + tid, lacc[tid]);
+        unsafeAtomicAdd(st + COUT + tid, lacc[COUT + tid]);
     }
 }
 
@@ -295,6 +297,7 @@ int launch_thin_impl(const gssd_conv_desc& d, hipStream_t stream) {
     p.bias = d.bias;
     p.out = d.out;
     p.stats = d.stats;
+    p.stats_rep = d.stats_rep;
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.in_pad = d.in_pad;

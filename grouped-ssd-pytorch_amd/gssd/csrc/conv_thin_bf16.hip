@@ -64,6 +64,12 @@ extern "C" int gssd_thin_timing_read(unsigned long long* out8) {
 #else
 #define TSTAMP(k)
 #endif
+// knock-out builds (scripts/thin_knockout.py; `make thin_ko`): which part of the tile loop costs what.  Results are WRONG on purpose.
+//   1 no producer transform   2 no fragment reads   4 no MFMAs   8 trivial epilogue (no bias / batch sums / pooling)   16 no stores   32 no patch DMA
+//   64 linear tile order   128 no unit swizzle on the DMA source   256 no batch-sum atomics   512 no weight prologue
+#ifndef THIN_KO
+#define THIN_KO 0
+#endif
 
 namespace {
 
@@ -80,6 +86,7 @@ struct ThinBfParams {
     const float* bias;
     u16* out;
     double* stats;
+    int stats_rep;
     const float* in_scale;
     const float* in_shift;
     const float* pool_sign;   // GSSD_CONV_POOL2: `out` is the 2x2 / stride-2 pooled raw map, max where pool_sign[c] >= 0 else min
@@ -122,14 +129,21 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = 32 * ks + 8 * kq;
-            wf[ks][j] = k < 9 * CIN_G ? *reinterpret_cast<const bf16x8*>(wr + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            wf[ks][j] = (k < 9 * CIN_G && !(THIN_KO & 512)) ? *reinterpret_cast<const bf16x8*>(wr + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
     // this lane's output channels (inside the group): cb .. cb + CPL
     const int cb = NT == 1 ? 4 * kq : 8 * kq;
-    float bias[CPL];
+    // bias and the pooled epilogue's BatchNorm-weight signs live in registers for the kernel's lifetime: an ordinary (VGPR-returning) load
+    // inside the tile loop makes hipcc wait vmcnt(0) where its destination registers are next written -- loads and stores share that
+    // counter on gfx950, so every row batch then waited for the previous batch's STORES to be acknowledged (round 4: the ISA of the
+    // pooled epilogue had one such wait per row pair, the unpooled <16,32> kernel one per 8-row batch)
+    float bias[CPL], sg[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) bias[c] = p.bias ? p.bias[g * COUT_G + cb + c] : 0.f;
+    for (int c = 0; c < CPL; ++c) {
+        bias[c] = p.bias ? p.bias[g * COUT_G + cb + c] : 0.f;
+        sg[c] = p.pool_sign ? p.pool_sign[g * COUT_G + cb + c] : 0.f;
+    }
 
     // ---- fragment offsets (elements) of M tile 0 per k-step: tap = k / CIN_G (clamped: zero weights beyond tap 8) ---------------
     int foff[KS];
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
 #ifdef THIN_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
-    const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bperm = (gridDim.x & 7) == 0 && !(THIN_KO & 64) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
@@ -171,16 +185,16 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
         for (int i = g; i < NINSTR; i += 4) {
             const int pp = i * PPI + lane / UPR;
             const int py = pp / PW, pxx = pp - py * PW;
-            const int lu = (lane % UPR) ^ swz<UPR>(pxx);
+            const int lu = (THIN_KO & 128) ? (lane % UPR) : (lane % UPR) ^ swz<UPR>(pxx);
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
             const bool ok = pp < NPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const u16* src = ok ? p.in + ((size_t)(b * p.H + iy) * p.W + ix) * CIN + lu * 8 : g_zero_thin_h;
-            dma16(src, patch + i * PPI * CIN);
+            if (!(THIN_KO & 32)) dma16(src, patch + i * PPI * CIN);
         }
         TSTAMP(0)
         __syncthreads();
         TSTAMP(1)
-        if constexpr (XF) {
+        if constexpr (XF && !(THIN_KO & 1)) {
             // producer BatchNorm + ReLU once per patch element (in-image pixels only: the rest stays 0 = padding after the transform).
             // A thread always transforms the SAME eight channels (unit tid % UPR of every (256 / UPR)-th pixel; the swizzle only
             // moves where that unit sits inside the pixel), so its scale / shift live in 16 registers for the kernel's lifetime.
@@ -213,21 +227,45 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
             for (int i = 0; i < RH; ++i) {
                 bf16x8 af[KS];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + (rb + i) * PW * CIN);
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (THIN_KO & 2) af[ks] = wf[ks][0];
+                    else af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + (rb + i) * PW * CIN);
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if (THIN_KO & 4) acc[i][j][ks & 3] += (float)af[ks][j];
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (THIN_KO & 8) {
+#pragma unroll
+                for (int i = 0; i < RH; ++i) {
+                    const int y = y0 + rb + i;
+                    if (y >= p.H || x >= p.W) continue;
+                    u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + cb;
+                    if (p.pool_sign) {
+                        if ((i & 1) || (r & 1)) continue;
+                        dst = p.out + ((size_t)(b * ((p.H + 1) >> 1) + (y >> 1)) * ((p.W + 1) >> 1) + (x >> 1)) * COUT + g * COUT_G + cb;
+                    }
+                    if constexpr (CPL == 4) {
+                        if (!(THIN_KO & 16)) *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)acc[i][0][0], (__bf16)acc[i][0][1], (__bf16)acc[i][0][2], (__bf16)acc[i][0][3]};
+                    } else {
+                        bf16x8 h;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) h[c] = (__bf16)acc[i][c >> 2][c & 3];
+                        if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
+                    }
+                    ssum[0] += acc[i][0][0];
+                }
+                continue;
             }
             if (p.pool_sign) {
                 // GSSD_CONV_POOL2 (include/gssd_hip.h): rows (i, i + 1) of a lane and columns (r, r ^ 1) of neighbouring lanes form one
                 // pooling window (tile origins are even); batch sums over every pixel as usual, then ONE value per window and channel --
                 // the maximum where the channel's BatchNorm weight is >= 0, the minimum where it is negative -- rounded to bf16 (the
                 // rounding commutes with max / min) and stored by the even lane at the pooled position.  The full map is never written.
-                float sg[CPL];
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) sg[c] = p.pool_sign[g * COUT_G + cb + c];
                 const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
 #pragma unroll
                 for (int i = 0; i < RH; i += 2) {
@@ -275,12 +313,12 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                             bf16x4 h;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
-                            *reinterpret_cast<bf16x4*>(dst) = h;
+                            if (!(THIN_KO & 16)) *reinterpret_cast<bf16x4*>(dst) = h;
                         } else {
                             bf16x8 h;
 #pragma unroll
                             for (int c = 0; c < 8; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
-                            *reinterpret_cast<bf16x8*>(dst) = h;
+                            if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
                         }
                     }
                 }
@@ -319,7 +357,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                     if (y < p.H && x < p.W) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + 4 * (kq & ~1);
-                        *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                        if (!(THIN_KO & 16)) *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                     }
                 }
             } else {
@@ -338,7 +376,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                     bf16x8 h;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) h[c] = (__bf16)v[c];
-                    *reinterpret_cast<bf16x8*>(dst) = h;
+                    if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
                 }
             }
         }
@@ -352,7 +390,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
         for (int k = 0; k < 6; ++k) atomicAdd(&g_thin_timing[k], tacc[k]);
     if (tid == 0) atomicAdd(&g_thin_timing[7], 1ull);
 #endif
-    if (p.stats) {
+    if (p.stats && !(THIN_KO & 256)) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             double s = (double)ssum[c], q = (double)ssq[c];
@@ -362,8 +400,9 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                 q += __shfl_xor(q, o, 64);
             }
             if (r == 0) {
-                unsafeAtomicAdd(p.stats + g * COUT_G + cb + c, s);
-                unsafeAtomicAdd(p.stats + COUT + g * COUT_G + cb + c, q);
+                double* st = gssd_stats_replica(p.stats, p.stats_rep, COUT);
+                unsafeAtomicAdd(st + g * COUT_G + cb + c, s);
+                unsafeAtomicAdd(st + COUT + g * COUT_G + cb + c, q);
             }
         }
     }
@@ -381,6 +420,7 @@ int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     p.bias = d.bias;
     p.out = reinterpret_cast<u16*>(d.out);
     p.stats = d.stats;
+    p.stats_rep = d.stats_rep;
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.pool_sign = (d.flags & GSSD_CONV_POOL2) ? d.pool_sign : nullptr;

@@ -29,6 +29,7 @@ struct ThinWinoParams {
     const float* bias;
     float* out;
     double* stats;
+    int stats_rep;
     const float* in_scale;
     const float* in_shift;
     const float* in_pad;
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
         ish = *reinterpret_cast<const f32x4*>(p.in_shift + g * 16 + kq * 4);
     }
     const float bias = p.bias ? p.bias[g * 16 + r] : 0.f;
+    // (kept in registers for the kernel's lifetime: a VGPR-returning load inside the tile loop costs a vmcnt(0) = a wait for the previous
+    // tile's stores, conv_thin_bf16.hip)
+    const f32x4 sg = p.pool_sign ? *reinterpret_cast<const f32x4*>(p.pool_sign + (tid & 15) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* zero = g_zero_page_tw2;
     for (int c = tid; c < 2 * TW_COUT; c += 256) lacc[c] = 0.0;
 
@@ -170,7 +174,6 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
                 // GSSD_CONV_POOL2: the staged 8 x 16 tile is 4 x 8 pooling windows (tile origins are even): a thread reduces the
                 // four pixels of a window for its 4 channels -- batch sums over ALL pixels as before -- and stores the maximum
                 // where the channel's BatchNorm weight is >= 0, the minimum where it is negative.  The full map is never written.
-                const f32x4 sg = *reinterpret_cast<const f32x4*>(p.pool_sign + c4 * 4);
                 const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
                 // batch sums: the same pixels in the same order as the unpooled epilogue (identical statistics), no store
 #pragma unroll
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv_thin_wino_kernel(const ThinWinoPa
         }
         __syncthreads();
         if (tid < TW_COUT) {
-            unsafeAtomicAdd(p.stats + tid, lacc[tid]);
-            unsafeAtomicAdd(p.stats + TW_COUT + tid, lacc[TW_COUT + tid]);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, TW_COUT);
+            unsafeAtomicAdd(st + tid, lacc[tid]);
+            unsafeAtomicAdd(st + TW_COUT + tid, lacc[TW_COUT + tid]);
         }
     }
 }
@@ -253,6 +257,7 @@ int launch_thin_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.bias = d.bias;
     p.out = d.out;
     p.stats = d.stats;
+    p.stats_rep = d.stats_rep;
     p.in_scale = d.in_scale;
     p.in_shift = d.in_shift;
     p.in_pad = d.in_pad;

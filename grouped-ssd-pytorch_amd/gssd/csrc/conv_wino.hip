@@ -55,6 +55,7 @@ struct WinoParams {
     const float* in_pad;
     const float* pool_sign;  // GSSD_CONV_POOL2: `out` is the 2x2 / stride-2 (ceil) pooled raw map, max where pool_sign[c] >= 0 else min
     double* stats;
+    int stats_rep;
     int B, H, W, in_stride, in_ch_off, Cout, cin_g, cout_g, cout_pad, out_stride, out_ch_off;
     int tiles_y, tiles_x, ntiles;      // per group: B * tiles_y * tiles_x
     int vec_ok;                        // bias / resid / out / pool_sign pointers are 16-byte aligned
@@ -425,8 +426,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 q += (double)red[(w * NB + tid) * 2 + 1];
             }
             const int n = g * p.cout_g + n0 + tid;
-            unsafeAtomicAdd(p.stats + n, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n, q);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n, s);
+            unsafeAtomicAdd(st + p.Cout + n, q);
         }
     }
 #ifdef WINO_TIMING
@@ -496,6 +498,7 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
     p.in_pad = d.in_pad;
     p.pool_sign = (d.flags & GSSD_CONV_POOL2) ? d.pool_sign : nullptr;
     p.stats = d.stats;
+    p.stats_rep = d.stats_rep;
     p.B = d.B;
     p.H = d.H;
     p.W = d.W;

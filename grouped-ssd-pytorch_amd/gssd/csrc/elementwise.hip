@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(
     const float* __restrict__ raw, float* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pk, int ps,
     int pp, const double* __restrict__ stats, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps, int training,
-    int relu) {
+    int relu, int srep) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_scale = sm;
     float* s_shift = sm + C;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(
         }
         double mean, var;
         if (training) {
-            mean = stats[c] / count;
-            var = stats[C + c] / count - mean * mean;
+            mean = gssd_stats_sum(stats, c, 2 * C, srep) / count;
+            var = gssd_stats_sum(stats, C + c, 2 * C, srep) / count - mean * mean;
             if (var < 0.0) var = 0.0;
             if (blockIdx.x == 0) {
                 const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float momentum, float eps, int training, int C, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ pad) {
+                                   float* __restrict__ shift, float* __restrict__ pad, int srep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double mean, var;
     if (training) {
-        mean = stats[c] / count;
-        var = stats[C + c] / count - mean * mean;
+        mean = gssd_stats_sum(stats, c, 2 * C, srep) / count;
+        var = gssd_stats_sum(stats, C + c, 2 * C, srep) / count - mean * mean;
         if (var < 0.0) var = 0.0;
         if (training == 1) {      // training == 2: batch statistics again (backward) without a second running update
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -419,8 +419,8 @@ extern "C" int gssd_pack_conv_weights_batched(const gssd_pack_item* items_dev, i
 extern "C" int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H, int W, int C, int Ho, int Wo,
                                      int pool_k, int pool_s, int pool_p, const double* stats, double count,
                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                     float momentum, float eps, int training, int relu, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(raw && out);
+                                     float momentum, float eps, int training, int relu, int stats_rep, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(raw && out && stats_rep >= 0);
     GSSD_CHECK_ARG(gamma == nullptr || (beta && running_mean && running_var));
     GSSD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Ho > 0 && Wo > 0);
     GSSD_CHECK_ARG(!training || gamma == nullptr || (stats != nullptr && count > 0));
@@ -430,18 +430,18 @@ extern "C" int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H,
     const int blocks = ew_blocks(total, EW_THREADS * 4, 2048);
     hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(blocks), dim3(EW_THREADS), 2 * C * sizeof(float), as_stream(stream),
                        raw, out, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, stats, count, gamma, beta, running_mean,
-                       running_var, momentum, eps, training, relu);
+                       running_var, momentum, eps, training, relu, stats_rep);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
 extern "C" int gssd_bn_finalize_f32(const double* stats, double count, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float eps, int training,
-                                    int C, float* scale, float* shift, float* pad, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && pad && C > 0);
+                                    int C, float* scale, float* shift, float* pad, int stats_rep, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && pad && C > 0 && stats_rep >= 0);
     GSSD_CHECK_ARG(!training || (stats != nullptr && count > 0));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, training, C, scale, shift, pad);
+                       beta, running_mean, running_var, momentum, eps, training, C, scale, shift, pad, stats_rep);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -43,7 +43,7 @@ __global__ void pack_input_bf16_kernel(const float* __restrict__ x, u16* __restr
 __global__ __launch_bounds__(256) void bn_relu_pool_bf16_kernel(
     const u16* __restrict__ raw, u16* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pk, int ps, int pp,
     const double* __restrict__ stats, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* running_mean, float* running_var, float momentum, float eps, int training, int relu) {
+    float* running_mean, float* running_var, float momentum, float eps, int training, int relu, int srep) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_scale = sm;
     float* s_shift = sm + C;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bf16_kernel(
         }
         double mean, var;
         if (training) {
-            mean = stats[c] / count;
-            var = stats[C + c] / count - mean * mean;
+            mean = gssd_stats_sum(stats, c, 2 * C, srep) / count;
+            var = gssd_stats_sum(stats, C + c, 2 * C, srep) / count - mean * mean;
             if (var < 0.0) var = 0.0;
             if (blockIdx.x == 0) {
                 const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -120,13 +120,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bf16_kernel(
 __global__ void bn_finalize_bf16_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                                         float eps, int training, int C, float* __restrict__ scale, float* __restrict__ shift,
-                                        u16* __restrict__ pad) {
+                                        u16* __restrict__ pad, int srep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double mean, var;
     if (training) {
-        mean = stats[c] / count;
-        var = stats[C + c] / count - mean * mean;
+        mean = gssd_stats_sum(stats, c, 2 * C, srep) / count;
+        var = gssd_stats_sum(stats, C + c, 2 * C, srep) / count - mean * mean;
         if (var < 0.0) var = 0.0;
         if (training == 1) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -188,8 +188,8 @@ extern "C" int gssd_pack_input_nhwc_bf16(const float* x_nchw, void* y_nhwc, int 
 extern "C" int gssd_bn_relu_pool_bf16(const void* raw, void* out, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
                                       int pool_p, const double* stats, double count, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
-                                      gssd_stream_t stream) {
-    GSSD_CHECK_ARG(raw && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 4096 && Ho > 0 && Wo > 0);
+                                      int stats_rep, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(stats_rep >= 0 && raw && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 4096 && Ho > 0 && Wo > 0);
     GSSD_CHECK_ARG(gamma == nullptr || (beta && running_mean && running_var));
     GSSD_CHECK_ARG(!(training && gamma) || (stats != nullptr && count > 0));
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
@@ -197,18 +197,18 @@ extern "C" int gssd_bn_relu_pool_bf16(const void* raw, void* out, int B, int H, 
     const long long total = (long long)B * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(bn_relu_pool_bf16_kernel, dim3(ew_blocks(total, EW_THREADS * 4, 2048)), dim3(EW_THREADS), 2 * C * sizeof(float),
                        as_stream(stream), reinterpret_cast<const u16*>(raw), reinterpret_cast<u16*>(out), B, H, W, C, Ho, Wo, pool_k,
-                       pool_s, pool_p, stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, relu);
+                       pool_s, pool_p, stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, relu, stats_rep);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
 extern "C" int gssd_bn_finalize_bf16(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
                                      float* running_var, float momentum, float eps, int training, int C, float* scale, float* shift,
-                                     void* pad_bf16, gssd_stream_t stream) {
+                                     void* pad_bf16, int stats_rep, gssd_stream_t stream) {
     GSSD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && pad_bf16 && C > 0);
     GSSD_CHECK_ARG(!training || (stats != nullptr && count > 0));
     hipLaunchKernelGGL(bn_finalize_bf16_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, C, scale, shift, reinterpret_cast<u16*>(pad_bf16));
+                       running_mean, running_var, momentum, eps, training, C, scale, shift, reinterpret_cast<u16*>(pad_bf16), stats_rep);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -266,8 +266,9 @@ __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const
             if (tid < BN && n0 + tid < p.Cout) {
                 const double sv = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
                 const double qv = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
-                unsafeAtomicAdd(p.stats + n0 + tid, sv);
-                unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, qv);
+                double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+                unsafeAtomicAdd(st + n0 + tid, sv);
+                unsafeAtomicAdd(st + p.Cout + n0 + tid, qv);
             }
         }
         return;
@@ -389,8 +390,9 @@ __global__ __launch_bounds__(256, BN == 256 ? 1 : 2) void gemm_slot_kernel(const
         if (tid < BN && n0 + tid < p.Cout) {
             const double s = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
             const double q = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
-            unsafeAtomicAdd(p.stats + n0 + tid, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, q);
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n0 + tid, s);
+            unsafeAtomicAdd(st + p.Cout + n0 + tid, q);
         }
     }
 }

@@ -296,13 +296,20 @@ class _Plan(_PlanBase):
             if id(m) not in seen:
                 seen.add(id(m))
                 uniq.append(m)
-        total = sum(2 * m.num_features for m in uniq)
+        # The trunk's batch sums are kept in R replicas (include/gssd_hip.h: gssd_conv_desc::stats_rep): device-scope fp64 atomics on one
+        # cache line are served serially, and the persistent trunk kernels flush every workgroup's sums at the END of the launch (conv2_1
+        # in bf16: 131 k atomics on 16 lines = 60 of its 140 us, profiles/r04_thin_knockout.txt).  R * C <= 2048 (at most 32): every
+        # trunk layer spreads its sums over 256 lines; the consumers add the replicas up in a fixed order.
+        trunk_bn = {id(m) for m in net.vgg if isinstance(m, torch.nn.BatchNorm2d)} if os.environ.get('GSSD_STATS_REP', '1') != '0' else set()
+        self.stat_rep = {id(m): (max(1, min(32, 2048 // m.num_features)) if id(m) in trunk_bn else 1) for m in uniq}
+        total = sum(2 * m.num_features * self.stat_rep[id(m)] for m in uniq)
         self.stats = torch.zeros(max(total, 2), device=dev, dtype=torch.float64)
         off = 0
         self.stat_of = {}
         for m in uniq:
-            self.stat_of[id(m)] = self.stats[off:off + 2 * m.num_features]
-            off += 2 * m.num_features
+            n = 2 * m.num_features * self.stat_rep[id(m)]
+            self.stat_of[id(m)] = self.stats[off:off + n]
+            off += n
         self.nbt = [m.num_batches_tracked for m in uniq]
 
         self._setup_spectral_norm([(n, getattr(net, n)) for n in ('self_attn_base_list', 'self_attn_list')
@@ -620,6 +627,7 @@ class _Plan(_PlanBase):
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
         st = self.eng_stat(bn)
+        srep = getattr(self, 'stat_rep', {}).get(id(bn), 0) if self.training else 0
         # Pooled trunk layers of a no-backward forward (conv1_2, conv2_2, conv3_3): max-pooling commutes with the monotone BatchNorm +
         # ReLU, and the direction of monotonicity is the sign of the BatchNorm weight, known before the launch.  The conv's epilogue
         # writes max- (gamma >= 0) or min- (gamma < 0) pooled RAW outputs, a quarter of the map, with the batch sums of the full map;
@@ -637,15 +645,15 @@ class _Plan(_PlanBase):
                                          stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                          stats=st if self.training else None,
                                          in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
-                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2, pool_sign=bn.weight.detach())
+                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2, pool_sign=bn.weight.detach(), stats_rep=srep)
             self._add(self.conv_fn, (C.byref(d),), keep=d)
             sc, sh = self._buf(Cout), self._buf(Cout)
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
+                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr(), srep))
             self.rec.append(('convbn', dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho,
-                                            Cout=Cout, desc=d, stats=st, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl, out=raw,
+                                            Cout=Cout, desc=d, stats=st, stats_rep=srep, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl, out=raw,
                                             Hp=Hp, xf=(sc, sh, pd), pooled=True)))
             self._layer = None
             return raw, Hp, Cout, (sc, sh, pd)
@@ -654,10 +662,10 @@ class _Plan(_PlanBase):
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
-                                     in_pad=in_xf[2] if in_xf else None)
+                                     in_pad=in_xf[2] if in_xf else None, stats_rep=srep)
         self._add(self.conv_fn, (C.byref(d),), keep=d)
         rec = dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho, Cout=Cout,
-                   desc=d, stats=st, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
+                   desc=d, stats=st, stats_rep=srep, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
         self.rec.append(('convbn', rec))
         if defer_bn:
             assert pool is None and relu
@@ -665,7 +673,7 @@ class _Plan(_PlanBase):
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
                       (st.data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr()))
+                       int(self.training), Cout, sc.data_ptr(), sh.data_ptr(), pd.data_ptr(), srep))
             rec.update(out=raw, Hp=Ho, xf=(sc, sh, pd))
             self._layer = None
             return raw, Ho, Cout, (sc, sh, pd)
@@ -678,7 +686,7 @@ class _Plan(_PlanBase):
         self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
                   (raw.data_ptr(), act.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, st.data_ptr(), float(B * Ho * Ho),
                    bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   float(bn.momentum), float(bn.eps), int(self.training), int(relu)),
+                   float(bn.momentum), float(bn.eps), int(self.training), int(relu), srep),
                   tag=('bn_relu_pool_bf16' if self.bf16 else 'bn_relu_pool', 0.0,
                        (2.0 if self.bf16 else 4.0) * B * Cout * (Ho * Ho + Hp * Hp)))
         rec.update(out=act, Hp=Hp, xf=None)
@@ -693,7 +701,7 @@ class _Plan(_PlanBase):
         Hp = ops.pool_out_size(H, k, s, p, ceil)
         out = self._abuf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_bf16 if self.bf16 else lib.gssd_bn_relu_pool_f32,
-                  (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0),
+                  (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, s, p, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0, 0),
                   tag=('bn_relu_pool_bf16' if self.bf16 else 'bn_relu_pool', 0.0, (2.0 if self.bf16 else 4.0) * B * Cc * (H * H + Hp * Hp)))
         self.rec.append(('pool', dict(x_in=x, out=out, H=H, C=Cc, k=k, s=s, p=p, Hp=Hp)))
         return out, Hp
@@ -1076,7 +1084,7 @@ class _PlanVanilla(_Plan):
                 Hp = ops.pool_out_size(H, k, st, pd, m.ceil_mode)
                 out = self._buf(B, Hp, Hp, Cc)
                 self._add(lib.gssd_bn_relu_pool_f32, (cur.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, k, st, pd, 0, 1.0, 0, 0,
-                                                      0, 0, 0.1, 1e-5, 0, 0))
+                                                      0, 0, 0.1, 1e-5, 0, 0, 0))
                 self.rec.append(('pool', dict(x_in=cur, out=out, H=H, C=Cc, k=k, s=st, p=pd, Hp=Hp)))
                 cur, H = out, Hp
                 i += 1

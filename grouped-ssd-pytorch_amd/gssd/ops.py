@@ -162,7 +162,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None):
+                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None, stats_rep=0):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -178,6 +178,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.split_k = split_k
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.wgt_wino = _p(wgt_wino)
+    d.stats_rep = int(stats_rep)
     d.pool_sign = _p(pool_sign)
     d.out_b_stride = out_b_stride
     d.flags = flags
@@ -262,20 +263,20 @@ def pack_weight_dgrad(w_oihw, groups, out=None):
 # elementwise
 # ------------------------------------------------------------------------------------------------
 def bn_relu_pool(raw, out, stats, count, gamma, beta, rmean, rvar, training, relu=True, pool=None, momentum=0.1,
-                 eps=1e-5):
+                 eps=1e-5, stats_rep=0):
     """raw/out NHWC.  pool = (k, s, p) or None."""
     B, H, W, Cc = raw.shape
     _, Ho, Wo, _ = out.shape
     pk, ps, pp = pool if pool else (0, 1, 0)
     check(lib.gssd_bn_relu_pool_f32(_p(raw), _p(out), B, H, W, Cc, Ho, Wo, pk, ps, pp, _p(stats), float(count),
                                     _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps, int(training), int(relu),
-                                    _stream()))
+                                    int(stats_rep), _stream()))
     return out
 
 
-def bn_finalize(stats, count, gamma, beta, rmean, rvar, training, scale, shift, pad, momentum=0.1, eps=1e-5):
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, training, scale, shift, pad, momentum=0.1, eps=1e-5, stats_rep=0):
     check(lib.gssd_bn_finalize_f32(_p(stats), float(count), _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
-                                   int(training), gamma.numel(), _p(scale), _p(shift), _p(pad), _stream()))
+                                   int(training), gamma.numel(), _p(scale), _p(shift), _p(pad), int(stats_rep), _stream()))
 
 
 def pool_out_size(n, k, s, p, ceil):
@@ -480,7 +481,7 @@ def detect_boxes(boxes, scores, overlap, top_k):
 # ------------------------------------------------------------------------------------------------
 # backward helpers (tests and the engine's backward plan use the same entry points)
 # ------------------------------------------------------------------------------------------------
-def bn_backward(dout, raw, fwd_stats, count, gamma, scale, shift, pool=None, relu=True, eps=1e-5, want_colsum=False):
+def bn_backward(dout, raw, fwd_stats, count, gamma, scale, shift, pool=None, relu=True, eps=1e-5, want_colsum=False, stats_rep=0):
     """d(conv output) of conv -> BN(train) -> ReLU -> (pool).  Returns (draw NHWC, dgamma, dbeta, colsum or None)."""
     B, H, W, Cc = raw.shape
     _, Ho, Wo, _ = dout.shape
@@ -492,7 +493,7 @@ def bn_backward(dout, raw, fwd_stats, count, gamma, scale, shift, pool=None, rel
                                      int(relu), _stream()))
     ca, cb, cc, dg, db = (torch.empty(Cc, device=dev) for _ in range(5))
     check(lib.gssd_bn_bwd_finalize_f32(_p(fwd_stats), float(count), _p(sums), _p(gamma), eps, Cc, _p(ca), _p(cb), _p(cc), _p(dg),
-                                       _p(db), _stream()))
+                                       _p(db), int(stats_rep), _stream()))
     cs = torch.zeros(Cc, device=dev, dtype=torch.float64) if want_colsum else None
     check(lib.gssd_bn_bwd_apply_f32(_p(dz), _p(raw), _p(ca), _p(cb), _p(cc), B * H * W, Cc, _p(cs), _stream()))
     return dz, dg, db, cs

@@ -147,7 +147,7 @@ class _PlanPixelLink(_Plan):
             pk, ps, pp, Hp = 0, 1, 0, H
         out = self._buf(B, Hp, Hp, Cc)
         self._add(lib.gssd_bn_relu_pool_f32, (x.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, pk, ps, pp, 0, 1.0, 0, 0, 0, 0, 0.1, 1e-5,
-                                              0, int(relu)))
+                                              0, int(relu), 0))
         self.rec.append(('relupool', dict(x_in=x, out=out, H=H, C=Cc, k=pk, s=ps, p=pp, Hp=Hp, relu=bool(relu))))
         return out, Hp
 

@@ -128,6 +128,13 @@ typedef struct gssd_conv_desc {
                            output (small-M / long-K launches such as the heads); plain epilogues only */
     int out_b_stride;   /* GSSD_OUT_SPLIT_T: floats between the transposed rows of out_b */
     int flags;          /* GSSD_CONV_* bits (bf16 entry point only) */
+    int stats_rep;      /* 0 / 1: `stats` is one [2*Cout] array.  R > 1: `stats` holds R replicas of [2*Cout] doubles, R * 2 * Cout in all
+                           (zero-filled by the caller); a workgroup adds its sums into replica (workgroup id mod R) and the consumers
+                           -- gssd_bn_finalize_*, gssd_bn_relu_pool_*, gssd_bn_bwd_finalize_f32, which take the same R -- add the
+                           replicas up in a fixed order.  Device-scope fp64 atomics on one cache line are served serially; the
+                           persistent trunk kernels flush every workgroup's sums at the end of the launch (conv2_1 in bf16: 131 k
+                           atomics on 16 lines = 60 of its 140 us).  The split of the sums over replicas depends on the grid, their
+                           total does not (up to fp64 rounding of the order of addition) */
     int64_t in_batch_stride, wgt_batch_stride, out_batch_stride, outb_batch_stride;
     int64_t out_off, outb_off; /* GSSD_OUT_HEADS: float offset of this source inside one image's rows */
 } gssd_conv_desc;
@@ -169,10 +176,11 @@ int gssd_cast_bf16_f32(const void* x, float* y, int64_t n, gssd_stream_t stream)
 int gssd_pack_input_nhwc_bf16(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int groups, gssd_stream_t stream);
 int gssd_bn_relu_pool_bf16(const void* raw, void* out, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p,
                            const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
-                           float* running_var, float momentum, float eps, int training, int relu, gssd_stream_t stream);
+                           float* running_var, float momentum, float eps, int training, int relu, int stats_rep,
+                           gssd_stream_t stream);
 int gssd_bn_finalize_bf16(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float eps, int training, int C, float* scale, float* shift,
-                          void* pad_bf16, gssd_stream_t stream);
+                          void* pad_bf16, int stats_rep, gssd_stream_t stream);
 int gssd_l2norm_bf16(const void* x, const float* weight, void* out, int64_t pixels, int C, float eps, gssd_stream_t stream);
 
 /* U[g][xi][co][ci] = (G g G^T)_xi of the packed K-major weights [Cout][tap*cin_g + ci] (row stride `row_stride`).
@@ -208,19 +216,20 @@ int gssd_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, 
  * biased variance come from `stats` (filled by the conv) over `count` elements per channel, and
  * running_mean / running_var are updated in place (momentum, unbiased variance);
  * training == 0: running statistics are used.  pool_k == 0 means no pooling.  gamma == NULL means
- * identity affine (plain ReLU / max-pool pass, e.g. pool4 after the DCN block).
+ * identity affine (plain ReLU / max-pool pass, e.g. pool4 after the DCN block).  stats_rep (here and in gssd_bn_finalize_* /
+ * gssd_bn_bwd_finalize_f32): the number of replicas `stats` holds (gssd_conv_desc::stats_rep of the conv that filled it; 0 / 1 = one).
  */
 int gssd_bn_relu_pool_f32(const float* raw, float* out, int B, int H, int W, int C, int Ho, int Wo, int pool_k,
                           int pool_s, int pool_p, const double* stats, double count, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                          int training, int relu, gssd_stream_t stream);
+                          int training, int relu, int stats_rep, gssd_stream_t stream);
 
 /* BatchNorm statistics -> per-channel affine, for consumers that apply BN+ReLU on the fly (gssd_conv_desc.in_scale):
  * scale = gamma / sqrt(var + eps), shift = beta - mean*scale, pad = -/+3e38 (mapped to <= 0 by the transform);
  * training != 0 uses the fp64 batch sums and updates running_mean / running_var like nn.BatchNorm2d. */
 int gssd_bn_finalize_f32(const double* stats, double count, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, float eps, int training, int C,
-                         float* scale, float* shift, float* pad, gssd_stream_t stream);
+                         float* scale, float* shift, float* pad, int stats_rep, gssd_stream_t stream);
 
 /* BatchNorm(train) + ReLU + max-pool backward, three launches (replaces autograd's native_batch_norm_backward /
  * threshold_backward / max_pool2d_with_indices_backward):
@@ -234,7 +243,7 @@ int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const float* sca
                            int relu, gssd_stream_t stream);
 int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, const double* bwd_sums, const float* gamma, float eps,
                              int C, float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta,
-                             gssd_stream_t stream);
+                             int stats_rep, gssd_stream_t stream);
 int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b, const float* coef_c,
                           int64_t pixels, int C, double* colsum, gssd_stream_t stream);
 /* The same for a layer WITHOUT pooling, straight from d(out): dz = dout * [raw * scale + shift > 0] (relu) is re-derived here, so

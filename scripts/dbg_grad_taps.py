@@ -68,14 +68,14 @@ for kind, r in plan.rec:
         sc, sh, pd_ = (torch.empty(Cout, device=dev) for _ in range(3))
         _lib.check(lib.gssd_bn_finalize_f32(r['stats'].data_ptr(), float(B * Ho * Ho), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), 2, Cout,
-                                            sc.data_ptr(), sh.data_ptr(), pd_.data_ptr(), st))
+                                            sc.data_ptr(), sh.data_ptr(), pd_.data_ptr(), r.get('stats_rep', 0), st))
         pool = r['pool']; pk, ps, pp = (pool[0], pool[1], pool[2]) if pool else (0, 1, 0)
         dz = torch.zeros(B, Ho, Ho, Cout, device=dev); sums = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
         _lib.check(lib.gssd_bn_bwd_reduce_f32(dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr(), sums.data_ptr(), B, Ho, Ho,
                                               Cout, r['Hp'], r['Hp'], pk, ps, pp, int(r['relu']), st))
         ca, cb, cc, dg, db = (torch.empty(Cout, device=dev) for _ in range(5))
         _lib.check(lib.gssd_bn_bwd_finalize_f32(r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(), float(bn.eps), Cout,
-                                                ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dg.data_ptr(), db.data_ptr(), st))
+                                                ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dg.data_ptr(), db.data_ptr(), r.get('stats_rep', 0), st))
         cs = torch.zeros(Cout, dtype=torch.float64, device=dev)
         _lib.check(lib.gssd_bn_bwd_apply_f32(dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), B * Ho * Ho, Cout, cs.data_ptr(), st))
         torch.cuda.synchronize()

@@ -221,7 +221,7 @@ def test_conv_bf16_fused_input_bn_relu(dev, Cin, Cout, H, k, st, pd):
     gmd, btd = gm.to(dev), bt.to(dev)          # (named: a temporary's storage is recycled as soon as .data_ptr() returns)
     _lib.check(_lib.lib.gssd_bn_finalize_bf16(stats.data_ptr(), float(B * H * H), gmd.data_ptr(), btd.data_ptr(),
                                               rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, Cin, sc.data_ptr(), sh.data_ptr(),
-                                              pdv.data_ptr(), st_))
+                                              pdv.data_ptr(), 0, st_))
     act = q(torch.relu(x * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)))
     ref = torch.nn.functional.conv2d(act, w, b, st, pd, 1, g)
     wp = ops.pack_weight_bf16(w.to(dev))
@@ -254,7 +254,7 @@ def test_elementwise_bf16(dev):
         pk, ps, pp = pool if pool else (0, 1, 0)
         _lib.check(lib.gssd_bn_relu_pool_bf16(rawd.data_ptr(), out.data_ptr(), B, H, H, Cc, Hp, Hp, pk, ps,
                                               pp, stats.data_ptr(), float(B * H * H), gmd.data_ptr(), btd.data_ptr(),
-                                              rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, 1, st))
+                                              rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, 1, 0, st))
         y = torch.relu(torch.nn.functional.batch_norm(raw, None, None, gm, bt, True, 0.1, 1e-5))
         if pool:
             y = torch.nn.functional.max_pool2d(y, pool[0], pool[1], pool[2])
@@ -450,7 +450,7 @@ def _layer_local_checks_sampled(plan, imgs):
             worst[r['name'] + '.raw'] = rel(raw, q(ref_raw))
             Cc = r['Cout']
             n = float(r['raw'].shape[0] * r['Ho'] * r['Ho'])
-            st = r['stats'].cpu()
+            st = r['stats'].cpu().view(max(r.get('stats_rep', 1), 1), 2 * Cc).sum(0)       # replicas of the batch sums add up
             mean, var = st[:Cc] / n, st[Cc:] / n - (st[:Cc] / n) ** 2
             full = r['raw'].float()                                        # whole batch, on the device (checker-side torch math)
             worst[r['name'] + '.mean'] = float(((full.mean(dim=(0, 1, 2)).double().cpu() - mean).abs() / (var.sqrt() + 1e-6)).max()) / 4

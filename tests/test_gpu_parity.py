@@ -4,6 +4,7 @@ reference-generated golden fixtures, called through the C ABI (ctypes -> libgssd
 Tolerances (BASELINE.json north_star): integer / index outputs bit-exact; fp32 activations and
 losses <= 1e-4 relative (max-abs-diff / max-abs-ref per tensor).
 """
+import ctypes
 import os
 import sys
 
@@ -279,6 +280,67 @@ def test_bn_relu_pool_backward(dev, ops, H, pool):
     assert rel(nchw(draw), x.grad) < 2e-4
     assert rel(dg, gm.grad) < 1e-4 and rel(db, bt.grad) < 1e-4
     assert float(cs.abs().max()) < 1e-2 * float(x.grad.abs().sum(dim=(0, 2, 3)).max())      # sum of d(raw) vanishes
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_batch_sum_replicas(dev, ops, bf16):
+    """gssd_conv_desc::stats_rep (round 4): the BatchNorm batch sums of a conv spread over R replicas (workgroup id mod R) add up to the
+    single-array sums, and the consumers -- gssd_bn_finalize_*, gssd_bn_relu_pool_*, the BatchNorm backward -- fold them: same scale /
+    shift / running statistics / outputs / gradients as with one array.  Shapes: a thin trunk layer (persistent kernel, where the
+    serialised atomics cost 60 us per launch), a Winograd / flat-window layer and a generic one."""
+    from gssd import _lib
+    g = torch.Generator().manual_seed(11)
+    for (B, H, Cin, Cout, groups) in ((4, 80, 64, 128, 4), (4, 40, 256, 256, 4), (3, 19, 64, 96, 1)):
+        x = torch.randn(B, H, H, Cin, generator=g)
+        w = torch.randn(Cout, Cin // groups, 3, 3, generator=g) * 0.1
+        bias = torch.randn(Cout, generator=g)
+        gm, bt = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        res = {}
+        for R in (0, 8):
+            stats = torch.zeros(max(R, 1) * 2 * Cout, dtype=torch.float64, device=dev)
+            if bf16:
+                xd, wp = x.to(dev).to(torch.bfloat16), ops.pack_weight_bf16(w.to(dev))
+                out = torch.empty(B, H, H, Cout, device=dev, dtype=torch.bfloat16)
+                fn = _lib.lib.gssd_conv2d_nhwc_bf16
+            else:
+                xd, wp = x.to(dev), ops.pack_weight(w.to(dev))
+                out = torch.empty(B, H, H, Cout, device=dev)
+                fn = _lib.lib.gssd_conv2d_nhwc_f32
+            U = ops.winograd_weight(wp, groups, Cin // groups) if (not bf16 and ops.winograd_eligible(3, 1, 1, 1, Cin // groups, Cout // groups, groups)) else None
+            d, _, _ = ops.make_conv_desc(xd, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // groups, Cout=Cout, groups=groups, k=3, pad=1,
+                                         bias=bias.to(dev), stats=stats, stats_rep=R, wgt_wino=U)
+            _lib.check(fn(ctypes.byref(d), torch.cuda.current_stream().cuda_stream))
+            sc, sh = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+            rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+            n = B * H * H
+            if bf16:
+                pdv = torch.empty(Cout, device=dev, dtype=torch.bfloat16)
+                _lib.check(_lib.lib.gssd_bn_finalize_bf16(stats.data_ptr(), float(n), gm.to(dev).data_ptr(), bt.to(dev).data_ptr(), rm.data_ptr(),
+                                                          rv.data_ptr(), 0.1, 1e-5, 1, Cout, sc.data_ptr(), sh.data_ptr(), pdv.data_ptr(), R,
+                                                          torch.cuda.current_stream().cuda_stream))
+                act = None
+            else:
+                pdv = torch.empty(Cout, device=dev)
+                ops.bn_finalize(stats, n, gm.to(dev), bt.to(dev), rm, rv, True, sc, sh, pdv, stats_rep=R)
+                act = torch.empty(B, H // 2, H // 2, Cout, device=dev)
+                rm2, rv2 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+                ops.bn_relu_pool(out, act, stats, n, gm.to(dev), bt.to(dev), rm2, rv2, True, True, (2, 2, 0), stats_rep=R)
+                dy = torch.randn(B, H // 2, H // 2, Cout, generator=torch.Generator().manual_seed(5)).to(dev)
+                draw, dg, db, _ = ops.bn_backward(dy, out, stats, n, gm.to(dev), sc, sh, pool=(2, 2, 0), stats_rep=R)
+                assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
+                act = (act, draw, dg, db)
+            folded = stats.view(max(R, 1), 2 * Cout).sum(0)
+            if R:
+                assert int((stats.view(R, 2 * Cout)[:, :Cout].abs().sum(1) > 0).sum()) > 1, 'sums landed in one replica only'
+            res[R] = (out.float(), folded, sc, sh, rm, rv, act)
+        a, b = res[0], res[8]
+        assert torch.equal(a[0], b[0])
+        assert rel(b[1], a[1]) < 1e-12                    # same fp32 partial sums, another order of the fp64 additions
+        for i in (2, 3, 4, 5):
+            assert rel(b[i], a[i]) < 1e-6
+        if a[6] is not None:
+            for u, v in zip(a[6], b[6]):
+                assert rel(v, u) < 1e-5
 
 
 def test_l2norm_gather_upsample_backward(dev, ops):
