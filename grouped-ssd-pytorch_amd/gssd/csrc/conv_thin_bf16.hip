@@ -98,19 +98,21 @@ __device__ __forceinline__ int swz(int col) {
     return UPR >= 8 ? (col & (UPR - 1)) & 15 : ((col ^ (col >> 2)) & (UPR - 1));
 }
 
-constexpr int RH = 8, TW = 16, PW = TW + 2;       // rows per MFMA / epilogue batch, tile width, patch width
+constexpr int TW = 16, PW = TW + 2;       // tile width, patch width
 
 // TH = output rows per staged patch (a multiple of RH): one DMA round trip, one transform pass and three barriers per TH x 16 pixels.
 // 16 rows where the (TH + 2) x 18 patch still lets 2-3 workgroups share a CU (<= 64 input channels): half the barriers and exposed
 // load latency per pixel of the 8-row tile and 10 % less halo (1.27 x instead of 1.41 x).
-template <int CIN_G, int COUT_G, bool XF, int TH>
+// POOL: the GSSD_CONV_POOL2 epilogue (its own instance: both epilogues in one kernel cost registers -- spills at the occupancy caps)
+template <int CIN_G, int COUT_G, bool XF, int TH, bool POOL>
 __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_kernel(const ThinBfParams p) {
+    constexpr int RH = 2;                          // rows per MFMA / epilogue batch: a row PAIR (pooling window rows, paired 16-byte stores)
     constexpr int PH = TH + 2, NPATCH = PH * PW;
     constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
     constexpr int UPR = CIN / 8;                   // 16-byte units per pixel
     constexpr int PPI = 64 / UPR;                  // pixels per DMA wave instruction
     constexpr int NT = COUT_G / 16;
-    constexpr int KS = (9 * CIN_G + 31) / 32;      // 32-k MFMA steps
+    constexpr int KR = (3 * CIN_G + 31) / 32;      // 32-k MFMA steps per INPUT ROW (its 3 taps x CIN_G channels, zero padded): 1 / 2 / 3
     constexpr int NINSTR = (NPATCH + PPI - 1) / PPI;
     constexpr int CPL = NT == 1 ? 4 : 8;           // consecutive output channels per lane
     extern __shared__ __attribute__((aligned(16))) u16 patch[];
@@ -120,17 +122,24 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int ntiles = p.B * tiles_per_img;
 
-    // ---- weights -> registers (A operand): lane (row rho = r of tile j, kq) holds W[channel(j, rho)][32 ks + 8 kq .. +8] ------
-    bf16x8 wf[KS][NT];
+    // ---- weights -> registers (A operand), K ordered by INPUT ROW: step (dy, kk) covers k' = 32 kk + 8 kq .. + 8 of the row's
+    // (dx, channel) run, dx = k' / CIN_G (zero weights where dx > 2).  Round 4: with the contraction ordered this way the B fragments
+    // of one input row (its KR shifted reads) serve the THREE output rows that touch it, so a row costs KR LDS reads instead of
+    // ceil(9 CIN_G / 32) (2 instead of 5 at 16 channels per group, 3 instead of 9 at 32) and they are issued a row pair ahead of
+    // their MFMAs -- the knock-out builds put 54 of conv1_2's 199 us into fragment reads the MFMAs waited for one by one.
+    bf16x8 wf[3][KR][NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int ch = NT == 1 ? r : 8 * (r >> 2) + 4 * j + (r & 3);
         const u16* wr = p.wgt + (size_t)(g * COUT_G + ch) * (9 * CIN_G);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 32 * ks + 8 * kq;
-            wf[ks][j] = (k < 9 * CIN_G && !(THIN_KO & 512)) ? *reinterpret_cast<const bf16x8*>(wr + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int kk = 0; kk < KR; ++kk) {
+                const int k = 32 * kk + 8 * kq, dx = k / CIN_G, c = k - dx * CIN_G;
+                wf[dy][kk][j] = (dx < 3 && !(THIN_KO & 512)) ? *reinterpret_cast<const bf16x8*>(wr + (dy * 3 + dx) * CIN_G + c)
+                                                             : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
     }
     // this lane's output channels (inside the group): cb .. cb + CPL
     const int cb = NT == 1 ? 4 * kq : 8 * kq;
@@ -138,25 +147,25 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     // inside the tile loop makes hipcc wait vmcnt(0) where its destination registers are next written -- loads and stores share that
     // counter on gfx950, so every row batch then waited for the previous batch's STORES to be acknowledged (round 4: the ISA of the
     // pooled epilogue had one such wait per row pair, the unpooled <16,32> kernel one per 8-row batch)
-    float bias[CPL], sg[CPL];
+    float bias[CPL];
+    unsigned smask[CPL];       // pooled epilogue: sign-flip mask of the channel (min = -max(-x): one max per window instead of max AND min)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         bias[c] = p.bias ? p.bias[g * COUT_G + cb + c] : 0.f;
-        sg[c] = p.pool_sign ? p.pool_sign[g * COUT_G + cb + c] : 0.f;
+        smask[c] = (POOL && p.pool_sign[g * COUT_G + cb + c] < 0.f) ? 0x80000000u : 0u;
     }
 
-    // ---- fragment offsets (elements) of M tile 0 per k-step: tap = k / CIN_G (clamped: zero weights beyond tap 8) ---------------
-    int foff[KS];
+    // ---- fragment offsets (elements) inside a patch row per k-step (lanes whose dx > 2 carry zero weights: they read dx = 2) -----
+    int foff[KR];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k = 32 * ks + 8 * kq;
-        int tap = k / CIN_G;
-        const int coff = k - tap * CIN_G;
-        if (tap > 8) tap = 8;
-        const int dy = tap / 3, dx = tap - 3 * dy;
+    for (int kk = 0; kk < KR; ++kk) {
+        const int k = 32 * kk + 8 * kq;
+        int dx = k / CIN_G;
+        const int coff = k - dx * CIN_G;
+        if (dx > 2) dx = 2;
         const int col = r + dx;
         const int unit = (g * CIN_G + coff) >> 3;
-        foff[ks] = (dy * PW + col) * CIN + ((unit ^ swz<UPR>(col)) << 3);
+        foff[kk] = col * CIN + ((unit ^ swz<UPR>(col)) << 3);
     }
 
     float ssum[CPL], ssq[CPL];
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     }
 
 #ifdef THIN_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
     const int bperm = (gridDim.x & 7) == 0 && !(THIN_KO & 64) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     for (int tile = bperm; tile < ntiles; tile += gridDim.x) {
@@ -198,54 +207,99 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
             // producer BatchNorm + ReLU once per patch element (in-image pixels only: the rest stays 0 = padding after the transform).
             // A thread always transforms the SAME eight channels (unit tid % UPR of every (256 / UPR)-th pixel; the swizzle only
             // moves where that unit sits inside the pixel), so its scale / shift live in 16 registers for the kernel's lifetime.
-            for (int pp = tid / UPR; pp < NPATCH; pp += 256 / UPR) {
-                const int py = pp / PW, pxx = pp - py * PW;
+            // Round 4 (knock-out builds: this pass cost 30 us of conv1_2's 199): the patch position advances by additions instead of a
+            // division per element, tiles whose patch lies inside the image skip the bounds tests (wave-uniform), the arithmetic runs on
+            // channel PAIRS (v_pk_fma_f32) and the ReLU on the rounded pairs (v_pk_max_i16 against 0: a negative bf16 is a negative int16;
+            // -0 and negatives that round to -0 become +0 exactly like fmaxf(x, 0) followed by the rounding).
+            constexpr int STEP = 256 / UPR, SY = STEP / PW, SX = STEP % PW;
+            const bool inside = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
+            int pp = tid / UPR, py = pp / PW, pxx = pp - py * PW;
+            for (; pp < NPATCH; pp += STEP) {
                 const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-                if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
-                u16* at = patch + (pp * UPR + ((tid % UPR) ^ swz<UPR>(pxx))) * 8;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(at);
+                if (inside || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)) {
+                    u16* at = patch + (pp * UPR + ((tid % UPR) ^ swz<UPR>(pxx))) * 8;
+                    typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    u32x4t v = *reinterpret_cast<const u32x4t*>(at);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * xs[e] + xh[e], 0.f);
-                *reinterpret_cast<bf16x8*>(at) = v;
+                    for (int e = 0; e < 4; ++e) {
+                        f32x2 x = {__builtin_bit_cast(float, v[e] << 16), __builtin_bit_cast(float, v[e] & 0xffff0000u)};
+                        x = __builtin_elementwise_fma(x, f32x2{xs[2 * e], xs[2 * e + 1]}, f32x2{xh[2 * e], xh[2 * e + 1]});
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        const bf16x2 h = {(__bf16)x[0], (__bf16)x[1]};
+                        const s16x2 z = __builtin_elementwise_max(__builtin_bit_cast(s16x2, h), s16x2{0, 0});
+                        v[e] = __builtin_bit_cast(unsigned, z);
+                    }
+                    *reinterpret_cast<u32x4t*>(at) = v;
+                }
+                py += SY;
+                pxx += SX;
+                if (pxx >= PW) {
+                    pxx -= PW;
+                    ++py;
+                }
             }
             TSTAMP(2)
             __syncthreads();
             TSTAMP(3)
         }
 
-        // ---- MFMAs straight from the patch: M tile i = tile row i (16 pixels wide), RH rows per batch ---------------------------
+        // ---- MFMAs straight from the patch, a row PAIR per step.  F[rho] = the KR fragments of input (patch) row 2 pr + rho; output rows
+        // 2 pr and 2 pr + 1 contract F[0..2] and F[1..3]; the fragments of the next pair's two new rows are read BEFORE this pair's MFMAs
         const int x = x0 + r;
-#pragma unroll 1
+        auto load_row = [&](int row, bf16x8 (&dst)[KR]) {
+#pragma unroll
+            for (int kk = 0; kk < KR; ++kk) {
+                if (THIN_KO & 2) dst[kk] = wf[0][kk][0];
+                else dst[kk] = *reinterpret_cast<const bf16x8*>(patch + foff[kk] + row * PW * CIN);
+            }
+        };
+        bf16x8 F[4][KR], G[2][KR];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) load_row(rho, F[rho]);
+#pragma unroll
         for (int rb = 0; rb < TH; rb += RH) {
             if (y0 + rb >= p.H) break;
+            if (rb + RH < TH) {
+                load_row(rb + 4, G[0]);
+                load_row(rb + 5, G[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[RH][NT];
 #pragma unroll
             for (int i = 0; i < RH; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < RH; ++i) {
-                bf16x8 af[KS];
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (THIN_KO & 2) af[ks] = wf[ks][0];
-                    else af[ks] = *reinterpret_cast<const bf16x8*>(patch + foff[ks] + (rb + i) * PW * CIN);
-                }
+                for (int kk = 0; kk < KR; ++kk)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                    for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        if (THIN_KO & 4) acc[i][j][ks & 3] += (float)af[ks][j];
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks], acc[i][j], 0, 0, 0);
-                    }
+                        for (int i = 0; i < RH; ++i) {
+                            if (THIN_KO & 4) acc[i][j][kk & 3] += (float)F[i + dy][kk][j];
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy][kk][j], F[i + dy][kk], acc[i][j], 0, 0, 0);
+                        }
+#pragma unroll
+            for (int kk = 0; kk < KR; ++kk) {
+                F[0][kk] = F[2][kk];
+                F[1][kk] = F[3][kk];
+                F[2][kk] = G[0][kk];
+                F[3][kk] = G[1][kk];
             }
+#ifdef THIN_TIMING
+            asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[RH - 1][NT - 1][3]));      // the MFMAs have retired
+#endif
+            TSTAMP(6)
             if (THIN_KO & 8) {
 #pragma unroll
                 for (int i = 0; i < RH; ++i) {
                     const int y = y0 + rb + i;
                     if (y >= p.H || x >= p.W) continue;
                     u16* dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * COUT + g * COUT_G + cb;
-                    if (p.pool_sign) {
+                    if (POOL) {
                         if ((i & 1) || (r & 1)) continue;
                         dst = p.out + ((size_t)(b * ((p.H + 1) >> 1) + (y >> 1)) * ((p.W + 1) >> 1) + (x >> 1)) * COUT + g * COUT_G + cb;
                     }
@@ -261,17 +315,65 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                 }
                 continue;
             }
-            if (p.pool_sign) {
+            if constexpr (POOL) {
                 // GSSD_CONV_POOL2 (include/gssd_hip.h): rows (i, i + 1) of a lane and columns (r, r ^ 1) of neighbouring lanes form one
                 // pooling window (tile origins are even); batch sums over every pixel as usual, then ONE value per window and channel --
                 // the maximum where the channel's BatchNorm weight is >= 0, the minimum where it is negative -- rounded to bf16 (the
                 // rounding commutes with max / min) and stored by the even lane at the pooled position.  The full map is never written.
                 const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+                // x ^ smask: the channel's values with the sign flipped where the BatchNorm weight is negative -- the window's maximum of
+                // those, flipped back, is the maximum (gamma >= 0) or the minimum (gamma < 0) of the window, exactly
+                auto flip = [](float v, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ m); };
+                if (y0 + rb + RH <= p.H && x0 + TW <= p.W) {
+                    // the 8 x 16 block lies inside the image (wave-uniform; 90 % of the tiles): no per-pixel guards.  Batch sums in the
+                    // unpooled epilogue's order and arithmetic form (CPL 4: multiply, then add; CPL 8: fused) -- identical statistics.
+#pragma unroll
+                    for (int i = 0; i < RH; i += 2) {
+                        float m[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            const float v0 = (CPL == 4 ? acc[i][0][c] : acc[i][c >> 2][c & 3]) + bias[c];
+                            const float v1 = (CPL == 4 ? acc[i + 1][0][c] : acc[i + 1][c >> 2][c & 3]) + bias[c];
+                            if constexpr (CPL == 4) {
+                                float q0 = v0 * v0, q1 = v1 * v1;
+                                asm volatile("" : "+v"(q0), "+v"(q1));          // (no contraction into the additions below)
+                                ssum[c] += v0;
+                                ssq[c] += q0;
+                                ssum[c] += v1;
+                                ssq[c] += q1;
+                            } else {
+                                ssum[c] += v0;
+                                ssq[c] = __builtin_fmaf(v0, v0, ssq[c]);
+                                ssum[c] += v1;
+                                ssq[c] = __builtin_fmaf(v1, v1, ssq[c]);
+                            }
+                            m[c] = fmaxf(flip(v0, smask[c]), flip(v1, smask[c]));
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c)        // neighbouring column = neighbouring lane: DPP quad_perm [1, 0, 3, 2]
+                            m[c] = fmaxf(m[c], __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, m[c]), 0xB1, 0xF, 0xF, true)));
+                        if (!(r & 1)) {
+                            u16* dst = p.out + ((size_t)(b * Hp + ((y0 + rb + i) >> 1)) * Wp + (x >> 1)) * COUT + g * COUT_G + cb;
+                            if constexpr (CPL == 4) {
+                                bf16x4 h;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) h[c] = (__bf16)flip(m[c], smask[c]);
+                                if (!(THIN_KO & 16)) *reinterpret_cast<bf16x4*>(dst) = h;
+                            } else {
+                                bf16x8 h;
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) h[c] = (__bf16)flip(m[c], smask[c]);
+                                if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
+                            }
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < RH; i += 2) {
                     const int y = y0 + rb + i;
                     const bool ok0 = y < p.H && x < p.W, ok1 = y + 1 < p.H && x < p.W;
-                    float mx[CPL], mn[CPL];
+                    float mx[CPL];
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) {
                         const float v0 = (CPL == 4 ? acc[i][0][c] : acc[i][c >> 2][c & 3]) + bias[c];
@@ -293,37 +395,33 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                                 ssq[c] += v1 * v1;
                             }
                         }
-                        mx[c] = ok1 ? fmaxf(v0, v1) : v0;
-                        mn[c] = ok1 ? fminf(v0, v1) : v0;
+                        mx[c] = ok1 ? fmaxf(flip(v0, smask[c]), flip(v1, smask[c])) : flip(v0, smask[c]);
                     }
                     // neighbouring column = neighbouring lane: DPP quad_perm [1, 0, 3, 2] (one VALU move, no LDS crossbar)
                     const bool pok = __builtin_amdgcn_mov_dpp((int)ok0, 0xB1, 0xF, 0xF, true) != 0;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) {
                         const float pmx = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx[c]), 0xB1, 0xF, 0xF, true));
-                        const float pmn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mn[c]), 0xB1, 0xF, 0xF, true));
-                        if (pok) {
-                            mx[c] = fmaxf(mx[c], pmx);
-                            mn[c] = fminf(mn[c], pmn);
-                        }
+                        if (pok) mx[c] = fmaxf(mx[c], pmx);
                     }
                     if (ok0 && !(r & 1)) {
                         u16* dst = p.out + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * COUT + g * COUT_G + cb;
                         if constexpr (CPL == 4) {
                             bf16x4 h;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
+                            for (int c = 0; c < 4; ++c) h[c] = (__bf16)flip(mx[c], smask[c]);
                             if (!(THIN_KO & 16)) *reinterpret_cast<bf16x4*>(dst) = h;
                         } else {
                             bf16x8 h;
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) h[c] = (__bf16)(sg[c] >= 0.f ? mx[c] : mn[c]);
+                            for (int c = 0; c < 8; ++c) h[c] = (__bf16)flip(mx[c], smask[c]);
                             if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
                         }
                     }
                 }
                 continue;
             }
+            if constexpr (!POOL) {
             // ---- epilogue: + bias, batch sums, 16-byte NHWC stores (lane: pixel (y0 + rb + i, x0 + r), CPL consecutive channels) -----
             if constexpr (CPL == 4) {
                 // 4 channels = 8 bytes per lane and row: rows are taken in pairs and the kq-even / kq-odd lane rows swap halves
@@ -379,6 +477,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
                     if (!(THIN_KO & 16)) *reinterpret_cast<bf16x8*>(dst) = h;
                 }
             }
+            }
         }
         TSTAMP(4)
         __syncthreads();          // every wave is done reading the patch
@@ -387,7 +486,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
 
 #ifdef THIN_TIMING
     if (lane == 0 && g == 1)
-        for (int k = 0; k < 6; ++k) atomicAdd(&g_thin_timing[k], tacc[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_thin_timing[k], tacc[k]);
     if (tid == 0) atomicAdd(&g_thin_timing[7], 1ull);
 #endif
     if (p.stats && !(THIN_KO & 256)) {
@@ -408,7 +507,7 @@ __global__ __launch_bounds__(256, (COUT_G > 16 ? 2 : 3)) void conv_thin_bf16_ker
     }
 }
 
-template <int CIN_G, int COUT_G, bool XF>
+template <int CIN_G, int COUT_G, bool XF, bool POOL>
 int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     constexpr int CIN = 4 * CIN_G;
     constexpr int TH = CIN <= 64 ? 16 : 8;
@@ -433,7 +532,7 @@ int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
     int grid = 256 * (COUT_G > 16 ? 2 : 3);
     if (ntiles < grid) grid = (int)ntiles;
-    hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF, TH>), dim3(grid), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF, TH, POOL>), dim3(grid), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -448,9 +547,11 @@ int gssd_try_conv_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
                           d.out_ch_off == 0 && !d.m_per_image && !d.relu && !d.gate && !d.resid && !d.alpha && d.split_k == 1 &&
                           d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && (d.flags == 0 || (d.flags == GSSD_CONV_POOL2 && d.pool_sign));
     if (!shape_ok) return 1;
-#define THIN_CASE(CI, CO)                                                                     \
-    if (d.cin_g == CI && cout_g == CO)                                                        \
-        return d.in_scale ? launch_thin_bf16<CI, CO, true>(d, stream) : launch_thin_bf16<CI, CO, false>(d, stream);
+    const bool pool = (d.flags & GSSD_CONV_POOL2) != 0;
+#define THIN_CASE(CI, CO)                                                                                                          \
+    if (d.cin_g == CI && cout_g == CO)                                                                                             \
+        return d.in_scale ? (pool ? launch_thin_bf16<CI, CO, true, true>(d, stream) : launch_thin_bf16<CI, CO, true, false>(d, stream)) \
+                          : (pool ? launch_thin_bf16<CI, CO, false, true>(d, stream) : launch_thin_bf16<CI, CO, false, false>(d, stream));
     THIN_CASE(8, 16)
     THIN_CASE(16, 16)
     THIN_CASE(16, 32)

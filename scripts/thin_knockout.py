@@ -26,13 +26,14 @@ def worker():
         b = torch.zeros(Cout, device=dev)
         Ho = H // 2 if pool else H
         out = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=torch.bfloat16)
-        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+        R = int(os.environ.get('KO_REP', '32'))
+        stats = torch.zeros(max(R, 1) * 2 * Cout, dtype=torch.float64, device=dev)
         sc, sh = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
         pdv = torch.zeros(Cin, device=dev, dtype=torch.bfloat16)
         sign = torch.randn(Cout, device=dev)
         d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // 4, Cout=Cout, groups=4, k=3, stride=1, pad=1,
                                      dil=1, bias=b, stats=stats, in_scale=sc if xf else None, in_shift=sh if xf else None,
-                                     in_pad=pdv if xf else None, flags=_lib.CONV_POOL2 if pool else 0, pool_sign=sign if pool else None)
+                                     in_pad=pdv if xf else None, flags=_lib.CONV_POOL2 if pool else 0, pool_sign=sign if pool else None, stats_rep=R)
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
             _lib.check(lib.gssd_conv2d_nhwc_bf16(C.byref(d), st))

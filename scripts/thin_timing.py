@@ -11,18 +11,20 @@ dev = torch.device('cuda:0')
 lib = _lib.lib
 rd = C.CDLL(_lib.LIB_PATH).gssd_thin_timing_read
 B = 32
-for (H, Cin, Cout, xf) in ((300, 32, 64, False), (300, 64, 64, True), (150, 64, 128, False), (150, 128, 128, True)):
+for (H, Cin, Cout, xf, pool) in ((300, 32, 64, False, False), (300, 64, 64, True, True), (300, 64, 64, True, False), (150, 64, 128, True, False), (150, 128, 128, True, True)):
     x = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
     w = torch.randn(Cout, Cin // 4, 3, 3, device=dev) * 0.1
     wp = ops.pack_weight_bf16(w)
     b = torch.zeros(Cout, device=dev)
-    out = torch.empty(B, H, H, Cout, device=dev, dtype=torch.bfloat16)
-    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    Ho = H // 2 if pool else H
+    out = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(32 * 2 * Cout, dtype=torch.float64, device=dev)
+    sign = torch.randn(Cout, device=dev)
     sc, sh = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
     pdv = torch.zeros(Cin, device=dev, dtype=torch.bfloat16)
     d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // 4, Cout=Cout, groups=4, k=3, stride=1, pad=1,
                                  dil=1, bias=b, stats=stats, in_scale=sc if xf else None, in_shift=sh if xf else None,
-                                 in_pad=pdv if xf else None)
+                                 in_pad=pdv if xf else None, stats_rep=32, flags=_lib.CONV_POOL2 if pool else 0, pool_sign=sign if pool else None)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         _lib.check(lib.gssd_conv2d_nhwc_bf16(C.byref(d), st))
@@ -39,9 +41,9 @@ for (H, Cin, Cout, xf) in ((300, 32, 64, False), (300, 64, 64, True), (150, 64, 
     rd(buf)
     t = list(buf)
     wgs = t[7] / n
-    tot = sum(t[:6])
-    names = ['dma issue', 'wait dma + barrier', 'transform', 'barrier', 'mfma + epilogue', 'barrier']
-    print(f'H {H} Cin {Cin} Cout {Cout} xf {xf}: {e0.elapsed_time(e1) / n * 1e3:.1f} us/launch, {wgs:.0f} workgroups, '
+    tot = sum(t[:7])
+    names = ['dma issue', 'wait dma + barrier', 'transform', 'barrier', 'epilogue (bias, sums, pooling, stores)', 'barrier', 'fragment reads + mfma']
+    print(f'H {H} Cin {Cin} Cout {Cout} xf {xf} pool {pool}: {e0.elapsed_time(e1) / n * 1e3:.1f} us/launch, {wgs:.0f} workgroups, '
           f'{tot / t[7]:.0f} cycles per workgroup in the tile loop')
-    for k in range(6):
-        print(f'    {names[k]:20s} {100.0 * t[k] / tot:5.1f} %   {t[k] / t[7]:10.0f} cycles per workgroup')
+    for k in range(7):
+        print(f'    {names[k]:40s} {100.0 * t[k] / tot:5.1f} %   {t[k] / t[7]:10.0f} cycles per workgroup')

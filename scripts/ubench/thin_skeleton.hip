@@ -174,7 +174,7 @@ void layer(const char* name, int B, int H, char* in, char* out) {
     P p{in, out, B, H, H, 0};
     const double bytes = (double)B * H * H * (IN_B + OUT_B);
     printf("== %s: B %d, %d x %d, %d B in + %d B out per pixel = %.0f MB\n", name, B, H, H, IN_B, OUT_B, bytes / 1e6);
-    for (int nm : {0, 10}) {
+    for (int nm : {0, 40, 120}) {
         p.nm = nm;
         printf(" -- %d MFMAs (16x16x32 bf16) per wave and 16-pixel row\n", nm);
         for (int wpc : {1, 2, 3, 4}) {
