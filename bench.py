@@ -485,7 +485,7 @@ def full_step_leg(a, net, crit, x, tg, dev, gd, world, B):
             n = red.finish() if world > 1 else sum(p.grad.numel() for p in params if p.grad is not None)
         opt.step()
         return n
-    for _ in range(2):
+    for _ in range(4):                           # (the backward plan captures its hipGraphs on its third run)
         nred = train_step()
     gd.barrier(dev)
     t0 = time.perf_counter()

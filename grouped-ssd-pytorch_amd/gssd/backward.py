@@ -25,6 +25,11 @@ from ._lib import lib
 
 
 BWD_STREAMS = os.environ.get('GSSD_BWD_STREAMS', '1') != '0'
+# GSSD_BWD_GRAPH=1: the backward plan replays from hipGraphs from its third run on (BackwardPlan._execute).  OFF by default: measured on
+# one MI355X (round 4, GSSD++ B = 32, 16 timed steps) the graph replay of the ~500-node, 8-stream backward is SLOWER than the eager
+# launches -- 52.9 against 48.9 ms per training step -- and at one rank the host is not the bottleneck (it enqueues a step in ~20 ms).
+# It is the form to try when 8 ranks share one host's cores (gloo test with 8 ranks on one GPU: tests/test_gpu_multi.py).
+USE_BWD_GRAPH = os.environ.get('GSSD_BWD_GRAPH', '0') == '1' and os.environ.get('GSSD_NO_GRAPH', '0') != '1'
 LEAF_SID = 1000
 HOIST_FROM = 1       # first branch stream id whose backward is hoisted (1 = all six; hoisting block 0 as well: GSSD 25.5 -> 23.3 ms)
 N_LEAF = 1           # leaf streams, taken in turn by the layers (measured: 1 -> 50.3 ms, 2 -> 50.8, 3 -> 51.2, 4 -> 52.1)
@@ -782,45 +787,97 @@ class BackwardPlan:
         return self._execute()
 
     def _execute(self):
-        if self.zero_list:
-            # one multi-tensor launch per dtype (a mixed fp32 / fp64 list takes _foreach_zero_'s slow path: ~180 fill launches a step)
-            if getattr(self, '_zero_groups', None) is None or sum(len(g) for g in self._zero_groups) != len(self.zero_list):
-                by = {}
-                for t in self.zero_list:
-                    by.setdefault(t.dtype, []).append(t)
-                self._zero_groups = list(by.values())
-            for grp in self._zero_groups:
-                torch._foreach_zero_(grp)
-        stream = torch.cuda.current_stream().cuda_stream
-        for fn, args in getattr(self.plan, 'pre', ()):          # bf16 forward plan: fp32 copies of what the forward stored (Bf16Shadow)
-            self._run_step(fn, args, stream)
+        """One backward over the static buffers.  From its third run on the plan replays itself from hipGraphs (round 4; VERDICT r3
+        item 6): the ~500 launches of a training step's backward are static -- preallocated buffers, descriptors by value, the same
+        stream forks every time -- so the host side shrinks from a ctypes call per kernel (27.6 ms per GSSD++ step, scripts/
+        host_vs_gpu.py) to a few graph launches.  With a gradient-segment hook (data-parallel training: gssd/dist.py starts a range's
+        all-reduce where its last writer has been enqueued) the step list is cut into one graph per segment and the hook runs
+        between them, on the host, exactly where the eager executor called it.  Opt-in (GSSD_BWD_GRAPH=1): see USE_BWD_GRAPH."""
         hook = self.segment_hook
+        fire = {}
         if hook is not None:
             if getattr(self, '_segs', None) is None:
                 self._segs = self.segments()
-            fire = {}
             for k, (lo, hi, ready) in enumerate(self._segs):
                 fire.setdefault(max(ready, 0), []).append(k)
-        if getattr(self, 'single_stream', False) or not (self.hoisted or any(x >= LEAF_SID for x in self.step_sid)):
-            for si, (fn, args) in enumerate(self.steps):
-                self._run_step(fn, args, stream)
-                if hook is not None and si in fire:
-                    for k in fire[si]:
-                        lo, hi, _ = self._segs[k]
-                        hook(k, self.flat[lo:hi])
+        cuts = sorted(fire) + ([len(self.steps) - 1] if (len(self.steps) - 1) not in fire else [])
+        ranges, lo = [], 0
+        for c in cuts:                                       # [lo, hi] inclusive step ranges, a hook point (or the end) behind each
+            ranges.append((lo, c))
+            lo = c + 1
+        self._nrun = getattr(self, '_nrun', 0) + 1
+        use_graph = USE_BWD_GRAPH and self._nrun > 2 and not getattr(self, 'single_stream', False)
+        if not use_graph:
+            for i, (lo, hi) in enumerate(ranges):
+                self._run_range(lo, hi, first=(i == 0), last=(i == len(ranges) - 1))
+                self._fire(hook, fire, hi)
             return [self.grads.get(id(p)) for p in self.param_order]
-        # branch chains on their own streams (forked behind the zeroing / d(loc), d(conf) copies above), joined where the trunk needs them
+        key = tuple(ranges)
+        cache = self.__dict__.setdefault('_graphs', {})
+        if key not in cache:
+            torch.cuda.synchronize(self.dev)
+            pool = torch.cuda.graph_pool_handle()
+            gs = []
+            for i, (lo, hi) in enumerate(ranges):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._run_range(lo, hi, first=(i == 0), last=(i == len(ranges) - 1))
+                gs.append(g)
+            cache[key] = gs                                  # (the capture executes nothing: the replay below is the run)
+        for (lo, hi), g in zip(ranges, cache[key]):
+            g.replay()
+            self._fire(hook, fire, hi)
+        return [self.grads.get(id(p)) for p in self.param_order]
+
+    def _fire(self, hook, fire, si):
+        if hook is not None and si in fire:
+            for k in fire[si]:
+                lo, hi, _ = self._segs[k]
+                hook(k, self.flat[lo:hi])
+
+    def _run_range(self, lo, hi, first, last):
+        """Steps lo .. hi (inclusive) on the current stream and the plan's branch / leaf streams; every stream forked here is folded
+        back into the current stream before returning (a range ends where a gradient segment is handed out, or at the end)."""
+        if first:
+            if self.zero_list:
+                # one multi-tensor launch per dtype (a mixed fp32 / fp64 list takes _foreach_zero_'s slow path: ~180 fill launches a step)
+                if getattr(self, '_zero_groups', None) is None or sum(len(g) for g in self._zero_groups) != len(self.zero_list):
+                    by = {}
+                    for t in self.zero_list:
+                        by.setdefault(t.dtype, []).append(t)
+                    self._zero_groups = list(by.values())
+                for grp in self._zero_groups:
+                    torch._foreach_zero_(grp)
+            stream0 = torch.cuda.current_stream().cuda_stream
+            for fn, args in getattr(self.plan, 'pre', ()):      # bf16 forward plan: fp32 copies of what the forward stored (Bf16Shadow)
+                self._run_step(fn, args, stream0)
         main = torch.cuda.current_stream()
+        stream = main.cuda_stream
+        if getattr(self, 'single_stream', False) or not (self.hoisted or any(x >= LEAF_SID for x in self.step_sid)):
+            for si in range(lo, hi + 1):
+                fn, args = self.steps[si]
+                self._run_step(fn, args, stream)
+            return
+        # branch chains on their own streams (forked behind everything enqueued so far), joined where the trunk needs them
         sides = {}
-        for sid in self.hoisted:
-            st = self.plan._side_stream(100 + sid)
-            st.wait_stream(main)
-            sides[sid] = st
+
+        def side(sid):
+            if sid not in sides:
+                st = self.plan._side_stream(100 + sid)
+                st.wait_stream(main)
+                sides[sid] = st
+            return sides[sid]
+        if first:
+            for sid in self.hoisted:
+                side(sid)
         leaves = [self.plan._side_stream(LEAF_SID + k) for k in range(N_LEAF)]
         dirty = [True] * N_LEAF                            # main has launches this leaf stream has not been ordered behind yet
-        for si, (fn, args) in enumerate(self.steps):
+        used_leaf = [False] * N_LEAF
+        for si in range(lo, hi + 1):
+            fn, args = self.steps[si]
             for w in self.step_wait.get(si, ()):
-                main.wait_stream(sides[w])
+                if w in sides:                               # (a branch whose steps all ran in an earlier range is already joined)
+                    main.wait_stream(sides[w])
             sid = self.step_sid[si]
             if sid == 0:
                 self._run_step(fn, args, stream)
@@ -830,30 +887,25 @@ class BackwardPlan:
                 if dirty[k]:
                     leaves[k].wait_stream(main)            # everything this launch reads was produced by earlier steps
                     dirty[k] = False
+                used_leaf[k] = True
                 self._run_step(fn, args, leaves[k].cuda_stream)
             else:
-                st = sides[sid]
+                st = side(sid)
                 if args is None or fn is _pack_dgrad_from_packed:
                     with torch.cuda.stream(st):
                         self._run_step(fn, args, st.cuda_stream)
                 else:
                     self._run_step(fn, args, st.cuda_stream)
-            if hook is not None and si in fire:
-                # a range of the flat gradient buffer is final once this step has run: fold every stream that may have written into it
-                # back into the main stream, then hand the range out (the all-reduce is ordered behind the main stream)
-                for st in sides.values():
-                    main.wait_stream(st)
-                for lf in leaves:
-                    main.wait_stream(lf)
-                dirty = [True] * N_LEAF
-                for k in fire[si]:
-                    lo, hi, _ = self._segs[k]
-                    hook(k, self.flat[lo:hi])
-        for w in self.step_wait.get(len(self.steps), ()):
-            main.wait_stream(sides[w])
-        for lf in leaves:
-            main.wait_stream(lf)
-        return [self.grads.get(id(p)) for p in self.param_order]
+        if last:
+            for w in self.step_wait.get(len(self.steps), ()):
+                if w in sides:
+                    main.wait_stream(sides[w])
+        # fold every stream that may have written gradients back into the main stream (a hook's all-reduce is ordered behind it)
+        for st in sides.values():
+            main.wait_stream(st)
+        for k, lf in enumerate(leaves):
+            if used_leaf[k]:
+                main.wait_stream(lf)
 
     def _run_step(self, fn, args, stream):
         if args is None:                         # host-side tensor bookkeeping (channel split of slice_and_cat's gradient)

@@ -530,7 +530,8 @@ int launch_thin_bf16(const gssd_conv_desc& d, hipStream_t stream) {
     p.tiles_x = (d.W + TW - 1) / TW;
     const size_t smem = (size_t)((NPATCH + PPI - 1) / PPI) * PPI * CIN * sizeof(u16);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
-    int grid = 256 * (COUT_G > 16 ? 2 : 3);
+    int grid = 256 * (COUT_G > 16 ? 2 : 3);      // workgroups per CU = the kernel's launch bound (three for conv2_1, whose 166 registers
+    //                                              would allow it: 90 us against 80 with two -- round 4)
     if (ntiles < grid) grid = (int)ntiles;
     hipLaunchKernelGGL((conv_thin_bf16_kernel<CIN_G, COUT_G, XF, TH, POOL>), dim3(grid), dim3(256), smem, stream, p);
     GSSD_CHECK_LAUNCH();

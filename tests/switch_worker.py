@@ -31,11 +31,15 @@ def main():
             loc0, conf0, _ = net(x)
     graphs = len(getattr(net._engine._last_plan, '_graphs', {}) or {})      # the no-backward plan of the three forwards above
     kernels0 = sorted({st.tag[0] for st in net._engine._last_plan.steps if st.tag is not None})
-    net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
-    loc, conf, pri = net(x)
-    ll, lc = crit((loc, conf, pri), tg)
-    (ll + lc).backward()
+    # GSSD_BWD_GRAPH=1: the backward plan replays from hipGraphs from its third run on -- three training steps from the same state
+    for _ in range(3 if os.environ.get('GSSD_BWD_GRAPH') == '1' else 1):
+        net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
+        net.zero_grad(set_to_none=True)
+        loc, conf, pri = net(x)
+        ll, lc = crit((loc, conf, pri), tg)
+        (ll + lc).backward()
     torch.cuda.synchronize()
+    bwd_graphs = len(getattr(net._engine._last_plan._bwd, '_graphs', {}) or {})
     idx = np.random.default_rng(0).integers(0, loc.numel(), 256)
     named = dict(net.named_parameters())
     keys = ['vgg.0.weight', 'vgg.14.weight', 'vgg.31.weight', 'fuse_11.weight', 'loc.0.weight', 'dcn_list.0.weight',
@@ -46,7 +50,7 @@ def main():
                loss=[float(ll), float(lc)],
                gnorm={k: float(named[k].grad.norm()) for k in keys},
                gsample={k: named[k].grad.reshape(-1)[:64].cpu().tolist() for k in keys},
-               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None} | set(kernels0)), graphs=graphs)
+               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None} | set(kernels0)), graphs=graphs, bwd_graphs=bwd_graphs)
     print('SWITCHJSON ' + json.dumps(out))
 
 

@@ -38,6 +38,7 @@ SWITCHES = [
     ('f32', {'GSSD_NO_GRAPH': '1'}, lambda o, base: o['graphs'] == 0 and base['graphs'] > 0),
     ('f32', {'GSSD_NO_BRANCH_STREAMS': '1'}, lambda o, base: True),
     ('f32', {'GSSD_BWD_STREAMS': '0'}, lambda o, base: True),
+    ('f32', {'GSSD_BWD_GRAPH': '1'}, lambda o, base: o['bwd_graphs'] > 0 and base['bwd_graphs'] == 0),
     ('f32', {'GSSD_NO_WINOGRAD': '1'}, lambda o, base: not any(k.startswith(('conv_wino', 'conv_thin_wino')) for k in o['kernels'])
      and any(k.startswith('conv_wino') for k in base['kernels'])),
     ('f32', {'GSSD_NO_GEMM_SLOT': '1'}, lambda o, base: True),
