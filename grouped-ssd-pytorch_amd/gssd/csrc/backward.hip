@@ -15,7 +15,7 @@ namespace {
 // element (non-overlapping pools) or atomically accumulated (overlapping, dz pre-zeroed).  Per-channel sums
 // s1 = sum dz, s2 = sum dz*raw feed the BatchNorm parameter gradients.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dz, double* __restrict__ sums, int B, int H,
                                                             int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
@@ -139,7 +139,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double
 
 // ``dsrc`` (optional): d(out) of a layer without pooling -- dz is then re-derived here as dsrc * [raw * scale + shift > 0] instead of
 // being written by the reduce pass and read back (one HBM pass less per layer)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
+__global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB,
                                                            const float* __restrict__ coefC, long long pixels, int C,
                                                            double* __restrict__ colsum, const float* __restrict__ dsrc,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
 }
 
 // column sums of a dense [rows][C] matrix (conv bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int C, int stride,
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long long rows, int C, int stride,
                                                      double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
@@ -297,6 +297,17 @@ inline int nblocks(long long items, int cap = 2048) {
     if (b > cap) b = cap;
     return (int)b;
 }
+// Grid-stride passes that end in per-workgroup fp64 atomics on a [C] / [2C] array (BatchNorm backward sums, bias column sums): every
+// workgroup finishes at about the same time and device-scope atomics on one cache line are served one after the other (~8 ns each,
+// round 4: 2048 workgroups x 128 sums of a 64-channel layer = 32 k atomics per line = a 260 us tail).  1024-thread workgroups give the
+// same 32 waves per CU with a quarter of the workgroups -- a quarter of the atomics.
+constexpr int WIDE = 1024;
+inline int nblocks_wide(long long items, int cap = 2048) {
+    long long b = (items + WIDE - 1) / WIDE;
+    if (b < 1) b = 1;
+    if (b > cap / 4) b = cap / 4;
+    return (int)b;
+}
 
 }  // namespace
 
@@ -308,7 +319,7 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
     GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblocks(total)), dim3(256), 2 * C * sizeof(float), as_stream(stream), dout,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
                        raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -327,7 +338,7 @@ extern "C" int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, c
 extern "C" int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b,
                                      const float* coef_c, int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dz && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(pixels * (C / 4))), dim3(256), C * sizeof(float), as_stream(stream),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
                        dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, nullptr, nullptr, nullptr, 0);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -338,7 +349,7 @@ extern "C" int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw,
                                             int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dout && draw && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(pixels * (C / 4))), dim3(256), C * sizeof(float), as_stream(stream),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
                        draw, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift, relu);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
@@ -346,7 +357,7 @@ extern "C" int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw,
 
 extern "C" int gssd_colsum_f32(const float* x, int64_t rows, int C, int row_stride, double* out, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && out && rows > 0 && C > 0 && C <= 4096 && row_stride >= C);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblocks(rows * C, 512)), dim3(256), C * sizeof(float), as_stream(stream), x,
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblocks_wide(rows * C, 512)), dim3(WIDE), C * sizeof(float), as_stream(stream), x,
                        (long long)rows, C, row_stride, out);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
