@@ -28,7 +28,7 @@ __device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN>
+template <int BN>            // (instantiated with 16 where a wave owns ONE 16-channel tile: no pairing, identity)
 __device__ __forceinline__ int chan_of_row(int row) {        // LDS row of the weight tile -> output channel inside the BN tile
     if (BN < 32) return row;
     const int j = row >> 4, rho = row & 15;
@@ -38,7 +38,14 @@ __device__ __forceinline__ int chan_of_row(int row) {        // LDS row of the w
 __device__ __forceinline__ float bf2f(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 
-template <int BM, int BN, int WM, int WN>
+// (csrc/conv_igemm.hip: the counted wait of the NSTG >= 3 K loop -- no fence, the ring's younger pieces stay in flight)
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// NSTG: LDS stages of the K loop; 3 = the small-map form (32- / 64-row tiles, two chunks in flight), see csrc/conv_igemm.hip
+template <int BM, int BN, int WM, int WN, int NSTG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv_desc p, const int M, const int tiles_per_group) {
     extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
         reinterpret_cast<const u16*>(p.wgt) + (size_t)img * p.wgt_batch_stride + (size_t)(g * cout_g) * p.wgt_row_stride;
     const u16* zero = g_zero_page_h;
     const bool xf = p.in_scale != nullptr;
-    float* xtab = reinterpret_cast<float*>(smem_h + 2 * STAGE);          // [2][cin_g]: scale | shift
+    float* xtab = reinterpret_cast<float*>(smem_h + NSTG * STAGE);       // [2][cin_g]: scale | shift
     if (xf) {
         for (int c = tid; c < p.cin_g; c += NTHR) {
             xtab[c] = p.in_scale[p.in_ch_off + g * p.cin_g + c];
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int row = (j * NW + wave) * 8 + row_in;
-        const int ch = chan_of_row<BN>(row);
+        const int ch = chan_of_row<(NT == 1 ? 16 : BN)>(row);
         b_ok[j] = (j * NW + wave) < BPIECES && (n0g + ch) < cout_g;
         b_off[j] = (n0g + ch) * p.wgt_row_stride + 8 * lq;
     }
@@ -164,11 +171,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
     const int fo1 = r * BK + (((4 + kq) ^ (r & 7)) << 3);
 
     int f_c0 = (ch_begin * BK + 8 * kq) % p.cin_g, f_c1 = (ch_begin * BK + 32 + 8 * kq) % p.cin_g;
-    if (ch_begin < ch_end) issue(ch_begin, 0);
-    __syncthreads();
+    static_assert(NSTG == 2 || BPIECES % NW == 0, "counted waits need the same number of DMA pieces per chunk in every wave");
+    constexpr int PER = AR + BR;                     // DMA pieces per chunk and wave
+    if constexpr (NSTG == 2) {
+        if (ch_begin < ch_end) issue(ch_begin, 0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int st = 0; st < NSTG - 1; ++st)
+            if (ch_begin + st < ch_end) issue(ch_begin + st, st);
+        if (xf) __syncthreads();
+    }
     for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int buf = (ch - ch_begin) & 1;
-        if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        int buf;
+        if constexpr (NSTG == 2) {
+            buf = (ch - ch_begin) & 1;
+            if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        } else {
+            buf = (ch - ch_begin) % NSTG;
+            if (NSTG >= 4 && ch + 2 < ch_end) wait_vm_barrier<2 * PER>();
+            else if (ch + 1 < ch_end) wait_vm_barrier<PER>();
+            else wait_vm_barrier<0>();
+            if (ch + NSTG - 1 < ch_end) issue(ch + NSTG - 1, (ch - ch_begin + NSTG - 1) % NSTG);
+        }
         const u16* As = smem_h + buf * STAGE + wm * WTM * BK;
         const u16* Bs = smem_h + buf * STAGE + BM * BK + wn * WTN * BK;
         bf16x8 af[2][MT], bf[2][NT];
@@ -212,8 +237,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
             f_c1 += BK;
             while (f_c1 >= p.cin_g) f_c1 -= p.cin_g;
         }
-        __syncthreads();
+        if constexpr (NSTG == 2) __syncthreads();
     }
+    if constexpr (NSTG != 2) __syncthreads();       // the epilogue reuses the stages
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // acc[i][j][e]: pixel m = m0 + wm*WTM + 16 i + r, channel (inside the BN tile) = chan_of_row(wn*WTN + 16 j + 4 kq + e)
@@ -381,12 +407,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTG = 2>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     static unsigned attr_mask = 0;
-    constexpr size_t smem_base = 2 * (size_t)(BM + BN) * BK * sizeof(u16);
+    constexpr size_t smem_base = NSTG * (size_t)(BM + BN) * BK * sizeof(u16);
     const size_t smem = smem_base + (d.in_scale ? 2 * (size_t)d.cin_g * sizeof(float) : 0);
-    auto kern = conv_bf16_kernel<BM, BN, WM, WN>;
+    auto kern = conv_bf16_kernel<BM, BN, WM, WN, NSTG>;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(smem_base + 8192)) != hipSuccess) {
@@ -518,6 +544,12 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
         if (rc != 1) return rc;
     }
     if (d.in_scale) GSSD_CHECK_ARG(d.cin_g <= 1024 && !d.m_per_image);
+    // small maps (<= 10 x 10 at batch 32; per-image GEMMs of <= 100 tokens): 32- / 64-row tiles, three-stage K loop (csrc/conv_igemm.hip)
+    static const bool no_small = getenv("GSSD_NO_SMALL_TILES") != nullptr;
+    if (!no_small && cout_g > 32 && d.split_k == 1 && !(d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 64 != 0)) {
+        if (M <= 512) return launch_cfg<32, 64, 1, 4, 3>(d, M, images, s);
+        if (M <= 4096) return launch_cfg<64, 64, 2, 2, 3>(d, M, images, s);
+    }
     if (cout_g > 64) {
         const long long mt = (M + 127) / 128, z = d.m_per_image ? images : d.split_k;
         const long long b128 = mt * d.groups * ((cout_g + 127) / 128) * z, b64 = mt * d.groups * ((cout_g + 63) / 64) * z;

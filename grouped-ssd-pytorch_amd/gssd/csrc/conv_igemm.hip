@@ -36,7 +36,19 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+// wait until at most N of this wave's LDS-DMA pieces are outstanding and this wave's fragment reads have returned, then the workgroup
+// barrier -- NO fence (a __syncthreads() waits vmcnt(0) and would drain the ring of the NSTG >= 3 form)
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// NSTG = LDS stages of the K loop.  2: the chunk's DMA is issued one chunk ahead and every chunk ends in a __syncthreads() -- right for
+// the large layers, whose MFMAs per chunk cover the load latency.  3 (round 4, the small-map launches: <= 10 x 10 maps, M <= 3200): two
+// chunks in flight under counted waits, and 32- / 64-row tiles -- with a 128-row tile a launch on the 1 x 1 map (M = 32) issued 4 x the
+// MFMAs it needed and paid one L2 round trip per 32-k chunk (17 - 25 us per launch for microseconds of work; the tail of a step is ~50
+// such launches in a dependent chain, profiles/r04_a_critical_path_f32.txt).
+template <int BM, int BN, int WM, int WN, int NSTG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_conv_desc p, const int M,
                                                          const int tiles_per_group) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
     // fused producer BatchNorm + ReLU: fragments are read as max(x*scale[c] + shift[c], 0); out-of-image taps DMA the
     // per-channel pad value (mapped to 0 by the transform) instead of the zero page
     const bool xf = p.in_scale != nullptr;
-    float* xtab = smem + 2 * STAGE;                  // [2][cin_g]: scale | shift of this group's input channels
+    float* xtab = smem + NSTG * STAGE;               // [2][cin_g]: scale | shift of this group's input channels
     if (xf) {
         for (int c = tid; c < p.cin_g; c += NTHR) {
             xtab[c] = p.in_scale[p.in_ch_off + g * p.cin_g + c];
@@ -169,11 +181,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
     const int fo1 = r * BK + (((4 + kq) ^ (r & 7)) << 2);
 
     int f_c0 = (ch_begin * BK + 4 * kq) % p.cin_g, f_c1 = (ch_begin * BK + 16 + 4 * kq) % p.cin_g;   // fragment channels
-    if (ch_begin < ch_end) issue(ch_begin, 0);
-    __syncthreads();
+    static_assert(NSTG == 2 || BPIECES % NW == 0, "counted waits need the same number of DMA pieces per chunk in every wave");
+    constexpr int PER = AR + BR;                     // DMA pieces per chunk and wave
+    if constexpr (NSTG == 2) {
+        if (ch_begin < ch_end) issue(ch_begin, 0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int st = 0; st < NSTG - 1; ++st)
+            if (ch_begin + st < ch_end) issue(ch_begin + st, st);
+        if (xf) __syncthreads();                     // (the scale / shift table; drains the prologue pieces: harmless)
+    }
     for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int buf = (ch - ch_begin) & 1;
-        if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        int buf;
+        if constexpr (NSTG == 2) {
+            buf = (ch - ch_begin) & 1;
+            if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        } else {
+            buf = (ch - ch_begin) % NSTG;
+            // chunk ch has landed (at most the younger chunks' pieces are outstanding); every wave is done with chunk ch - 1's stage
+            if (NSTG >= 4 && ch + 2 < ch_end) wait_vm_barrier<2 * PER>();
+            else if (ch + 1 < ch_end) wait_vm_barrier<PER>();
+            else wait_vm_barrier<0>();
+            if (ch + NSTG - 1 < ch_end) issue(ch + NSTG - 1, (ch - ch_begin + NSTG - 1) % NSTG);
+        }
         const float* As = smem + buf * STAGE + wm * WTM * BK;
         const float* Bs = smem + buf * STAGE + BM * BK + wn * WTN * BK;
         // both 16-k fragment sets are requested up front: the second set's LDS latency hides behind the first set's MFMAs
@@ -215,8 +246,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
             f_c1 += BK;
             while (f_c1 >= p.cin_g) f_c1 -= p.cin_g;
         }
-        __syncthreads();
+        if constexpr (NSTG == 2) __syncthreads();
     }
+    if constexpr (NSTG != 2) __syncthreads();       // the epilogue's reduction reuses the stages
 
     // ---- epilogue ---------------------------------------------------------------------------
     const float gate = p.gate ? *p.gate : 0.f;
@@ -337,12 +369,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const gssd_con
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTG = 2>
 int launch_cfg(const gssd_conv_desc& d, int M, int images, hipStream_t stream) {
     static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
-    constexpr size_t smem_base = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    constexpr size_t smem_base = NSTG * (size_t)(BM + BN) * BK * sizeof(float);
     const size_t smem = smem_base + (d.in_scale ? 2 * (size_t)d.cin_g * sizeof(float) : 0);
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, NSTG>;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(smem_base + 4096)) != hipSuccess) {
@@ -424,6 +456,12 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         static const bool no_slot = getenv("GSSD_NO_GEMM_SLOT") != nullptr;      // ablation switch (scripts/layer_times.py)
         const int rc = no_slot ? 1 : gssd_try_gemm_slot(d, s);                   // large plain 1x1 convs / GEMMs: 128 x 256 slot stream
         if (rc != 1) return rc;
+    }
+    // small maps (<= 10 x 10 at batch 32; per-image GEMMs of <= 100 tokens): 32- / 64-row tiles, three-stage K loop
+    static const bool no_small = getenv("GSSD_NO_SMALL_TILES") != nullptr;       // ablation switch
+    if (!no_small && cout_g > 32 && d.split_k == 1 && !(d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 64 != 0)) {
+        if (M <= 512) return launch_cfg<32, 64, 1, 4, 3>(d, M, images, s);
+        if (M <= 4096) return launch_cfg<64, 64, 2, 2, 3>(d, M, images, s);
     }
     if (cout_g > 64) {
         // 128x128 tiles run 2 workgroups per CU (LDS), 128x64 tiles 3: pick the one whose last round of workgroups is

@@ -69,6 +69,11 @@ def conv_tag(d, real_cin_g=None, bf16=False):
         e64 = 0.94 * b64 / (-(-b64 // 768) * 768)
         if e64 > e128 or d.K <= 256:
             inst = '128x64'
+    # small maps: 32- / 64-row tiles with a three-stage K loop (csrc/conv_igemm.hip, csrc/conv_bf16.hip: the same host rule)
+    Ms = d.Ho * d.Wo * (1 if d.m_per_image else d.B)
+    if (cout_g > 32 and d.split_k == 1 and Ms <= 4096 and os.environ.get('GSSD_NO_SMALL_TILES') is None
+            and not (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 64 != 0)):
+        inst = '32x64' if Ms <= 512 else '64x64'
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if bf16:
         if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75

@@ -42,6 +42,10 @@ SWITCHES = [
     ('f32', {'GSSD_NO_WINOGRAD': '1'}, lambda o, base: not any(k.startswith(('conv_wino', 'conv_thin_wino')) for k in o['kernels'])
      and any(k.startswith('conv_wino') for k in base['kernels'])),
     ('f32', {'GSSD_NO_GEMM_SLOT': '1'}, lambda o, base: True),
+    ('f32', {'GSSD_NO_SMALL_TILES': '1'}, lambda o, base: not any(k.startswith(('conv_igemm<32x', 'conv_igemm<64x')) for k in o['kernels'])
+     and any(k.startswith(('conv_igemm<32x', 'conv_igemm<64x')) for k in base['kernels'])),
+    ('bf16', {'GSSD_NO_SMALL_TILES': '1'}, lambda o, base: not any(k.startswith(('conv_bf16<32x', 'conv_bf16<64x')) for k in o['kernels'])
+     and any(k.startswith(('conv_bf16<32x', 'conv_bf16<64x')) for k in base['kernels'])),
     ('f32', {'GSSD_NO_WGRAD_SLOT': '1'}, lambda o, base: True),
     ('f32', {'GSSD_GEMM_SLOT_SWAP': '0'}, lambda o, base: True),
     # (at this test's batch of 4 the deformable conv has 92 tiles for 256 CUs and keeps the one-tile form either way: the stream-K form
