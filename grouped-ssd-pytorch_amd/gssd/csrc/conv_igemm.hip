@@ -460,8 +460,10 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     // small maps (<= 10 x 10 at batch 32; per-image GEMMs of <= 100 tokens): 32- / 64-row tiles, three-stage K loop
     static const bool no_small = getenv("GSSD_NO_SMALL_TILES") != nullptr;       // ablation switch
     if (!no_small && cout_g > 32 && d.split_k == 1 && !(d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 64 != 0)) {
-        if (M <= 512) return launch_cfg<32, 64, 1, 4, 3>(d, M, images, s);
-        if (M <= 4096) return launch_cfg<64, 64, 2, 2, 3>(d, M, images, s);
+        // (per-image GEMMs count all their images: the 19 x 19 projections -- 361 tokens x 32 images -- keep the 128-row tiles)
+        const long long mtot = (long long)M * images;
+        if (mtot <= 512 || (d.m_per_image && mtot <= 4096 && M <= 128)) return launch_cfg<32, 64, 1, 4, 3>(d, M, images, s);
+        if (mtot <= 4096) return launch_cfg<64, 64, 2, 2, 3>(d, M, images, s);
     }
     if (cout_g > 64) {
         // 128x128 tiles run 2 workgroups per CU (LDS), 128x64 tiles 3: pick the one whose last round of workgroups is

@@ -70,10 +70,10 @@ def conv_tag(d, real_cin_g=None, bf16=False):
         if e64 > e128 or d.K <= 256:
             inst = '128x64'
     # small maps: 32- / 64-row tiles with a three-stage K loop (csrc/conv_igemm.hip, csrc/conv_bf16.hip: the same host rule)
-    Ms = d.Ho * d.Wo * (1 if d.m_per_image else d.B)
-    if (cout_g > 32 and d.split_k == 1 and Ms <= 4096 and os.environ.get('GSSD_NO_SMALL_TILES') is None
+    Ms, Mtot = d.Ho * d.Wo * (1 if d.m_per_image else d.B), d.Ho * d.Wo * d.B
+    if (cout_g > 32 and d.split_k == 1 and Mtot <= 4096 and os.environ.get('GSSD_NO_SMALL_TILES') is None
             and not (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 64 != 0)):
-        inst = '32x64' if Ms <= 512 else '64x64'
+        inst = '32x64' if (Mtot <= 512 or (d.m_per_image and Ms <= 128)) else '64x64'
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if bf16:
         if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
@@ -1023,6 +1023,8 @@ class _Plan(_PlanBase):
             if not obj and not first and not (last and self.training and self.nbt):
                 continue
             g = torch.cuda.CUDAGraph()
+            # (measured and rejected, round 4: capturing the trunk on a high-priority stream so that a branch's chip-filling launches
+            # do not take CUs from the critical path's next kernel -- 12.21 -> 13.34 ms fp32, 3.95 -> 5.03 ms bf16)
             with torch.cuda.graph(g, pool=pool):
                 if first:
                     if self.training:
