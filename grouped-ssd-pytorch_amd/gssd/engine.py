@@ -305,7 +305,10 @@ class _Plan(_PlanBase):
         # cache line are served serially, and the persistent trunk kernels flush every workgroup's sums at the END of the launch (conv2_1
         # in bf16: 131 k atomics on 16 lines = 60 of its 140 us, profiles/r04_thin_knockout.txt).  R * C <= 2048 (at most 32): every
         # trunk layer spreads its sums over 256 lines; the consumers add the replicas up in a fixed order.
-        trunk_bn = {id(m) for m in net.vgg if isinstance(m, torch.nn.BatchNorm2d)} if os.environ.get('GSSD_STATS_REP', '1') != '0' else set()
+        # bf16 storage mode only: the fp32 trunk kernels are compute-bound, their workgroups finish spread out and the tail is not
+        # there to remove (scripts/thin_f32_probe.py: conv1_1 248 us with one array, 260 with 32 replicas, 224 without batch sums)
+        trunk_bn = ({id(m) for m in net.vgg if isinstance(m, torch.nn.BatchNorm2d)}
+                    if (self.bf16 and os.environ.get('GSSD_STATS_REP', '1') != '0') else set())
         self.stat_rep = {id(m): (max(1, min(32, 2048 // m.num_features)) if id(m) in trunk_bn else 1) for m in uniq}
         total = sum(2 * m.num_features * self.stat_rep[id(m)] for m in uniq)
         self.stats = torch.zeros(max(total, 2), device=dev, dtype=torch.float64)
@@ -338,6 +341,24 @@ class _Plan(_PlanBase):
         assert len(self.head_descs) == 6
         self._finish_heads()
         self._place_sn_step()
+        self._place_branch0()
+
+    def _place_branch0(self):
+        """Branch 0 (L2Norm -> [SA] -> fuse_11 -> head on the 38 x 38 map: ~1.2 ms of chip-filling launches in GSSD++) was registered right
+        behind the block after conv4_3, so its stream forked there and its launches shared the CUs with conv5_x / conv6 / conv7 -- the
+        critical path, which then ran 1.5 - 2.5 x slower than alone (profiles/r04b_critical_path_f32.txt).  Registered behind conv7
+        instead, the branch forks there: the trunk's heavy layers run alone, and the branch fills the chip under the small-map tail
+        (SA-base, extras), whose launches have 1 .. 100 workgroups.  GSSD_BRANCH0_LATE=0 keeps the registration order."""
+        # (measured: GSSD++ 12.14 -> 12.10 ms fp32, 3.89 -> 3.86 ms bf16; plain GSSD, whose branch 0 is two small launches, 5.55 -> 5.63 ms)
+        if (os.environ.get('GSSD_BRANCH0_LATE', '1') == '0' or getattr(self, '_mark_conv7', None) is None
+                or not self.eng.net.use_self_attention):
+            return
+        idx = [i for i, st in enumerate(self.steps) if st.sid == 1]
+        if not idx or idx[-1] - idx[0] + 1 != len(idx) or idx[-1] >= self._mark_conv7:
+            return                                    # (not one contiguous block in front of the mark: leave the order alone)
+        a, b, c = idx[0], idx[-1] + 1, self._mark_conv7
+        block = self.steps[a:b]
+        self.steps[a:c] = self.steps[b:c] + block     # indices < a and >= c are unchanged (_pack_step, _reduce_steps)
 
     def _place_sn_step(self):
         """The spectral-norm launch (its own stream inside the captured graph) was registered first, which makes it a ROOT node of the
@@ -395,6 +416,7 @@ class _Plan(_PlanBase):
             cur, H, Cc, xf = self._conv_bn(f'vgg.{vi}', conv, bn, cur, H, Cc, g, relu=True, in_xf=xf, defer_bn=(li == 0))
             vi += 3
         sources = [src0]
+        self._mark_conv7 = len(self.steps)           # (everything up to conv7's BatchNorm pass is enqueued: _place_branch0)
         sab_i, sa_i = 1, 1
         if net.use_self_attention_base:
             cur, _ = self._self_attn('self_attn_base_list', sab_i, cur, H, Cc, need_out2=False, want_map=self.want_maps)
