@@ -363,6 +363,9 @@ int gssd_try_conv_thin(const gssd_conv_desc& d, hipStream_t stream) {
     if (!shape_ok || (d.flags & GSSD_CONV_POOL2)) return 1;      // (no pooled epilogue here: conv1_2 takes the Winograd thin kernel)
     if (d.cin_g == 4 && cout_g == 16) return launch_thin<4, 16>(d, stream);
     if (d.cin_g == 16 && cout_g == 16) return launch_thin<16, 16>(d, stream);
-    if (d.cin_g == 16 && cout_g == 32) return launch_thin<16, 32>(d, stream);
+    // conv2_1 with Winograd weights goes to conv_wino<32> (round 4: this direct kernel is pipe-bound -- fp32 MFMA + VALU 93 % busy -- at
+    // 2.25 x the MACs of the Winograd form: 300 -> 262 us at B = 32); GSSD_CONV21_WINO=0 keeps it here
+    static const bool c21_wino = []() { const char* e = getenv("GSSD_CONV21_WINO"); return !(e && e[0] == '0'); }();
+    if (d.cin_g == 16 && cout_g == 32) return (c21_wino && d.wgt_wino) ? 1 : launch_thin<16, 32>(d, stream);
     return 1;
 }

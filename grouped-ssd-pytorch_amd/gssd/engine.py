@@ -83,6 +83,8 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     elif (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
             and (d.cin_g, cout_g) in ((4, 16), (16, 16), (16, 32)) and not d.m_per_image and d.split_k == 1):
         name = f'conv_thin<{d.cin_g},{cout_g}>'          # gssd_try_conv_thin (csrc/conv_thin.hip)
+        if d.wgt_wino and (d.cin_g, cout_g) == (16, 32) and os.environ.get('GSSD_CONV21_WINO', '1') != '0':
+            name = 'conv_wino<32>'                       # conv2_1 with Winograd weights: handed on to gssd_try_conv_wino
         if d.wgt_wino and (d.cin_g, cout_g) == (16, 16) and not d.resid:
             name = 'conv_thin_wino<16,16>'               # gssd_try_conv_thin_wino (csrc/conv_thin_wino.hip)
     elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g, d.groups) and not d.m_per_image
