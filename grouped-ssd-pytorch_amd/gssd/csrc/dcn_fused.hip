@@ -109,17 +109,32 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
     const int nchunks = dg * cpc * 9;
     // Stream-K, phase-aligned: every workgroup first computes `sk_full` whole tiles (round i: slot i * R + rank, like the rounds of the
     // one-tile grid -- all workgroups of an XCD then stream the same weight chunk at the same time, which is what keeps the 9.4 MB weight
-    // slab an L2 hit), then its span of the (slot, chunk) space of the XCD's remaining tiles (fewer than R)
+    // slab an L2 hit), then its share of the XCD's T remaining tiles (T < R).  Round 4: the remaining phase is aligned too.  Ranks 0 ..
+    // T-1 OWN a tile each and compute its chunks [0, n_o), side by side through the same weight chunks; ranks T .. R-1 HELP: they share
+    // the tails [n_o, N) of the T tiles as equal contiguous spans of that (tile, tail chunk) space, n_o = N T / R, so every workgroup
+    // has the same number of chunks.  (Round 3 cut the (tile, chunk) space into R equal spans: the 32 workgroups of an XCD then sat at
+    // 32 different chunk positions and each streamed the 9.4 MB slab from the Infinity Cache on its own -- PMC 2.64 GB per launch.)
     long long sk_pos = 0, sk_hi = 0;
-    int sk_full = 0, sk_round = 0, sk_R = 1, sk_rank = 0;
+    int sk_full = 0, sk_round = 0, sk_R = 1, sk_rank = 0, sk_T = 0, sk_no = 0;
     if (SK) {
         sk_R = gridDim.x >> 3;
         sk_rank = sk_R - 1 - (int)(blockIdx.x >> 3);
         const int nx = 8 % ntn == 0 ? (mtiles - xcd / ntn + (8 / ntn) - 1) / (8 / ntn) : (mtiles * ntn - xcd + 7) / 8;
         sk_full = (nx > 0 ? nx : 0) / sk_R;
-        const long long tot = (long long)((nx > 0 ? nx : 0) - sk_full * sk_R) * nchunks;
-        sk_pos = tot * sk_rank / sk_R;
-        sk_hi = tot * (sk_rank + 1) / sk_R;
+        sk_T = (nx > 0 ? nx : 0) - sk_full * sk_R;
+        if (sk_T > 0) {
+            sk_no = (int)(((long long)nchunks * sk_T + sk_R / 2) / sk_R);
+            sk_no = sk_no < 1 ? 1 : (sk_no > nchunks - 1 ? nchunks - 1 : sk_no);
+            if (sk_rank < sk_T) {                        // owner: positions are the chunks of its own tile
+                sk_pos = 0;
+                sk_hi = sk_no;
+            } else {                                     // helper: positions in the (tile, tail chunk) space
+                const long long tot = (long long)sk_T * (nchunks - sk_no);
+                const int h = sk_rank - sk_T, nh = sk_R - sk_T;
+                sk_pos = tot * h / nh;
+                sk_hi = tot * (h + 1) / nh;
+            }
+        }
         if (sk_full == 0 && sk_pos >= sk_hi) return;
     }
     int mt = 0, nt = 0, m0 = 0, c_begin = 0, c_end = nchunks, tile_id = 0;
@@ -269,12 +284,20 @@ __global__ __launch_bounds__(256, 1) void dcn_fused_kernel(const float* __restri
                 c_end = nchunks;
             } else {
                 if (sk_pos >= sk_hi) break;
-                const int rs = (int)(sk_pos / nchunks);
-                slot_i = sk_full * sk_R + rs;
-                c_begin = (int)(sk_pos - (long long)rs * nchunks);
-                const long long left = sk_hi - sk_pos;
-                c_end = (nchunks - c_begin) < left ? nchunks : c_begin + (int)left;
-                sk_pos += c_end - c_begin;
+                if (sk_rank < sk_T) {
+                    slot_i = sk_full * sk_R + sk_rank;
+                    c_begin = 0;
+                    c_end = sk_no;
+                    sk_pos = sk_hi;
+                } else {
+                    const int L = nchunks - sk_no;
+                    const int rs = (int)(sk_pos / L);
+                    slot_i = sk_full * sk_R + rs;
+                    c_begin = sk_no + (int)(sk_pos - (long long)rs * L);
+                    const long long left = sk_hi - sk_pos;
+                    c_end = (nchunks - c_begin) < left ? nchunks : c_begin + (int)left;
+                    sk_pos += c_end - c_begin;
+                }
             }
             tile_of(slot_i, mt, nt);
             m0 = mt * BM;
