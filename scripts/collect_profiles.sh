@@ -37,3 +37,12 @@ f=$(find $R/gpurun_out/${tag}_prof_pl -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_pixellink_b32_kernel_stats.csv
 cd $R
 tail -3 gpurun_out/${tag}_bench.err
+# round 4: per-queue timeline + critical path of one step (fp32, bf16)
+cd /tmp
+for dt in f32 bf16; do
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_cp_$dt -o p -- python3 $R/bench.py --full-step 0 --cpu-sample 0 --no-input-stage --no-secondary --no-bf16 --no-events --steps 20 --warmup 5 --steady 0 --dtype $dt > /dev/null 2>&1
+  f=$(find $R/gpurun_out/${tag}_cp_$dt -name '*kernel_trace.csv' | head -1)
+  [ -n "$f" ] && python3 $R/scripts/critical_path.py $f "GSSD++ B=32 $dt fwd+loss, hipGraph replay (rocprofv3 --kernel-trace)" 8 > $R/gpurun_out/${tag}_critical_path_$dt.txt
+done
+cd $R
+python3 scripts/host_vs_gpu.py > gpurun_out/${tag}_host_vs_gpu.txt 2>/dev/null

@@ -19,11 +19,11 @@ for d in sorted(glob.glob(f'{root}/gpurun_out/pmc_thin_*')):
     for f in glob.glob(d + '/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            if 'conv_thin_bf16' in n or 'conv_bf16_kernel<128, 64' in n:
+            if 'conv_thin_bf16' in n or 'conv_bf16_kernel<128, 64' in n or 'conv_flat_bf16' in n or 'dcn_bf16' in n or 'flash_attn_mixed' in n:
                 k = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
                 agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, cs in agg.items():
     print(k)
     for c, v in cs.items():
-        print(f'   {c:34s} n={len(v):3d} mean={sum(v)/len(v):.4g}')
+        print(f"   {c:34s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
 PY
