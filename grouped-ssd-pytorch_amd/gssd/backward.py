@@ -30,6 +30,10 @@ BWD_STREAMS = os.environ.get('GSSD_BWD_STREAMS', '1') != '0'
 # launches -- 52.9 against 48.9 ms per training step -- and at one rank the host is not the bottleneck (it enqueues a step in ~20 ms).
 # It is the form to try when 8 ranks share one host's cores (gloo test with 8 ranks on one GPU: tests/test_gpu_multi.py).
 USE_BWD_GRAPH = os.environ.get('GSSD_BWD_GRAPH', '0') == '1' and os.environ.get('GSSD_NO_GRAPH', '0') != '1'
+# bf16 storage mode: the data-gradient convs / GEMMs (NT form: d(input) = d(output) * W) run on the bf16 matrix cores -- d(output) and the
+# packed weight rounded to bf16 once per launch, fp32 accumulation, fp32 gradient maps (round 4).  GSSD_BWD_BF16=0
+# keeps the fp32 kernels on fp32 copies.
+BWD_BF16 = os.environ.get('GSSD_BWD_BF16', '1') != '0'
 LEAF_SID = 1000
 HOIST_FROM = 1       # first branch stream id whose backward is hoisted (1 = all six; hoisting block 0 as well: GSSD 25.5 -> 23.3 ms)
 N_LEAF = 1           # leaf streams, taken in turn by the layers (measured: 1 -> 50.3 ms, 2 -> 50.8, 3 -> 51.2, 4 -> 52.1)
@@ -198,6 +202,7 @@ class BackwardPlan:
     def __init__(self, plan):
         self.plan = plan
         self.B, self.dev = plan.B, plan.dev
+        self.bf16_ops = BWD_BF16 and isinstance(plan, Bf16Shadow)      # NT GEMMs / data-gradient convs on the bf16 matrix cores
         self.steps = []
         self.keep = []
         self.grads = {}          # id(param) -> fp32 grad tensor
@@ -339,6 +344,13 @@ class BackwardPlan:
             pd = dil * (k - 1) - pad
         existing = self._grad_of(x_in)
         g = existing if existing is not None else self._buf(B, H, H, Cin)
+        if self.bf16_ops and (Cout // groups) % 8 == 0 and Cout % 8 == 0:
+            # bf16 storage mode: d(input) on the bf16 matrix cores -- d(output) and the flipped / transposed weight rounded to bf16 once,
+            # fp32 accumulation, fp32 gradient map (an existing contribution is added in fp32)
+            self._nt_bf16(src, wd, g, B=B, H=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin, groups=groups, k=k, pad=pd, dil=dil,
+                          resid=existing, expect_H=H)
+            self.gbuf[x_in.data_ptr()] = g
+            return
         ud = None
         from .engine import USE_WINOGRAD
         if USE_WINOGRAD and ops.winograd_eligible(k, 1, pd, dil, Cout // groups, Cin // groups, groups):
@@ -349,6 +361,20 @@ class BackwardPlan:
         assert Hout == H, (Hout, H)
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
         self.gbuf[x_in.data_ptr()] = g
+
+    def _nt_bf16(self, src, w, out, *, B, H, in_stride, cin_g, Cout, groups=1, k=1, pad=0, dil=1, resid=None, expect_H=None):
+        """out (fp32 NHWC) [+= resid] = conv(src, w) with both operands rounded to bf16 for the launch (fp32 accumulate): two cast
+        launches + gssd_conv2d_nhwc_bf16 with GSSD_CONV_OUT_F32 (| GSSD_CONV_RESID_F32)."""
+        s16 = torch.empty(src.shape, device=self.dev, dtype=torch.bfloat16)
+        w16 = torch.empty(w.shape, device=self.dev, dtype=torch.bfloat16)
+        self.keep += [s16, w16]
+        self._add(lib.gssd_cast_f32_bf16, (src.data_ptr(), s16.data_ptr(), src.numel()))
+        self._add(lib.gssd_cast_f32_bf16, (w.data_ptr(), w16.data_ptr(), w.numel()))
+        d, Hout, _ = ops.make_conv_desc(s16, w16, out, B=B, H=H, W=H, in_stride=in_stride, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
+                                        pad=pad, dil=dil, resid=resid, wgt_row_stride=w.stride(0),
+                                        flags=_lib.CONV_OUT_F32 | (_lib.CONV_RESID_F32 if resid is not None else 0))
+        assert expect_H is None or Hout == expect_H, (Hout, expect_H)
+        self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, s16, w16))
 
     def _wgrad(self, fdesc, dy, conv, cin_g_real, cin_g_pad, k, Cout, row0=0, param=None):
         """packed dW (zeroed each run) -> OIHW grad of ``param`` (rows [row0, row0 + param.shape[0]) of the packed matrix)."""
@@ -732,8 +758,11 @@ class BackwardPlan:
         wt = self._buf(Kc, Cout)
         self._add(lib.gssd_scaled_transpose_f32, (w_main.data_ptr(), 0, wt.data_ptr(), Cout, Kc), keep=w_main)
         dcols = self._buf(B * H * H, Kc)
-        d_dc, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d_dc),), keep=(d_dc, wt))
+        if self.bf16_ops:
+            self._nt_bf16(dy, wt, dcols, B=B, H=H, in_stride=Cout, cin_g=Cout, Cout=Kc)      # 436 GFLOP: 3.4 ms in fp32
+        else:
+            d_dc, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
+            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d_dc),), keep=(d_dc, wt))
         # sampling backward: d(x) by atomics, d(offset / mask logits) per pixel
         gx = self._grad_of(x)
         if gx is None:

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
                         t *= gate;
                         if (p.out2 && nok[c]) reinterpret_cast<u16*>(p.out2)[o + c] = f2bf(t);
                     }
-                    if (rp && nok[c]) t += bf2f(rp[o + c]);
+                    if (rp && nok[c]) t += (p.flags & GSSD_CONV_RESID_F32) ? reinterpret_cast<const float*>(p.resid)[o + c] : bf2f(rp[o + c]);
                     v[c] = t;
                 }
             }

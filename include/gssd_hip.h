@@ -163,6 +163,9 @@ int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
  * still those of the full map).  Only the kernels that support it accept the flag (fp32: the Winograd trunk kernels; bf16: the thin
  * kernels with 16 / 32 output channels per group); everything else returns GSSD_EINVAL. */
 #define GSSD_CONV_POOL2 8
+/* bf16 entry point: `resid` is an fp32 map of the OUTPUT's geometry (with GSSD_CONV_OUT_F32: the backward of the bf16 storage mode
+ * accumulates a data gradient computed on the bf16 matrix cores into an fp32 gradient map).  Default: `resid` has the input's type (bf16). */
+#define GSSD_CONV_RESID_F32 16
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,
