@@ -299,13 +299,13 @@ class BackwardPlan:
             self.step_sid.append(self._cur_sid)
 
     # ------------------------------------------------------------------------------------------------
-    def _add(self, fn, args, keep=None):
+    def _add(self, fn, args, keep=None, leaf=None):
         self.steps.append((fn, args))
         # launches that only finish parameter gradients (weight gradients and their unpacking, bias column sums, spectral-norm and
         # sigma gradients, the DCN column matrix for its weight gradient) feed nothing downstream: in the trunk they go to the "leaf"
         # stream, off the d(activation) chain -- on the small maps the chain's launches no longer queue behind them, and the tails of
         # the big ones overlap
-        leaf = BWD_STREAMS and self._cur_sid == 0 and fn in _leaf_fns()
+        leaf = BWD_STREAMS and self._cur_sid == 0 and (fn in _leaf_fns() if leaf is None else leaf)
         self.step_sid.append(LEAF_SID + self._layer_no % N_LEAF if leaf else self._cur_sid)
         if keep is not None:
             self.keep.append(keep)
@@ -375,6 +375,25 @@ class BackwardPlan:
                                         flags=_lib.CONV_OUT_F32 | (_lib.CONV_RESID_F32 if resid is not None else 0))
         assert expect_H is None or Hout == expect_H, (Hout, expect_H)
         self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, s16, w16))
+
+    def _wgrad_nt_bf16(self, x, ld_x, cin, dy, ld_dy, cout, M, dwp, ld_w, groups=1):
+        """dwp[n][k] (fp32, zero-filled each run) += sum_m dy[m][n] x[m][k] on the bf16 matrix cores: both operands transposed + rounded
+        to bf16 (gssd_transpose_cast_f32_bf16: the reduction index m becomes the contiguous one), then one split-K NT launch of
+        gssd_conv2d_nhwc_bf16 per group with the transposed d(output) as its "image" of ``cout`` one-pixel rows."""
+        Mp = -(-M // 64) * 64
+        dyT = torch.zeros(cout, Mp, device=self.dev, dtype=torch.bfloat16)          # columns [M, Mp) stay zero
+        xT = torch.zeros(cin, Mp, device=self.dev, dtype=torch.bfloat16)
+        self.keep += [dyT, xT]
+        self._add(lib.gssd_transpose_cast_f32_bf16, (dy.data_ptr() if torch.is_tensor(dy) else dy, dyT.data_ptr(), M, cout, ld_dy, Mp),
+                  leaf=True)
+        self._add(lib.gssd_transpose_cast_f32_bf16, (x.data_ptr() if torch.is_tensor(x) else x, xT.data_ptr(), M, cin, ld_x, Mp), leaf=True)
+        cg, ng = cin // groups, cout // groups
+        tiles = -(-ng // 128) * -(-cg // (128 if cg > 64 else 64))
+        split = int(max(1, min(64, Mp // 256, 2048 // (tiles * groups))))
+        for g in range(groups):
+            d, _, _ = ops.make_conv_desc(dyT[g * ng:], xT[g * cg:], dwp[g * ng:], B=1, H=1, W=ng, in_stride=Mp, cin_g=Mp, Cout=cg,
+                                         wgt_row_stride=Mp, out_stride=ld_w, split_k=split, flags=_lib.CONV_OUT_F32)
+            self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, dyT, xT), leaf=True)
 
     def _wgrad(self, fdesc, dy, conv, cin_g_real, cin_g_pad, k, Cout, row0=0, param=None):
         """packed dW (zeroed each run) -> OIHW grad of ``param`` (rows [row0, row0 + param.shape[0]) of the packed matrix)."""
@@ -749,8 +768,11 @@ class BackwardPlan:
         self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
         # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- the slot-scheduled TN / NT GEMMs (csrc/wgrad_slot.hip, csrc/gemm_slot.hip; no vendor library)
         dwp = self._buf(Cout, Kc, zero_each_run=True)
-        d_c, _, _ = ops.make_conv_desc(cols, None, None, B=B, H=H, W=H, in_stride=Kc, cin_g=Kc, Cout=Cout)
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_c), dy.data_ptr(), dwp.data_ptr()), keep=d_c)
+        if self.bf16_ops:
+            self._wgrad_nt_bf16(cols, Kc, Kc, dy, Cout, Cout, B * H * H, dwp, Kc)            # 436 GFLOP: 3.3 ms as an fp32 TN GEMM
+        else:
+            d_c, _, _ = ops.make_conv_desc(cols, None, None, B=B, H=H, W=H, in_stride=Kc, cin_g=Kc, Cout=Cout)
+            self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_c), dy.data_ptr(), dwp.data_ptr()), keep=d_c)
         self._unpack(dwp, Kc, 0, m.weight, Cin, Cin, 3)
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dy.data_ptr(), B * H * H, Cout, Cout, cs.data_ptr()))

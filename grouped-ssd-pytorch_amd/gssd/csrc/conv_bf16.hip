@@ -340,7 +340,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const gssd_conv
                 for (int c = 0; c < CPL; ++c) v[c] = fmaxf(v[c], 0.f);
             }
             if (out_f32) {
-                if (all_ok) {
+                if (p.split_k > 1) {                   // K slices accumulate into a zero-filled map (weight gradients as NT GEMMs)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+                        if (nok[c]) unsafeAtomicAdd(p.out + o + c, v[c]);
+                } else if (all_ok) {
 #pragma unroll
                     for (int c = 0; c < CPL; c += 4) *reinterpret_cast<f32x4*>(p.out + o + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
                 } else {
@@ -519,8 +523,10 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
     if (d.m_per_image) GSSD_CHECK_ARG(d.in_batch_stride % 8 == 0 && d.wgt_batch_stride % 8 == 0);
     GSSD_CHECK_ARG(d.split_k >= 1 && d.split_k <= 64);
     GSSD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr) && (d.in_scale == nullptr) == (d.in_pad == nullptr));
-    // split-K accumulates with fp32 atomics into a zero-filled fp32 output: the heads only
-    if (d.split_k > 1) GSSD_CHECK_ARG(out_f32 && !d.m_per_image && !d.stats && !d.relu && !d.gate && !d.resid && d.out_mode != GSSD_OUT_TRANSPOSED);
+    // split-K accumulates with fp32 atomics into a zero-filled fp32 output: the heads and plain NHWC fp32 outputs
+    if (d.split_k > 1)
+        GSSD_CHECK_ARG(out_f32 && !d.m_per_image && !d.stats && !d.relu && !d.gate && !d.resid &&
+                       (d.out_mode == GSSD_OUT_HEADS || d.out_mode == GSSD_OUT_NHWC));
     GSSD_CHECK_ARG((d.H + 2 * d.pad - d.dil * (d.KH - 1) - 1) / d.stride + 1 == d.Ho);
     GSSD_CHECK_ARG((d.W + 2 * d.pad - d.dil * (d.KW - 1) - 1) / d.stride + 1 == d.Wo);
     const int images = d.m_per_image ? d.B : 1;

@@ -207,6 +207,54 @@ __global__ void scaled_transpose_kernel(const float* __restrict__ w, const float
     }
 }
 
+// y[c][r] = bf16(x[r][c]): 64 x 64 tiles through LDS, 16-byte reads and writes.  The weight gradients of the bf16 storage mode run as NT
+// GEMMs on the bf16 matrix cores over the TRANSPOSED operands (reduction index = pixel, contiguous): gssd/backward.py::_wgrad_nt_bf16
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long rows,
+                                                                   int cols, long long ld_x, long long ld_y) {
+    __shared__ float tile[64][65];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int i = tid; i < 64 * 16; i += 256) {             // 64 rows x 16 float4
+        const int rr = i >> 4, q = i & 15;
+        const long long r = r0 + rr;
+        const int c = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (c + 3 < cols && ((ld_x | (long long)c0) & 3) == 0) {
+                const float4 t = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < cols) v[e] = x[r * ld_x + c + e];
+            }
+        }
+        for (int e = 0; e < 4; ++e) tile[rr][4 * q + e] = v[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 8; i += 256) {              // 64 output rows (c) x 8 pieces of 8 r
+        const int cc = i >> 3, p = i & 7;
+        const int c = c0 + cc;
+        const long long r = r0 + 8 * p;
+        if (c >= cols || r >= rows) continue;
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = __builtin_bit_cast(unsigned short, (__bf16)tile[8 * p + e][cc]);
+        unsigned short* dst = y + (long long)c * ld_y + r;
+        if (r + 7 < rows) {
+            uint4 v;
+            v.x = h[0] | ((unsigned)h[1] << 16);
+            v.y = h[2] | ((unsigned)h[3] << 16);
+            v.z = h[4] | ((unsigned)h[5] << 16);
+            v.w = h[6] | ((unsigned)h[7] << 16);
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (r + e < rows) dst[e] = h[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, double* out) {
     __shared__ double red[4];
     double acc = 0.0;
@@ -320,6 +368,17 @@ extern "C" int gssd_scaled_transpose_f32(const float* w, const float* alpha, flo
     const long long total = (long long)rows * cols;
     hipLaunchKernelGGL(scaled_transpose_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w, alpha, out, rows, cols);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_transpose_cast_f32_bf16(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y,
+                                            gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_x >= cols && ld_y >= rows && ld_y % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
+                   ((uintptr_t)x % 16) == 0);
+    GSSD_CHECK_ARG((rows + 63) / 64 < (1ll << 31) && (cols + 63) / 64 < 65536);
+    hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0,
+                       as_stream(stream), x, reinterpret_cast<unsigned short*>(y), (long long)rows, cols, (long long)ld_x, (long long)ld_y);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -446,6 +446,10 @@ int gssd_sn_weight_grad_f32(const float* dw_eff, int ld_dw, const float* w_orig,
                             gssd_stream_t stream);
 /* out[c][n] = w[n][c] * alpha[n] (alpha may be NULL): data-gradient weights of a spectrally normalised 1x1 conv */
 int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, int rows, int cols, gssd_stream_t stream);
+/* y[c][r] = bf16(x[r][c]) for r < rows, c < cols; x rows ld_x floats apart, y rows ld_y bf16 apart (ld_y >= rows, a multiple of 8).  The
+ * bf16 storage mode's weight gradients dW[n][k] = sum_m dY[m][n] A[m][k] run as NT GEMMs over the transposed operands (reduction index
+ * m contiguous) on the bf16 matrix cores: gssd_conv2d_nhwc_bf16 with in = dY^T, wgt = A^T, split_k > 1, GSSD_CONV_OUT_F32. */
+int gssd_transpose_cast_f32_bf16(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, gssd_stream_t stream);
 /* *out += sum a[i]*b[i] (fp64); out = a*x + b*y; y = scale[0]*x (fp64 -> fp32); d(sigma) = dot[0] + sum_c bias[c]*colsum[c] */
 int gssd_dot_f32(const float* a, const float* b, int64_t n, double* out, gssd_stream_t stream);
 int gssd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, gssd_stream_t stream);

@@ -525,6 +525,41 @@ def test_full_size_properties_bf16(dev, name):
     assert np.array_equal(det[b:b + 1], ref)
 
 
+@pytest.mark.parametrize('M,cin,cout,groups', [(4 * 19 * 19, 1152, 512, 1), (1000, 72, 40, 1), (777, 256, 512, 4), (64, 8, 8, 1)])
+def test_wgrad_nt_bf16(dev, M, cin, cout, groups):
+    """The bf16 storage mode's weight gradient dW[n][k] = sum_m dY[m][n] X[m][k] (gssd/backward.py::_wgrad_nt_bf16):
+    gssd_transpose_cast_f32_bf16 is exact (a transposed round-to-nearest-even cast, strided source, ragged edges, pad columns untouched)
+    and the split-K NT launch over the transposed operands equals the float64 product of the bf16-rounded operands."""
+    from gssd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(M + cin)
+    ld_x = cin + 8
+    x = torch.from_numpy(rng.normal(size=(M, ld_x)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rng.normal(size=(M, cout)).astype(np.float32)).to(dev)
+    Mp = -(-M // 64) * 64
+    xT = torch.full((cin, Mp), 7.0, device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib.gssd_transpose_cast_f32_bf16(x.data_ptr(), xT.data_ptr(), M, cin, ld_x, Mp, st))
+    assert torch.equal(xT[:, :M], x[:, :cin].t().to(torch.bfloat16))
+    assert bool((xT[:, M:] == 7.0).all())
+
+    class Plan:                                   # the two members the helper touches
+        pass
+    from gssd.backward import BackwardPlan
+    steps = []
+    p = Plan()
+    p.dev, p.keep = dev, []
+    p._add = lambda fn, args, keep=None, leaf=None: steps.append((fn, args))
+    dwp = torch.zeros(cout, cin // groups, device=dev)
+    BackwardPlan._wgrad_nt_bf16(p, x, ld_x, cin, dy, cout, cout, M, dwp, cin // groups, groups=groups)
+    for fn, args in steps:
+        _lib.check(fn(*args, st))
+    xq, dq = q(x[:, :cin].cpu()).double(), q(dy.cpu()).double()
+    cg, ng = cin // groups, cout // groups
+    ref = torch.cat([dq[:, g * ng:(g + 1) * ng].t() @ xq[:, g * cg:(g + 1) * cg] for g in range(groups)])
+    assert rel(dwp.double().cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize('name', list(NETS))
 def test_bf16_backward_gradients(dev, name):
     """configs[4] is a TRAINING config (train_lesion_multiphase_v2.py:242-253): the bf16 storage mode trains with a mixed-precision
