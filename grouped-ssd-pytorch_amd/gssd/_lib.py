@@ -73,6 +73,8 @@ SIGNATURES = {
     'gssd_winograd_weight_elems': (C.c_longlong, [c_i, c_i, c_i]),
     'gssd_winograd_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv2d_wgrad_f32': (c_i, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp]),
+    'gssd_conv2d_wgrad_bf16': (c_i, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp]),
+    'gssd_conv2d_wgrad_bf16_supported': (c_i, [C.POINTER(ConvDesc)]),
     'gssd_unpack_conv_weight_grad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_pack_conv_weight_dgrad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_relu_pool_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_d, c_fp, c_fp,

@@ -206,6 +206,13 @@ int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int grou
  * Data gradient: a stride-1 conv's dgrad is a forward gssd_conv2d_nhwc_f32 over dy with the weights packed by
  * gssd_pack_conv_weight_dgrad (rows = input channels, k' = flipped tap * cout_g + co) and pad' = dil*(k-1) - pad. */
 int gssd_conv2d_wgrad_f32(const gssd_conv_desc* d, const float* dy, float* dw_packed, gssd_stream_t stream);
+/* The same weight gradient on the bf16 matrix cores (training step of the bf16 storage mode): d->in and dy are bf16 (dy [B*Ho*Wo][Cout]),
+ * dw_packed is fp32 and zero-filled; a deferred BatchNorm + ReLU on the input (d->in_scale / d->in_shift, fp32) is applied to the staged
+ * input in fp32 and rounded to bf16 like the forward does (d->in_pad is not read: out-of-image pixels are zero).  Shapes: the grouped 3x3
+ * stride-1 pad-1 trunk convolutions (16 -> 16 / 32 and 32 -> 32 channels per group with groups % 4 == 0; 32 / 64 -> multiples of 64;
+ * 128 -> multiples of 32) -- gssd_conv2d_wgrad_bf16_supported() returns 1 for them; anything else is GSSD_EINVAL, not a fallback. */
+int gssd_conv2d_wgrad_bf16(const gssd_conv_desc* d, const void* dy, float* dw_packed, gssd_stream_t stream);
+int gssd_conv2d_wgrad_bf16_supported(const gssd_conv_desc* d);
 int gssd_unpack_conv_weight_grad(const float* w_packed, float* w_oihw, int Cout, int cin_g, int KH, int KW,
                                  int cin_g_pad, int Kpad, int accumulate, gssd_stream_t stream);
 int gssd_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int groups, int cin_g, int KH, int KW,

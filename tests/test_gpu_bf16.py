@@ -525,6 +525,58 @@ def test_full_size_properties_bf16(dev, name):
     assert np.array_equal(det[b:b + 1], ref)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,groups', [
+    (2, 37, 37, 64, 64, 4),        # conv1_2: 16 -> 16 per group, a wave per phase group
+    (2, 30, 41, 64, 128, 4),       # conv2_1: 16 -> 32
+    (2, 21, 21, 128, 128, 4),      # conv2_2: 32 -> 32, 36 accumulator tiles per wave
+    (2, 19, 26, 128, 256, 4),      # conv3_1: 32 -> 64
+    (2, 19, 19, 256, 256, 4),      # conv3_2: 64 -> 64
+    (1, 23, 17, 256, 512, 4),      # conv4_1: 64 -> 128, two output splits
+    (2, 19, 19, 512, 512, 4),      # conv4_2 .. conv5_3: 128 -> 128, four output splits
+    (1, 13, 9, 128, 96, 1),        # one group, 96 outputs: masked last split
+    (3, 8, 16, 64, 64, 1),         # exactly one tile per image
+])
+@pytest.mark.parametrize('xf', [False, True])
+def test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf):
+    """gssd_conv2d_wgrad_bf16 (csrc/conv_wgrad_bf16.hip: LDS transpose reads feeding v_mfma_f32_16x16x32_bf16) against the float64 weight
+    gradient of the conv over the SAME bf16 operands: the input after its deferred BatchNorm + ReLU rounded to bf16 (what the forward's
+    MFMA saw), d(output) rounded to bf16.  Random operands with a distinct value everywhere: a wrong tap, transposed fragment or swizzle
+    cannot pass.  The input sits at a channel offset inside wider rows."""
+    from gssd import ops, _lib
+    import ctypes as C
+    rng = np.random.default_rng(B * 1000 + H * 10 + Cin + Cout)
+    ld, off = Cin + 16, 8
+    xs = q(torch.from_numpy(rng.normal(size=(B, H, W, ld)).astype(np.float32)))
+    dy = q(torch.from_numpy(rng.normal(size=(B, H, W, Cout)).astype(np.float32)))
+    # scale / shift on coarse binary grids: x * sc + sh is exact in fp32, fused or not, so the rounded operand is unambiguous
+    sc = torch.from_numpy((np.round(rng.uniform(0.5, 1.5, size=ld) * 8) / 8).astype(np.float32))
+    sh = torch.from_numpy((np.round(rng.normal(0, 0.5, size=ld) * 64) / 64).astype(np.float32))
+    x = xs[..., off:off + Cin]
+    if xf:
+        x = q(torch.relu(x * sc[off:off + Cin] + sh[off:off + Cin]))
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+    w = torch.zeros(Cout, Cin // groups, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, groups)
+    (y * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    ref = w.grad
+    xd, dyd = xs.to(dev).to(torch.bfloat16), dy.to(dev).to(torch.bfloat16)
+    scd, shd = sc.to(dev), sh.to(dev)
+    cg = Cin // groups
+    d, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=3, pad=1,
+                                 in_scale=scd if xf else None, in_shift=shd if xf else None)
+    assert _lib.lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d)) == 1
+    dwp = torch.zeros(Cout, 9 * cg, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):         # accumulates: two launches = twice the gradient
+        _lib.check(_lib.lib.gssd_conv2d_wgrad_bf16(C.byref(d), dyd.data_ptr(), dwp.data_ptr(), st))
+    got = (dwp.cpu().double() / 2).view(Cout, 9, cg).permute(0, 2, 1).reshape(Cout, cg, 3, 3)
+    assert rel(got, ref) < 2e-5, rel(got, ref)
+    # not a supported shape: refused, no fallback
+    d2, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=1)
+    assert _lib.lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d2)) == 0
+    assert _lib.lib.gssd_conv2d_wgrad_bf16(C.byref(d2), dyd.data_ptr(), dwp.data_ptr(), st) == -1      # GSSD_EINVAL
+
+
 @pytest.mark.parametrize('M,cin,cout,groups', [(4 * 19 * 19, 1152, 512, 1), (1000, 72, 40, 1), (777, 256, 512, 4), (64, 8, 8, 1)])
 def test_wgrad_nt_bf16(dev, M, cin, cout, groups):
     """The bf16 storage mode's weight gradient dW[n][k] = sum_m dY[m][n] X[m][k] (gssd/backward.py::_wgrad_nt_bf16):
