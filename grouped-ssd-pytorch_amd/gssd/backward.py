@@ -125,6 +125,8 @@ class Bf16Shadow:
                 q['Cin'] = 16
             first = False
             if kind == 'convbn':
+                # the stored bf16 input itself, for the weight gradient on the bf16 matrix cores (csrc/conv_wgrad_bf16.hip)
+                q['x16'], q['Cin16'] = (r['x_in'], r['Cin']) if r['x_in'].dtype == torch.bfloat16 else (None, None)
                 q['x_in'], q['raw'] = S(r['x_in']), S(r['raw'])
                 q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'])
                 q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'], r.get('stats_rep', 0))
@@ -362,13 +364,24 @@ class BackwardPlan:
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
         self.gbuf[x_in.data_ptr()] = g
 
+    def _cast16(self, t):
+        """bf16 copy of a FINAL fp32 gradient map (one cast launch where it is first asked for; the data-gradient conv and the weight
+        gradient of a layer share it)."""
+        c = self.__dict__.setdefault('_c16', {})
+        k = t.data_ptr()
+        if k not in c:
+            t16 = torch.empty(t.shape, device=self.dev, dtype=torch.bfloat16)
+            self.keep.append((t, t16))
+            self._add(lib.gssd_cast_f32_bf16, (t.data_ptr(), t16.data_ptr(), t.numel()), leaf=False)
+            c[k] = t16
+        return c[k]
+
     def _nt_bf16(self, src, w, out, *, B, H, in_stride, cin_g, Cout, groups=1, k=1, pad=0, dil=1, resid=None, expect_H=None):
         """out (fp32 NHWC) [+= resid] = conv(src, w) with both operands rounded to bf16 for the launch (fp32 accumulate): two cast
         launches + gssd_conv2d_nhwc_bf16 with GSSD_CONV_OUT_F32 (| GSSD_CONV_RESID_F32)."""
-        s16 = torch.empty(src.shape, device=self.dev, dtype=torch.bfloat16)
+        s16 = self._cast16(src)
         w16 = torch.empty(w.shape, device=self.dev, dtype=torch.bfloat16)
-        self.keep += [s16, w16]
-        self._add(lib.gssd_cast_f32_bf16, (src.data_ptr(), s16.data_ptr(), src.numel()))
+        self.keep.append(w16)
         self._add(lib.gssd_cast_f32_bf16, (w.data_ptr(), w16.data_ptr(), w.numel()))
         d, Hout, _ = ops.make_conv_desc(s16, w16, out, B=B, H=H, W=H, in_stride=in_stride, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                                         pad=pad, dil=dil, resid=resid, wgt_row_stride=w.stride(0),
@@ -475,7 +488,23 @@ class BackwardPlan:
         # weight gradient (the forward descriptor carries the input geometry and the fused input transform)
         cin_g_pad = Cin // groups
         cin_g_real = conv.weight.shape[1]
-        dwp, K = self._wgrad(r['desc'], dz, conv, cin_g_real, cin_g_pad, r['k'], Cout)
+        d16 = None
+        if self.bf16_ops and r.get('x16') is not None and cin_g_real == cin_g_pad:
+            ix = r['in_xf']
+            d16, _, _ = ops.make_conv_desc(r['x16'], None, None, B=B, H=H, W=H, in_stride=r['Cin16'], cin_g=r['Cin16'] // groups, Cout=Cout,
+                                           groups=groups, k=r['k'], stride=r['stride'], pad=r['pad'], dil=r['dil'],
+                                           in_scale=ix[0] if ix else None, in_shift=ix[1] if ix else None)
+            if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d16)):
+                d16 = None
+        if d16 is not None:
+            # bf16 storage mode, grouped 3x3 trunk layers: the STORED bf16 input and the bf16-rounded d(pre-activation) on the bf16
+            # matrix cores (fp32 accumulation, fp32 gradient); 3 - 6 x the fp32 kernels
+            K = r['k'] * r['k'] * cin_g_pad
+            dwp = self._buf(Cout, K, zero_each_run=True)
+            dz16 = self._cast16(dz)
+            self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d16), dz16.data_ptr(), dwp.data_ptr()), keep=(d16, dz16), leaf=True)
+        else:
+            dwp, K = self._wgrad(r['desc'], dz, conv, cin_g_real, cin_g_pad, r['k'], Cout)
         self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
         if need_dgrad:
             self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
