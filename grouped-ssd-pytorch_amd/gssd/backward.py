@@ -71,7 +71,6 @@ class Bf16Shadow:
         self.real = plan
         self.B, self.dev, self.P, self.nc = plan.B, plan.dev, plan.P, plan.nc
         self.training = plan.training
-        self.pre = []
         self._keep = []
         self._s = {}                 # data_ptr of a bf16 forward tensor -> its fp32 shadow
         self._xf = {}                # data_ptr of a deferred BatchNorm's scale vector -> (scale, shift, pad_fp32)
@@ -81,7 +80,12 @@ class Bf16Shadow:
         f32 = torch.float32
         casts, later = [], []
 
-        def S(t):
+        self._lazy = {}              # data_ptr of an fp32 shadow whose cast is not scheduled (yet) -> the cast step
+
+        def S(t, lazy=False):
+            """fp32 shadow of a stored bf16 map.  ``lazy``: the shadow exists (the backward plan keys its gradient buffers by it) but the
+            cast runs only if some step asks for its CONTENT (``need``): the conv + BatchNorm layers read the bf16 maps themselves
+            (gssd_bn_bwd_*_mixed, gssd_conv2d_wgrad_bf16), so most trunk maps are never copied."""
             if t is None or t.dtype == f32:
                 return t
             k = t.data_ptr()
@@ -89,8 +93,12 @@ class Bf16Shadow:
                 sh = torch.empty(t.shape, device=dev, dtype=f32)
                 self._s[k] = sh
                 self._keep.append((t, sh))
-                casts.append((lib.gssd_cast_bf16_f32, (t.data_ptr(), sh.data_ptr(), t.numel())))
-            return self._s[k]
+                self._lazy[sh.data_ptr()] = (lib.gssd_cast_bf16_f32, (t.data_ptr(), sh.data_ptr(), t.numel()))
+            sh = self._s[k]
+            if not lazy:
+                self.need(sh)
+            return sh
+        self._casts = casts
 
         def XF(xf, bn, stats, count, Cc, srep=0):
             if xf is None:
@@ -127,8 +135,10 @@ class Bf16Shadow:
             if kind == 'convbn':
                 # the stored bf16 input itself, for the weight gradient on the bf16 matrix cores (csrc/conv_wgrad_bf16.hip)
                 q['x16'], q['Cin16'] = (r['x_in'], r['Cin']) if r['x_in'].dtype == torch.bfloat16 else (None, None)
-                q['x_in'], q['raw'] = S(r['x_in']), S(r['raw'])
-                q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'])
+                q['raw16'] = r['raw'] if r['raw'].dtype == torch.bfloat16 else None
+                lz = BWD_BF16
+                q['x_in'], q['raw'] = S(r['x_in'], lz), S(r['raw'], lz)
+                q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'], lz)
                 q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'], r.get('stats_rep', 0))
             elif kind == 'head':
                 q['src'] = S(r['src'])
@@ -194,7 +204,17 @@ class Bf16Shadow:
                     ops.pack_weight(cw.weight, hw, nloc)
                 later.append((refresh_h, None))
         self.rec = rec
-        self.pre = casts + later
+        self._later = later
+
+    @property
+    def pre(self):
+        return self._casts + self._later
+
+    def need(self, t):
+        """Schedule the cast of a lazily shadowed map (a step is about to read the fp32 CONTENT of ``t``); no-op for anything else."""
+        step = self._lazy.pop(t.data_ptr(), None) if t is not None else None
+        if step is not None:
+            self._casts.append(step)
 
     def _side_stream(self, sid):
         return self.real._side_stream(sid)
@@ -469,23 +489,8 @@ class BackwardPlan:
         pk, ps, pp = (pool[0], pool[1], pool[2]) if pool else (0, 1, 0)
         dz = self._buf(B, Ho, Ho, Cout, zero_each_run=bool(pool and ps < pk))
         sums = self._buf(2 * Cout, dtype=torch.float64, zero_each_run=True)
-        # without pooling the reduce pass only sums (dz = NULL) and the apply pass re-derives dz from d(out): 5 instead of 6 HBM passes
-        self._add(lib.gssd_bn_bwd_reduce_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0,
-                                               sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
-        ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
-        self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
-                                                 float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
-                                                 self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr(), r.get('stats_rep', 0)))
-        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
-        if pool:
-            self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
-                                                  B * Ho * Ho, Cout, cs.data_ptr()))
-        else:
-            self._add(lib.gssd_bn_bwd_apply_masked_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), int(r['relu']),
-                                                         ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dz.data_ptr(), B * Ho * Ho, Cout,
-                                                         cs.data_ptr()))
-        self._bias_from_colsum(cs, conv.bias)
-        # weight gradient (the forward descriptor carries the input geometry and the fused input transform)
+        # bf16 storage mode: which precision do the consumers of d(pre-activation) read?  (weight gradient: csrc/conv_wgrad_bf16.hip for the
+        # grouped 3x3 trunk shapes; data gradient: gssd_conv2d_nhwc_bf16 when the channel counts allow 16-byte rows)
         cin_g_pad = Cin // groups
         cin_g_real = conv.weight.shape[1]
         d16 = None
@@ -496,6 +501,41 @@ class BackwardPlan:
                                            in_scale=ix[0] if ix else None, in_shift=ix[1] if ix else None)
             if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d16)):
                 d16 = None
+        dg16 = bool(need_dgrad and self.bf16_ops and (Cout // groups) % 8 == 0 and Cout % 8 == 0 and r['stride'] == 1)   # (stride 2: the
+        # zero-insertion pass reads the fp32 map)
+        raw16 = r.get('raw16') if self.bf16_ops else None
+        mixed = raw16 is not None                                 # BatchNorm backward reads the forward's bf16 map itself
+        want16 = mixed and (d16 is not None or dg16)
+        want32 = (d16 is None) or (need_dgrad and not dg16) or not mixed
+        dz16 = torch.empty(B, Ho, Ho, Cout, device=self.dev, dtype=torch.bfloat16) if want16 else None
+        if want16:
+            self.keep.append(dz16)
+            self.__dict__.setdefault('_c16', {})[dz.data_ptr()] = dz16      # _cast16(dz) finds it: no cast launch
+        if not mixed:
+            self._need(raw)
+        # without pooling the reduce pass only sums (dz = NULL) and the apply pass re-derives dz from d(out): 5 instead of 6 HBM passes
+        self._add(lib.gssd_bn_bwd_reduce_mixed if mixed else lib.gssd_bn_bwd_reduce_f32,
+                  (dout.data_ptr(), (raw16 if mixed else raw).data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0,
+                   sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
+        ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
+        self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
+                                                 float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                                 self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr(), r.get('stats_rep', 0)))
+        cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
+        if mixed:
+            self._add(lib.gssd_bn_bwd_apply_mixed, (0 if pool else dout.data_ptr(), dz.data_ptr(), dz16.data_ptr() if want16 else 0,
+                                                    raw16.data_ptr(), 0 if pool else sc.data_ptr(), 0 if pool else sh.data_ptr(),
+                                                    int(r['relu']), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), B * Ho * Ho, Cout,
+                                                    cs.data_ptr(), int(want32)), keep=(raw16, dz16))
+        elif pool:
+            self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                                  B * Ho * Ho, Cout, cs.data_ptr()))
+        else:
+            self._add(lib.gssd_bn_bwd_apply_masked_f32, (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), int(r['relu']),
+                                                         ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dz.data_ptr(), B * Ho * Ho, Cout,
+                                                         cs.data_ptr()))
+        self._bias_from_colsum(cs, conv.bias)
+        # weight gradient (the forward descriptor carries the input geometry and the fused input transform)
         if d16 is not None:
             # bf16 storage mode, grouped 3x3 trunk layers: the STORED bf16 input and the bf16-rounded d(pre-activation) on the bf16
             # matrix cores (fp32 accumulation, fp32 gradient); 3 - 6 x the fp32 kernels
@@ -504,10 +544,17 @@ class BackwardPlan:
             dz16 = self._cast16(dz)
             self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d16), dz16.data_ptr(), dwp.data_ptr()), keep=(d16, dz16), leaf=True)
         else:
+            self._need(r['x_in'])
             dwp, K = self._wgrad(r['desc'], dz, conv, cin_g_real, cin_g_pad, r['k'], Cout)
         self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
         if need_dgrad:
             self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
+
+    def _need(self, t):
+        """A step reads the fp32 CONTENT of a stored map: schedule its cast if the bf16 shadow plan shadows it lazily."""
+        n = getattr(self.plan, 'need', None)
+        if n is not None:
+            n(t)
 
     def _convrelu(self, r, need_dgrad=True):
         """conv + ReLU without BatchNorm (vanilla SSD, models/ssd.py:104-118; the grouped batch_norm=False graph): dz = d(out) * [out > 0] (the mask of the

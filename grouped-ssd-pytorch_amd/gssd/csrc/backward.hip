@@ -9,13 +9,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+typedef unsigned short u16;
+
+// four consecutive channels of a stored map: fp32, or bf16 as the bf16 storage mode keeps it (the mixed-precision backward reads the
+// forward's own maps instead of fp32 copies of them)
+template <typename RT>
+__device__ __forceinline__ f32x4 ld4(const RT* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 ld4<u16>(const u16* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void st4_bf16(u16* p, const f32x4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4*>(p) = h;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // Pass 1: window-centric.  One thread per (pooled output position, channel quad).  z = raw*scale + shift, a = relu(z);
 // the window's first maximum of a receives d_out; ReLU's mask (z > 0) is applied; dz is written for every window
 // element (non-overlapping pools) or atomically accumulated (overlapping, dz pre-zeroed).  Per-channel sums
 // s1 = sum dz, s2 = sum dz*raw feed the BatchNorm parameter gradients.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
+template <typename RT>
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const RT* __restrict__ raw,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dz, double* __restrict__ sums, int B, int H,
                                                             int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
@@ -39,7 +64,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
             const f32x4 g = *reinterpret_cast<const f32x4*>(dout + i * 4);
             if (pk == 0) {
                 const size_t o = (size_t)i * 4;           // Ho == H, Wo == W: dout and raw share one dense layout
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + o);
+                const f32x4 rv = ld4<RT>(raw + o);
                 const f32x4 z = rv * sc + sh;
                 f32x4 d;
 #pragma unroll
@@ -64,7 +89,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
                     for (int dx = 0; dx < pk; ++dx) {
                         const int xx = x0 + dx;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + (((size_t)b * H + yy) * W + xx) * C + 4 * c4);
+                        const f32x4 rv = ld4<RT>(raw + (((size_t)b * H + yy) * W + xx) * C + 4 * c4);
                         f32x4 a = rv * sc + sh;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -138,13 +163,15 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double
 }
 
 // ``dsrc`` (optional): d(out) of a layer without pooling -- dz is then re-derived here as dsrc * [raw * scale + shift > 0] instead of
-// being written by the reduce pass and read back (one HBM pass less per layer)
-__global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
+// being written by the reduce pass and read back (one HBM pass less per layer).  ``dz16`` (optional): the result as bf16, what the bf16
+// data-gradient conv and weight gradient read; ``store_f32`` = 0 leaves ``dz`` as it was (only read, when dsrc is NULL).
+template <typename RT>
+__global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ dz, const RT* __restrict__ raw,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB,
                                                            const float* __restrict__ coefC, long long pixels, int C,
                                                            double* __restrict__ colsum, const float* __restrict__ dsrc,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int relu) {
+                                                           int relu, u16* __restrict__ dz16, int store_f32) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C4 = C >> 2;
     if (colsum) {
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ 
             sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
         }
         for (long long i = i0; i < total; i += stride) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(raw + i * 4);
+            const f32x4 rv = ld4<RT>(raw + i * 4);
             f32x4 d;
             if (dsrc) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(dsrc + i * 4);
@@ -177,7 +204,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ 
                 d = *reinterpret_cast<const f32x4*>(dz + i * 4);
             }
             const f32x4 o = a * d + bb * rv + cc;
-            *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+            if (store_f32) *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+            if (dz16) st4_bf16(dz16 + i * 4, o);
             acc += o;
         }
     }
@@ -319,8 +347,34 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
     GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
                        raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_bwd_reduce_mixed(const float* dout, const void* raw_bf16, const float* scale, const float* shift, float* dz,
+                                        double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
+                                        int pool_p, int relu, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dout && raw_bf16 && (dz || (pool_k == 0 && sums)) && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<u16>, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
+                       reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_bn_bwd_apply_mixed(const float* dout, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale,
+                                       const float* shift, int relu, const float* coef_a, const float* coef_b, const float* coef_c,
+                                       int64_t pixels, int C, double* colsum, int store_f32, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(raw_bf16 && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG((dout || dz) && (dz_bf16 || store_f32) && (!store_f32 || dz) && (scale == nullptr) == (shift == nullptr));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<u16>, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
+                       dz, reinterpret_cast<const u16*>(raw_bf16), coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift,
+                       relu, reinterpret_cast<u16*>(dz_bf16), store_f32);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -338,8 +392,8 @@ extern "C" int gssd_bn_bwd_finalize_f32(const double* fwd_stats, double count, c
 extern "C" int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, const float* coef_b,
                                      const float* coef_c, int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dz && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
-                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, nullptr, nullptr, nullptr, 0);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
+                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, nullptr, nullptr, nullptr, 0, nullptr, 1);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -349,8 +403,8 @@ extern "C" int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw,
                                             int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dout && draw && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
-                       draw, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
+                       draw, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift, relu, nullptr, 1);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
