@@ -147,6 +147,7 @@ class Bf16Shadow:
             elif kind == 'slice_cat':
                 q['a'], q['b'], q['out'] = S(r['a']), S(r['b']), S(r['out'])
             elif kind == 'dcn':
+                q['x16'] = r['x_in'] if r['x_in'].dtype == torch.bfloat16 else None
                 q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
             elif kind == 'sa':
                 q['x_in'], q['out'], q['ag'] = S(r['x_in']), S(r['out']), S(r['ag'])
@@ -875,7 +876,16 @@ class BackwardPlan:
         if OMC != 27 * dg:
             d_w, _, _ = ops.make_conv_desc(x, None, None, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=OMC, k=3, pad=1)
         dwo = self._buf(OMC, Kc, zero_each_run=True)
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_w), dom.data_ptr(), dwo.data_ptr()), keep=d_w)
+        d16 = None
+        if self.bf16_ops and r.get('x16') is not None and OMC % 8 == 0:
+            d16, _, _ = ops.make_conv_desc(r['x16'], None, None, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=OMC, k=3, pad=1)
+            if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d16)):
+                d16 = None
+        if d16 is not None:                # dense 3x3, 512 -> 112: four 128-channel input blocks of csrc/conv_wgrad_bf16.hip
+            dom16 = self._cast16(dom)
+            self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d16), dom16.data_ptr(), dwo.data_ptr()), keep=(d16, dom16), leaf=True)
+        else:
+            self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_w), dom.data_ptr(), dwo.data_ptr()), keep=d_w)
         self._unpack(dwo, Kc, 0, cm.weight, Cin, Cin, 3)
         cs2 = self._buf(OMC, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dom.data_ptr(), B * H * H, OMC, OMC, cs2.data_ptr()))

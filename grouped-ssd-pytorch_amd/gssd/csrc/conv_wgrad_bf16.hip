@@ -43,6 +43,9 @@ struct WgBfParams {
     const float* in_scale;
     const float* in_shift;
     int B, H, W, in_stride, in_ch_off, Cout, cout_g, co_splits, tiles_y, tiles_x;
+    // grouped: cout_goff = cout_g, k_row = 9 * CIN_G, k_tap = CIN_G, k_goff = 0.  Dense convs run as `groups` blocks of CIN_G input
+    // channels that all feed the SAME outputs: cout_goff = 0, k_row = 9 * Cin, k_tap = Cin, k_goff = CIN_G.
+    int cout_goff, k_row, k_tap, k_goff;
 };
 
 // swizzle of the 32-byte chunk index by the pixel column: NC chunks per pixel
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
     const u16* in_g = p.in + p.in_ch_off + g0 * CIN_G;
     // dY channels of the workgroup: groups g0 .. g0 + NG - 1, channels [cs * NCOW, + NCOW) of each (NG > 1 only with co_splits == 1 and
     // NCOW == cout_g: one contiguous range)
-    const u16* dy_g = p.dy + g0 * p.cout_g + cs * NCOW;
+    const u16* dy_g = p.dy + g0 * p.cout_goff + cs * NCOW;
 
     if constexpr (XF) {
         for (int i = tid; i < NG * CIN_G; i += 256) {
@@ -218,7 +221,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
     }
 
     // ---- flush: D rows = co (kq*4 + e), columns = ci r ------------------------------------------------------------------------------
-    constexpr int K = 9 * CIN_G;
 #pragma unroll
     for (int c = 0; c < COB; ++c) {
         const int col0 = cs * NCOW + (wc * COB + c) * 16 + kq * 4;          // channel inside the group
@@ -228,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (col0 + e >= p.cout_g) continue;
-                const int co = (g0 + gl) * p.cout_g + col0 + e;
-                unsafeAtomicAdd(p.dw + (size_t)co * K + tap * CIN_G + ct * 16 + r, acc[c][t][e]);
+                const int co = (g0 + gl) * p.cout_goff + col0 + e;
+                unsafeAtomicAdd(p.dw + (size_t)co * p.k_row + tap * p.k_tap + (g0 + gl) * p.k_goff + ct * 16 + r, acc[c][t][e]);
             }
         }
     }
@@ -251,7 +253,13 @@ int launch_wgrad_bf16(const gssd_conv_desc& d, const void* dy, float* dw, hipStr
     p.in_stride = d.in_stride;
     p.in_ch_off = d.in_ch_off;
     p.Cout = d.Cout;
+    const bool dense = d.groups == 1 && d.cin_g != CIN_G;          // blocks of CIN_G input channels, one set of outputs
+    const int nblk = dense ? d.cin_g / CIN_G : d.groups;
     p.cout_g = d.Cout / d.groups;
+    p.cout_goff = dense ? 0 : p.cout_g;
+    p.k_row = 9 * d.cin_g;
+    p.k_tap = d.cin_g;
+    p.k_goff = dense ? CIN_G : 0;
     p.co_splits = (p.cout_g + NCOW - 1) / NCOW;
     p.tiles_y = (d.H + 7) / 8;
     p.tiles_x = (d.W + 15) / 16;
@@ -267,7 +275,7 @@ int launch_wgrad_bf16(const gssd_conv_desc& d, const void* dy, float* dw, hipStr
     }
     gssd_attr_done(&attr_mask);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
-    const int gy = d.groups / NG * p.co_splits;
+    const int gy = nblk / NG * p.co_splits;
     int gx = 512 / gy;                                    // two resident workgroups per CU
     if (gx < 1) gx = 1;
     if (ntiles < gx) gx = (int)ntiles;
@@ -281,9 +289,10 @@ bool shape_ok(const gssd_conv_desc& d) {
     if (d.Cout % d.groups || d.in_stride % 8 || d.in_ch_off % 8 || d.Cout % 8) return false;
     if ((long long)d.B * d.H * d.W * d.in_stride >= (1ll << 31) || (long long)d.B * d.H * d.W * d.Cout >= (1ll << 31)) return false;
     const int cg = d.cin_g, ng = d.Cout / d.groups;
+    if (d.groups == 1 && cg > 128) return cg % 128 == 0;      // dense: 128-channel input blocks, any multiple of 8 outputs
     if (d.groups % 4 == 0 && ((cg == 16 && (ng == 16 || ng == 32)) || (cg == 32 && ng == 32))) return true;
     if (cg == 32 || cg == 64) return ng % 64 == 0;
-    if (cg == 128) return ng % 32 == 0;
+    if (cg == 128) return ng % 32 == 0 || d.groups == 1;
     return false;
 }
 
@@ -311,6 +320,7 @@ extern "C" int gssd_conv2d_wgrad_bf16(const gssd_conv_desc* dp, const void* dy, 
     if (cg == 32 && ng == 32 && d.groups % 4 == 0) { GSSD_WB(32, 4, 2, 1, 1) }        // conv2_2: 36 tiles per wave
     if (cg == 32) { GSSD_WB(32, 1, 2, 2, 2) }                    // conv3_1: 64 output channels per workgroup, 18 tiles per wave
     if (cg == 64) { GSSD_WB(64, 1, 2, 2, 2) }                    // conv3_2 / conv3_3 / conv4_1: 36 tiles per wave
-    GSSD_WB(128, 1, 2, 1, 4)                                     // conv4_2 .. conv5_3: 32 output channels per workgroup, 36 tiles per wave
+    GSSD_WB(128, 1, 2, 1, 4)                                     // conv4_2 .. conv5_3 and the dense convs (DCN offset / mask conv, heads): 32
+                                                                 // output channels per workgroup, 36 tiles per wave
 #undef GSSD_WB
 }

@@ -918,7 +918,8 @@ class _Plan(_PlanBase):
         w_main = eng._pack(f'dcn_list.{li}.wt', build_w)
         # offsets / mask logits stay fp32 in both modes; rows padded to a multiple of 4 channels (27 * dg is one only for dg = 4, 8, ..):
         # the weight-gradient and data-gradient kernels of the offset conv want 16-byte aligned channel vectors
-        OMC = ops.round_up(27 * dg, 4)
+        # (bf16 mode: a multiple of 8 -- the training step's bf16 data / weight gradients of the offset conv read 16-byte bf16 rows)
+        OMC = ops.round_up(27 * dg, 8 if self.bf16 else 4)
         om = self._buf(B, H, H, OMC)
         if OMC != 27 * dg:
             om.zero_()

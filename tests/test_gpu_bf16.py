@@ -349,6 +349,8 @@ def _layer_local_checks(plan, net, name):
             m, xin = r['mod'], nchw(r['x_in'].float().cpu())
             om_ref = F.conv2d(xin, q(m.conv_offset_mask.weight.detach().cpu()), m.conv_offset_mask.bias.detach().cpu(), 1, 1)
             om = nchw(r['om'].cpu())
+            assert float(om[:, 27 * r['dg']:].abs().max()) == 0.0 if om.shape[1] > 27 * r['dg'] else True     # pad channels of the rows
+            om = om[:, :27 * r['dg']]
             worst['dcn.om'] = rel(om, om_ref)
             o1, o2, mk = torch.chunk(om, 3, dim=1)                       # the HIP path's own offsets / mask logits
             ref = O.dcn_v2_conv(xin, torch.cat((o1, o2), 1), torch.sigmoid(mk), q(m.weight.detach().cpu()), m.bias.detach().cpu(), 1, 1, 1,
@@ -535,6 +537,8 @@ def test_full_size_properties_bf16(dev, name):
     (2, 19, 19, 512, 512, 4),      # conv4_2 .. conv5_3: 128 -> 128, four output splits
     (1, 13, 9, 128, 96, 1),        # one group, 96 outputs: masked last split
     (3, 8, 16, 64, 64, 1),         # exactly one tile per image
+    (2, 19, 19, 512, 112, 1),      # dense (the DCN offset / mask conv): four 128-channel input blocks feed the same 112 outputs
+    (2, 10, 10, 256, 40, 1),       # dense, two input blocks, 40 outputs (heads with padded rows)
 ])
 @pytest.mark.parametrize('xf', [False, True])
 def test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf):
