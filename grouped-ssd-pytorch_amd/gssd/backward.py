@@ -150,6 +150,8 @@ class Bf16Shadow:
                 q['x16'] = r['x_in'] if r['x_in'].dtype == torch.bfloat16 else None
                 q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
             elif kind == 'sa':
+                bf = torch.bfloat16
+                q['x16'], q['ag16'] = (r['x_in'] if r['x_in'].dtype == bf else None), (r['ag'] if r['ag'].dtype == bf else None)
                 q['x_in'], q['out'], q['ag'] = S(r['x_in']), S(r['out']), S(r['ag'])
                 q['out2'] = S(r['out2']) if r['out2'] is not None else None
             else:
@@ -192,7 +194,7 @@ class Bf16Shadow:
                                              in_batch_stride=N * Cc, out_batch_stride=C2 * Np4)
                 self._keep.append((d, gT, w32, bg))
                 later.append((lib.gssd_conv2d_nhwc_f32, (C.byref(d),)))
-                q.update(gT=gT, Np=Np4, Nkp=Np4, lse=None)
+                q.update(gT=gT, Np=Np4, Nkp=Np4)          # (lse: the forward's own, fp32)
             elif kind == 'head':
                 i, Cs, A = r['i'], r['C'], r['A']
                 nloc = A * 4
@@ -397,7 +399,7 @@ class BackwardPlan:
             c[k] = t16
         return c[k]
 
-    def _nt_bf16(self, src, w, out, *, B, H, in_stride, cin_g, Cout, groups=1, k=1, pad=0, dil=1, resid=None, expect_H=None):
+    def _nt_bf16(self, src, w, out, *, B, H, in_stride, cin_g, Cout, groups=1, k=1, pad=0, dil=1, resid=None, expect_H=None, gate=None):
         """out (fp32 NHWC) [+= resid] = conv(src, w) with both operands rounded to bf16 for the launch (fp32 accumulate): two cast
         launches + gssd_conv2d_nhwc_bf16 with GSSD_CONV_OUT_F32 (| GSSD_CONV_RESID_F32)."""
         s16 = self._cast16(src)
@@ -405,7 +407,7 @@ class BackwardPlan:
         self.keep.append(w16)
         self._add(lib.gssd_cast_f32_bf16, (w.data_ptr(), w16.data_ptr(), w.numel()))
         d, Hout, _ = ops.make_conv_desc(s16, w16, out, B=B, H=H, W=H, in_stride=in_stride, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
-                                        pad=pad, dil=dil, resid=resid, wgt_row_stride=w.stride(0),
+                                        pad=pad, dil=dil, resid=resid, gate=gate, wgt_row_stride=w.stride(0),
                                         flags=_lib.CONV_OUT_F32 | (_lib.CONV_RESID_F32 if resid is not None else 0))
         assert expect_H is None or Hout == expect_H, (Hout, expect_H)
         self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, s16, w16))
@@ -428,6 +430,18 @@ class BackwardPlan:
             d, _, _ = ops.make_conv_desc(dyT[g * ng:], xT[g * cg:], dwp[g * ng:], B=1, H=1, W=ng, in_stride=Mp, cin_g=Mp, Cout=cg,
                                          wgt_row_stride=Mp, out_stride=ld_w, split_k=split, flags=_lib.CONV_OUT_F32)
             self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, dyT, xT), leaf=True)
+
+    def _wgrad_1x1_bf16(self, x16, ld_x, cin, dy16, cout, M, dwp, groups=1, in_xf=None, leaf=None):
+        """dwp[cout][cin / groups] (fp32, zero-filled each run) += dy^T x over M rows, both operands bf16 in their natural [row][channel]
+        layout: csrc/conv_wgrad_bf16.hip as a 1x1 "conv" over an (M / 16) x 16 pixel map.  False when the shape is not one of its."""
+        if M % 16:
+            return False
+        d, _, _ = ops.make_conv_desc(x16, None, None, B=1, H=M // 16, W=16, in_stride=ld_x, cin_g=cin // groups, Cout=cout, groups=groups,
+                                     in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None)
+        if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d)):
+            return False
+        self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d), dy16.data_ptr(), dwp.data_ptr()), keep=(d, x16, dy16), leaf=leaf)
+        return True
 
     def _wgrad(self, fdesc, dy, conv, cin_g_real, cin_g_pad, k, Cout, row0=0, param=None):
         """packed dW (zeroed each run) -> OIHW grad of ``param`` (rows [row0, row0 + param.shape[0]) of the packed matrix)."""
@@ -497,7 +511,9 @@ class BackwardPlan:
         d16 = None
         if self.bf16_ops and r.get('x16') is not None and cin_g_real == cin_g_pad:
             ix = r['in_xf']
-            d16, _, _ = ops.make_conv_desc(r['x16'], None, None, B=B, H=H, W=H, in_stride=r['Cin16'], cin_g=r['Cin16'] // groups, Cout=Cout,
+            flat = r['k'] == 1 and r['stride'] == 1 and r['pad'] == 0 and (B * H * H) % 16 == 0    # 1x1: the map as (M / 16) x 16 pixels
+            d16, _, _ = ops.make_conv_desc(r['x16'], None, None, B=1 if flat else B, H=B * H * H // 16 if flat else H, W=16 if flat else H,
+                                           in_stride=r['Cin16'], cin_g=r['Cin16'] // groups, Cout=Cout,
                                            groups=groups, k=r['k'], stride=r['stride'], pad=r['pad'], dil=r['dil'],
                                            in_scale=ix[0] if ix else None, in_shift=ix[1] if ix else None)
             if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d16)):
@@ -734,8 +750,11 @@ class BackwardPlan:
         wd_o = self._buf(C2, Cc)
         self._add(lib.gssd_scaled_transpose_f32, (w_o.data_ptr(), a_o.data_ptr(), wd_o.data_ptr(), Cc, C2), keep=w_o)
         dag = self._buf(B, N, C2)
-        d_dag, _, _ = mk(T, wd_o, dag, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2)
-        self._add(fn, (C.byref(d_dag),), keep=d_dag)
+        if self.bf16_ops:             # the block's four dense GEMMs over the tokens on the bf16 matrix cores (fp32 accumulation)
+            self._nt_bf16(T, wd_o, dag, B=B, H=H, in_stride=Cc, cin_g=Cc, Cout=C2)
+        else:
+            d_dag, _, _ = mk(T, wd_o, dag, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2)
+            self._add(fn, (C.byref(d_dag),), keep=d_dag)
         # sigma, o bias, o weight
         dot = self._buf(1, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_dot_f32, (dag.data_ptr(), ag.data_ptr(), M * C2, dot.data_ptr()))
@@ -746,7 +765,8 @@ class BackwardPlan:
         d_o, _, _ = mk(ag, None, None, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc)
         dwo = self._buf(Cc, C2, zero_each_run=True)
         sndot = self._buf(4, dtype=torch.float64, zero_each_run=True)      # <dW_eff, W> of the block's four convs
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_o), T.data_ptr(), dwo.data_ptr()), keep=d_o)
+        if not (self.bf16_ops and r.get('ag16') is not None and self._wgrad_1x1_bf16(r['ag16'], C2, C2, self._cast16(T), Cc, M, dwo)):
+            self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_o), T.data_ptr(), dwo.data_ptr()), keep=d_o)
         self._add(lib.gssd_sn_weight_grad_f32, (dwo.data_ptr(), C2, cv['attn'].weight_orig.data_ptr(), cv['attn'].weight_u.data_ptr(),
                                                 cv['attn'].weight_v.data_ptr(), a_o.data_ptr(), sig.data_ptr(), sndot[3:].data_ptr(),
                                                 self._pgrad(cv['attn'].weight_orig).data_ptr(), Cc, C2))
@@ -795,7 +815,8 @@ class BackwardPlan:
         # projection weights / biases
         d_p, _, _ = mk(x, None, None, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=CT)
         dwp = self._buf(CT, Cc, zero_each_run=True)
-        self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_p), dtpg.data_ptr(), dwp.data_ptr()), keep=d_p)
+        if not (self.bf16_ops and r.get('x16') is not None and self._wgrad_1x1_bf16(r['x16'], Cc, Cc, self._cast16(dtpg), CT, M, dwp)):
+            self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_p), dtpg.data_ptr(), dwp.data_ptr()), keep=d_p)
         csP = self._buf(CT, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dtpg.data_ptr(), M, CT, CT, csP.data_ptr()))
         for si, (key, row0, rows) in enumerate((('theta', 0, C8), ('phi', C8, C8), ('g', C4, C2))):
@@ -811,8 +832,12 @@ class BackwardPlan:
         if existed:
             resid = self._buf(B, H, H, Cc)
             self._add(lib.gssd_axpby_f32, (g_out.data_ptr(), gx.data_ptr(), resid.data_ptr(), M * Cc, 1.0, 1.0))
-        d_dx, _, _ = mk(dtpg, wd_p, gx, B=B, H=H, W=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
-        self._add(fn, (C.byref(d_dx),), keep=(d_dx, sig))
+        if self.bf16_ops:
+            self._nt_bf16(dtpg, wd_p, gx, B=B, H=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
+            self.keep.append(sig)
+        else:
+            d_dx, _, _ = mk(dtpg, wd_p, gx, B=B, H=H, W=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
+            self._add(fn, (C.byref(d_dx),), keep=(d_dx, sig))
 
     def _slice_cat(self, r):
         a, b, out, groups, Ca, Cb = r['a'], r['b'], r['out'], r['groups'], r['Ca'], r['Cb']

@@ -43,9 +43,10 @@ struct WgBfParams {
     const float* in_scale;
     const float* in_shift;
     int B, H, W, in_stride, in_ch_off, Cout, cout_g, co_splits, tiles_y, tiles_x;
-    // grouped: cout_goff = cout_g, k_row = 9 * CIN_G, k_tap = CIN_G, k_goff = 0.  Dense convs run as `groups` blocks of CIN_G input
-    // channels that all feed the SAME outputs: cout_goff = 0, k_row = 9 * Cin, k_tap = Cin, k_goff = CIN_G.
-    int cout_goff, k_row, k_tap, k_goff;
+    // A group's cin_g input channels are walked as bpg blocks of CIN_G channels (bpg = 1: the trunk's grouped convs; groups = 1: a dense
+    // conv as cin / CIN_G blocks feeding the same outputs).  Block blk = group * bpg + bi reads input channels [blk * CIN_G, + CIN_G),
+    // the group's cout_g output channels, and owns columns tap * cin_g + bi * CIN_G + .. of the packed rows (k_row = taps * cin_g).
+    int bpg, cin_g, k_row;
 };
 
 // swizzle of the 32-byte chunk index by the pixel column: NC chunks per pixel
@@ -59,14 +60,16 @@ __device__ __forceinline__ int swz(int col) {
 
 // CIN_G: input channels per group; NG: groups per workgroup (one wave each when NG == 4); a wave owns COB 16-channel output blocks and
 // EPW of the 9 * CIN_G / 16 (tap, 16-input-channel) entries; WCO x WEN waves per group (NG * WCO * WEN == 4).
-template <int CIN_G, int NG, int COB, int WCO, int WEN, bool XF>
+template <int CIN_G, int NG, int COB, int WCO, int WEN, bool XF, int NTAP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParams p) {
+    static_assert(NTAP == 9 || NTAP == 1, "3x3 (stride 1, pad 1) or 1x1");
     static_assert(NG * WCO * WEN == 4, "four waves");
 #ifndef SCHED_EVERY
 #define SCHED_EVERY 4
 #endif
-    constexpr int TH = 8, TW = 16, PW = TW + 2, NPATCH = (TH + 2) * PW, NPIX = TH * TW;
-    constexpr int NCI = CIN_G / 16, CPW = NCI / WEN, EPW = 9 * CPW;     // a wave's entries: 9 taps x CPW of the NCI 16-channel input chunks
+    constexpr int HALO = NTAP == 9 ? 1 : 0, NDX = NTAP == 9 ? 3 : 1;
+    constexpr int TH = 8, TW = 16, PW = TW + 2 * HALO, NPATCH = (TH + 2 * HALO) * PW, NPIX = TH * TW;
+    constexpr int NCI = CIN_G / 16, CPW = NCI / WEN, EPW = NTAP * CPW;  // a wave's entries: the taps x CPW of the NCI 16-channel input chunks
     static_assert(NCI % WEN == 0 && (CPW & (CPW - 1)) == 0 && (COB & (COB - 1)) == 0, "chunk split");
     constexpr int NCOW = 16 * COB * WCO;                    // output channels per group and workgroup
     constexpr int NC = NG * NCI;                            // 32-byte chunks per patch pixel
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
     const u16* in_g = p.in + p.in_ch_off + g0 * CIN_G;
     // dY channels of the workgroup: groups g0 .. g0 + NG - 1, channels [cs * NCOW, + NCOW) of each (NG > 1 only with co_splits == 1 and
     // NCOW == cout_g: one contiguous range)
-    const u16* dy_g = p.dy + g0 * p.cout_goff + cs * NCOW;
+    const int grp0 = g0 / p.bpg;
+    const u16* dy_g = p.dy + grp0 * p.cout_g + cs * NCOW;
 
     if constexpr (XF) {
         for (int i = tid; i < NG * CIN_G; i += 256) {
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
         a_addr[t] = ((((kq >> 1) * TW + col) * NCD) * 16 + (swz<NCD>(col) << 4) + sq * 4) ^ (((gl * WCO + wc) * COB) << 4);
     }
     // B (patch): column 8 t + 4 (kq & 1) + sj + dx, row 2 s + (kq >> 1) + dy
-    int b_addr[3][2];
+    int b_addr[NDX][2];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+    for (int dx = 0; dx < NDX; ++dx)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int col = 8 * t + 4 * (kq & 1) + sj + dx;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
             const int py = pp / PW, pxx = pp - py * PW;
             const int u = lane % UP;
             const int ch = (((u >> 1) ^ swz<NC>(pxx)) << 4) + ((u & 1) << 3);
-            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            const int iy = y0 - HALO + py, ix = x0 - HALO + pxx;
             const bool ok = pp < NPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const u16* src = ok ? in_g + ((size_t)(b * p.H + iy) * p.W + ix) * p.in_stride + ch : zero;
             dma16(src, patch + i * PPI * NC * 16);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
             for (int i = tid; i < NPATCH * UP; i += 256) {
                 const int pp = i / UP, u = i - pp * UP;
                 const int py = pp / PW, pxx = pp - py * PW;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+                const int iy = y0 - HALO + py, ix = x0 - HALO + pxx;
                 if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
                 const int ch = (((u >> 1) ^ swz<NC>(pxx)) << 4) + ((u & 1) << 3);
                 uint4* q = reinterpret_cast<uint4*>(patch + pp * NC * 16 + u * 8);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
             for (int t = 0; t < 2; ++t) {
                 asm volatile("" : "+v"(a_addr[t]));
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) asm volatile("" : "+v"(b_addr[dx][t]));
+                for (int dx = 0; dx < NDX; ++dx) asm volatile("" : "+v"(b_addr[dx][t]));
             }
             bf16x8 A[COB];
 #pragma unroll
@@ -230,17 +234,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParam
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (col0 + e >= p.cout_g) continue;
-                const int co = (g0 + gl) * p.cout_goff + col0 + e;
-                unsafeAtomicAdd(p.dw + (size_t)co * p.k_row + tap * p.k_tap + (g0 + gl) * p.k_goff + ct * 16 + r, acc[c][t][e]);
+                const int blk = g0 + gl, grp = blk / p.bpg, bi = blk - grp * p.bpg;
+                const int co = grp * p.cout_g + col0 + e;
+                unsafeAtomicAdd(p.dw + (size_t)co * p.k_row + tap * p.cin_g + bi * CIN_G + ct * 16 + r, acc[c][t][e]);
             }
         }
     }
 }
 
-template <int CIN_G, int NG, int COB, int WCO, int WEN, bool XF>
+template <int CIN_G, int NG, int COB, int WCO, int WEN, bool XF, int NTAP>
 int launch_wgrad_bf16(const gssd_conv_desc& d, const void* dy, float* dw, hipStream_t stream) {
     constexpr int NCI = CIN_G / 16, NC = NG * NCI, NCD = NG * COB * WCO, NCOW = 16 * COB * WCO;
-    constexpr int UP = 2 * NC, PPI = 64 / UP, NPI = (180 + PPI - 1) / PPI;
+    constexpr int NPATCH = NTAP == 9 ? 180 : 128;
+    constexpr int UP = 2 * NC, PPI = 64 / UP, NPI = (NPATCH + PPI - 1) / PPI;
     WgBfParams p;
     p.in = reinterpret_cast<const u16*>(d.in);
     p.dy = reinterpret_cast<const u16*>(dy);
@@ -253,18 +259,16 @@ int launch_wgrad_bf16(const gssd_conv_desc& d, const void* dy, float* dw, hipStr
     p.in_stride = d.in_stride;
     p.in_ch_off = d.in_ch_off;
     p.Cout = d.Cout;
-    const bool dense = d.groups == 1 && d.cin_g != CIN_G;          // blocks of CIN_G input channels, one set of outputs
-    const int nblk = dense ? d.cin_g / CIN_G : d.groups;
+    p.bpg = d.cin_g / CIN_G;
+    const int nblk = d.groups * p.bpg;
     p.cout_g = d.Cout / d.groups;
-    p.cout_goff = dense ? 0 : p.cout_g;
-    p.k_row = 9 * d.cin_g;
-    p.k_tap = d.cin_g;
-    p.k_goff = dense ? CIN_G : 0;
+    p.cin_g = d.cin_g;
+    p.k_row = NTAP * d.cin_g;
     p.co_splits = (p.cout_g + NCOW - 1) / NCOW;
     p.tiles_y = (d.H + 7) / 8;
     p.tiles_x = (d.W + 15) / 16;
     const size_t smem = ((size_t)NPI * PPI * NC * 16 + 128 * NCD * 16) * sizeof(u16) + 2 * NG * CIN_G * sizeof(float);
-    auto kern = conv_wgrad_bf16_kernel<CIN_G, NG, COB, WCO, WEN, XF>;
+    auto kern = conv_wgrad_bf16_kernel<CIN_G, NG, COB, WCO, WEN, XF, NTAP>;
     static unsigned attr_mask = 0;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
@@ -285,15 +289,16 @@ int launch_wgrad_bf16(const gssd_conv_desc& d, const void* dy, float* dw, hipStr
 }
 
 bool shape_ok(const gssd_conv_desc& d) {
-    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && !d.m_per_image && d.groups > 0)) return false;
-    if (d.Cout % d.groups || d.in_stride % 8 || d.in_ch_off % 8 || d.Cout % 8) return false;
+    const bool k3 = d.KH == 3 && d.KW == 3 && d.pad == 1, k1 = d.KH == 1 && d.KW == 1 && d.pad == 0;
+    if (!((k3 || k1) && d.stride == 1 && d.dil == 1 && !d.m_per_image && d.groups > 0)) return false;
+    if (d.Cout % d.groups || d.in_stride % 8 || d.in_ch_off % 8 || d.Cout % 8 || (d.Cout / d.groups) % 8) return false;
     if ((long long)d.B * d.H * d.W * d.in_stride >= (1ll << 31) || (long long)d.B * d.H * d.W * d.Cout >= (1ll << 31)) return false;
     const int cg = d.cin_g, ng = d.Cout / d.groups;
-    if (d.groups == 1 && cg > 128) return cg % 128 == 0;      // dense: 128-channel input blocks, any multiple of 8 outputs
+    if (cg > 128) return cg % 128 == 0;                       // 128-channel input blocks of a group (dense convs: one group)
+    if (k1) return cg == 128 || cg == 64;
     if (d.groups % 4 == 0 && ((cg == 16 && (ng == 16 || ng == 32)) || (cg == 32 && ng == 32))) return true;
     if (cg == 32 || cg == 64) return ng % 64 == 0;
-    if (cg == 128) return ng % 32 == 0 || d.groups == 1;
-    return false;
+    return cg == 128;
 }
 
 }  // namespace
@@ -312,9 +317,14 @@ extern "C" int gssd_conv2d_wgrad_bf16(const gssd_conv_desc* dp, const void* dy, 
     }
     const int cg = d.cin_g, ng = d.Cout / d.groups;
     hipStream_t s = as_stream(stream);
-#define GSSD_WB(CI, NG_, COB_, WCO_, WEN_)                                                                       \
-    return d.in_scale ? launch_wgrad_bf16<CI, NG_, COB_, WCO_, WEN_, true>(d, dy, dw_packed, s)                  \
-                      : launch_wgrad_bf16<CI, NG_, COB_, WCO_, WEN_, false>(d, dy, dw_packed, s);
+#define GSSD_WB1(CI, NG_, COB_, WCO_, WEN_, NT)                                                                  \
+    return d.in_scale ? launch_wgrad_bf16<CI, NG_, COB_, WCO_, WEN_, true, NT>(d, dy, dw_packed, s)              \
+                      : launch_wgrad_bf16<CI, NG_, COB_, WCO_, WEN_, false, NT>(d, dy, dw_packed, s);
+#define GSSD_WB(CI, NG_, COB_, WCO_, WEN_) GSSD_WB1(CI, NG_, COB_, WCO_, WEN_, 9)
+    if (d.KH == 1) {                                             // 1x1: the tile is the patch; 64 output channels per workgroup
+        if (cg == 64) { GSSD_WB1(64, 1, 4, 1, 4, 1) }
+        GSSD_WB1(128, 1, 4, 1, 4, 1)                             // (cg a multiple of 128: blocks)
+    }
     if (cg == 16 && ng == 16) { GSSD_WB(16, 4, 1, 1, 1) }        // conv1_2: a wave per phase group, 9 tiles
     if (cg == 16 && ng == 32) { GSSD_WB(16, 4, 2, 1, 1) }        // conv2_1: 18 tiles per wave
     if (cg == 32 && ng == 32 && d.groups % 4 == 0) { GSSD_WB(32, 4, 2, 1, 1) }        // conv2_2: 36 tiles per wave
@@ -323,4 +333,5 @@ extern "C" int gssd_conv2d_wgrad_bf16(const gssd_conv_desc* dp, const void* dy, 
     GSSD_WB(128, 1, 2, 1, 4)                                     // conv4_2 .. conv5_3 and the dense convs (DCN offset / mask conv, heads): 32
                                                                  // output channels per workgroup, 36 tiles per wave
 #undef GSSD_WB
+#undef GSSD_WB1
 }

@@ -218,7 +218,8 @@ typedef unsigned short u16;
 
 template <int D, int C2, int BKV>
 __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* __restrict__ tp, const u16* __restrict__ gT,
-                                                                  u16* __restrict__ out, int N, int Np32, int qtiles) {
+                                                                  u16* __restrict__ out, int N, int Np32, int qtiles,
+                                                                  float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                                            // [BKV][D] fp32
     u16* const Vs = reinterpret_cast<u16*>(smem + BKV * D);            // [C2][BKV] bf16, keys permuted inside 32-blocks
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_run;
+    if (lse != nullptr && q < N && kq == 0) lse[(size_t)b * N + q] = m_run + logf(l_run);       // for the training step's backward
     if (q < N) {
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         u16* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
 }
 
 template <int D, int C2, int BKV>
-int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np32, hipStream_t stream) {
+int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np32, float* lse, hipStream_t stream) {
     constexpr int smem = BKV * D * (int)sizeof(float) + C2 * BKV * (int)sizeof(u16);
     static unsigned attr_mask = 0;
     auto kern = flash_attn_mixed_kernel<D, C2, BKV>;
@@ -351,7 +353,7 @@ int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np3
     }
     gssd_attr_done(&attr_mask);
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles, lse);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -382,16 +384,16 @@ extern "C" int gssd_self_attn_core_f32(const float* tp, const float* gT, void* o
 }
 
 extern "C" int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,
-                                         gssd_stream_t stream) {
+                                         float* lse, gssd_stream_t stream) {
     GSSD_CHECK_ARG(tp && gT_bf16 && out_bf16 && B > 0 && N > 0 && Np32 >= N && Np32 % 32 == 0);
     GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)gT_bf16 % 16) == 0 && ((uintptr_t)out_bf16 % 8) == 0);
     GSSD_CHECK_ARG((long long)B * ((N + 63) / 64) < (1ll << 31));
     hipStream_t s = as_stream(stream);
     const u16* g = reinterpret_cast<const u16*>(gT_bf16);
     u16* o = reinterpret_cast<u16*>(out_bf16);
-    if (D == 64 && C2 == 256) return launch_mixed<64, 256, 64>(tp, g, o, B, N, Np32, s);
-    if (D == 128 && C2 == 512) return launch_mixed<128, 512, 32>(tp, g, o, B, N, Np32, s);
-    if (D == 32 && C2 == 128) return launch_mixed<32, 128, 64>(tp, g, o, B, N, Np32, s);
+    if (D == 64 && C2 == 256) return launch_mixed<64, 256, 64>(tp, g, o, B, N, Np32, lse, s);
+    if (D == 128 && C2 == 512) return launch_mixed<128, 512, 32>(tp, g, o, B, N, Np32, lse, s);
+    if (D == 32 && C2 == 128) return launch_mixed<32, 128, 64>(tp, g, o, B, N, Np32, lse, s);
     gssd_set_error("self-attention core (bf16 values): unsupported (theta/phi channels %d, g channels %d)", D, C2);
     return GSSD_EINVAL;
 }

@@ -859,7 +859,7 @@ class _Plan(_PlanBase):
             self._add(fn, (C.byref(d1a),), keep=(d1a, w_tpg, b_tpg))
             self._add(fn, (C.byref(d1b),), keep=d1b)
         # training keeps the rows' log-sum-exp: the backward rebuilds the probabilities from it in a GEMM epilogue
-        lse = self._buf(B, N) if (self.training and not self.bf16) else None
+        lse = self._buf(B, N) if self.training else None
         # max_pool_factor > 1 (layers/self_attn.py:57-59, 67, 76): keys / values average-pooled to a P x P grid before the core
         P = max(H // int(sa.max_pool_factor), 1)
         pooled = P != H
@@ -874,7 +874,8 @@ class _Plan(_PlanBase):
                                                        C8, 0, lse.data_ptr() if lse is not None else 0),
                       tag=(f'flash_attn<{C8},{C2}>', 2.0 * B * N * Nk * (C8 + C2), 4.0 * B * (N * C8 + Nk * C8 + C2 * Nkp + N * C2)))
         elif self.bf16:
-            self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2),
+            self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2,
+                                                      lse.data_ptr() if lse is not None else 0),
                       tag=(f'flash_attn_bf16v<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), B * (4.0 * N * C4 + 2.0 * C2 * Np + 2.0 * N * C2)))
         else:
             self._add(lib.gssd_self_attn_core_kv_f32, (tp.data_ptr(), tp[0, 0, C8:].data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, N, Np,

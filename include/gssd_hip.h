@@ -325,9 +325,10 @@ int gssd_conv_flat_bf16_tile(int pixels_per_workgroup);
 
 /* bf16-storage variant (configs[4]): theta | phi fp32 and the logits on the fp32 matrix cores (a bf16 logit would move its
  * probability by tens of percent), g^T and the probabilities bf16 on v_mfma_f32_16x16x32_bf16 (80 % of the block's FLOPs), out bf16.
- * gT rows are Np32 (multiple of 32) bf16 long with the token order of GSSD_CONV_OUTB_BF16_PERM32. */
+ * gT rows are Np32 (multiple of 32) bf16 long with the token order of GSSD_CONV_OUTB_BF16_PERM32.
+ * lse (optional, [B][N] fp32): the rows' log-sum-exp, kept by training forwards for the backward's exp(s - lse) GEMM epilogue. */
 int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf16, int B, int N, int Np32, int D, int C2,
-                              gssd_stream_t stream);
+                              float* lse, gssd_stream_t stream);
 
 /* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
  * Replaces nn.Softmax(dim=-1) on the attention logits (layers/self_attn.py:72). */

@@ -541,7 +541,7 @@ def test_full_size_properties_bf16(dev, name):
     (2, 10, 10, 256, 40, 1),       # dense, two input blocks, 40 outputs (heads with padded rows)
 ])
 @pytest.mark.parametrize('xf', [False, True])
-def test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf):
+def test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf, k=3):
     """gssd_conv2d_wgrad_bf16 (csrc/conv_wgrad_bf16.hip: LDS transpose reads feeding v_mfma_f32_16x16x32_bf16) against the float64 weight
     gradient of the conv over the SAME bf16 operands: the input after its deferred BatchNorm + ReLU rounded to bf16 (what the forward's
     MFMA saw), d(output) rounded to bf16.  Random operands with a distinct value everywhere: a wrong tap, transposed fragment or swizzle
@@ -559,26 +559,39 @@ def test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf):
     if xf:
         x = q(torch.relu(x * sc[off:off + Cin] + sh[off:off + Cin]))
     xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
-    w = torch.zeros(Cout, Cin // groups, 3, 3, dtype=torch.float64, requires_grad=True)
-    y = torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, groups)
+    w = torch.zeros(Cout, Cin // groups, k, k, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, w, None, 1, k // 2, 1, groups)
     (y * dy.permute(0, 3, 1, 2).double()).sum().backward()
     ref = w.grad
     xd, dyd = xs.to(dev).to(torch.bfloat16), dy.to(dev).to(torch.bfloat16)
     scd, shd = sc.to(dev), sh.to(dev)
     cg = Cin // groups
-    d, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=3, pad=1,
+    d, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=k, pad=k // 2,
                                  in_scale=scd if xf else None, in_shift=shd if xf else None)
     assert _lib.lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d)) == 1
-    dwp = torch.zeros(Cout, 9 * cg, device=dev)
+    dwp = torch.zeros(Cout, k * k * cg, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(2):         # accumulates: two launches = twice the gradient
         _lib.check(_lib.lib.gssd_conv2d_wgrad_bf16(C.byref(d), dyd.data_ptr(), dwp.data_ptr(), st))
-    got = (dwp.cpu().double() / 2).view(Cout, 9, cg).permute(0, 2, 1).reshape(Cout, cg, 3, 3)
+    got = (dwp.cpu().double() / 2).view(Cout, k * k, cg).permute(0, 2, 1).reshape(Cout, cg, k, k)
     assert rel(got, ref) < 2e-5, rel(got, ref)
     # not a supported shape: refused, no fallback
-    d2, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=1)
+    d2, _, _ = ops.make_conv_desc(xd, None, None, B=B, H=H, W=W, in_stride=ld, in_ch_off=off, cin_g=cg, Cout=Cout, groups=groups, k=3, pad=1,
+                                  stride=2)
     assert _lib.lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d2)) == 0
     assert _lib.lib.gssd_conv2d_wgrad_bf16(C.byref(d2), dyd.data_ptr(), dwp.data_ptr(), st) == -1      # GSSD_EINVAL
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,groups', [
+    (1, 45, 16, 512, 384, 1),      # Self_Attn's merged projection: dense 1x1, four input blocks, six output splits
+    (1, 23, 16, 256, 512, 1),      # the o conv
+    (2, 19, 19, 1024, 1024, 4),    # conv7: grouped 1x1, two 128-channel blocks per group
+    (1, 5, 16, 64, 24, 1),         # one 64-channel block, masked outputs
+])
+@pytest.mark.parametrize('xf', [False, True])
+def test_conv_wgrad_bf16_1x1(dev, B, H, W, Cin, Cout, groups, xf):
+    """The 1x1 form of csrc/conv_wgrad_bf16.hip (the tile is the patch): dense and grouped, input blocks inside a group."""
+    test_conv_wgrad_bf16(dev, B, H, W, Cin, Cout, groups, xf, k=1)
 
 
 @pytest.mark.parametrize('M,cin,cout,groups', [(4 * 19 * 19, 1152, 512, 1), (1000, 72, 40, 1), (777, 256, 512, 4), (64, 8, 8, 1)])
@@ -722,10 +735,12 @@ def test_self_attn_core_bf16_values(dev, N, D, C2):
     gp[:, :, perm[:N]] = g
     d_tp, d_g = tp.to(dev), gp.to(dev).to(torch.bfloat16)
     out = torch.full((B, N, C2), float('nan'), device=dev, dtype=torch.bfloat16)
-    _lib.check(lib.gssd_self_attn_core_bf16v(d_tp.data_ptr(), d_g.data_ptr(), out.data_ptr(), B, N, Np, D, C2,
+    lse = torch.full((B, N), float('nan'), device=dev)
+    _lib.check(lib.gssd_self_attn_core_bf16v(d_tp.data_ptr(), d_g.data_ptr(), out.data_ptr(), B, N, Np, D, C2, lse.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     s = torch.bmm(tp[:, :, :D].double(), tp[:, :, D:].double().transpose(1, 2))
+    assert float((lse.cpu().double() - torch.logsumexp(s, dim=-1)).abs().max()) < 2e-3      # (the denominator sums bf16-rounded probabilities) what the training step's backward reads
     p = q(torch.exp(s - s.max(dim=-1, keepdim=True).values).float()).double()
     ref = torch.bmm(p, q(g).double().transpose(1, 2)) / p.sum(dim=-1, keepdim=True)
     got = out.float().cpu().double()
