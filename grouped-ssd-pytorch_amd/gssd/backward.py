@@ -863,15 +863,27 @@ class BackwardPlan:
         dy = self._grad_of(r['out'])
         Kc = 9 * Cin
         # the fused forward keeps no column matrix: rebuild it here for the weight gradient
-        cols = self._buf(B * H * H, Kc)
-        OMC = r['omc']                           # channel stride of the offset / mask rows (27 * dg rounded up to 4)
-        self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, OMC))
+        OMC = r['omc']                           # channel stride of the offset / mask rows (27 * dg rounded up to 4; 8 in bf16 mode)
+        M = B * H * H
+        cols16 = None
+        if self.bf16_ops and r.get('x16') is not None and M % 16 == 0:
+            # bf16 storage mode: the columns in bf16 from the bf16 map the forward sampled; the weight gradient reads them as they are
+            cols16 = torch.empty(M, Kc, device=self.dev, dtype=torch.bfloat16)
+            self.keep.append(cols16)
+            self._add(lib.gssd_dcn_im2col_bf16, (r['x16'].data_ptr(), om.data_ptr(), cols16.data_ptr(), B, H, H, Cin, dg, OMC), leaf=True)
+        else:
+            cols = self._buf(B * H * H, Kc)
+            self._add(lib.gssd_dcn_im2col_f32, (x.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cin, dg, OMC))
         w_main = self._buf(Cout, Kc)
         self._add(lib.gssd_pack_conv_weight, (m.weight.data_ptr(), w_main.data_ptr(), Cout, Cin, 3, 3, Cin, Kc), keep=m)
         # main weight / bias: dW[Cout][9*Cin] = dY^T . cols, d(cols) = dY . W  -- the slot-scheduled TN / NT GEMMs (csrc/wgrad_slot.hip, csrc/gemm_slot.hip; no vendor library)
         dwp = self._buf(Cout, Kc, zero_each_run=True)
-        if self.bf16_ops:
-            self._wgrad_nt_bf16(cols, Kc, Kc, dy, Cout, Cout, B * H * H, dwp, Kc)            # 436 GFLOP: 3.3 ms as an fp32 TN GEMM
+        if cols16 is not None and self._wgrad_1x1_bf16(cols16, Kc, Kc, self._cast16(dy), Cout, M, dwp, leaf=True):
+            pass                                                                             # 436 GFLOP: 3.3 ms as an fp32 TN GEMM
+        elif cols16 is not None:
+            raise _lib.GssdError('deformable conv: no bf16 weight-gradient kernel for this shape')
+        elif self.bf16_ops:
+            self._wgrad_nt_bf16(cols, Kc, Kc, dy, Cout, Cout, B * H * H, dwp, Kc)
         else:
             d_c, _, _ = ops.make_conv_desc(cols, None, None, B=B, H=H, W=H, in_stride=Kc, cin_g=Kc, Cout=Cout)
             self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_c), dy.data_ptr(), dwp.data_ptr()), keep=d_c)

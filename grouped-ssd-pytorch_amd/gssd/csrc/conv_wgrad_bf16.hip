@@ -323,6 +323,8 @@ extern "C" int gssd_conv2d_wgrad_bf16(const gssd_conv_desc* dp, const void* dy, 
 #define GSSD_WB(CI, NG_, COB_, WCO_, WEN_) GSSD_WB1(CI, NG_, COB_, WCO_, WEN_, 9)
     if (d.KH == 1) {                                             // 1x1: the tile is the patch; 64 output channels per workgroup
         if (cg == 64) { GSSD_WB1(64, 1, 4, 1, 4, 1) }
+        // long rows (the deformable conv's 9 * Cin columns): 128 x 128 gradient blocks halve the L2 -> LDS traffic per MFMA
+        if (cg >= 2048 && ng % 128 == 0) { GSSD_WB1(128, 1, 4, 2, 2, 1) }
         GSSD_WB1(128, 1, 4, 1, 4, 1)                             // (cg a multiple of 128: blocks)
     }
     if (cg == 16 && ng == 16) { GSSD_WB(16, 4, 1, 1, 1) }        // conv1_2: a wave per phase group, 9 tiles

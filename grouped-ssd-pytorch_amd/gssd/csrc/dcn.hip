@@ -11,8 +11,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict__ x, const float* __restrict__ om,
-                                                         float* __restrict__ cols, int B, int H, int W, int C, int dg,
+// element type of the sampled map / of the column matrix: fp32, or bf16 for the training step of the bf16 storage mode (the forward
+// sampled the SAME bf16 map, interpolated in fp32 and rounded its columns to bf16: csrc/dcn_bf16.hip)
+template <typename T>
+__device__ __forceinline__ f32x4 ld4c(const T* p, int c);
+template <>
+__device__ __forceinline__ f32x4 ld4c<float>(const float* p, int c) {
+    return reinterpret_cast<const f32x4*>(p)[c];
+}
+template <>
+__device__ __forceinline__ f32x4 ld4c<unsigned short>(const unsigned short* p, int c) {
+    const uint2 v = reinterpret_cast<const uint2*>(p)[c];
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void st4c(float* p, int c, const f32x4 v) { reinterpret_cast<f32x4*>(p)[c] = v; }
+__device__ __forceinline__ void st4c(unsigned short* p, int c, const f32x4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<bf16x4*>(p)[c] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                         T* __restrict__ cols, int B, int H, int W, int C, int dg,
                                                          int om_stride) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
@@ -35,9 +56,9 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
         const float m = 1.f / (1.f + expf(-ml));            // torch.sigmoid (dcn_v2_custom.py:83)
         const float py = (float)(h - 1 + tap / 3) + dy;
         const float px = (float)(w - 1 + tap % 3) + dx;
-        float* dst = cols + (bp * 9 + tap) * C + d * cpg;
+        T* dst = cols + (bp * 9 + tap) * C + d * cpg;
         if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) {
-            for (int c = lane; c < cpg4; c += 64) reinterpret_cast<f32x4*>(dst)[c] = zero4;
+            for (int c = lane; c < cpg4; c += 64) st4c(dst, c, zero4);
             continue;
         }
         const float y0f = floorf(py), x0f = floorf(px);
@@ -48,14 +69,14 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
         const float w01 = (y0ok && x1ok) ? hy * lx * m : 0.f;
         const float w10 = (y1ok && x0ok) ? ly * hx * m : 0.f;
         const float w11 = (y1ok && x1ok) ? ly * lx * m : 0.f;
-        const float* xb = x + (size_t)b * HW * C + d * cpg;
-        const f32x4* p00 = reinterpret_cast<const f32x4*>(xb + (size_t)((y0ok ? y0 : 0) * W + (x0ok ? x0 : 0)) * C);
-        const f32x4* p01 = reinterpret_cast<const f32x4*>(xb + (size_t)((y0ok ? y0 : 0) * W + (x1ok ? x0 + 1 : 0)) * C);
-        const f32x4* p10 = reinterpret_cast<const f32x4*>(xb + (size_t)((y1ok ? y0 + 1 : 0) * W + (x0ok ? x0 : 0)) * C);
-        const f32x4* p11 = reinterpret_cast<const f32x4*>(xb + (size_t)((y1ok ? y0 + 1 : 0) * W + (x1ok ? x0 + 1 : 0)) * C);
+        const T* xb = x + (size_t)b * HW * C + d * cpg;
+        const T* p00 = xb + (size_t)((y0ok ? y0 : 0) * W + (x0ok ? x0 : 0)) * C;
+        const T* p01 = xb + (size_t)((y0ok ? y0 : 0) * W + (x1ok ? x0 + 1 : 0)) * C;
+        const T* p10 = xb + (size_t)((y1ok ? y0 + 1 : 0) * W + (x0ok ? x0 : 0)) * C;
+        const T* p11 = xb + (size_t)((y1ok ? y0 + 1 : 0) * W + (x1ok ? x0 + 1 : 0)) * C;
         for (int c = lane; c < cpg4; c += 64) {
-            const f32x4 v = p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11;
-            reinterpret_cast<f32x4*>(dst)[c] = v;
+            const f32x4 v = ld4c<T>(p00, c) * w00 + ld4c<T>(p01, c) * w01 + ld4c<T>(p10, c) * w10 + ld4c<T>(p11, c) * w11;
+            st4c(dst, c, v);
         }
     }
 }
@@ -388,7 +409,21 @@ extern "C" int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols,
     const long long units = (long long)B * H * W * 9 * dg;
     long long blocks = (units + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(dcn_im2col_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, om, cols, B, H, W, C, dg,
+    hipLaunchKernelGGL(dcn_im2col_kernel<float>, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, om, cols, B, H, W, C, dg,
+                       om_stride);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_dcn_im2col_bf16(const void* x_bf16, const float* om, void* cols_bf16, int B, int H, int W, int C, int dg,
+                                    int om_stride, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x_bf16 && om && cols_bf16 && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0);
+    GSSD_CHECK_ARG(C % (4 * dg) == 0 && om_stride >= 27 * dg && ((uintptr_t)x_bf16 % 8) == 0 && ((uintptr_t)cols_bf16 % 8) == 0);
+    const long long units = (long long)B * H * W * 9 * dg;
+    long long blocks = (units + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(dcn_im2col_kernel<unsigned short>, dim3((int)blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned short*>(x_bf16), om, reinterpret_cast<unsigned short*>(cols_bf16), B, H, W, C, dg,
                        om_stride);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

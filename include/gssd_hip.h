@@ -362,6 +362,10 @@ int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int do_power_it
  */
 int gssd_dcn_im2col_f32(const float* x, const float* om, float* cols, int B, int H, int W, int C, int dg,
                         int om_stride, gssd_stream_t stream);
+/* The same column matrix in bf16 from the bf16 map the bf16 forward sampled (fp32 interpolation, rounded once): the operand of the
+ * training step's bf16 weight gradient. */
+int gssd_dcn_im2col_bf16(const void* x_bf16, const float* om, void* cols_bf16, int B, int H, int W, int C, int dg, int om_stride,
+                         gssd_stream_t stream);
 
 /* Fused modulated deformable 3x3 conv (stride 1 / pad 1 / dil 1): sampling + contraction + bias in one kernel, no column
  * buffer.  Replaces the whole `_DCNv2.apply(input, offset, mask, weight, bias, ...)` call of layers/dcn_v2_custom.py:84-89
