@@ -60,6 +60,7 @@ SIGNATURES = {
     'gssd_conv2d_nhwc_bf16': (c_i, [C.POINTER(ConvDesc), c_fp]),
     'gssd_pack_conv_weight_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_cast_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_fp]),
+    'gssd_cast_rows_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
     'gssd_transpose_cast_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_i, c_i64, c_i64, c_fp]),
     'gssd_cast_bf16_f32': (c_i, [c_fp, c_fp, c_i64, c_fp]),
     'gssd_pack_input_nhwc_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),

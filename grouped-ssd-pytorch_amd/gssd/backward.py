@@ -141,6 +141,7 @@ class Bf16Shadow:
                 q['out'] = q['raw'] if r['out'] is r['raw'] else S(r['out'], lz)
                 q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'], r.get('stats_rep', 0))
             elif kind == 'head':
+                q['src16'] = r['src'] if r['src'].dtype == torch.bfloat16 else None
                 q['src'] = S(r['src'])
             elif kind in ('pool', 'l2norm'):
                 q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
@@ -467,8 +468,24 @@ class BackwardPlan:
         dyh = self._buf(B, H, H, Cout)
         self._add(lib.gssd_heads_gather_f32, (self.dloc.data_ptr(), self.dconf.data_ptr(), dyh.data_ptr(), B, H * H, A, nc,
                                               self.plan.P, r['off']))
-        fdesc, _, _ = ops.make_conv_desc(r['src'], None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=Cout, k=3, pad=1)
-        dwp, K = self._wgrad(fdesc, dyh, None, Cs, Cs, 3, Cout)
+        Cp = ops.round_up(Cout, 8)
+        d16 = None
+        if self.bf16_ops and r.get('src16') is not None:
+            d16, _, _ = ops.make_conv_desc(r['src16'], None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=Cp, k=3, pad=1)
+            if not lib.gssd_conv2d_wgrad_bf16_supported(C.byref(d16)):
+                d16 = None
+        if d16 is not None:
+            # bf16 storage mode: the merged head gradient widened to a multiple of 8 channels (bf16, zero pad), both GEMMs on bf16
+            dyh16 = torch.empty(B, H, H, Cp, device=self.dev, dtype=torch.bfloat16)
+            self.keep.append(dyh16)
+            self._add(lib.gssd_cast_rows_f32_bf16, (dyh.data_ptr(), dyh16.data_ptr(), B * H * H, Cout, Cout, Cp))
+            self.__dict__.setdefault('_c16', {})[dyh.data_ptr()] = dyh16
+            K = 9 * Cs
+            dwp = self._buf(Cp, K, zero_each_run=True)
+            self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d16), dyh16.data_ptr(), dwp.data_ptr()), keep=d16, leaf=True)
+        else:
+            fdesc, _, _ = ops.make_conv_desc(r['src'], None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=Cout, k=3, pad=1)
+            dwp, K = self._wgrad(fdesc, dyh, None, Cs, Cs, 3, Cout)
         self._unpack(dwp, K, 0, r['loc'].weight, Cs, Cs, 3)
         self._unpack(dwp, K, A * 4, r['conf'].weight, Cs, Cs, 3)
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
@@ -476,13 +493,19 @@ class BackwardPlan:
         self._bias_from_colsum(cs, r['loc'].bias, 0)
         self._bias_from_colsum(cs, r['conf'].bias, A * 4)
         # d(source): the merged head weight [Cout][9*Cs] viewed as one conv
-        wd = self._buf(Cs, 9 * Cout)
         hw = self.plan.eng._packed[f"heads.{r['i']}.w"]          # packed forward rows [Cout][9*Cs] (k = tap*Cs + c)
-        self._add(_pack_dgrad_from_packed, (hw, wd, Cout, Cs))
         existing = self._grad_of(r['src'])
         g = existing if existing is not None else self._buf(B, H, H, Cs)
-        d, _, _ = ops.make_conv_desc(dyh, wd, g, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Cs, k=3, pad=1, resid=existing)
-        self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
+        if d16 is not None:
+            wd = torch.zeros(Cs, 9 * Cp, device=self.dev)          # pad columns stay zero
+            self.keep.append(wd)
+            self._add(_pack_dgrad_from_packed, (hw, wd, Cout, Cs, Cp))
+            self._nt_bf16(dyh, wd, g, B=B, H=H, in_stride=Cp, cin_g=Cp, Cout=Cs, k=3, pad=1, resid=existing, expect_H=H)
+        else:
+            wd = self._buf(Cs, 9 * Cout)
+            self._add(_pack_dgrad_from_packed, (hw, wd, Cout, Cs))
+            d, _, _ = ops.make_conv_desc(dyh, wd, g, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Cs, k=3, pad=1, resid=existing)
+            self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
         self.gbuf[r['src'].data_ptr()] = g
 
     def _convbn(self, r, need_dgrad=True):
@@ -1121,6 +1144,10 @@ def conv_weight_ptr(conv, cin_g_expected):
     return conv.weight.data_ptr()
 
 
-def _pack_dgrad_from_packed(hw, wd, Cout, Cs):
-    """Merged head weights [Cout][9][Cs] (forward packing) -> dgrad rows [Cs][9 flipped][Cout] (tiny: plain tensor ops)."""
-    wd.copy_(hw.view(Cout, 9, Cs).flip(1).permute(2, 1, 0).reshape(Cs, 9 * Cout))
+def _pack_dgrad_from_packed(hw, wd, Cout, Cs, Cp=None):
+    """Merged head weights [Cout][9][Cs] (forward packing) -> dgrad rows [Cs][9 flipped][Cout] (tiny: plain tensor ops); ``Cp``: the
+    rows' channel count widened to Cp (the pad stays zero)."""
+    if Cp is None or Cp == Cout:
+        wd.copy_(hw.view(Cout, 9, Cs).flip(1).permute(2, 1, 0).reshape(Cs, 9 * Cout))
+    else:
+        wd.view(Cs, 9, Cp)[:, :, :Cout].copy_(hw.view(Cout, 9, Cs).flip(1).permute(2, 1, 0))

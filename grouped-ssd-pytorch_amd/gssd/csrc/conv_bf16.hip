@@ -468,7 +468,27 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ x, float* __restric
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[8 * n8 + threadIdx.x] = bf2f(x[8 * n8 + threadIdx.x]);
 }
 
+// y[r][c] = bf16(x[r][c]) for c < cols, 0 for cols <= c < ld_y: rows widened to a multiple of 8 channels for the 16-byte lanes of the
+// bf16 kernels (the merged head gradients: 36 -> 40 channels)
+__global__ void cast_rows_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, long long rows, int cols, int ld_x, int ld_y) {
+    const long long total = rows * ld_y;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld_y;
+        const int c = (int)(i - r * ld_y);
+        y[i] = c < cols ? f2bf(x[r * ld_x + c]) : (u16)0;
+    }
+}
+
 }  // namespace
+
+extern "C" int gssd_cast_rows_f32_bf16(const float* x, void* y, int64_t rows, int cols, int ld_x, int ld_y, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_x >= cols && ld_y >= cols);
+    const long long total = rows * ld_y;
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), x, reinterpret_cast<u16*>(y), (long long)rows, cols, ld_x, ld_y);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
 
 extern "C" int gssd_cast_bf16_f32(const void* x, float* y, int64_t n, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && y && n > 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0);

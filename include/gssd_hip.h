@@ -471,6 +471,8 @@ int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, in
 /* y[c][r] = bf16(x[r][c]) for r < rows, c < cols; x rows ld_x floats apart, y rows ld_y bf16 apart (ld_y >= rows, a multiple of 8).  The
  * bf16 storage mode's weight gradients dW[n][k] = sum_m dY[m][n] A[m][k] run as NT GEMMs over the transposed operands (reduction index
  * m contiguous) on the bf16 matrix cores: gssd_conv2d_nhwc_bf16 with in = dY^T, wgt = A^T, split_k > 1, GSSD_CONV_OUT_F32. */
+/* y[r][c] = bf16(x[r][c]) for c < cols and 0 for cols <= c < ld_y (rows widened to a multiple of 8 channels for the bf16 kernels). */
+int gssd_cast_rows_f32_bf16(const float* x, void* y, int64_t rows, int cols, int ld_x, int ld_y, gssd_stream_t stream);
 int gssd_transpose_cast_f32_bf16(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, gssd_stream_t stream);
 /* *out += sum a[i]*b[i] (fp64); out = a*x + b*y; y = scale[0]*x (fp64 -> fp32); d(sigma) = dot[0] + sum_c bias[c]*colsum[c] */
 int gssd_dot_f32(const float* a, const float* b, int64_t n, double* out, gssd_stream_t stream);
