@@ -55,17 +55,19 @@ class _EngView:
 class Bf16Shadow:
     """fp32 view of a bf16-storage forward plan (BASELINE.json configs[4] as a TRAINING config,
     train_lesion_multiphase_v2.py:242-253): the backward of the bf16 mode is mixed precision -- the forward computed and STORED its
-    activations in bf16 (bf16 MFMA, fp32 accumulate); the backward runs the fp32 backward plan (fp32 master weights, fp32 gradients,
-    fp32 MFMA) on exact fp32 copies of those stored activations, i.e. it differentiates the fp32 graph AT the rounded activations
-    (straight-through rounding; the oracle's ``bf16='ste'``).  What the bf16 forward does not keep in a form the fp32 backward reads is
-    rebuilt at the start of every backward (``pre`` steps, on the main stream before the branch streams fork):
-      * one gssd_cast_bf16_f32 per stored activation (~2 GB read, ~4 GB written at batch 32);
+    activations in bf16 (bf16 MFMA, fp32 accumulate); the backward differentiates the fp32 graph AT the rounded activations
+    (straight-through rounding; the oracle's ``bf16='ste'``) with fp32 master weights, fp32 gradients and fp32 accumulation.
+    This class gives BackwardPlan the records of the forward plan with fp32 shadows of the stored maps (the plan keys its gradient
+    buffers by them) and rebuilds, at the start of every backward (``pre`` steps, on the main stream before the branch streams fork),
+    what the bf16 forward does not keep in a form the backward reads:
+      * gssd_cast_bf16_f32 of a stored map -- only where a step reads the fp32 CONTENT (``need``; eager for pools, L2Norm, Self_Attn,
+        DCN sampling, heads).  With GSSD_BWD_BF16 (default) the conv + BatchNorm layers read the bf16 maps themselves
+        (gssd_bn_bwd_*_mixed, gssd_conv2d_wgrad_bf16: records carry ``x16`` / ``raw16`` / ``src16`` / ``ag16``), their shadows stay
+        uncast; GSSD_BWD_BF16=0 casts every map (the round-3 form: the fp32 backward plan on fp32 copies);
       * the pad vectors of the deferred BatchNorms in fp32 (gssd_bn_finalize_f32, mode 2 = no second running-statistics update);
       * Self_Attn's value projection g^T in fp32 token order (the forward's copy is bf16 in the 32-key order of the bf16 attention
-        core): one fp32 1x1 conv per block from the fp32 copy of the block's input; the attention map is re-materialised by the
-        backward's explicit softmax path (the bf16 core keeps no log-sum-exp);
-      * fp32 packed copies of the weights the backward reads in packed form (merged head rows, merged theta | phi | g rows).
-    bf16 kernels for the backward itself (bf16 dgrad / wgrad operands) are not built: gradients are fp32 end to end."""
+        core): one fp32 1x1 conv per block from the fp32 copy of the block's input (the rows' log-sum-exp is the forward's own);
+      * fp32 packed copies of the weights the backward reads in packed form (merged head rows, merged theta | phi | g rows)."""
 
     def __init__(self, plan):
         self.real = plan

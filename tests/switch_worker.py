@@ -40,6 +40,7 @@ def main():
         (ll + lc).backward()
     torch.cuda.synchronize()
     bwd_graphs = len(getattr(net._engine._last_plan._bwd, '_graphs', {}) or {})
+    bwd_fns = sorted({getattr(fn, '__name__', '') for fn, _ in net._engine._last_plan._bwd.steps} - {''})     # C-ABI entry points of the backward plan
     idx = np.random.default_rng(0).integers(0, loc.numel(), 256)
     named = dict(net.named_parameters())
     keys = ['vgg.0.weight', 'vgg.14.weight', 'vgg.31.weight', 'fuse_11.weight', 'loc.0.weight', 'dcn_list.0.weight',
@@ -50,7 +51,7 @@ def main():
                loss=[float(ll), float(lc)],
                gnorm={k: float(named[k].grad.norm()) for k in keys},
                gsample={k: named[k].grad.reshape(-1)[:64].cpu().tolist() for k in keys},
-               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None} | set(kernels0)), graphs=graphs, bwd_graphs=bwd_graphs)
+               kernels=sorted({st.tag[0] for st in plan.steps if st.tag is not None} | set(kernels0)), graphs=graphs, bwd_graphs=bwd_graphs, bwd_fns=bwd_fns)
     print('SWITCHJSON ' + json.dumps(out))
 
 
