@@ -189,8 +189,20 @@ class Bf16Shadow:
                     ops.copy_into(w32[C8:C4], sa.snconv1x1_phi.weight_orig)
                     ops.copy_into(w32[C4:], sa.snconv1x1_g.weight_orig)
                 later.append((refresh, None))
-                gT = torch.empty(B, C2, Np4, device=dev, dtype=f32)
                 a_tpg = r['inv_sigma'][0]
+                if (BWD_BF16 and r['kp'] is None and r.get('lse') is not None and q.get('x16') is not None
+                        and lib.gssd_self_attn_flash_bwd_supported(C8, C2)):
+                    # flash-style attention backward (csrc/sa_flash_bwd.hip): g token-major in bf16 from the block's bf16 input and the
+                    # forward's own bf16 weights -- no fp32 g^T, no [N][N] maps
+                    g16 = torch.empty(B, N, C2, device=dev, dtype=torch.bfloat16)
+                    wq, bq = plan.eng._packed[name + '.tpg.w@bf16'], plan.eng._packed[name + '.tpg.b@bf16']      # (Engine._pack's bf16-mode keys)
+                    d, _, _ = ops.make_conv_desc(q['x16'], wq[C4:], g16, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=bq[C4:],
+                                                 alpha=a_tpg[C4:])
+                    self._keep.append((d, g16, wq, bq))
+                    later.append((lib.gssd_conv2d_nhwc_bf16, (C.byref(d),)))
+                    q.update(g16=g16, gT=None, Np=Np4, Nkp=Np4)
+                    continue
+                gT = torch.empty(B, C2, Np4, device=dev, dtype=f32)
                 bg = sa.snconv1x1_g.bias.detach()
                 d, _, _ = ops.make_conv_desc(q['x_in'], w32[C4:], gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=bg,
                                              alpha=a_tpg[C4:], out_mode=_lib.OUT_TRANSPOSED, out_stride=Np4, m_per_image=True,
@@ -799,9 +811,30 @@ class BackwardPlan:
         # average-pooled copies (max_pool_factor > 1) -- then the key-side gradients come out per cell and are un-pooled below
         Nk, Nkp, pooled = r['Nk'], r['Nkp'], r['kp'] is not None
         keys, krow, vals = (r['kp'], C8, r['gTp']) if pooled else (tp[0, 0, C8:], C4, gT)
+        lse = r.get('lse')
+        flash = self.bf16_ops and r.get('g16') is not None and lse is not None and not pooled
+        dtpg = self._buf(B, N, CT)
+        if flash:
+            # bf16 storage mode: d theta | d phi | d g in two launches of the flash-style kernel, no [N][N] map
+            Dv = self._buf(B, N)
+            self._add(lib.gssd_rowdot_f32, (dag.data_ptr(), ag.data_ptr(), Dv.data_ptr(), M, C2))
+            self._add(lib.gssd_self_attn_flash_bwd_bf16, (tp.data_ptr(), self._cast16(tp).data_ptr(), r['g16'].data_ptr(),
+                                                          self._cast16(dag).data_ptr(), lse.data_ptr(), Dv.data_ptr(), dtpg.data_ptr(),
+                                                          B, N, C8, C2), keep=(r['g16'], lse))
+        else:
+            self._sa_explicit(r, dtpg, dag, ag, tp, keys, krow, vals, lse, pooled)
+        self._sa_tail(r, dtpg, g_out, gx, existed, x, a_tpg, w_tpg, cv, sig, sndot)
+
+    def _sa_explicit(self, r, dtpg, dag, ag, tp, keys, krow, vals, lse, pooled):
+        B, N, Np, Cc, H = self.B, r['N'], r['Np'], r['C'], r['H']
+        C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+        CT = C4 + C2
+        M = B * N
+        Nk, Nkp = r['Nk'], r['Nkp']
+        mk = ops.make_conv_desc
+        fn = lib.gssd_conv2d_nhwc_f32
         A = self._buf(B, N, Nkp)
         dA = self._buf(B, N, Nkp)
-        lse = r.get('lse')
         if lse is not None:
             # A = exp(theta . keys^T - lse) and dS = A o (d(ag)' . values - D), D_i = <d(ag)'_i, ag_i> = rowsum(A o dA): both in the
             # epilogue of the GEMM that produces the logits / dA -- no pass over the [N, Nk] maps for softmax or its backward
@@ -821,7 +854,6 @@ class BackwardPlan:
                                            N * Nkp, B, 1.0, 0))
             self._add(lib.gssd_softmax_bwd_rows_f32, (A.data_ptr(), dA.data_ptr(), B * N, Nk, Nkp))
         # [d theta | d phi | d g] token-major, one buffer (the gradient of the merged projection's output)
-        dtpg = self._buf(B, N, CT)
         self._add(lib.gssd_bgemm_f32, (dA.data_ptr(), keys.data_ptr(), dtpg.data_ptr(), N, C8, Nk, Nkp, krow, CT, 0, 0, N * Nkp, Nk * krow,
                                        N * CT, B, 1.0, 0))
         if pooled:
@@ -837,6 +869,14 @@ class BackwardPlan:
                                            N * C4, N * CT, B, 1.0, 0))
             self._add(lib.gssd_bgemm_f32, (A.data_ptr(), dag.data_ptr(), dtpg[0, 0, C4:].data_ptr(), N, C2, N, Np, C2, CT, 1, 0, N * Np,
                                            N * C2, N * CT, B, 1.0, 0))
+
+    def _sa_tail(self, r, dtpg, g_out, gx, existed, x, a_tpg, w_tpg, cv, sig, sndot):
+        B, N, Cc, H = self.B, r['N'], r['C'], r['H']
+        C8, C2, C4 = Cc // 8, Cc // 2, Cc // 4
+        CT = C4 + C2
+        M = B * N
+        mk = ops.make_conv_desc
+        fn = lib.gssd_conv2d_nhwc_f32
         # projection weights / biases
         d_p, _, _ = mk(x, None, None, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=CT)
         dwp = self._buf(CT, Cc, zero_each_run=True)

@@ -748,6 +748,39 @@ def test_self_attn_core_bf16_values(dev, N, D, C2):
     assert float((got - ref).abs().max() / ref.abs().max()) <= BF_ULP_LOW
 
 
+@pytest.mark.parametrize('B,N,D,C2', [(2, 1444, 64, 256), (3, 361, 64, 256), (2, 100, 32, 128), (1, 65, 64, 256), (2, 9, 32, 128)])
+def test_self_attn_flash_bwd(dev, B, N, D, C2):
+    """gssd_self_attn_flash_bwd_bf16 (csrc/sa_flash_bwd.hip) against the float64 backward of attn_g = softmax(theta phi^T) g over the same
+    operands: fp32 theta / phi, bf16-rounded g and d(attn_g); lse and D_i = <d(attn_g)_i, attn_g_i> are inputs, as the plan hands them
+    over.  Inside, P and dS are rounded to bf16 before they are contracted (relative 2^-9 per element, uncorrelated): 5e-3 of the
+    tensors' scale in L2.  Ragged N exercises the masked last blocks of both the owned and the streamed side."""
+    from gssd import _lib
+    rng = np.random.default_rng(N + D)
+    th = torch.from_numpy(rng.normal(0, 0.6, size=(B, N, D)).astype(np.float32))
+    ph = torch.from_numpy(rng.normal(0, 0.6, size=(B, N, D)).astype(np.float32))
+    g = q(torch.from_numpy(rng.normal(size=(B, N, C2)).astype(np.float32)))
+    dag = q(torch.from_numpy(rng.normal(size=(B, N, C2)).astype(np.float32)))
+    S = torch.bmm(th.double(), ph.double().transpose(1, 2))
+    lse = torch.logsumexp(S, dim=-1)
+    P = torch.exp(S - lse.unsqueeze(-1))
+    O = torch.bmm(P, g.double())
+    Dv = (dag.double() * O).sum(-1)
+    dP = torch.bmm(dag.double(), g.double().transpose(1, 2))
+    dS = P * (dP - Dv.unsqueeze(-1))
+    ref = torch.cat([torch.bmm(dS, ph.double()), torch.bmm(dS.transpose(1, 2), th.double()), torch.bmm(P.transpose(1, 2), dag.double())], dim=-1)
+    tp = torch.cat([th, ph], dim=-1).contiguous().to(dev)
+    out = torch.full((B, N, 2 * D + C2), float('nan'), device=dev)
+    args = (tp, tp.to(torch.bfloat16), g.to(dev).to(torch.bfloat16), dag.to(dev).to(torch.bfloat16), lse.float().to(dev), Dv.float().to(dev), out)
+    assert _lib.lib.gssd_self_attn_flash_bwd_supported(D, C2) == 1 and _lib.lib.gssd_self_attn_flash_bwd_supported(128, 512) == 0
+    _lib.check(_lib.lib.gssd_self_attn_flash_bwd_bf16(*[a.data_ptr() for a in args], B, N, D, C2, torch.cuda.current_stream().cuda_stream))
+    got = out.double().cpu()
+    assert bool(torch.isfinite(got).all())
+    for name, sl in (('d theta', slice(0, D)), ('d phi', slice(D, 2 * D)), ('d g', slice(2 * D, None))):
+        e = l2rel(got[..., sl], ref[..., sl])
+        print(f'    flash backward N = {N}: {name} relative L2 {e:.2e}')
+        assert e < 5e-3, (name, e)
+
+
 @pytest.mark.parametrize('name,flags,args', [
     ('g1', dict(groups_vgg=1, groups_extra=1), (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1)),
     ('g2pp', dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
