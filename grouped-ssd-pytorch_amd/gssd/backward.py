@@ -366,6 +366,8 @@ class BackwardPlan:
         return g
 
     def _grad_of(self, t):
+        if t.data_ptr() in self.__dict__.get('_g16', {}):
+            raise _lib.GssdError('this gradient map exists in bf16 only (a thin trunk layer): its one reader is the BatchNorm backward')
         return self.gbuf.get(t.data_ptr())
 
     # gradient contribution of a conv to its input: dX (+)= conv(dY, flipped weights)
@@ -384,6 +386,22 @@ class BackwardPlan:
             pd = dil * (k - 1) - pad
         existing = self._grad_of(x_in)
         g = existing if existing is not None else self._buf(B, H, H, Cin)
+        thin = (self.bf16_ops and existing is None and groups == 4 and k == 3 and stride == 1 and pd == 1 and dil == 1 and H * H >= 75 * 75
+                and (Cout // groups, Cin // groups) in ((16, 16), (32, 32)) and x_in.data_ptr() in self._bn_outs16())
+        if thin:
+            # conv1_2 / conv2_2: their data gradient is the one contribution to the producer's d(out) and that map's one reader is the
+            # producer's BatchNorm backward -- the patch-staged thin bf16 conv kernel (595 -> ~200 us at 300 x 300) writes it in bf16
+            g16 = torch.empty(B, H, H, Cin, device=self.dev, dtype=torch.bfloat16)
+            s16 = self._cast16(src)
+            w16 = torch.empty(wd.shape, device=self.dev, dtype=torch.bfloat16)
+            self.keep += [g16, w16]
+            self._add(lib.gssd_cast_f32_bf16, (wd.data_ptr(), w16.data_ptr(), wd.numel()))
+            d, Hout, _ = ops.make_conv_desc(s16, w16, g16, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin, groups=groups,
+                                            k=k, pad=pd, dil=dil)
+            assert Hout == H
+            self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, s16, w16, g16))
+            self.__dict__.setdefault('_g16', {})[x_in.data_ptr()] = g16
+            return
         if self.bf16_ops and (Cout // groups) % 8 == 0 and Cout % 8 == 0:
             # bf16 storage mode: d(input) on the bf16 matrix cores -- d(output) and the flipped / transposed weight rounded to bf16 once,
             # fp32 accumulation, fp32 gradient map (an existing contribution is added in fp32)
@@ -525,7 +543,8 @@ class BackwardPlan:
     def _convbn(self, r, need_dgrad=True):
         B, H, Ho, Hp, Cin, Cout, groups = self.B, r['H'], r['Ho'], r['Hp'], r['Cin'], r['Cout'], r['groups']
         conv, bn, raw = r['conv'], r['bn'], r['raw']
-        dout = self._grad_of(r['out'])
+        dout16 = self.__dict__.get('_g16', {}).pop(r['out'].data_ptr(), None)      # d(out) as a bf16 map (see _dgrad): this is its reader
+        dout = dout16 if dout16 is not None else self._grad_of(r['out'])
         if dout is None:
             raise _lib.GssdError(f"no gradient reaches {r['name']}")
         # scale / shift of this layer's BatchNorm (deferred layers already hold them from the forward)
@@ -569,15 +588,15 @@ class BackwardPlan:
             self._need(raw)
         # without pooling the reduce pass only sums (dz = NULL) and the apply pass re-derives dz from d(out): 5 instead of 6 HBM passes
         self._add(lib.gssd_bn_bwd_reduce_mixed if mixed else lib.gssd_bn_bwd_reduce_f32,
-                  (dout.data_ptr(), (raw16 if mixed else raw).data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0,
-                   sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
+                  ((dout.data_ptr(), int(dout16 is not None), raw16.data_ptr()) if mixed else (dout.data_ptr(), raw.data_ptr())) +
+                  (sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0, sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
         ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
         self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
                                                  float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
                                                  self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr(), r.get('stats_rep', 0)))
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         if mixed:
-            self._add(lib.gssd_bn_bwd_apply_mixed, (0 if pool else dout.data_ptr(), dz.data_ptr(), dz16.data_ptr() if want16 else 0,
+            self._add(lib.gssd_bn_bwd_apply_mixed, (0 if pool else dout.data_ptr(), int(dout16 is not None), dz.data_ptr(), dz16.data_ptr() if want16 else 0,
                                                     raw16.data_ptr(), 0 if pool else sc.data_ptr(), 0 if pool else sh.data_ptr(),
                                                     int(r['relu']), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), B * Ho * Ho, Cout,
                                                     cs.data_ptr(), int(want32)), keep=(raw16, dz16))
@@ -603,6 +622,15 @@ class BackwardPlan:
         self._unpack(dwp, K, 0, conv.weight, cin_g_real, cin_g_pad, r['k'])
         if need_dgrad:
             self._dgrad(r, dz, r['x_in'], conv, groups, Cin, H, Ho, Cout, r['k'], r['stride'], r['pad'], r['dil'])
+
+    def _bn_outs16(self):
+        """Outputs of conv + BatchNorm layers whose backward reads bf16 maps (gssd_bn_bwd_*_mixed takes a bf16 d(out) too)."""
+        s = self.__dict__.get('_bn_outs_set')
+        if s is None:
+            s = {q['out'].data_ptr() for kind, q in self.plan.rec if kind == 'convbn' and q.get('raw16') is not None and not q['pool']
+                 and q['out'] is q['raw']} if self.bf16_ops else set()
+            self._bn_outs_set = s
+        return s
 
     def _need(self, t):
         """A step reads the fp32 CONTENT of a stored map: schedule its cast if the bf16 shadow plan shadows it lazily."""

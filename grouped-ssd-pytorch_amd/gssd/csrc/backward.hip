@@ -39,8 +39,8 @@ __device__ __forceinline__ void st4_bf16(u16* p, const f32x4 v) {
 // element (non-overlapping pools) or atomically accumulated (overlapping, dz pre-zeroed).  Per-channel sums
 // s1 = sum dz, s2 = sum dz*raw feed the BatchNorm parameter gradients.
 // -----------------------------------------------------------------------------------------------------------------
-template <typename RT>
-__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const RT* __restrict__ raw,
+template <typename RT, typename DT = float>
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const DT* __restrict__ dout, const RT* __restrict__ raw,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dz, double* __restrict__ sums, int B, int H,
                                                             int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
     }
     if (i0 < stride)
         for (long long i = i0; i < total; i += stride) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dout + i * 4);
+            const f32x4 g = ld4<DT>(dout + i * 4);
             if (pk == 0) {
                 const size_t o = (size_t)i * 4;           // Ho == H, Wo == W: dout and raw share one dense layout
                 const f32x4 rv = ld4<RT>(raw + o);
@@ -165,11 +165,11 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double
 // ``dsrc`` (optional): d(out) of a layer without pooling -- dz is then re-derived here as dsrc * [raw * scale + shift > 0] instead of
 // being written by the reduce pass and read back (one HBM pass less per layer).  ``dz16`` (optional): the result as bf16, what the bf16
 // data-gradient conv and weight gradient read; ``store_f32`` = 0 leaves ``dz`` as it was (only read, when dsrc is NULL).
-template <typename RT>
+template <typename RT, typename DT = float>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ dz, const RT* __restrict__ raw,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB,
                                                            const float* __restrict__ coefC, long long pixels, int C,
-                                                           double* __restrict__ colsum, const float* __restrict__ dsrc,
+                                                           double* __restrict__ colsum, const DT* __restrict__ dsrc,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int relu, u16* __restrict__ dz16, int store_f32) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ 
             const f32x4 rv = ld4<RT>(raw + i * 4);
             f32x4 d;
             if (dsrc) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(dsrc + i * 4);
+                const f32x4 g = ld4<DT>(dsrc + i * 4);
                 const f32x4 z = rv * sc + sh;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
@@ -353,28 +353,39 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
     return GSSD_OK;
 }
 
-extern "C" int gssd_bn_bwd_reduce_mixed(const float* dout, const void* raw_bf16, const float* scale, const float* shift, float* dz,
-                                        double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
+extern "C" int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const void* raw_bf16, const float* scale, const float* shift,
+                                        float* dz, double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
                                         int pool_p, int relu, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dout && raw_bf16 && (dz || (pool_k == 0 && sums)) && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
     GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<u16>, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
-                       reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    if (dout_bf16)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, u16>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream),
+                           reinterpret_cast<const u16*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, H, W, C, Ho,
+                           Wo, pool_k, pool_s, pool_p, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, float>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),
+                           as_stream(stream), reinterpret_cast<const float*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz,
+                           sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
-extern "C" int gssd_bn_bwd_apply_mixed(const float* dout, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale,
+extern "C" int gssd_bn_bwd_apply_mixed(const void* dout, int dout_bf16, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale,
                                        const float* shift, int relu, const float* coef_a, const float* coef_b, const float* coef_c,
                                        int64_t pixels, int C, double* colsum, int store_f32, gssd_stream_t stream) {
     GSSD_CHECK_ARG(raw_bf16 && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     GSSD_CHECK_ARG((dout || dz) && (dz_bf16 || store_f32) && (!store_f32 || dz) && (scale == nullptr) == (shift == nullptr));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<u16>, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
-                       dz, reinterpret_cast<const u16*>(raw_bf16), coef_a, coef_b, coef_c, (long long)pixels, C, colsum, dout, scale, shift,
-                       relu, reinterpret_cast<u16*>(dz_bf16), store_f32);
+    if (dout_bf16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<u16, u16>), dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float),
+                           as_stream(stream), dz, reinterpret_cast<const u16*>(raw_bf16), coef_a, coef_b, coef_c, (long long)pixels, C, colsum,
+                           reinterpret_cast<const u16*>(dout), scale, shift, relu, reinterpret_cast<u16*>(dz_bf16), store_f32);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<u16, float>), dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float),
+                           as_stream(stream), dz, reinterpret_cast<const u16*>(raw_bf16), coef_a, coef_b, coef_c, (long long)pixels, C, colsum,
+                           reinterpret_cast<const float*>(dout), scale, shift, relu, reinterpret_cast<u16*>(dz_bf16), store_f32);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -393,7 +404,7 @@ extern "C" int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* c
                                      const float* coef_c, int64_t pixels, int C, double* colsum, gssd_stream_t stream) {
     GSSD_CHECK_ARG(dz && raw && coef_a && coef_b && coef_c && pixels > 0 && C > 0 && C % 4 == 0 && C <= 4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks_wide(pixels * (C / 4))), dim3(WIDE), C * sizeof(float), as_stream(stream),
-                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, nullptr, nullptr, nullptr, 0, nullptr, 1);
+                       dz, raw, coef_a, coef_b, coef_c, (long long)pixels, C, colsum, (const float*)nullptr, nullptr, nullptr, 0, nullptr, 1);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -261,13 +261,14 @@ int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, cons
 /* The same two passes for the training step of the bf16 storage mode: `raw_bf16` is the forward's own stored map (bf16), gradients stay
  * fp32.  gssd_bn_bwd_apply_mixed: d = dout * [relu mask] when dout != NULL, else d is read from dz (what the pooled reduce pass wrote);
  * the result a*d + b*raw + c goes to dz_bf16 (bf16, when != NULL: the operand of the bf16 data-gradient conv and weight gradient) and,
- * when store_f32 != 0, to dz. */
-int gssd_bn_bwd_reduce_mixed(const float* dout, const void* raw_bf16, const float* scale, const float* shift, float* dz, double* sums,
-                             int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p, int relu,
+ * when store_f32 != 0, to dz.  dout_bf16 != 0: d(out) itself is a bf16 map (the two thin trunk layers whose consumer's data-gradient conv
+ * runs on the patch-staged bf16 kernel, which stores bf16). */
+int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const void* raw_bf16, const float* scale, const float* shift, float* dz,
+                             double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p, int relu,
                              gssd_stream_t stream);
-int gssd_bn_bwd_apply_mixed(const float* dout, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale, const float* shift,
-                            int relu, const float* coef_a, const float* coef_b, const float* coef_c, int64_t pixels, int C,
-                            double* colsum, int store_f32, gssd_stream_t stream);
+int gssd_bn_bwd_apply_mixed(const void* dout, int dout_bf16, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale,
+                            const float* shift, int relu, const float* coef_a, const float* coef_b, const float* coef_c, int64_t pixels,
+                            int C, double* colsum, int store_f32, gssd_stream_t stream);
 int gssd_bn_bwd_apply_masked_f32(const float* dout, const float* raw, const float* scale, const float* shift, int relu,
                                  const float* coef_a, const float* coef_b, const float* coef_c, float* draw, int64_t pixels, int C,
                                  double* colsum, gssd_stream_t stream);
