@@ -386,19 +386,23 @@ class BackwardPlan:
             pd = dil * (k - 1) - pad
         existing = self._grad_of(x_in)
         g = existing if existing is not None else self._buf(B, H, H, Cin)
-        thin = (self.bf16_ops and existing is None and groups == 4 and k == 3 and stride == 1 and pd == 1 and dil == 1 and H * H >= 75 * 75
-                and (Cout // groups, Cin // groups) in ((16, 16), (32, 32)) and x_in.data_ptr() in self._bn_outs16())
-        if thin:
-            # conv1_2 / conv2_2: their data gradient is the one contribution to the producer's d(out) and that map's one reader is the
-            # producer's BatchNorm backward -- the patch-staged thin bf16 conv kernel (595 -> ~200 us at 300 x 300) writes it in bf16
+        lowp = False
+        if self.bf16_ops and existing is None and stride == 1 and x_in.data_ptr() in self._bn_outs16():
+            # the trunk's fast bf16 conv kernels store bf16: usable where this data gradient is the ONE contribution to the producer's
+            # d(out) and that map's one reader is the producer's BatchNorm backward (which takes a bf16 d(out))
             g16 = torch.empty(B, H, H, Cin, device=self.dev, dtype=torch.bfloat16)
+            w16 = torch.empty(Cin, k * k * (Cout // groups), device=self.dev, dtype=torch.bfloat16)
+            d, Hout, _ = ops.make_conv_desc(src, w16, g16, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin, groups=groups,
+                                            k=k, pad=pd, dil=dil)
+            thin = (groups == 4 and k == 3 and pd == 1 and dil == 1 and H * H >= 75 * 75
+                    and (Cout // groups, Cin // groups) in ((16, 16), (32, 32)))                 # csrc/conv_thin_bf16.hip: conv1_2, conv2_2
+            lowp = Hout == H and (thin or bool(lib.gssd_conv_flat_bf16_takes(C.byref(d))))       # csrc/conv_flat_bf16.hip: conv3_2 .. conv5_3
+        if lowp:
             s16 = self._cast16(src)
-            w16 = torch.empty(wd.shape, device=self.dev, dtype=torch.bfloat16)
             self.keep += [g16, w16]
             self._add(lib.gssd_cast_f32_bf16, (wd.data_ptr(), w16.data_ptr(), wd.numel()))
             d, Hout, _ = ops.make_conv_desc(s16, w16, g16, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin, groups=groups,
                                             k=k, pad=pd, dil=dil)
-            assert Hout == H
             self._add(lib.gssd_conv2d_nhwc_bf16, (C.byref(d),), keep=(d, s16, w16, g16))
             self.__dict__.setdefault('_g16', {})[x_in.data_ptr()] = g16
             return
@@ -627,8 +631,17 @@ class BackwardPlan:
         """Outputs of conv + BatchNorm layers whose backward reads bf16 maps (gssd_bn_bwd_*_mixed takes a bf16 d(out) too)."""
         s = self.__dict__.get('_bn_outs_set')
         if s is None:
-            s = {q['out'].data_ptr() for kind, q in self.plan.rec if kind == 'convbn' and q.get('raw16') is not None and not q['pool']
-                 and q['out'] is q['raw']} if self.bf16_ops else set()
+            s = set()
+            if self.bf16_ops:
+                # consumers per stored map: only a map with ONE reader (the next conv) may get a bf16 gradient
+                n = {}
+                for kind, q in self.plan.rec:
+                    for key in ('x_in', 'src', 'a', 'b'):
+                        t = q.get(key)
+                        if torch.is_tensor(t):
+                            n[t.data_ptr()] = n.get(t.data_ptr(), 0) + 1
+                s = {q['out'].data_ptr() for kind, q in self.plan.rec
+                     if kind == 'convbn' and q.get('raw16') is not None and n.get(q['out'].data_ptr(), 0) == 1}
             self._bn_outs_set = s
         return s
 
