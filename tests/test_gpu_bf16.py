@@ -748,6 +748,81 @@ def test_self_attn_core_bf16_values(dev, N, D, C2):
     assert float((got - ref).abs().max() / ref.abs().max()) <= BF_ULP_LOW
 
 
+@pytest.mark.parametrize('pool', [None, (2, 2, 0), (3, 1, 1)])
+@pytest.mark.parametrize('dout_bf16', [False, True])
+def test_bn_backward_mixed(dev, pool, dout_bf16):
+    """gssd_bn_bwd_{reduce,apply}_mixed (the bf16 storage mode's BatchNorm backward: reads the forward's bf16 raw map, optionally a bf16
+    d(out), writes d(pre-activation) in bf16 and / or fp32) against the fp32 entry points on fp32 copies of the SAME values: the fp32
+    outputs, the sums and the parameter gradients are identical bit for bit up to the order of the atomics (1e-6), the bf16 output is
+    the fp32 one rounded once."""
+    from gssd import ops, _lib
+    lib = _lib.lib
+    rng = np.random.default_rng(5)
+    B, H, Cc = 3, 20, 64
+    raw = q(torch.from_numpy(rng.normal(size=(B, H, H, Cc)).astype(np.float32))).to(dev)
+    pk, ps, pp = pool if pool else (0, 1, 0)
+    Ho = (H + 2 * pp - pk) // ps + 1 if pool else H
+    dout = torch.from_numpy(rng.normal(size=(B, Ho, Ho, Cc)).astype(np.float32))
+    dout = (q(dout) if dout_bf16 else dout).to(dev)
+    gm = torch.from_numpy(rng.uniform(0.5, 1.5, size=Cc).astype(np.float32)).to(dev)
+    n = B * H * H
+    stats = torch.cat([raw.double().sum((0, 1, 2)), (raw.double() ** 2).sum((0, 1, 2))]).contiguous()
+    mean = stats[:Cc] / n
+    inv = 1.0 / torch.sqrt(stats[Cc:] / n - mean * mean + 1e-5)
+    sc = (gm.double() * inv).float()
+    sh = (0.1 - mean * gm.double() * inv).float()
+    ref_dz, ref_dg, ref_db, ref_cs = ops.bn_backward(dout, raw, stats, n, gm, sc, sh, pool=pool, want_colsum=True)
+    if not pool:            # the plan's no-pool form: sums only, then the masked apply
+        pass
+    st = torch.cuda.current_stream().cuda_stream
+    raw16 = raw.to(torch.bfloat16)
+    d_in = dout.to(torch.bfloat16) if dout_bf16 else dout
+    dz = torch.zeros_like(raw) if (pool and ps < pk) else torch.full_like(raw, float('nan'))
+    dz16 = torch.full(raw.shape, float('nan'), device=dev, dtype=torch.bfloat16)
+    sums = torch.zeros(2 * Cc, device=dev, dtype=torch.float64)
+    _lib.check(lib.gssd_bn_bwd_reduce_mixed(d_in.data_ptr(), int(dout_bf16), raw16.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                            dz.data_ptr() if pool else 0, sums.data_ptr(), B, H, H, Cc, Ho, Ho, pk, ps, pp, 1, st))
+    ca, cb, cc, dg, db = (torch.empty(Cc, device=dev) for _ in range(5))
+    _lib.check(lib.gssd_bn_bwd_finalize_f32(stats.data_ptr(), float(n), sums.data_ptr(), gm.data_ptr(), 1e-5, Cc, ca.data_ptr(), cb.data_ptr(),
+                                            cc.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, st))
+    cs = torch.zeros(Cc, device=dev, dtype=torch.float64)
+    _lib.check(lib.gssd_bn_bwd_apply_mixed(0 if pool else d_in.data_ptr(), int(dout_bf16), dz.data_ptr(), dz16.data_ptr(), raw16.data_ptr(),
+                                           0 if pool else sc.data_ptr(), 0 if pool else sh.data_ptr(), 1, ca.data_ptr(), cb.data_ptr(),
+                                           cc.data_ptr(), n, Cc, cs.data_ptr(), 1, st))
+    assert rel(dz, ref_dz) < 1e-6 and rel(dg, ref_dg) < 1e-6 and rel(db, ref_db) < 1e-6
+    # (the column sums of a BatchNorm backward vanish analytically: both are rounding noise of the same size)
+    assert float((cs - ref_cs).abs().max()) < 1e-6 * float(dz.abs().sum(dim=(0, 1, 2)).max())
+    assert torch.equal(dz16, dz.to(torch.bfloat16))
+    # store_f32 = 0 leaves dz alone (no-pool form)
+    if not pool:
+        dz2 = torch.full_like(raw, 7.0)
+        _lib.check(lib.gssd_bn_bwd_apply_mixed(d_in.data_ptr(), int(dout_bf16), dz2.data_ptr(), dz16.data_ptr(), raw16.data_ptr(), sc.data_ptr(),
+                                               sh.data_ptr(), 1, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), n, Cc, 0, 0, st))
+        assert bool((dz2 == 7.0).all()) and torch.equal(dz16, dz.to(torch.bfloat16))
+
+
+def test_bf16_helpers_of_the_backward(dev):
+    """gssd_cast_rows_f32_bf16 (rows widened with zero pad) and gssd_dcn_im2col_bf16 (the bf16 twin of gssd_dcn_im2col_f32: same sampling
+    of the same bf16-representable map, interpolation in fp32, one rounding)."""
+    from gssd import _lib
+    lib = _lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.normal(size=(77, 40)).astype(np.float32)).to(dev)
+    y = torch.full((77, 40), float('nan'), device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.gssd_cast_rows_f32_bf16(x.data_ptr(), y.data_ptr(), 77, 36, 40, 40, st))
+    assert torch.equal(y[:, :36], x[:, :36].to(torch.bfloat16)) and bool((y[:, 36:] == 0).all())
+    B, H, Cc, dg = 2, 9, 128, 4
+    OMC = 112
+    xm = q(torch.from_numpy(rng.normal(size=(B, H, H, Cc)).astype(np.float32))).to(dev)
+    om = torch.from_numpy(rng.normal(0, 1.5, size=(B, H, H, OMC)).astype(np.float32)).to(dev)
+    cols = torch.empty(B * H * H, 9 * Cc, device=dev)
+    cols16 = torch.full((B * H * H, 9 * Cc), float('nan'), device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.gssd_dcn_im2col_f32(xm.data_ptr(), om.data_ptr(), cols.data_ptr(), B, H, H, Cc, dg, OMC, st))
+    _lib.check(lib.gssd_dcn_im2col_bf16(xm.to(torch.bfloat16).data_ptr(), om.data_ptr(), cols16.data_ptr(), B, H, H, Cc, dg, OMC, st))
+    assert torch.equal(cols16, cols.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize('B,N,D,C2', [(2, 1444, 64, 256), (3, 361, 64, 256), (2, 100, 32, 128), (1, 65, 64, 256), (2, 9, 32, 128)])
 def test_self_attn_flash_bwd(dev, B, N, D, C2):
     """gssd_self_attn_flash_bwd_bf16 (csrc/sa_flash_bwd.hip) against the float64 backward of attn_g = softmax(theta phi^T) g over the same
