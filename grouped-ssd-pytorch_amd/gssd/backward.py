@@ -144,7 +144,7 @@ class Bf16Shadow:
                 q['xf'] = XF(r['xf'], r['bn'], r['stats'], B * r['Ho'] * r['Ho'], r['Cout'], r.get('stats_rep', 0))
             elif kind == 'head':
                 q['src16'] = r['src'] if r['src'].dtype == torch.bfloat16 else None
-                q['src'] = S(r['src'])
+                q['src'] = S(r['src'], BWD_BF16)          # (content read only by the fp32 weight-gradient fallback)
             elif kind in ('pool', 'l2norm'):
                 q['x_in'], q['out'] = S(r['x_in']), S(r['out'])
             elif kind == 'slice_cat':
@@ -155,7 +155,7 @@ class Bf16Shadow:
             elif kind == 'sa':
                 bf = torch.bfloat16
                 q['x16'], q['ag16'] = (r['x_in'] if r['x_in'].dtype == bf else None), (r['ag'] if r['ag'].dtype == bf else None)
-                q['x_in'], q['out'], q['ag'] = S(r['x_in']), S(r['out']), S(r['ag'])
+                q['x_in'], q['out'], q['ag'] = S(r['x_in'], BWD_BF16), S(r['out']), S(r['ag'])
                 q['out2'] = S(r['out2']) if r['out2'] is not None else None
             else:
                 raise _lib.GssdError(f'bf16 backward: no fp32 view for a {kind} record')
@@ -202,6 +202,7 @@ class Bf16Shadow:
                     later.append((lib.gssd_conv2d_nhwc_bf16, (C.byref(d),)))
                     q.update(g16=g16, gT=None, Np=Np4, Nkp=Np4)
                     continue
+                self.need(q['x_in'])                      # the fp32 g^T conv below reads the block input's fp32 copy
                 gT = torch.empty(B, C2, Np4, device=dev, dtype=f32)
                 bg = sa.snconv1x1_g.bias.detach()
                 d, _, _ = ops.make_conv_desc(q['x_in'], w32[C4:], gT, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, bias=bg,
@@ -520,6 +521,7 @@ class BackwardPlan:
             dwp = self._buf(Cp, K, zero_each_run=True)
             self._add(lib.gssd_conv2d_wgrad_bf16, (C.byref(d16), dyh16.data_ptr(), dwp.data_ptr()), keep=d16, leaf=True)
         else:
+            self._need(r['src'])
             fdesc, _, _ = ops.make_conv_desc(r['src'], None, None, B=B, H=H, W=H, in_stride=Cs, cin_g=Cs, Cout=Cout, k=3, pad=1)
             dwp, K = self._wgrad(fdesc, dyh, None, Cs, Cs, 3, Cout)
         self._unpack(dwp, K, 0, r['loc'].weight, Cs, Cs, 3)
@@ -922,6 +924,7 @@ class BackwardPlan:
         d_p, _, _ = mk(x, None, None, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=CT)
         dwp = self._buf(CT, Cc, zero_each_run=True)
         if not (self.bf16_ops and r.get('x16') is not None and self._wgrad_1x1_bf16(r['x16'], Cc, Cc, self._cast16(dtpg), CT, M, dwp)):
+            self._need(x)
             self._add(lib.gssd_conv2d_wgrad_f32, (C.byref(d_p), dtpg.data_ptr(), dwp.data_ptr()), keep=d_p)
         csP = self._buf(CT, dtype=torch.float64, zero_each_run=True)
         self._add(lib.gssd_colsum_f32, (dtpg.data_ptr(), M, CT, CT, csP.data_ptr()))
