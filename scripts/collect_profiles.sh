@@ -46,3 +46,9 @@ for dt in f32 bf16; do
 done
 cd $R
 python3 scripts/host_vs_gpu.py > gpurun_out/${tag}_host_vs_gpu.txt 2>/dev/null
+# round 4 (late): the bf16 training step -- critical path of a full step, the GSSD (no attention / DCN) bf16 step, the round-3 form for the A/B
+f=$(find $R/gpurun_out/${tag}_prof_fsb -name '*kernel_trace.csv' | head -1)
+[ -n "$f" ] && python3 scripts/critical_path.py $f "GSSD++ B=32 bf16 storage mode, FULL training step, eager backward (rocprofv3 --kernel-trace)" 5 > gpurun_out/${tag}_critical_path_bf16_fullstep.txt
+python3 bench.py --config gssd --dtype bf16 --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > gpurun_out/${tag}_gssd_b32_bf16_fullstep.json 2>> gpurun_out/${tag}_bench.err
+GSSD_BWD_BF16=0 python3 bench.py --dtype bf16 --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --no-events --full-step 8 > gpurun_out/${tag}_gssdpp_b32_bf16_fullstep_round3_backward.json 2>> gpurun_out/${tag}_bench.err
+python3 scripts/bench_wgrad_bf16.py > gpurun_out/${tag}_wgrad_bf16.txt 2>/dev/null
