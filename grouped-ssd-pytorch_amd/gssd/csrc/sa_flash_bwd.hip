@@ -53,15 +53,17 @@ struct FbParams {
 constexpr int OWN = 64, STR = 32;
 
 template <int D, int C2, bool OWN_KEYS>
-__global__ __launch_bounds__(256, 2) void sa_flash_bwd_kernel(const FbParams p) {
+__global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(const FbParams p) {      // (128, 512): 256 accumulator +
+    // operand registers per lane -- one workgroup per CU with the unified 512-register file
     constexpr int DI = D / 16, CS = C2 / 32, CT = C2 / 16, CTOT = 2 * D + C2;
     constexpr int UF = D / 4;                    // 16-byte units per fp32 row
     constexpr int UD = D / 8, NCD = D / 16;      // 16-byte units / 32-byte chunks per bf16 [D] row
     constexpr int UC = C2 / 8, NCC = C2 / 16;    // the same per bf16 [C2] row
-    static_assert(UF == 16 || UF == 8, "D = 64 or 32");
+    static_assert(UF == 32 || UF == 16 || UF == 8, "D = 128, 64 or 32");
+    constexpr int XF = (UF < 16 ? UF : 16) - 1;      // fp32 rows: 16-byte units XOR-swizzled in their low four bits
     static_assert(NCC >= 8 && UC % 16 == 0, "C2 >= 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fb[];
-    float* Sf = reinterpret_cast<float*>(smem_fb);                       // [STR][D] fp32, units XOR (t & (UF - 1))
+    float* Sf = reinterpret_cast<float*>(smem_fb);                       // [STR][D] fp32, units XOR (t & XF)
     u16* Sd = reinterpret_cast<u16*>(Sf + STR * D);                     // [STR][D] bf16 for transpose reads, chunks XOR swz
     u16* An = Sd + STR * D;                                             // [STR][C2] bf16, natural 16-byte reads: units XOR (t & 15)
     u16* At = An + STR * C2;                                            // [STR][C2] bf16, transpose reads: chunks XOR (t & 7)   (OWN_KEYS)
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void sa_flash_bwd_kernel(const FbParams p) 
             for (int i = wave; i < STR / RF; i += 4) {
                 const int t = i * RF + lane / UF, u = lane % UF;
                 const int tok = s0 + t;
-                const void* src = tok < N ? (const void*)(str_f + (size_t)tok * (2 * D) + 4 * (u ^ (t & (UF - 1)))) : zero;
+                const void* src = tok < N ? (const void*)(str_f + (size_t)tok * (2 * D) + 4 * (u ^ (t & XF))) : zero;
                 dma16(src, Sf + i * RF * D);
             }
             constexpr int RD = 64 / UD;
@@ -136,10 +138,8 @@ __global__ __launch_bounds__(256, 2) void sa_flash_bwd_kernel(const FbParams p) 
                 const void* src = tok < N ? (const void*)(str_d + (size_t)tok * (2 * D) + (((u >> 1) ^ sw) << 4) + ((u & 1) << 3)) : zero;
                 dma16(src, Sd + i * RD * D);
             }
-            constexpr int RC = 64 / UC > 0 ? 64 / UC : 1;                // rows per piece (UC <= 64: C2 <= 512)
-            constexpr int PPR = UC / 64 > 0 ? UC / 64 : 1;               // pieces per row (C2 = 1024 would need more: not instantiated)
+            constexpr int RC = 64 / UC;                                  // rows per piece
             static_assert(UC <= 64, "C2 <= 512");
-            (void)PPR;
             for (int i = wave; i < STR / RC; i += 4) {
                 const int t = i * RC + lane / UC, u = lane % UC;
                 const int tok = s0 + t;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void sa_flash_bwd_kernel(const FbParams p) 
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < DI; ++i) {
-                const f32x4 qf = *reinterpret_cast<const f32x4*>(Sf + t * D + (((4 * i + kq) ^ (t & (UF - 1))) << 2));
+                const f32x4 qf = *reinterpret_cast<const f32x4*>(Sf + t * D + (((4 * i + kq) ^ (t & XF)) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], kown[i][e], s, 0, 0, 0);
             }
@@ -251,7 +251,9 @@ int launch_fb(const FbParams& p0, int B, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int gssd_self_attn_flash_bwd_supported(int D, int C2) { return (D == 64 && C2 == 256) || (D == 32 && C2 == 128) ? 1 : 0; }
+extern "C" int gssd_self_attn_flash_bwd_supported(int D, int C2) {
+    return (D == 64 && C2 == 256) || (D == 32 && C2 == 128) || (D == 128 && C2 == 512) ? 1 : 0;
+}
 
 extern "C" int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* g_bf16, const void* dag_bf16, const float* lse,
                                              const float* dvec, float* dtpg, int B, int N, int D, int C2, gssd_stream_t stream) {
@@ -272,6 +274,7 @@ extern "C" int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf1
     hipStream_t s = as_stream(stream);
     if (D == 64 && C2 == 256) return launch_fb<64, 256>(p, B, s);
     if (D == 32 && C2 == 128) return launch_fb<32, 128>(p, B, s);
+    if (D == 128 && C2 == 512) return launch_fb<128, 512>(p, B, s);
     gssd_set_error("attention backward (flash form): unsupported (theta/phi channels %d, g channels %d)", D, C2);
     return GSSD_EINVAL;
 }

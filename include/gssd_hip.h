@@ -336,7 +336,7 @@ int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf
  * token-major rows of 2 D + C2 floats).  tp [B][N][2D] fp32 (theta | phi) and its bf16 copy tp_bf16; g_bf16, dag_bf16 [B][N][C2] bf16
  * token-major; lse [B][N] from the forward (gssd_self_attn_core_bf16v); dvec[b][i] = <d(attn_g)_i, attn_g_i> (gssd_rowdot_f32).  The
  * logits are recomputed on the fp32 matrix cores, everything else on bf16 operands with fp32 accumulation.  (D, C2) in {(64, 256),
- * (32, 128)}: gssd_self_attn_flash_bwd_supported; anything else is GSSD_EINVAL (the caller keeps the explicit-map path). */
+ * (32, 128), (128, 512)}: gssd_self_attn_flash_bwd_supported; anything else is GSSD_EINVAL (the caller keeps the explicit-map path). */
 int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* g_bf16, const void* dag_bf16, const float* lse,
                                   const float* dvec, float* dtpg, int B, int N, int D, int C2, gssd_stream_t stream);
 int gssd_self_attn_flash_bwd_supported(int D, int C2);

@@ -823,7 +823,7 @@ def test_bf16_helpers_of_the_backward(dev):
     assert torch.equal(cols16, cols.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize('B,N,D,C2', [(2, 1444, 64, 256), (3, 361, 64, 256), (2, 100, 32, 128), (1, 65, 64, 256), (2, 9, 32, 128)])
+@pytest.mark.parametrize('B,N,D,C2', [(2, 1444, 64, 256), (3, 361, 64, 256), (2, 100, 32, 128), (1, 65, 64, 256), (2, 9, 32, 128), (2, 361, 128, 512)])
 def test_self_attn_flash_bwd(dev, B, N, D, C2):
     """gssd_self_attn_flash_bwd_bf16 (csrc/sa_flash_bwd.hip) against the float64 backward of attn_g = softmax(theta phi^T) g over the same
     operands: fp32 theta / phi, bf16-rounded g and d(attn_g); lse and D_i = <d(attn_g)_i, attn_g_i> are inputs, as the plan hands them
@@ -846,7 +846,7 @@ def test_self_attn_flash_bwd(dev, B, N, D, C2):
     tp = torch.cat([th, ph], dim=-1).contiguous().to(dev)
     out = torch.full((B, N, 2 * D + C2), float('nan'), device=dev)
     args = (tp, tp.to(torch.bfloat16), g.to(dev).to(torch.bfloat16), dag.to(dev).to(torch.bfloat16), lse.float().to(dev), Dv.float().to(dev), out)
-    assert _lib.lib.gssd_self_attn_flash_bwd_supported(D, C2) == 1 and _lib.lib.gssd_self_attn_flash_bwd_supported(128, 512) == 0
+    assert _lib.lib.gssd_self_attn_flash_bwd_supported(D, C2) == 1 and _lib.lib.gssd_self_attn_flash_bwd_supported(256, 1024) == 0
     _lib.check(_lib.lib.gssd_self_attn_flash_bwd_bf16(*[a.data_ptr() for a in args], B, N, D, C2, torch.cuda.current_stream().cuda_stream))
     got = out.double().cpu()
     assert bool(torch.isfinite(got).all())
