@@ -573,11 +573,12 @@ def main():
         bfull = None
         if a.full_step > 0 and world == 1:
             # configs[4] as a training config: bf16 forward + loss, mixed-precision backward (fp32 gradients at the stored bf16
-            # activations, gssd/backward.py::Bf16Shadow), SGD on the fp32 master weights
-            a2.full_step = min(a.full_step, 4)
+            # activations, bf16 operands: gssd/backward.py), SGD on the fp32 master weights
+            a2.full_step = min(a.full_step, 8)
             try:
                 bfull = full_step_leg(a2, bnet, bcrit, bx, btg, dev, gd, world, B)
-                bfull['note'] = 'bf16 forward + loss, mixed-precision backward (fp32 backward plan on fp32 copies of the stored bf16 activations), SGD on fp32 masters'
+                bfull['note'] = ('bf16 forward + loss, mixed-precision backward on bf16 operands (fp32 masters, gradients and accumulation; '
+                                 'GSSD_BWD_BF16=0: the fp32 backward plan on fp32 copies of the stored maps), SGD on fp32 masters')
             except Exception as e:                                  # noqa: BLE001 -- reported in the line
                 bfull = {'error': f'{type(e).__name__}: {e}'[:300]}
         del bnet, bcrit, bx, btg
