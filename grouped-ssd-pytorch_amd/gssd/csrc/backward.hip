@@ -59,20 +59,36 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const DT* __restric
         sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
         sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
     }
-    if (i0 < stride)
+    // no pooling: a streaming pass -- four independent iterations' loads in flight per thread (two 8 / 16-byte loads per iteration did not
+    // cover the HBM latency at 32 waves per CU: ~60 % of the copy rate)
+    auto plain = [&](long long i, const f32x4 g, const f32x4 rv) {
+        const size_t o = (size_t)i * 4;                   // Ho == H, Wo == W: dout and raw share one dense layout
+        const f32x4 z = rv * sc + sh;
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
+        if (dz) *reinterpret_cast<f32x4*>(dz + o) = d;      // (sums only: the apply pass re-derives dz from dout)
+        a1 += d;
+        a2 += d * rv;
+    };
+    if (i0 < stride && pk == 0) {
+        long long i = i0;
+        for (; i + 3 * stride < total; i += 4 * stride) {
+            f32x4 g[4], rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = ld4<DT>(dout + (i + j * stride) * 4);
+                rv[j] = ld4<RT>(raw + (i + j * stride) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) plain(i + j * stride, g[j], rv[j]);
+        }
+        for (; i < total; i += stride) plain(i, ld4<DT>(dout + i * 4), ld4<RT>(raw + i * 4));
+    }
+    if (i0 < stride && pk != 0)
         for (long long i = i0; i < total; i += stride) {
             const f32x4 g = ld4<DT>(dout + i * 4);
-            if (pk == 0) {
-                const size_t o = (size_t)i * 4;           // Ho == H, Wo == W: dout and raw share one dense layout
-                const f32x4 rv = ld4<RT>(raw + o);
-                const f32x4 z = rv * sc + sh;
-                f32x4 d;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
-                if (dz) *reinterpret_cast<f32x4*>(dz + o) = d;      // (sums only: the apply pass re-derives dz from dout)
-                a1 += d;
-                a2 += d * rv;
-            } else {
+            {
                 // pixel index fits 32 bits (checked by the launcher): 32-bit divisions instead of three 64-bit ones
                 unsigned t = (unsigned)(i / C4);
                 const int xo = (int)(t % (unsigned)Wo);
@@ -192,22 +208,31 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ 
             sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
             sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
         }
-        for (long long i = i0; i < total; i += stride) {
-            const f32x4 rv = ld4<RT>(raw + i * 4);
-            f32x4 d;
+        auto one = [&](long long i, const f32x4 rv, const f32x4 gin) {
+            f32x4 d = gin;
             if (dsrc) {
-                const f32x4 g = ld4<DT>(dsrc + i * 4);
                 const f32x4 z = rv * sc + sh;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? g[e] : 0.f;
-            } else {
-                d = *reinterpret_cast<const f32x4*>(dz + i * 4);
+                for (int e = 0; e < 4; ++e) d[e] = (!relu || z[e] > 0.f) ? gin[e] : 0.f;
             }
             const f32x4 o = a * d + bb * rv + cc;
             if (store_f32) *reinterpret_cast<f32x4*>(dz + i * 4) = o;
             if (dz16) st4_bf16(dz16 + i * 4, o);
             acc += o;
+        };
+        auto gload = [&](long long i) -> f32x4 { return dsrc ? ld4<DT>(dsrc + i * 4) : *reinterpret_cast<const f32x4*>(dz + i * 4); };
+        long long i = i0;
+        for (; i + 3 * stride < total; i += 4 * stride) {      // four iterations' loads in flight (see bn_bwd_reduce_kernel)
+            f32x4 rv[4], g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rv[j] = ld4<RT>(raw + (i + j * stride) * 4);
+                g[j] = gload(i + j * stride);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) one(i + j * stride, rv[j], g[j]);
         }
+        for (; i < total; i += stride) one(i, ld4<RT>(raw + i * 4), gload(i));
     }
     if (colsum) {
 #pragma unroll
