@@ -10,6 +10,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 typedef unsigned short u16;
+#ifndef BN_UNR
+#define BN_UNR 2
+#endif
+#ifndef BN_OCC
+#define BN_OCC 8          // waves per SIMD the streaming BatchNorm-backward kernels are compiled for (8 = two 1024-thread workgroups per CU)
+#endif
 
 // four consecutive channels of a stored map: fp32, or bf16 as the bf16 storage mode keeps it (the mixed-precision backward reads the
 // forward's own maps instead of fp32 copies of them)
@@ -39,8 +45,10 @@ __device__ __forceinline__ void st4_bf16(u16* p, const f32x4 v) {
 // element (non-overlapping pools) or atomically accumulated (overlapping, dz pre-zeroed).  Per-channel sums
 // s1 = sum dz, s2 = sum dz*raw feed the BatchNorm parameter gradients.
 // -----------------------------------------------------------------------------------------------------------------
-template <typename RT, typename DT = float>
-__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const DT* __restrict__ dout, const RT* __restrict__ raw,
+// POOL = false (pool_k == 0) is its own instantiation: the window code's registers (71) kept the streaming form at ONE 1024-thread
+// workgroup per CU; alone it fits 64 registers = two workgroups (8 waves per SIMD)
+template <typename RT, typename DT, bool POOL>
+__global__ __launch_bounds__(1024, POOL ? 4 : BN_OCC) void bn_bwd_reduce_kernel(const DT* __restrict__ dout, const RT* __restrict__ raw,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dz, double* __restrict__ sums, int B, int H,
                                                             int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
@@ -59,8 +67,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const DT* __restric
         sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
         sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
     }
-    // no pooling: a streaming pass -- four independent iterations' loads in flight per thread (two 8 / 16-byte loads per iteration did not
-    // cover the HBM latency at 32 waves per CU: ~60 % of the copy rate)
+    // no pooling: a streaming pass -- BN_UNR independent iterations' loads in flight per thread (two 8 / 16-byte loads per iteration did not
+    // cover the HBM latency at 32 waves per CU: ~60 % of the copy rate; 4 iterations cost half the resident waves: 2 keeps them)
     auto plain = [&](long long i, const f32x4 g, const f32x4 rv) {
         const size_t o = (size_t)i * 4;                   // Ho == H, Wo == W: dout and raw share one dense layout
         const f32x4 z = rv * sc + sh;
@@ -71,21 +79,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const DT* __restric
         a1 += d;
         a2 += d * rv;
     };
-    if (i0 < stride && pk == 0) {
+    if (!POOL && i0 < stride) {
         long long i = i0;
-        for (; i + 3 * stride < total; i += 4 * stride) {
-            f32x4 g[4], rv[4];
+        for (; i + (BN_UNR - 1) * stride < total; i += BN_UNR * stride) {
+            f32x4 g[BN_UNR], rv[BN_UNR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < BN_UNR; ++j) {
                 g[j] = ld4<DT>(dout + (i + j * stride) * 4);
                 rv[j] = ld4<RT>(raw + (i + j * stride) * 4);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) plain(i + j * stride, g[j], rv[j]);
+            for (int j = 0; j < BN_UNR; ++j) plain(i + j * stride, g[j], rv[j]);
         }
         for (; i < total; i += stride) plain(i, ld4<DT>(dout + i * 4), ld4<RT>(raw + i * 4));
     }
-    if (i0 < stride && pk != 0)
+    if (POOL && i0 < stride)
         for (long long i = i0; i < total; i += stride) {
             const f32x4 g = ld4<DT>(dout + i * 4);
             {
@@ -182,7 +190,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ fstats, double
 // being written by the reduce pass and read back (one HBM pass less per layer).  ``dz16`` (optional): the result as bf16, what the bf16
 // data-gradient conv and weight gradient read; ``store_f32`` = 0 leaves ``dz`` as it was (only read, when dsrc is NULL).
 template <typename RT, typename DT = float>
-__global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ dz, const RT* __restrict__ raw,
+__global__ __launch_bounds__(1024, BN_OCC) void bn_bwd_apply_kernel(float* __restrict__ dz, const RT* __restrict__ raw,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB,
                                                            const float* __restrict__ coefC, long long pixels, int C,
                                                            double* __restrict__ colsum, const DT* __restrict__ dsrc,
@@ -222,15 +230,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_kernel(float* __restrict__ 
         };
         auto gload = [&](long long i) -> f32x4 { return dsrc ? ld4<DT>(dsrc + i * 4) : *reinterpret_cast<const f32x4*>(dz + i * 4); };
         long long i = i0;
-        for (; i + 3 * stride < total; i += 4 * stride) {      // four iterations' loads in flight (see bn_bwd_reduce_kernel)
-            f32x4 rv[4], g[4];
+        for (; i + (BN_UNR - 1) * stride < total; i += BN_UNR * stride) {      // BN_UNR iterations' loads in flight (see bn_bwd_reduce_kernel)
+            f32x4 rv[BN_UNR], g[BN_UNR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < BN_UNR; ++j) {
                 rv[j] = ld4<RT>(raw + (i + j * stride) * 4);
                 g[j] = gload(i + j * stride);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) one(i + j * stride, rv[j], g[j]);
+            for (int j = 0; j < BN_UNR; ++j) one(i + j * stride, rv[j], g[j]);
         }
         for (; i < total; i += stride) one(i, ld4<RT>(raw + i * 4), gload(i));
     }
@@ -372,8 +380,12 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
     GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream), dout,
-                       raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    if (pool_k)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float, true>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),
+                           as_stream(stream), dout, raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float, false>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),
+                           as_stream(stream), dout, raw, scale, shift, dz, sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -386,14 +398,16 @@ extern "C" int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const v
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
     GSSD_CHECK_ARG((long long)B * Ho * Wo < (1ll << 32));
-    if (dout_bf16)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, u16>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float), as_stream(stream),
-                           reinterpret_cast<const u16*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, H, W, C, Ho,
-                           Wo, pool_k, pool_s, pool_p, relu);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, float>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),
-                           as_stream(stream), reinterpret_cast<const float*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz,
-                           sums, B, H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu);
+#define GSSD_RED(DT_, POOL_)                                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, DT_, POOL_>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),             \
+                       as_stream(stream), reinterpret_cast<const DT_*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, \
+                       H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu)
+    if (dout_bf16) {
+        if (pool_k) GSSD_RED(u16, true); else GSSD_RED(u16, false);
+    } else {
+        if (pool_k) GSSD_RED(float, true); else GSSD_RED(float, false);
+    }
+#undef GSSD_RED
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
