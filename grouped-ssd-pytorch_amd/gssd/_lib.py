@@ -84,7 +84,7 @@ SIGNATURES = {
     'gssd_bn_bwd_reduce_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_bwd_finalize_f32': (c_i, [c_fp, c_d, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp]),
     'gssd_bn_bwd_apply_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_fp]),
-    'gssd_bn_bwd_reduce_mixed': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_bn_bwd_reduce_mixed': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_bn_bwd_apply_mixed': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_i, c_fp]),
     'gssd_bn_bwd_apply_masked_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_fp, c_fp]),
     'gssd_colsum_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp, c_fp]),

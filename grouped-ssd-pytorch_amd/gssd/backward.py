@@ -593,19 +593,33 @@ class BackwardPlan:
         if not mixed:
             self._need(raw)
         # without pooling the reduce pass only sums (dz = NULL) and the apply pass re-derives dz from d(out): 5 instead of 6 HBM passes
-        self._add(lib.gssd_bn_bwd_reduce_mixed if mixed else lib.gssd_bn_bwd_reduce_f32,
-                  ((dout.data_ptr(), int(dout16 is not None), raw16.data_ptr()) if mixed else (dout.data_ptr(), raw.data_ptr())) +
-                  (sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0, sums.data_ptr(), B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
+        # mixed + a non-overlapping pool: the routed (un-pooled) gradient travels from the reduce pass to the apply pass as a bf16 map
+        dzp16 = torch.empty(B, Ho, Ho, Cout, device=self.dev, dtype=torch.bfloat16) if (mixed and pool and ps >= pk) else None
+        if mixed:
+            self._add(lib.gssd_bn_bwd_reduce_mixed,
+                      (dout.data_ptr(), int(dout16 is not None), raw16.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                       dz.data_ptr() if (pool and dzp16 is None) else 0, dzp16.data_ptr() if dzp16 is not None else 0, sums.data_ptr(),
+                       B, Ho, Ho, Cout, Hp, Hp, pk, ps, pp, int(r['relu'])), keep=dzp16)
+        else:
+            self._add(lib.gssd_bn_bwd_reduce_f32,
+                      (dout.data_ptr(), raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), dz.data_ptr() if pool else 0, sums.data_ptr(), B, Ho, Ho,
+                       Cout, Hp, Hp, pk, ps, pp, int(r['relu'])))
         ca, cb, cc = self._buf(Cout), self._buf(Cout), self._buf(Cout)
         self._add(lib.gssd_bn_bwd_finalize_f32, (r['stats'].data_ptr(), float(B * Ho * Ho), sums.data_ptr(), bn.weight.data_ptr(),
                                                  float(bn.eps), Cout, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
                                                  self._pgrad(bn.weight).data_ptr(), self._pgrad(bn.bias).data_ptr(), r.get('stats_rep', 0)))
         cs = self._buf(Cout, dtype=torch.float64, zero_each_run=True)
         if mixed:
-            self._add(lib.gssd_bn_bwd_apply_mixed, (0 if pool else dout.data_ptr(), int(dout16 is not None), dz.data_ptr(), dz16.data_ptr() if want16 else 0,
-                                                    raw16.data_ptr(), 0 if pool else sc.data_ptr(), 0 if pool else sh.data_ptr(),
-                                                    int(r['relu']), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), B * Ho * Ho, Cout,
-                                                    cs.data_ptr(), int(want32)), keep=(raw16, dz16))
+            if dzp16 is not None:          # d = the bf16 map the reduce pass routed through the pool (already masked)
+                src, src16, msk = dzp16.data_ptr(), 1, False
+            elif pool:                     # d = dz as the reduce pass wrote it (overlapping windows: fp32 atomics)
+                src, src16, msk = 0, 0, False
+            else:                          # d = d(out) o [pre-activation > 0], re-derived here
+                src, src16, msk = dout.data_ptr(), int(dout16 is not None), True
+            self._add(lib.gssd_bn_bwd_apply_mixed, (src, src16, dz.data_ptr(), dz16.data_ptr() if want16 else 0, raw16.data_ptr(),
+                                                    sc.data_ptr() if msk else 0, sh.data_ptr() if msk else 0, int(r['relu']) if msk else 0,
+                                                    ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), B * Ho * Ho, Cout, cs.data_ptr(),
+                                                    int(want32)), keep=(raw16, dz16))
         elif pool:
             self._add(lib.gssd_bn_bwd_apply_f32, (dz.data_ptr(), raw.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
                                                   B * Ho * Ho, Cout, cs.data_ptr()))

@@ -51,7 +51,9 @@ template <typename RT, typename DT, bool POOL>
 __global__ __launch_bounds__(1024, POOL ? 4 : BN_OCC) void bn_bwd_reduce_kernel(const DT* __restrict__ dout, const RT* __restrict__ raw,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dz, double* __restrict__ sums, int B, int H,
-                                                            int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu) {
+                                                            int W, int C, int Ho, int Wo, int pk, int ps, int pp, int relu,
+                                                            u16* __restrict__ dzb = nullptr) {       // dzb: non-overlapping pools may
+    // hand the routed gradient to the apply pass as a bf16 map instead of dz (half the bytes of that round trip)
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] s1 | [C] s2
     const int C4 = C >> 2;
     for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
@@ -136,9 +138,11 @@ __global__ __launch_bounds__(1024, POOL ? 4 : BN_OCC) void bn_bwd_reduce_kernel(
                         f32x4 d;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) d[e] = (bi[e] == dy * pk + dx && (!relu || best[e] > 0.f)) ? g[e] : 0.f;
-                        float* o = dz + (((size_t)b * H + yy) * W + xx) * C + 4 * c4;
+                        const size_t oi = (((size_t)b * H + yy) * W + xx) * C + 4 * c4;
+                        float* o = dz + oi;
                         if (!overlap) {
-                            *reinterpret_cast<f32x4*>(o) = d;
+                            if (dzb) st4_bf16(dzb + oi, d);
+                            else *reinterpret_cast<f32x4*>(o) = d;
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -391,9 +395,10 @@ extern "C" int gssd_bn_bwd_reduce_f32(const float* dout, const float* raw, const
 }
 
 extern "C" int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const void* raw_bf16, const float* scale, const float* shift,
-                                        float* dz, double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s,
-                                        int pool_p, int relu, gssd_stream_t stream) {
-    GSSD_CHECK_ARG(dout && raw_bf16 && (dz || (pool_k == 0 && sums)) && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+                                        float* dz, void* dz_bf16, double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k,
+                                        int pool_s, int pool_p, int relu, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(dout && raw_bf16 && (dz || dz_bf16 || (pool_k == 0 && sums)) && B > 0 && C > 0 && C % 4 == 0 && C <= 4096);
+    GSSD_CHECK_ARG(!dz_bf16 || (pool_k > 0 && pool_s >= pool_k));          // the bf16 hand-over: non-overlapping pools only (plain stores)
     GSSD_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (pool_k == 0) GSSD_CHECK_ARG(Ho == H && Wo == W);
     const long long total = (long long)B * Ho * Wo * (C / 4);
@@ -401,7 +406,7 @@ extern "C" int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const v
 #define GSSD_RED(DT_, POOL_)                                                                                                            \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<u16, DT_, POOL_>), dim3(nblocks_wide(total)), dim3(WIDE), 2 * C * sizeof(float),             \
                        as_stream(stream), reinterpret_cast<const DT_*>(dout), reinterpret_cast<const u16*>(raw_bf16), scale, shift, dz, sums, B, \
-                       H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu)
+                       H, W, C, Ho, Wo, pool_k, pool_s, pool_p, relu, reinterpret_cast<u16*>(dz_bf16))
     if (dout_bf16) {
         if (pool_k) GSSD_RED(u16, true); else GSSD_RED(u16, false);
     } else {

@@ -262,10 +262,12 @@ int gssd_bn_bwd_apply_f32(float* dz, const float* raw, const float* coef_a, cons
  * fp32.  gssd_bn_bwd_apply_mixed: d = dout * [relu mask] when dout != NULL, else d is read from dz (what the pooled reduce pass wrote);
  * the result a*d + b*raw + c goes to dz_bf16 (bf16, when != NULL: the operand of the bf16 data-gradient conv and weight gradient) and,
  * when store_f32 != 0, to dz.  dout_bf16 != 0: d(out) itself is a bf16 map (the two thin trunk layers whose consumer's data-gradient conv
- * runs on the patch-staged bf16 kernel, which stores bf16). */
+ * runs on the patch-staged bf16 kernel, which stores bf16).
+ * gssd_bn_bwd_reduce_mixed, dz_bf16 != NULL (non-overlapping pools): the routed gradient goes out as a bf16 map instead of dz; the apply
+ * pass then takes it as its d(out) (dout = that map, dout_bf16 = 1, relu = 0, scale = shift = NULL). */
 int gssd_bn_bwd_reduce_mixed(const void* dout, int dout_bf16, const void* raw_bf16, const float* scale, const float* shift, float* dz,
-                             double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p, int relu,
-                             gssd_stream_t stream);
+                             void* dz_bf16, double* sums, int B, int H, int W, int C, int Ho, int Wo, int pool_k, int pool_s, int pool_p,
+                             int relu, gssd_stream_t stream);
 int gssd_bn_bwd_apply_mixed(const void* dout, int dout_bf16, float* dz, void* dz_bf16, const void* raw_bf16, const float* scale,
                             const float* shift, int relu, const float* coef_a, const float* coef_b, const float* coef_c, int64_t pixels,
                             int C, double* colsum, int store_f32, gssd_stream_t stream);

@@ -781,7 +781,7 @@ def test_bn_backward_mixed(dev, pool, dout_bf16):
     dz16 = torch.full(raw.shape, float('nan'), device=dev, dtype=torch.bfloat16)
     sums = torch.zeros(2 * Cc, device=dev, dtype=torch.float64)
     _lib.check(lib.gssd_bn_bwd_reduce_mixed(d_in.data_ptr(), int(dout_bf16), raw16.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                            dz.data_ptr() if pool else 0, sums.data_ptr(), B, H, H, Cc, Ho, Ho, pk, ps, pp, 1, st))
+                                            dz.data_ptr() if pool else 0, 0, sums.data_ptr(), B, H, H, Cc, Ho, Ho, pk, ps, pp, 1, st))
     ca, cb, cc, dg, db = (torch.empty(Cc, device=dev) for _ in range(5))
     _lib.check(lib.gssd_bn_bwd_finalize_f32(stats.data_ptr(), float(n), sums.data_ptr(), gm.data_ptr(), 1e-5, Cc, ca.data_ptr(), cb.data_ptr(),
                                             cc.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, st))
@@ -793,6 +793,18 @@ def test_bn_backward_mixed(dev, pool, dout_bf16):
     # (the column sums of a BatchNorm backward vanish analytically: both are rounding noise of the same size)
     assert float((cs - ref_cs).abs().max()) < 1e-6 * float(dz.abs().sum(dim=(0, 1, 2)).max())
     assert torch.equal(dz16, dz.to(torch.bfloat16))
+    if pool and ps >= pk and dout_bf16:
+        # non-overlapping pool: the routed gradient handed over as a bf16 map (exact here: d(out) is bf16-representable) -- same results
+        dzp = torch.full(raw.shape, float('nan'), device=dev, dtype=torch.bfloat16)
+        sums2 = torch.zeros_like(sums)
+        _lib.check(lib.gssd_bn_bwd_reduce_mixed(d_in.data_ptr(), 1, raw16.data_ptr(), sc.data_ptr(), sh.data_ptr(), 0, dzp.data_ptr(),
+                                                sums2.data_ptr(), B, H, H, Cc, Ho, Ho, pk, ps, pp, 1, st))
+        assert rel(sums2, sums) < 1e-6           # (fp32 per-thread partial sums, fp64 atomics in any order)
+        dz3 = torch.full_like(raw, float('nan'))
+        dz163 = torch.full(raw.shape, float('nan'), device=dev, dtype=torch.bfloat16)
+        _lib.check(lib.gssd_bn_bwd_apply_mixed(dzp.data_ptr(), 1, dz3.data_ptr(), dz163.data_ptr(), raw16.data_ptr(), 0, 0, 0, ca.data_ptr(),
+                                               cb.data_ptr(), cc.data_ptr(), n, Cc, 0, 1, st))
+        assert rel(dz3, ref_dz) < 1e-6 and torch.equal(dz163, dz3.to(torch.bfloat16))
     # store_f32 = 0 leaves dz alone (no-pool form)
     if not pool:
         dz2 = torch.full_like(raw, 7.0)
