@@ -475,8 +475,8 @@ extern "C" int gssd_slice_and_cat_f32(const float* a, const float* b, float* out
 extern "C" int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int do_power_iteration, float eps,
                                       gssd_stream_t stream) {
     GSSD_CHECK_ARG(items_dev && n > 0);
-    // rows + cols <= 1536 for every Self_Attn conv of the path (512x1024 is the largest)
-    const size_t smem = (2048 + 16) * sizeof(float);
+    // rows + cols <= 1536 for every Self_Attn conv of the path (512 x 1024 is the largest); --feature_scale 2 doubles both (3072)
+    const size_t smem = (4096 + 16) * sizeof(float);
     hipLaunchKernelGGL(spectral_norm_kernel, dim3(n), dim3(1024), smem, as_stream(stream), items_dev,
                        do_power_iteration, eps);
     GSSD_CHECK_LAUNCH();

@@ -56,7 +56,9 @@ template <int D, int C2, int BKV>
 __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(const float* __restrict__ tp, const float* __restrict__ kp,
                                                            const float* __restrict__ gT, float* __restrict__ out, int N, int Nk,
                                                            int Np, int qtiles, int d_real, int kstride, int out_bf16,
-                                                           float* __restrict__ lse) {
+                                                           float* __restrict__ lse, int out_stride, int g_batch_rows) {
+    // out_stride / g_batch_rows: the launch may cover a C2-wide SLICE of wider rows (g channels 1024 = two launches of 512: the
+    // accumulators of all 1024 would need 256 registers)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                    // [BKV][D]
     float* const Vs = smem + BKV * D;          // [C2][BKV]
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     const int tps = 2 * d_real;                                   // floats per token of tp (d_real <= D; D - d_real zero filled)
     const float* tpb = tp + (size_t)b * N * tps;
     const float* kpb = kp + (size_t)b * Nk * kstride;            // keys: phi of the same tokens (kp = tp + d_real, Nk = N) or
-    const float* gTb = gT + (size_t)b * C2 * Np;                  // the pooled phi / g of max_pool_factor > 1 (Nk < N)
+    const float* gTb = gT + (size_t)b * g_batch_rows * Np;        // the pooled phi / g of max_pool_factor > 1 (Nk < N)
 
     // query fragments: B operand, lane (q, kq) holds theta[q][16 i + 4 kq + s]
     f32x4 qf[DI];
@@ -172,14 +174,14 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
     if (q < N) {
         if (out_bf16) {             // bf16 storage mode (configs[4]): the o conv reads bf16
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            unsigned short* dst = reinterpret_cast<unsigned short*>(out) + ((size_t)b * N + q) * C2 + 4 * kq;
+            unsigned short* dst = reinterpret_cast<unsigned short*>(out) + ((size_t)b * N + q) * out_stride + 4 * kq;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const f32x4 v = o[c] * inv;
                 *reinterpret_cast<bf16x4*>(dst + 16 * c) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             }
         } else {
-            float* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+            float* dst = out + ((size_t)b * N + q) * out_stride + 4 * kq;
 #pragma unroll
             for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(dst + 16 * c) = o[c] * inv;
         }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, (C2 > 256 ? 1 : 2)) void flash_attn_kernel(con
 
 template <int D, int C2, int BKV>
 int launch(const float* tp, const float* kp, const float* gT, float* out, int B, int N, int Nk, int Np, int d_real, int kstride,
-           int out_bf16, float* lse, hipStream_t stream) {
+           int out_bf16, float* lse, hipStream_t stream, int out_stride = C2, int g_batch_rows = C2) {
     constexpr int smem = (BKV * D + C2 * BKV) * (int)sizeof(float);
     static unsigned attr_mask = 0;
     auto kern = flash_attn_kernel<D, C2, BKV>;
@@ -200,7 +202,8 @@ int launch(const float* tp, const float* kp, const float* gT, float* out, int B,
         gssd_attr_done(&attr_mask);
     }
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16, lse);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, kp, gT, out, N, Nk, Np, qtiles, d_real, kstride, out_bf16, lse,
+                       out_stride, g_batch_rows);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -219,7 +222,7 @@ typedef unsigned short u16;
 template <int D, int C2, int BKV>
 __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* __restrict__ tp, const u16* __restrict__ gT,
                                                                   u16* __restrict__ out, int N, int Np32, int qtiles,
-                                                                  float* __restrict__ lse) {
+                                                                  float* __restrict__ lse, int out_stride, int g_batch_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ks = smem;                                            // [BKV][D] fp32
     u16* const Vs = reinterpret_cast<u16*>(smem + BKV * D);            // [C2][BKV] bf16, keys permuted inside 32-blocks
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
     const int b = blockIdx.x / qtiles, qt = blockIdx.x - b * qtiles;
     const int q = qt * 64 + wave * 16 + r;
     const float* tpb = tp + (size_t)b * N * (2 * D);
-    const u16* gTb = gT + (size_t)b * C2 * Np32;
+    const u16* gTb = gT + (size_t)b * g_batch_rows * Np32;
 
     f32x4 qf[DI];
 #pragma unroll
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
     if (lse != nullptr && q < N && kq == 0) lse[(size_t)b * N + q] = m_run + logf(l_run);       // for the training step's backward
     if (q < N) {
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        u16* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
+        u16* dst = out + ((size_t)b * N + q) * out_stride + 4 * kq;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const f32x4 v = o[c] * inv;
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_mixed_kernel(const float* _
 }
 
 template <int D, int C2, int BKV>
-int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np32, float* lse, hipStream_t stream) {
+int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np32, float* lse, hipStream_t stream, int out_stride = C2,
+                 int g_batch_rows = C2) {
     constexpr int smem = BKV * D * (int)sizeof(float) + C2 * BKV * (int)sizeof(u16);
     static unsigned attr_mask = 0;
     auto kern = flash_attn_mixed_kernel<D, C2, BKV>;
@@ -353,7 +357,7 @@ int launch_mixed(const float* tp, const u16* gT, u16* out, int B, int N, int Np3
     }
     gssd_attr_done(&attr_mask);
     const int qtiles = (N + 63) / 64;
-    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles, lse);
+    hipLaunchKernelGGL(kern, dim3(B * qtiles), dim3(256), smem, stream, tp, gT, out, N, Np32, qtiles, lse, out_stride, g_batch_rows);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -370,6 +374,13 @@ extern "C" int gssd_self_attn_core_kv_f32(const float* tp, const float* kp, cons
     GSSD_CHECK_ARG(D > 0 && D % 4 == 0 && C2 > 0 && kstride >= D && kstride % 4 == 0);
     if (D == 64 && C2 == 256) return launch<64, 256, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
     if (D == 128 && C2 == 512) return launch<128, 512, 32>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
+    if (D == 256 && C2 == 1024) {           // --feature_scale 2 on the 2048-channel map: two launches of 512 g channels each
+        const size_t esz = out_bf16 ? 2 : 4;
+        const int rc = launch<256, 512, 32>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s, 1024, 1024);
+        if (rc != GSSD_OK) return rc;
+        return launch<256, 512, 32>(tp, kp, gT + (size_t)512 * Nkp, reinterpret_cast<float*>(reinterpret_cast<char*>(out) + 512 * esz), B, N, Nk,
+                                    Nkp, D, kstride, out_bf16, nullptr, s, 1024, 1024);
+    }
     if (D == 32 && C2 == 128) return launch<32, 128, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
     if (D <= 16 && C2 == 32) return launch<16, 32, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);     // small maps (Self_Attn(64): op-level tests)
     if (D <= 16 && C2 == 64) return launch<16, 64, 64>(tp, kp, gT, out, B, N, Nk, Nkp, D, kstride, out_bf16, lse, s);
@@ -393,6 +404,11 @@ extern "C" int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, v
     u16* o = reinterpret_cast<u16*>(out_bf16);
     if (D == 64 && C2 == 256) return launch_mixed<64, 256, 64>(tp, g, o, B, N, Np32, lse, s);
     if (D == 128 && C2 == 512) return launch_mixed<128, 512, 32>(tp, g, o, B, N, Np32, lse, s);
+    if (D == 256 && C2 == 1024) {           // two launches of 512 g channels each (see gssd_self_attn_core_kv_f32)
+        const int rc = launch_mixed<256, 512, 32>(tp, g, o, B, N, Np32, lse, s, 1024, 1024);
+        if (rc != GSSD_OK) return rc;
+        return launch_mixed<256, 512, 32>(tp, g + (size_t)512 * Np32, o + 512, B, N, Np32, nullptr, s, 1024, 1024);
+    }
     if (D == 32 && C2 == 128) return launch_mixed<32, 128, 64>(tp, g, o, B, N, Np32, lse, s);
     gssd_set_error("self-attention core (bf16 values): unsupported (theta/phi channels %d, g channels %d)", D, C2);
     return GSSD_EINVAL;

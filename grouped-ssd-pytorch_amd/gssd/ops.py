@@ -316,8 +316,8 @@ def sn_items_tensor(items, device):
     for i, (w, u, v, s) in enumerate(items):
         rows = w.shape[0]
         cols = w.numel() // rows
-        if rows + cols > 2048:
-            raise _lib.GssdError(f'spectral norm: rows + cols = {rows + cols} exceeds the kernel\'s 2048-float LDS vectors')
+        if rows + cols > 4096:
+            raise _lib.GssdError(f'spectral norm: rows + cols = {rows + cols} exceeds the kernel\'s 4096-float LDS vectors')
         arr[i].w, arr[i].u, arr[i].v, arr[i].inv_sigma, arr[i].rows, arr[i].cols = _p(w), _p(u), _p(v), _p(s), rows, cols
     raw = bytes(arr)
     return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

@@ -23,6 +23,7 @@ FLAG_NETS = {
     'mpf2': (True, 4, 4, 1, True, True, True, 1, 4, True, False, 2),
     'mpf3_sa': (True, 4, 4, 1, True, True, True, 0, 1, False, False, 3),
     'fs2': (True, 4, 4, 2, True, False, False, 0, 1, False, False, 1),
+    'fs2pp': (True, 4, 4, 2, True, True, True, 1, 4, True, False, 1),           # round 4: GSSD++ with every channel width doubled
     'dcn2_detach': (True, 4, 4, 1, True, True, True, 2, 1, True, True, 1),      # two DCN layers, one deformable group, detached SAB
     'dcn_nocat': (True, 4, 4, 1, True, False, False, 1, 4, False, False, 1),     # DCN on the plain conv4_3 map (512 -> 512)
     # round 3: --groups_vgg / --groups_extra other than 4 (train_lesion_multiphase_v2.py:47-48)

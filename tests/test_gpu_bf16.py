@@ -871,7 +871,10 @@ def test_self_attn_flash_bwd(dev, B, N, D, C2):
 @pytest.mark.parametrize('name,flags,args', [
     ('g1', dict(groups_vgg=1, groups_extra=1), (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1)),
     ('g2pp', dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
-                  dcn_cat_sab=True), (True, 2, 2, 1, True, True, True, 1, 4, True, False, 1))])
+                  dcn_cat_sab=True), (True, 2, 2, 1, True, True, True, 1, 4, True, False, 1)),
+    # --feature_scale 2 with Self_Attn / DCN: the (256, 1024) attention block as two launches of 512 g channels
+    ('fs2pp', dict(feature_scale=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True),
+     (True, 4, 4, 2, True, True, True, 1, 4, True, False, 1))])
 def test_bf16_group_counts(dev, name, flags, args):
     """--groups_vgg / --groups_extra 1 and 2 in the bf16 storage mode (the input pack writes 12 -> 16 / 6 -> 8 channels per group; every
     layer runs the generic bf16 kernels).  End to end at B = 2 the bf16 graph is far from the fp32 one (ill-conditioned small-batch
