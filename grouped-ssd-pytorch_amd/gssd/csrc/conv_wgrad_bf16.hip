@@ -25,6 +25,8 @@ typedef unsigned short u16;
 
 namespace {
 
+constexpr int SCHED_EVERY = 4;         // entries between two scheduling barriers of the k-step (bounds the fragment reads in flight)
+
 __device__ __attribute__((aligned(16))) u16 g_zero_page_wb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
@@ -64,9 +66,6 @@ template <int CIN_G, int NG, int COB, int WCO, int WEN, bool XF, int NTAP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBfParams p) {
     static_assert(NTAP == 9 || NTAP == 1, "3x3 (stride 1, pad 1) or 1x1");
     static_assert(NG * WCO * WEN == 4, "four waves");
-#ifndef SCHED_EVERY
-#define SCHED_EVERY 4
-#endif
     constexpr int HALO = NTAP == 9 ? 1 : 0, NDX = NTAP == 9 ? 3 : 1;
     constexpr int TH = 8, TW = 16, PW = TW + 2 * HALO, NPATCH = (TH + 2 * HALO) * PW, NPIX = TH * TW;
     constexpr int NCI = CIN_G / 16, CPW = NCI / WEN, EPW = NTAP * CPW;  // a wave's entries: the taps x CPW of the NCI 16-channel input chunks
