@@ -868,6 +868,20 @@ def test_self_attn_flash_bwd(dev, B, N, D, C2):
         assert e < 5e-3, (name, e)
 
 
+def test_training_soak_batch32():
+    """scripts/train_soak.py: 30 SGD steps of GSSD++ on one batch of 32 (the BENCHMARKED batch: every large-map kernel of the backward,
+    the bf16 gradient maps, the flash-style attention backward at N = 1444) in fp32 and in the bf16 storage mode, in a process of its
+    own -- both losses stay finite and at least halve (the script asserts it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'train_soak.py'), '30'], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-600:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'ratio bf16 / f32' in r.stdout
+
+
 @pytest.mark.parametrize('name,flags,args', [
     ('g1', dict(groups_vgg=1, groups_extra=1), (True, 1, 1, 1, True, False, False, 0, 1, False, False, 1)),
     ('g2pp', dict(groups_vgg=2, groups_extra=2, use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
