@@ -10,10 +10,6 @@
 #ifndef COL2IM_KO
 #define COL2IM_KO 0      // scripts/col2im_knockout.sh
 #endif
-#ifndef COL2IM_MERGED
-#define COL2IM_MERGED 0  // 1: every wave reduces AND scatters a third of the units, d(x) window by ds_add_f32 -- measured 3.0 -> 9.0 ms
-                         // (LDS float atomics serialise): kept for scripts/col2im_knockout.sh, not for use
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -269,56 +265,6 @@ __global__ __launch_bounds__(192) void dcn_col2im_kernel(const float* __restrict
             lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_lx), q));
             m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_m), q));
         };
-#if COL2IM_MERGED
-        {
-            // every wave takes a third of the chunk's units and does BOTH jobs for them: the d(offset / mask) wave sums and the d(x)
-            // window accumulation -- the latter with LDS float atomics (ds_add_f32, no return), so no wave owns the window and no
-            // read-modify-write round trip sits between two units (the scatter wave's serial chain cost ~420 cycles per unit; the
-            // atomics make the sum order, hence the last bits of d(x), depend on the run -- as the global flush below already does)
-#pragma unroll
-            for (int q0 = 0; q0 < DC_CH; q0 += 9) {
-                float s_m[3], s_y[3], s_x[3], mm[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int q = q0 + 3 * k + wave;                      // wave-uniform
-                    const int gi = __builtin_amdgcn_readlane(v_gi, q);
-                    const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_ly), q));
-                    const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_lx), q));
-                    const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_m), q));
-                    mm[k] = m;
-                    const bool on = (gi & 48) == 48;
-                    const float g = on ? gbuf[q * 64 + lane] : 0.f;
-                    const float hy = 1.f - ly, hx = 1.f - lx;
-                    const int wofs = (on ? gi >> 8 : 0) * 64 + lane;
-                    const float* wp = xw + wofs;
-                    const float r00 = wp[0], r01 = wp[64], r10 = wp[WW * 64], r11 = wp[WW * 64 + 64];
-                    const float v00 = (gi & 1) ? r00 : 0.f, v01 = (gi & 2) ? r01 : 0.f;
-                    const float v10 = (gi & 4) ? r10 : 0.f, v11 = (gi & 8) ? r11 : 0.f;
-                    s_m[k] = g * (v00 * (hy * hx) + v01 * (hy * lx) + v10 * (ly * hx) + v11 * (ly * lx));
-                    s_y[k] = g * ((v10 - v00) * hx + (v11 - v01) * lx);
-                    s_x[k] = g * ((v01 - v00) * hy + (v11 - v10) * ly);
-                    if (on) {                                             // wave-uniform
-                        const float gm = g * m;
-                        float* ap = dw + wofs;
-                        if (gi & 1) atomicAdd(ap, gm * (hy * hx));
-                        if (gi & 2) atomicAdd(ap + 64, gm * (hy * lx));
-                        if (gi & 4) atomicAdd(ap + WW * 64, gm * (ly * hx));
-                        if (gi & 8) atomicAdd(ap + WW * 64 + 64, gm * (ly * lx));
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int u = c * DC_CH + q0 + 3 * k + wave;
-                    const float t_m = wave_sum_dpp(s_m[k]), t_y = wave_sum_dpp(s_y[k]), t_x = wave_sum_dpp(s_x[k]);
-                    if (lane == 0) {
-                        dacc[u * 3] = t_y * mm[k];
-                        dacc[u * 3 + 1] = t_x * mm[k];
-                        dacc[u * 3 + 2] = t_m * mm[k] * (1.f - mm[k]);
-                    }
-                }
-            }
-        }
-#else
         if (wave < 2) {
             if (!(COL2IM_KO & 16))
             // reduce waves: units q = wave, wave + 2, ...; three units per trip, branch free (a unit that does not contribute reads
@@ -378,7 +324,6 @@ __global__ __launch_bounds__(192) void dcn_col2im_kernel(const float* __restrict
                 wp[WW * 64 + 64] = a11 + ((gi & 8) ? gm * (ly * lx) : 0.f);
             }
         }
-#endif
         __syncthreads();                                              // chunk c consumed by all waves, chunk c + 1 landed
     }
     // ---- flush: d(x) window (one atomic per element: neighbouring tiles' windows overlap) and the three d(om) scalars per unit ----
