@@ -109,7 +109,8 @@ SIGNATURES = {
     'gssd_pixellink_final_bwd_f32': (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_pixellink_loss_bwd_f32': (c_i, [c_fp] * 10 + [c_i, c_i, c_i, c_fp]),
     'gssd_pixellink_decode_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_fp]),
-    'gssd_self_attn_flash_bwd_bf16': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_self_attn_flash_bwd_bf16': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_cast_split_f32_bf16': (c_i, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     'gssd_self_attn_flash_bwd_supported': (c_i, [c_i, c_i]),
     'gssd_self_attn_core_bf16v': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),

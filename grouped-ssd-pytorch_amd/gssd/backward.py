@@ -875,9 +875,14 @@ class BackwardPlan:
             # bf16 storage mode: d theta | d phi | d g in two launches of the flash-style kernel, no [N][N] map
             Dv = self._buf(B, N)
             self._add(lib.gssd_rowdot_f32, (dag.data_ptr(), ag.data_ptr(), Dv.data_ptr(), M, C2))
-            self._add(lib.gssd_self_attn_flash_bwd_bf16, (tp.data_ptr(), self._cast16(tp).data_ptr(), r['g16'].data_ptr(),
+            # theta | phi as a two-term bf16 split: the logits are recomputed on the bf16 matrix cores to 2^-16 (GSSD_FLASH_BWD_X3=0: fp32 MFMA)
+            tph = torch.empty(tp.shape, device=self.dev, dtype=torch.bfloat16)
+            tpl = torch.empty(tp.shape, device=self.dev, dtype=torch.bfloat16)
+            self._add(lib.gssd_cast_split_f32_bf16, (tp.data_ptr(), tph.data_ptr(), tpl.data_ptr(), tp.numel()))
+            x3 = os.environ.get('GSSD_FLASH_BWD_X3', '1') != '0'
+            self._add(lib.gssd_self_attn_flash_bwd_bf16, (tp.data_ptr(), tph.data_ptr(), tpl.data_ptr() if x3 else 0, r['g16'].data_ptr(),
                                                           self._cast16(dag).data_ptr(), lse.data_ptr(), Dv.data_ptr(), dtpg.data_ptr(),
-                                                          B, N, C8, C2), keep=(r['g16'], lse))
+                                                          B, N, C8, C2), keep=(r['g16'], lse, tph, tpl))
         else:
             self._sa_explicit(r, dtpg, dag, ag, tp, keys, krow, vals, lse, pooled)
         self._sa_tail(r, dtpg, g_out, gx, existed, x, a_tpg, w_tpg, cv, sig, sndot)

@@ -468,6 +468,16 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ x, float* __restric
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[8 * n8 + threadIdx.x] = bf2f(x[8 * n8 + threadIdx.x]);
 }
 
+// hi = bf16(x), lo = bf16(x - hi): the two-term split whose three cross products reproduce an fp32 product to 2^-16 on the bf16 matrix cores
+__global__ void cast_split_bf16_kernel(const float* __restrict__ x, u16* __restrict__ hi, u16* __restrict__ lo, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const u16 h = f2bf(v);
+        hi[i] = h;
+        lo[i] = f2bf(v - bf2f(h));
+    }
+}
+
 // y[r][c] = bf16(x[r][c]) for c < cols, 0 for cols <= c < ld_y: rows widened to a multiple of 8 channels for the 16-byte lanes of the
 // bf16 kernels (the merged head gradients: 36 -> 40 channels)
 __global__ void cast_rows_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, long long rows, int cols, int ld_x, int ld_y) {
@@ -480,6 +490,14 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ x, u16* __restri
 }
 
 }  // namespace
+
+extern "C" int gssd_cast_split_f32_bf16(const float* x, void* hi, void* lo, int64_t n, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && hi && lo && n > 0);
+    hipLaunchKernelGGL(cast_split_bf16_kernel, dim3((int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                       reinterpret_cast<u16*>(hi), reinterpret_cast<u16*>(lo), (long long)n);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
 
 extern "C" int gssd_cast_rows_f32_bf16(const float* x, void* y, int64_t rows, int cols, int ld_x, int ld_y, gssd_stream_t stream) {
     GSSD_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_x >= cols && ld_y >= cols);

@@ -41,7 +41,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const u16* p0, const u16* p1) {
 
 struct FbParams {
     const float* tp;       // [B][N][2D] fp32: theta | phi
-    const u16* tp16;       // the same, bf16
+    const u16* tp16;       // the same, bf16: hi = bf16(x)
+    const u16* tp16lo;     // lo = bf16(x - hi): theta phi^T is recomputed as hi.hi + hi.lo + lo.hi on the bf16 matrix cores (NULL: fp32 MFMA)
     const u16* g16;        // [B][N][C2] bf16, token-major
     const u16* dag16;      // [B][N][C2] bf16: d(attn_g)
     const float* lse;      // [B][N]
@@ -52,7 +53,10 @@ struct FbParams {
 
 constexpr int OWN = 64, STR = 32;
 
-template <int D, int C2, bool OWN_KEYS>
+// X3: the logits from the two-term bf16 split of theta / phi -- three v_mfma_f32_16x16x32_bf16 per 32 channels instead of eight
+// v_mfma_f32_16x16x4_f32 (1/5 of the matrix-pipe time; the dropped lo.lo term is 2^-16 of a product: a logit of magnitude 50 moves by
+// < 1e-3, its probability by < 0.1 % -- a quarter of the bf16 rounding P gets anyway)
+template <int D, int C2, bool OWN_KEYS, bool X3>
 __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(const FbParams p) {      // (128, 512): 256 accumulator +
     // operand registers per lane -- one workgroup per CU with the unified 512-register file
     constexpr int DI = D / 16, CS = C2 / 32, CT = C2 / 16, CTOT = 2 * D + C2;
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fb[];
     float* Sf = reinterpret_cast<float*>(smem_fb);                       // [STR][D] fp32, units XOR (t & XF)
     u16* Sd = reinterpret_cast<u16*>(Sf + STR * D);                     // [STR][D] bf16 for transpose reads, chunks XOR swz
+    u16* Sl = reinterpret_cast<u16*>(Sf);                               // X3: the lo image [STR][D] bf16 in place of the fp32 one (same layout as Sd)
     u16* An = Sd + STR * D;                                             // [STR][C2] bf16, natural 16-byte reads: units XOR (t & 15)
     u16* At = An + STR * C2;                                            // [STR][C2] bf16, transpose reads: chunks XOR (t & 7)   (OWN_KEYS)
     float* ls = reinterpret_cast<float*>(OWN_KEYS ? At + STR * C2 : At);    // [STR] lse, [STR] D of the streamed queries          (OWN_KEYS)
@@ -80,16 +85,38 @@ __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(c
     const float* own_f = p.tp + bN * (2 * D) + (OWN_KEYS ? D : 0);      // phi (keys) or theta (queries)
     const float* str_f = p.tp + bN * (2 * D) + (OWN_KEYS ? 0 : D);
     const u16* str_d = p.tp16 + bN * (2 * D) + (OWN_KEYS ? 0 : D);
+    const u16* str_l = X3 ? p.tp16lo + bN * (2 * D) + (OWN_KEYS ? 0 : D) : nullptr;
     const u16* own_c = (OWN_KEYS ? p.g16 : p.dag16) + bN * C2;
     const u16* str_c = (OWN_KEYS ? p.dag16 : p.g16) + bN * C2;
     const void* zero = g_zero_page_fb;
 
     // ---- the own side: operand fragments in registers for the whole kernel -----------------------------------------------------------
-    f32x4 kown[DI];
+    constexpr int DS = D / 32;
+    f32x4 kown[X3 ? 1 : DI];
+    bf16x8 kh[X3 ? DS : 1], kl[X3 ? DS : 1];       // X3: lane (own token r, kq) holds channels 32 s + 8 kq .. + 7, split hi / lo
     bf16x8 vown[CS];
+    if constexpr (!X3) {
 #pragma unroll
-    for (int i = 0; i < DI; ++i)
-        kown[i] = own_ok ? *reinterpret_cast<const f32x4*>(own_f + (size_t)own_tok * (2 * D) + 16 * i + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < DI; ++i)
+            kown[i] = own_ok ? *reinterpret_cast<const f32x4*>(own_f + (size_t)own_tok * (2 * D) + 16 * i + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
+            if (own_ok) {
+                a = *reinterpret_cast<const f32x4*>(own_f + (size_t)own_tok * (2 * D) + 32 * s + 8 * kq);
+                bq = *reinterpret_cast<const f32x4*>(own_f + (size_t)own_tok * (2 * D) + 32 * s + 8 * kq + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 h0 = (__bf16)a[e], h1 = (__bf16)bq[e];
+                kh[s][e] = h0;
+                kh[s][4 + e] = h1;
+                kl[s][e] = (__bf16)(a[e] - (float)h0);
+                kl[s][4 + e] = (__bf16)(bq[e] - (float)h1);
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < CS; ++s) {
         if (own_ok) vown[s] = *reinterpret_cast<const bf16x8*>(own_c + (size_t)own_tok * C2 + 32 * s + 8 * kq);
@@ -124,6 +151,7 @@ __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(c
         // ---- stage the streamed block -------------------------------------------------------------------------------------------------
         {
             constexpr int RF = 64 / UF;                                  // rows per DMA piece
+            if constexpr (!X3)
             for (int i = wave; i < STR / RF; i += 4) {
                 const int t = i * RF + lane / UF, u = lane % UF;
                 const int tok = s0 + t;
@@ -135,8 +163,9 @@ __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(c
                 const int t = i * RD + lane / UD, u = lane % UD;
                 const int tok = s0 + t;
                 const int sw = NCD >= 8 ? (t & 7) : NCD == 4 ? ((t >> 1) & 3) : ((t >> 2) & 1);
-                const void* src = tok < N ? (const void*)(str_d + (size_t)tok * (2 * D) + (((u >> 1) ^ sw) << 4) + ((u & 1) << 3)) : zero;
-                dma16(src, Sd + i * RD * D);
+                const size_t so = (size_t)tok * (2 * D) + (((u >> 1) ^ sw) << 4) + ((u & 1) << 3);
+                dma16(tok < N ? (const void*)(str_d + so) : zero, Sd + i * RD * D);
+                if constexpr (X3) dma16(tok < N ? (const void*)(str_l + so) : zero, Sl + i * RD * D);
             }
             constexpr int RC = 64 / UC;                                  // rows per piece
             static_assert(UC <= 64, "C2 <= 512");
@@ -167,11 +196,25 @@ __global__ __launch_bounds__(256, (D >= 128 ? 1 : 2)) void sa_flash_bwd_kernel(c
         for (int h = 0; h < 2; ++h) {
             const int t = 16 * h + r;                                    // the row this lane FEEDS (A operand); its results are rows 4 kq + e
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!X3) {
 #pragma unroll
-            for (int i = 0; i < DI; ++i) {
-                const f32x4 qf = *reinterpret_cast<const f32x4*>(Sf + t * D + (((4 * i + kq) ^ (t & XF)) << 2));
+                for (int i = 0; i < DI; ++i) {
+                    const f32x4 qf = *reinterpret_cast<const f32x4*>(Sf + t * D + (((4 * i + kq) ^ (t & XF)) << 2));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], kown[i][e], s, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], kown[i][e], s, 0, 0, 0);
+                }
+            } else {
+                const int swt = NCD >= 8 ? (t & 7) : NCD == 4 ? ((t >> 1) & 3) : ((t >> 2) & 1);
+#pragma unroll
+                for (int q = 0; q < DS; ++q) {
+                    const int U = 4 * q + kq;                         // 16-byte unit of the row: channels 32 q + 8 kq ..
+                    const int off = t * D + (((U >> 1) ^ swt) << 4) + ((U & 1) << 3);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Sd + off);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Sl + off);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, kh[q], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, kl[q], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, kh[q], s, 0, 0, 0);
+                }
             }
             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -231,17 +274,19 @@ int launch_fb(const FbParams& p0, int B, hipStream_t stream) {
     p.own_blocks = (p.N + OWN - 1) / OWN;
     const size_t base = (size_t)STR * D * 4 + (size_t)STR * D * 2 + (size_t)STR * C2 * 2;
     const size_t smem_k = base + (size_t)STR * C2 * 2 + 2 * STR * sizeof(float), smem_q = base;
-    auto kk = sa_flash_bwd_kernel<D, C2, true>;
-    auto kq = sa_flash_bwd_kernel<D, C2, false>;
-    static unsigned attr_mask = 0;
-    if (gssd_attr_needed(&attr_mask)) {
+    const bool x3 = p.tp16lo != nullptr;
+    auto kk = x3 ? sa_flash_bwd_kernel<D, C2, true, true> : sa_flash_bwd_kernel<D, C2, true, false>;
+    auto kq = x3 ? sa_flash_bwd_kernel<D, C2, false, true> : sa_flash_bwd_kernel<D, C2, false, false>;
+    static unsigned attr_mask[2] = {0, 0};
+    unsigned* am = &attr_mask[x3 ? 1 : 0];
+    if (gssd_attr_needed(am)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_k) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q) != hipSuccess) {
             gssd_set_error("hipFuncSetAttribute failed (attention backward)");
             return GSSD_ELAUNCH;
         }
     }
-    gssd_attr_done(&attr_mask);
+    gssd_attr_done(am);
     hipLaunchKernelGGL(kk, dim3(B * p.own_blocks), dim3(256), smem_k, stream, p);
     GSSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(kq, dim3(B * p.own_blocks), dim3(256), smem_q, stream, p);
@@ -255,8 +300,9 @@ extern "C" int gssd_self_attn_flash_bwd_supported(int D, int C2) {
     return (D == 64 && C2 == 256) || (D == 32 && C2 == 128) || (D == 128 && C2 == 512) ? 1 : 0;
 }
 
-extern "C" int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* g_bf16, const void* dag_bf16, const float* lse,
-                                             const float* dvec, float* dtpg, int B, int N, int D, int C2, gssd_stream_t stream) {
+extern "C" int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* tp_bf16_lo, const void* g_bf16,
+                                             const void* dag_bf16, const float* lse, const float* dvec, float* dtpg, int B, int N, int D,
+                                             int C2, gssd_stream_t stream) {
     GSSD_CHECK_ARG(tp && tp_bf16 && g_bf16 && dag_bf16 && lse && dvec && dtpg && B > 0 && N > 0);
     GSSD_CHECK_ARG(((uintptr_t)tp % 16) == 0 && ((uintptr_t)tp_bf16 % 16) == 0 && ((uintptr_t)g_bf16 % 16) == 0 &&
                    ((uintptr_t)dag_bf16 % 16) == 0 && ((uintptr_t)dtpg % 16) == 0);
@@ -264,6 +310,7 @@ extern "C" int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf1
     FbParams p;
     p.tp = tp;
     p.tp16 = reinterpret_cast<const u16*>(tp_bf16);
+    p.tp16lo = reinterpret_cast<const u16*>(tp_bf16_lo);
     p.g16 = reinterpret_cast<const u16*>(g_bf16);
     p.dag16 = reinterpret_cast<const u16*>(dag_bf16);
     p.lse = lse;

@@ -338,9 +338,11 @@ int gssd_self_attn_core_bf16v(const float* tp, const void* gT_bf16, void* out_bf
  * token-major rows of 2 D + C2 floats).  tp [B][N][2D] fp32 (theta | phi) and its bf16 copy tp_bf16; g_bf16, dag_bf16 [B][N][C2] bf16
  * token-major; lse [B][N] from the forward (gssd_self_attn_core_bf16v); dvec[b][i] = <d(attn_g)_i, attn_g_i> (gssd_rowdot_f32).  The
  * logits are recomputed on the fp32 matrix cores, everything else on bf16 operands with fp32 accumulation.  (D, C2) in {(64, 256),
- * (32, 128), (128, 512)}: gssd_self_attn_flash_bwd_supported; anything else is GSSD_EINVAL (the caller keeps the explicit-map path). */
-int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* g_bf16, const void* dag_bf16, const float* lse,
-                                  const float* dvec, float* dtpg, int B, int N, int D, int C2, gssd_stream_t stream);
+ * (32, 128), (128, 512)}: gssd_self_attn_flash_bwd_supported; anything else is GSSD_EINVAL (the caller keeps the explicit-map path).
+ * tp_bf16_lo (optional): bf16(tp - tp_bf16), from gssd_cast_split_f32_bf16 -- the logits are then recomputed as hi.hi + hi.lo + lo.hi on the
+ * bf16 matrix cores (2^-16 of a product dropped) instead of the fp32 ones: 1/5 of the logits' matrix-pipe time. */
+int gssd_self_attn_flash_bwd_bf16(const float* tp, const void* tp_bf16, const void* tp_bf16_lo, const void* g_bf16, const void* dag_bf16,
+                                  const float* lse, const float* dvec, float* dtpg, int B, int N, int D, int C2, gssd_stream_t stream);
 int gssd_self_attn_flash_bwd_supported(int D, int C2);
 
 /* Row softmax in place over [rows][row_stride], first n columns; pad columns are zeroed.
@@ -485,6 +487,8 @@ int gssd_scaled_transpose_f32(const float* w, const float* alpha, float* out, in
  * bf16 storage mode's weight gradients dW[n][k] = sum_m dY[m][n] A[m][k] run as NT GEMMs over the transposed operands (reduction index
  * m contiguous) on the bf16 matrix cores: gssd_conv2d_nhwc_bf16 with in = dY^T, wgt = A^T, split_k > 1, GSSD_CONV_OUT_F32. */
 /* y[r][c] = bf16(x[r][c]) for c < cols and 0 for cols <= c < ld_y (rows widened to a multiple of 8 channels for the bf16 kernels). */
+/* hi = bf16(x), lo = bf16(x - hi). */
+int gssd_cast_split_f32_bf16(const float* x, void* hi, void* lo, int64_t n, gssd_stream_t stream);
 int gssd_cast_rows_f32_bf16(const float* x, void* y, int64_t rows, int cols, int ld_x, int ld_y, gssd_stream_t stream);
 int gssd_transpose_cast_f32_bf16(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, gssd_stream_t stream);
 /* *out += sum a[i]*b[i] (fp64); out = a*x + b*y; y = scale[0]*x (fp64 -> fp32); d(sigma) = dot[0] + sum_c bias[c]*colsum[c] */

@@ -857,15 +857,22 @@ def test_self_attn_flash_bwd(dev, B, N, D, C2):
     ref = torch.cat([torch.bmm(dS, ph.double()), torch.bmm(dS.transpose(1, 2), th.double()), torch.bmm(P.transpose(1, 2), dag.double())], dim=-1)
     tp = torch.cat([th, ph], dim=-1).contiguous().to(dev)
     out = torch.full((B, N, 2 * D + C2), float('nan'), device=dev)
-    args = (tp, tp.to(torch.bfloat16), g.to(dev).to(torch.bfloat16), dag.to(dev).to(torch.bfloat16), lse.float().to(dev), Dv.float().to(dev), out)
+    st = torch.cuda.current_stream().cuda_stream
+    tph, tpl = torch.empty_like(tp, dtype=torch.bfloat16), torch.empty_like(tp, dtype=torch.bfloat16)
+    _lib.check(_lib.lib.gssd_cast_split_f32_bf16(tp.data_ptr(), tph.data_ptr(), tpl.data_ptr(), tp.numel(), st))
+    assert torch.equal(tph, tp.to(torch.bfloat16)) and torch.equal(tpl, (tp - tph.float()).to(torch.bfloat16))
     assert _lib.lib.gssd_self_attn_flash_bwd_supported(D, C2) == 1 and _lib.lib.gssd_self_attn_flash_bwd_supported(256, 1024) == 0
-    _lib.check(_lib.lib.gssd_self_attn_flash_bwd_bf16(*[a.data_ptr() for a in args], B, N, D, C2, torch.cuda.current_stream().cuda_stream))
-    got = out.double().cpu()
-    assert bool(torch.isfinite(got).all())
-    for name, sl in (('d theta', slice(0, D)), ('d phi', slice(D, 2 * D)), ('d g', slice(2 * D, None))):
-        e = l2rel(got[..., sl], ref[..., sl])
-        print(f'    flash backward N = {N}: {name} relative L2 {e:.2e}')
-        assert e < 5e-3, (name, e)
+    g16, dag16, lse32, dv32 = g.to(dev).to(torch.bfloat16), dag.to(dev).to(torch.bfloat16), lse.float().to(dev), Dv.float().to(dev)
+    for form, lo in (('logits as hi.hi + hi.lo + lo.hi on bf16 MFMA', tpl.data_ptr()), ('logits on fp32 MFMA', 0)):
+        out.fill_(float('nan'))
+        _lib.check(_lib.lib.gssd_self_attn_flash_bwd_bf16(tp.data_ptr(), tph.data_ptr(), lo, g16.data_ptr(), dag16.data_ptr(), lse32.data_ptr(),
+                                                          dv32.data_ptr(), out.data_ptr(), B, N, D, C2, st))
+        got = out.double().cpu()
+        assert bool(torch.isfinite(got).all())
+        for name, sl in (('d theta', slice(0, D)), ('d phi', slice(D, 2 * D)), ('d g', slice(2 * D, None))):
+            e = l2rel(got[..., sl], ref[..., sl])
+            print(f'    flash backward N = {N}, {form}: {name} relative L2 {e:.2e}')
+            assert e < 5e-3, (name, e)
 
 
 def test_training_soak_batch32():

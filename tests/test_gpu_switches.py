@@ -56,6 +56,8 @@ SWITCHES = [
     ('bf16', {'GSSD_FLAT_BM': '128'}, lambda o, base: all(k.endswith(',128>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
     ('bf16', {'GSSD_FLAT_BM': '256'}, lambda o, base: any(k.endswith(',256>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
     ('bf16', {'GSSD_FLAT_PERSIST': '0'}, lambda o, base: True),
+    # flash-style attention backward with its logits recomputed on the fp32 matrix cores instead of the three-product bf16 split
+    ('bf16', {'GSSD_FLASH_BWD_X3': '0'}, lambda o, base: 'gssd_self_attn_flash_bwd_bf16' in o['bwd_fns']),
     # the round-3 form of the bf16 training step: the fp32 backward plan on fp32 copies of every stored map
     ('bf16', {'GSSD_BWD_BF16': '0'}, lambda o, base: 'gssd_conv2d_wgrad_bf16' in base['bwd_fns'] and 'gssd_bn_bwd_apply_mixed' in base['bwd_fns']
      and not any(f in o['bwd_fns'] for f in ('gssd_conv2d_wgrad_bf16', 'gssd_bn_bwd_apply_mixed', 'gssd_dcn_im2col_bf16'))),
