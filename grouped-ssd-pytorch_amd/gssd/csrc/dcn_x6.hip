@@ -1,0 +1,343 @@
+// fp32 fused modulated deformable 3x3 convolution on the BF16 matrix cores with fp32-equivalent products (round 4, experiment behind
+// GSSD_DCN_X6): the same algorithm and entry contract as dcn_fused.hip (fp32 x, fp32 offsets, fp32 blend, fp32 weights, fp32 output).
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 matrix rate on gfx950.  An fp32 number is the exact sum of three bf16 numbers
+// (x = h + m + l, 8 + 8 + 8 mantissa bits, each rounded to nearest); a product x y is then h h' + (h m' + m h') + (h l' + l h' + m m') + terms
+// below 2^-24 |x y| -- six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to the last bit or two, and still cost 3/8 of the
+// fp32 instruction's matrix-pipe time.  The sampled column is blended in fp32 exactly as before and split into its three planes when it is
+// written to LDS; the weights are split once, when they are packed.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#ifndef X6_KO
+#define X6_KO 0        // knock-outs (scripts/dcn_x6_knockout.sh): 1 no blend / split VALU, 2 no MFMAs, 4 no weight DMA, 8 no x loads
+#endif
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKC = 32;          // tile; channels per K chunk: 64-byte bf16 rows
+constexpr int WTM = 64, WTN = 64, MT = WTM / 16, NT = WTN / 16;
+constexpr int NP = 3;                                 // planes of the split
+constexpr int A_STAGE = BM * BKC, B_STAGE = BN * BKC;            // u16 elements per plane
+constexpr int LDS_BYTES = 2 * NP * (A_STAGE + B_STAGE) * 2 + 9 * BM * 16 + 9 * BM * 4;
+
+__device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int swz(int row) { return (row & 8) ? 3 : 0; }       // 64-byte rows: conflict-free ds_read_b128
+
+__device__ __forceinline__ int chan_of_row(int row) {        // LDS row of the weight tile -> output channel inside the BN tile
+    const int j = row >> 4, rho = row & 15;
+    return 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3);
+}
+
+// x = h + m + l, each bf16 (round to nearest even); exact to 2^-25 |x|
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// wp: [3 planes][n_tiles][chunks][BN rows in staging order][32] bf16 (slot-swizzled), chunk = (d * cpg/32 + c32) * 9 + tap
+__global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict__ x, const float* __restrict__ om,
+                                                       const u16* __restrict__ wp, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
+                                                       int Cout, int ntn, int mtiles, long long plane_elems) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
+    u16* const As = smem_h;                                   // [2][3][BM][32]
+    u16* const Bs = smem_h + 2 * NP * A_STAGE;                // [2][3][BN][32]
+    f32x4* const setw = reinterpret_cast<f32x4*>(smem_h + 2 * NP * (A_STAGE + B_STAGE));            // [9][BM]
+    int* const setp = reinterpret_cast<int*>(smem_h + 2 * NP * (A_STAGE + B_STAGE) + 9 * BM * 8);   // [9][BM]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    int mt, nt;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        if (8 % ntn == 0) {
+            nt = xcd % ntn;
+            mt = slot * (8 / ntn) + xcd / ntn;
+        } else {
+            const int id = slot * 8 + xcd;
+            nt = id % ntn;
+            mt = id / ntn;
+        }
+    }
+    if (mt >= mtiles) return;
+    const int m0 = mt * BM;
+    const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;
+    const int nchunks = dg * cpc * 9;
+    const u16* wslab = wp + (size_t)nt * nchunks * B_STAGE;      // plane 0; plane p at + p * plane_elems
+
+    f32x4 acc[MT][NT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
+
+    // gather roles: thread -> (pixel row pl = (tid >> 2) + 64*j, 8-channel slot q = tid & 3)
+    const int gq = tid & 3, gp = tid >> 2;
+    const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
+    const int fo = r * BKC + ((kq ^ swz(r)) << 3);
+
+    auto setups = [&](int d) {
+        for (int e = tid; e < 9 * BM; e += 256) {
+            const int tap = e / BM, pl = e - tap * BM;
+            const int m = m0 + pl;
+            f32x4 wv = zero4;
+            int pos = 0;
+            if (m < M) {
+                const int b = m / HW, pix = m - b * HW;
+                const int h = pix / W, w = pix - h * W;
+                const float* omp = om + (size_t)m * om_stride;
+                const float dy = omp[d * 18 + 2 * tap];
+                const float dx = omp[d * 18 + 2 * tap + 1];
+                const float ml = omp[dg * 18 + d * 9 + tap];
+                const float msk = 1.f / (1.f + expf(-ml));
+                const float py = (float)(h - 1 + tap / 3) + dy;
+                const float px = (float)(w - 1 + tap % 3) + dx;
+                if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
+                    const float y0f = floorf(py), x0f = floorf(px);
+                    const int y0 = (int)y0f, x0 = (int)x0f;
+                    const float ly = py - y0f, lx = px - x0f, hy = 1.f - ly, hx = 1.f - lx;
+                    const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+                    wv[0] = (y0ok && x0ok) ? hy * hx * msk : 0.f;
+                    wv[1] = (y0ok && x1ok) ? hy * lx * msk : 0.f;
+                    wv[2] = (y1ok && x0ok) ? ly * hx * msk : 0.f;
+                    wv[3] = (y1ok && x1ok) ? ly * lx * msk : 0.f;
+                    const int ya = y0ok ? y0 : 0, xa = x0ok ? x0 : 0;
+                    const int yb = y1ok ? y0 + 1 : H - 1, xb = x1ok ? x0 + 1 : W - 1;
+                    pos = (int)((unsigned)(b * HW + ya * W + xa) | ((unsigned)(xb - xa) << 30) | ((unsigned)(yb - ya) << 31));
+                }
+            }
+            setw[e] = wv;
+            setp[e] = pos;
+        }
+    };
+
+    int ch_tap = 0, ch_c = 0, ch_d = 0;
+    f32x4 gw[2];
+    f32x4 gv[2][4][2];                                      // [cell][corner][half]: 8 fp32 channels per corner
+
+    auto gather_issue = [&]() {
+        if (X6_KO & 8) return;
+        const int cb = ch_d * cpg + ch_c * BKC + gq * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = ch_tap * BM + gp + 64 * j;
+            gw[j] = setw[e];
+            const int pos = setp[e];
+            const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
+            const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
+            const unsigned i10 = i00 + dyb * (unsigned)W;
+            const float* p0 = x + (size_t)i00 * (unsigned)C + cb;
+            const float* p1 = x + (size_t)(i00 + dxb) * (unsigned)C + cb;
+            const float* p2 = x + (size_t)i10 * (unsigned)C + cb;
+            const float* p3 = x + (size_t)(i10 + dxb) * (unsigned)C + cb;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                gv[j][0][hh] = *reinterpret_cast<const f32x4*>(p0 + 4 * hh);
+                gv[j][1][hh] = *reinterpret_cast<const f32x4*>(p1 + 4 * hh);
+                gv[j][2][hh] = *reinterpret_cast<const f32x4*>(p2 + 4 * hh);
+                gv[j][3][hh] = *reinterpret_cast<const f32x4*>(p3 + 4 * hh);
+            }
+        }
+    };
+    auto gather_finish = [&](int buf) {
+        if (X6_KO & 1) return;
+        u16* Ad = As + buf * NP * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 oh, om_, ol;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                // the blend of dcn_fused.hip: the same four products, the same order
+                const f32x4 v = gv[j][0][hh] * gw[j][0] + gv[j][1][hh] * gw[j][1] + gv[j][2][hh] * gw[j][2] + gv[j][3][hh] * gw[j][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 h, m, l;
+                    split3(v[e], h, m, l);
+                    oh[4 * hh + e] = h;
+                    om_[4 * hh + e] = m;
+                    ol[4 * hh + e] = l;
+                }
+            }
+            *reinterpret_cast<bf16x8*>(Ad + a_wr0 + j * 64 * BKC) = oh;
+            *reinterpret_cast<bf16x8*>(Ad + A_STAGE + a_wr0 + j * 64 * BKC) = om_;
+            *reinterpret_cast<bf16x8*>(Ad + 2 * A_STAGE + a_wr0 + j * 64 * BKC) = ol;
+        }
+    };
+    auto b_issue = [&](int chunk, int buf) {
+        if (X6_KO & 4) return;
+        u16* dst = Bs + buf * NP * B_STAGE;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            const u16* src = wslab + (size_t)pl * plane_elems + (size_t)chunk * B_STAGE + lane * 8;
+#pragma unroll
+            for (int j = 0; j < B_STAGE / 512 / 4; ++j) {
+                const int piece = j * 4 + wave;                        // 1-KiB pieces of the plane's tile
+                dma16(src + piece * 512, dst + pl * B_STAGE + piece * 512);
+            }
+        }
+    };
+    auto advance = [&]() {
+        if (++ch_tap == 9) {
+            ch_tap = 0;
+            if (++ch_c == cpc) {
+                ch_c = 0;
+                ++ch_d;
+            }
+        }
+    };
+
+    setups(0);
+    __syncthreads();
+    gather_issue();
+    b_issue(0, 0);
+    gather_finish(0);
+    advance();
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) {
+            if (ch_tap == 0 && ch_c == 0) {
+                setups(ch_d);
+                __syncthreads();
+            }
+            gather_issue();
+            b_issue(ch + 1, buf ^ 1);
+        }
+        const u16* Ab = As + buf * NP * A_STAGE + wm * WTM * BKC + fo;
+        const u16* Bb = Bs + buf * NP * B_STAGE + wn * WTN * BKC + fo;
+        bf16x8 af[NP][MT], bf[NP][NT];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_STAGE + i * 16 * BKC);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_STAGE + j * 16 * BKC);
+        }
+        // six products per fragment pair, smallest first (a: column planes, b: weight planes)
+        if (!(X6_KO & 2))
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][j], af[1][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2][j], af[0][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[2][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][j], af[0][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[1][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[0][i], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        if (more) {
+            gather_finish(buf ^ 1);
+            advance();
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, 16-byte NHWC fp32 stores (lane: pixel = lane & 15, 8 consecutive channels per tile pair) -----------
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+        const int n0 = nt * BN + wn * WTN + 32 * u + 8 * kq;
+        float bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = (bias && n0 + c < Cout) ? bias[n0 + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r;
+            if (m >= M) continue;
+            float* dst = out + (size_t)m * Cout + n0;
+            if (n0 + 8 <= Cout) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][2 * u][0] + bv[0], acc[i][2 * u][1] + bv[1], acc[i][2 * u][2] + bv[2], acc[i][2 * u][3] + bv[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) =
+                    f32x4{acc[i][2 * u + 1][0] + bv[4], acc[i][2 * u + 1][1] + bv[5], acc[i][2 * u + 1][2] + bv[6], acc[i][2 * u + 1][3] + bv[7]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (n0 + c < Cout) dst[c] = acc[i][2 * u + (c >> 2)][c & 3] + bv[c];
+            }
+        }
+    }
+}
+
+// OIHW fp32 [Cout][C][3][3] -> three bf16 planes, each [n_tiles][chunks][BN staging rows][32] with the slot swizzle; rows beyond Cout zero
+__global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int C, int dg, long long total) {
+    const int cpg = C / dg, cpc = cpg / BKC, nchunks = dg * cpc * 9;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        const int slot = (int)((i >> 3) & 3);
+        const int row = (int)((i >> 5) % BN);
+        const long long t = (i >> 5) / BN;
+        const int chunk = (int)(t % nchunks);
+        const int nt = (int)(t / nchunks);
+        const int q = slot ^ swz(row);
+        const int tap = chunk % 9, cc = chunk / 9;
+        const int c = cc * BKC + q * 8 + e;
+        const int n = nt * BN + chan_of_row(row);
+        __bf16 h, m, l;
+        split3(n < Cout ? w[((size_t)n * C + c) * 9 + tap] : 0.f, h, m, l);
+        wp[i] = __builtin_bit_cast(u16, h);
+        wp[i + total] = __builtin_bit_cast(u16, m);
+        wp[i + 2 * total] = __builtin_bit_cast(u16, l);
+    }
+}
+
+}  // namespace
+
+extern "C" long long gssd_dcn_packed_weight_elems_x6(int Cout, int C) {          // bf16 elements (three planes)
+    if (Cout <= 0 || C <= 0 || C % BKC != 0) return -1;
+    return 3ll * ((Cout + BN - 1) / BN) * BN * 9 * C;
+}
+
+extern "C" int gssd_dcn_pack_weight_x6(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(w_oihw && w_packed && Cout > 0 && C > 0 && dg > 0 && C % dg == 0 && (C / dg) % BKC == 0);
+    const long long total = gssd_dcn_packed_weight_elems_x6(Cout, C) / 3;
+    hipLaunchKernelGGL(dcn_pack_weight_x6_kernel, dim3((int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w_oihw, reinterpret_cast<u16*>(w_packed), Cout, C, dg, total);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H,
+                                   int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream) {
+    GSSD_CHECK_ARG(x && om && w_packed && out && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0 && Cout > 0 && Cout % 8 == 0);
+    GSSD_CHECK_ARG(C % dg == 0 && (C / dg) % BKC == 0 && om_stride >= 27 * dg);
+    GSSD_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)out % 16) == 0);
+    const long long Mll = (long long)B * H * W;
+    GSSD_CHECK_ARG(Mll < (1ll << 30) && Mll * C < (1ll << 32));          // 30-bit pixel index + 2 flag bits; 32-bit element offsets
+    const int M = (int)Mll;
+    const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
+    static unsigned attr_mask = 0;
+    if (gssd_attr_needed(&attr_mask)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess) {
+            gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", LDS_BYTES);
+            return GSSD_ELAUNCH;
+        }
+        gssd_attr_done(&attr_mask);
+    }
+    int blocks;
+    if (8 % ntn == 0) {
+        const int per = 8 / ntn;
+        blocks = ((mtiles + per - 1) / per) * 8;
+    } else {
+        blocks = ((mtiles * ntn + 7) / 8) * 8;
+    }
+    hipLaunchKernelGGL(dcn_x6_kernel, dim3(blocks), dim3(256), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
+                       out, M, H, W, C, dg, om_stride, Cout, ntn, mtiles, gssd_dcn_packed_weight_elems_x6(Cout, C) / 3);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}

@@ -34,6 +34,8 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
+# fp32 mode: the deformable conv on the bf16 matrix cores with three-plane operands (csrc/dcn_x6.hip; experiment, off by default: DESIGN 10)
+DCN_X6 = os.environ.get('GSSD_DCN_X6', '0') == '1'
 # GSSD_NO_GRAPH=1 keeps every forward an eager list of launches (debugging / ablation)
 USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
 # GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
@@ -906,17 +908,17 @@ class _Plan(_PlanBase):
         w_om = self._packed_conv(f'dcn_list.{li}.om', m.conv_offset_mask)
 
         def build_w(out, m=m, Cin=Cin, dg=dg):
-            elems = lib.gssd_dcn_packed_weight_elems_bf16 if self.bf16 else lib.gssd_dcn_packed_weight_elems
-            pack = lib.gssd_dcn_pack_weight_bf16 if self.bf16 else lib.gssd_dcn_pack_weight_f32
+            elems = lib.gssd_dcn_packed_weight_elems_bf16 if self.bf16 else lib.gssd_dcn_packed_weight_elems_x6 if DCN_X6 else lib.gssd_dcn_packed_weight_elems
+            pack = lib.gssd_dcn_pack_weight_bf16 if self.bf16 else lib.gssd_dcn_pack_weight_x6 if DCN_X6 else lib.gssd_dcn_pack_weight_f32
             if out is None:
                 n = int(elems(m.out_channels, Cin))
                 if n <= 0:
                     raise _lib.GssdError(f'deformable conv: unsupported shape Cin {Cin}, Cout {m.out_channels}')
-                out = torch.empty(n, device=self.dev, dtype=self.adt)
+                out = torch.empty(n, device=self.dev, dtype=torch.bfloat16 if (DCN_X6 and not self.bf16) else self.adt)
             _lib.check(pack(m.weight.detach().contiguous().data_ptr(), out.data_ptr(), m.out_channels, Cin, dg,
                             torch.cuda.current_stream().cuda_stream))
             return out
-        w_main = eng._pack(f'dcn_list.{li}.wt', build_w)
+        w_main = eng._pack(f'dcn_list.{li}.wt' + ('.x6' if (DCN_X6 and not self.bf16) else ''), build_w)
         # offsets / mask logits stay fp32 in both modes; rows padded to a multiple of 4 channels (27 * dg is one only for dg = 4, 8, ..):
         # the weight-gradient and data-gradient kernels of the offset conv want 16-byte aligned channel vectors
         # (bf16 mode: a multiple of 8 -- the training step's bf16 data / weight gradients of the offset conv read 16-byte bf16 rows)
@@ -935,9 +937,9 @@ class _Plan(_PlanBase):
         self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H
         esz = 2.0 if self.bf16 else 4.0
-        self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_f32,
+        self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_x6 if DCN_X6 else lib.gssd_dcn_forward_f32,
                   (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout),
-                  keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
+                  keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_x6<128x128>' if DCN_X6 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
                                     esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))

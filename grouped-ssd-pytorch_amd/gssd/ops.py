@@ -359,6 +359,22 @@ def dcn_forward(x, om, w_oihw, bias, dg, w_packed=None):
     return out
 
 
+def dcn_forward_x6(x, om, w_oihw, bias, dg):
+    """The same op through csrc/dcn_x6.hip (fp32 in / out, three-plane bf16 split on the bf16 matrix cores)."""
+    _need_cuda(x, om, w_oihw)
+    B, H, W, Cc = x.shape
+    w = w_oihw.detach().contiguous().float()
+    Cout = w.shape[0]
+    n = int(lib.gssd_dcn_packed_weight_elems_x6(Cout, Cc))
+    if n <= 0:
+        raise _lib.GssdError(f'deformable conv (x6): unsupported shape C {Cc}, Cout {Cout}')
+    wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    check(lib.gssd_dcn_pack_weight_x6(_p(w), _p(wp), Cout, Cc, dg, _stream()))
+    out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+    check(lib.gssd_dcn_forward_x6(_p(x), _p(om), _p(wp), _p(bias), _p(out), B, H, W, Cc, dg, om.shape[-1], Cout, _stream()))
+    return out
+
+
 def dcn_col2im(x, om, dcols, dx, dom, dg):
     """Backward of :func:`dcn_im2col`: ADDS d(x) into ``dx`` and d(om) (offsets + mask logits) into ``dom``."""
     B, H, W, Cc = x.shape

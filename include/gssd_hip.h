@@ -417,6 +417,13 @@ int gssd_dcn_streamk_status(unsigned* xcc_map);
 int gssd_dcn_streamk_reset(gssd_stream_t stream);
 
 /* bf16 storage variant (configs[4]): x, w_packed, out bf16; om, bias fp32; fp32 blend and accumulation */
+/* The fp32 deformable conv on the bf16 matrix cores with fp32-equivalent products (csrc/dcn_x6.hip): every operand as the exact sum of
+ * three bf16 planes, six bf16 MFMAs per product term set (everything above 2^-24 of a product), fp32 accumulation; same argument meaning
+ * as gssd_dcn_forward_f32 with w_packed from gssd_dcn_pack_weight_x6 (gssd_dcn_packed_weight_elems_x6 bf16 elements). */
+long long gssd_dcn_packed_weight_elems_x6(int Cout, int C);
+int gssd_dcn_pack_weight_x6(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
+int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H, int W, int C,
+                        int dg, int om_stride, int Cout, gssd_stream_t stream);
 long long gssd_dcn_packed_weight_elems_bf16(int Cout, int C);
 int gssd_dcn_pack_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
 int gssd_dcn_forward_bf16(const void* x, const float* om, const void* w_packed, const float* bias, void* out, int B, int H, int W,

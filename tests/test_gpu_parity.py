@@ -2134,3 +2134,22 @@ def test_dcn_streamk_is_placement_independent(dev, ops):
     finally:
         lib.gssd_dcn_streamk(prev)
     assert lib.gssd_dcn_streamk_status(None) & ~2 == 0
+
+
+def test_dcn_x6_matches_fused(dev, ops):
+    """csrc/dcn_x6.hip (experiment, GSSD_DCN_X6=1): the fp32 deformable conv with every operand as the exact sum of three bf16 planes and six
+    bf16 MFMAs per product -- fp32-equivalent: it must agree with the fp32-MFMA kernel to fp32 summation-order noise and with the
+    float64 evaluation as well as that kernel does.  Shapes with a ragged last pixel tile and a masked channel tile."""
+    rng = np.random.default_rng(77)
+    for (B, Cc, H, dg, Cout) in ((2, 128, 13, 4, 136), (1, 256, 19, 1, 512)):
+        x = torch.from_numpy(rng.normal(size=(B, H, H, Cc)).astype(np.float32)).to(dev)
+        om = torch.from_numpy(rng.normal(0, 1.5, size=(B, H, H, 27 * dg)).astype(np.float32)).to(dev)
+        w = torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cc, 3, 3)).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.normal(size=Cout).astype(np.float32)).to(dev)
+        ref = ops.dcn_forward(x, om, w, b, dg)
+        got = ops.dcn_forward_x6(x, om, w, b, dg)
+        o1, o2, m = torch.chunk(nchw(om.cpu()).double(), 3, dim=1)
+        r64 = O.dcn_v2_conv(nchw(x.cpu()).double(), torch.cat((o1, o2), 1), torch.sigmoid(m), w.cpu().double(), b.cpu().double(), 1, 1, 1, dg)
+        e_x6, e_f = rel(nchw(got), r64), rel(nchw(ref), r64)
+        print(f'dcn x6 vs float64 {e_x6:.2e}; fp32-MFMA kernel vs float64 {e_f:.2e}; x6 vs fp32-MFMA {rel(got, ref):.2e}')
+        assert e_x6 < 2e-6 + 2 * e_f and rel(got, ref) < 1e-5
