@@ -208,7 +208,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
     # Per-launch HIP events cost ~3 us of GPU idle each.  Two untimed passes bracket EVERY tagged launch (the `kernels`
     # breakdown and the choice of the dominant instance); in the timed region only the dominant instance's launches are
     # bracketed, live, on the launch stream -- that is where `roofline` comes from.
-    sagg, events, trunk = None, None, None
+    sagg, events, trunk, runner_up = None, None, None, None
     if not a.no_events:
         survey = EventList()
         net.__dict__['_events'] = survey
@@ -230,7 +230,12 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
         # the dominant KERNEL: the instance with the most time among those launched at most 12 times per step (a bucket of dozens
         # of small-map launches of one tile shape is not one kernel, and bracketing it would cut the hipGraph into as many pieces)
         cands = {k: v for k, v in sagg.items() if v[0] // 2 <= 12} or sagg
-        events.only = {max(cands, key=lambda k: cands[k][1])}
+        top = max(cands, key=lambda k: cands[k][1])
+        # a near-tie (within 10 %) between the single-launch deformable conv and a ten-launch instance goes to the single launch: one cut of
+        # the hipGraph instead of ten inside the timed region, and the kernel every earlier round reported
+        one = [k for k in cands if k.startswith('dcn_') and cands[k][1] >= 0.9 * cands[top][1]]
+        events.only = {one[0] if one else top}
+        runner_up = dict(kernel=top, ms_per_step=round(cands[top][1] / 2, 4)) if (one and one[0] != top) else None
     # one more untimed step in exactly the timed region's launch mode (hipGraph segments around the bracketed kernel): the graph
     # capture of that mode happens here, not inside the K timed steps, whatever --warmup is
     for _ in range(3):
@@ -283,32 +288,48 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                                  ms_per_step=round(ms / 2, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 2),
                                  alg_gbs=round(by / (ms * 1e-3) / 1e9, 1))
         agg = aggregate(events)
+
+        def make_roof(dom):
+            n, ms, fl, by = agg[dom]
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(cfg if dtype == 'f32' else f'{cfg}_{dtype}', {}).get(dom, {}).get('hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+            wino = dom.startswith('conv_wino') or dom.startswith('conv_thin_wino')
+            x6 = dom.startswith('dcn_x6')
+            if ach_b / PEAK_HBM_GBS > ach_t / peak_t:
+                roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
+            elif wino:
+                # Winograd F(2x2,3x3) issues 2.25x fewer MFMA FLOPs than the direct convolution it computes: `achieved` / `frac` are the
+                # ISSUED FLOPs against the matrix pipe (what a roofline fraction means); the direct-convolution rate is reported under its own name
+                roof = dict(bound='mfma', achieved=round(ach_t / 2.25, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / 2.25 / peak_t, 4),
+                            direct_conv_tflops=round(ach_t, 2), direct_conv_over_peak=round(ach_t / peak_t, 4))
+            elif x6:
+                # csrc/dcn_x6.hip: fp32-equivalent products as six bf16 MFMAs over three-plane operands -- `achieved` / `frac` are the ISSUED
+                # bf16 FLOPs (6 x algorithmic) against the bf16 matrix peak; the algorithmic (fp32-equivalent) rate has its own name
+                roof = dict(bound='mfma', achieved=round(6 * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                            frac=round(6 * ach_t / PEAK_BF16_TFLOPS, 4), fp32_equivalent_tflops=round(ach_t, 2),
+                            fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
+            else:
+                roof = dict(bound='mfma', achieved=round(ach_t, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / peak_t, 4))
+            roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
+                        alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
+                        note=('fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product (everything above 2^-24), fp32 '
+                              'accumulation: fp32-equivalent results (tests/test_gpu_parity.py::test_dcn_x6_matches_fused); GSSD_DCN_X6=0 runs '
+                              'the fp32-MFMA kernel' if x6
+                              else 'fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
+                              else 'bf16 MFMA, fp32 accumulate')
+                             + ('; Winograd F(2x2,3x3): achieved / frac = ISSUED MFMA FLOPs (direct-convolution FLOPs / 2.25) against the '
+                                'matrix pipe; direct_conv_tflops = the algorithmic (direct-convolution) rate' if wino else ''))
+            return roof
         dom = max(agg, key=lambda k: agg[k][1])
-        n, ms, fl, by = agg[dom]
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(cfg if dtype == 'f32' else f'{cfg}_{dtype}', {}).get(dom, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
-        wino = dom.startswith('conv_wino') or dom.startswith('conv_thin_wino')
-        if ach_b / PEAK_HBM_GBS > ach_t / peak_t:
-            roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
-        elif wino:
-            # Winograd F(2x2,3x3) issues 2.25x fewer MFMA FLOPs than the direct convolution it computes: `achieved` / `frac` are the ISSUED
-            # FLOPs against the matrix pipe (what a roofline fraction means); the direct-convolution rate is reported under its own name
-            roof = dict(bound='mfma', achieved=round(ach_t / 2.25, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / 2.25 / peak_t, 4),
-                        direct_conv_tflops=round(ach_t, 2), direct_conv_over_peak=round(ach_t / peak_t, 4))
-        else:
-            roof = dict(bound='mfma', achieved=round(ach_t, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / peak_t, 4))
-        roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
-                    alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
-                    note=('fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
-                          else 'bf16 MFMA, fp32 accumulate')
-                         + ('; Winograd F(2x2,3x3): achieved / frac = ISSUED MFMA FLOPs (direct-convolution FLOPs / 2.25) against the '
-                            'matrix pipe; direct_conv_tflops = the algorithmic (direct-convolution) rate' if wino else ''))
+        roof = make_roof(dom)
+        if runner_up:
+            roof['near_tie_with'] = runner_up
     # the HBM-side companion of `roofline`: the heaviest of the byte-bound trunk layers (the patch-staged thin kernels of conv1_1 ..
     # conv2_2: arithmetic intensity below the ridge in both storage modes), from the untimed survey passes' per-launch HIP events
     roof_hbm = None

@@ -17,11 +17,17 @@ typedef unsigned short u16;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKC = 32;          // tile; channels per K chunk: 64-byte bf16 rows
-constexpr int WTM = 64, WTN = 64, MT = WTM / 16, NT = WTN / 16;
+#ifndef X6_BN
+#define X6_BN 256
+#endif
+// BN = 256: the sampled columns are computed for two output tiles instead of four (the kernel is bound by the fp32 corner loads); the three
+// weight planes of a chunk are then 48 KB, so they are staged in ONE buffer: fragments to registers, barrier, next chunk's DMA behind the MFMAs
+constexpr int BM = 128, BN = X6_BN, BKC = 32;          // tile; channels per K chunk: 64-byte bf16 rows
+constexpr int WTM = 64, WTN = BN / 2, MT = WTM / 16, NT = WTN / 16;
+constexpr int NBS = BN > 128 ? 1 : 2;                 // weight stages
 constexpr int NP = 3;                                 // planes of the split
 constexpr int A_STAGE = BM * BKC, B_STAGE = BN * BKC;            // u16 elements per plane
-constexpr int LDS_BYTES = 2 * NP * (A_STAGE + B_STAGE) * 2 + 9 * BM * 16 + 9 * BM * 4;
+constexpr int LDS_BYTES = (2 * NP * A_STAGE + NBS * NP * B_STAGE) * 2 + 9 * BM * 16 + 9 * BM * 4;
 
 __device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -51,8 +57,8 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
     u16* const As = smem_h;                                   // [2][3][BM][32]
     u16* const Bs = smem_h + 2 * NP * A_STAGE;                // [2][3][BN][32]
-    f32x4* const setw = reinterpret_cast<f32x4*>(smem_h + 2 * NP * (A_STAGE + B_STAGE));            // [9][BM]
-    int* const setp = reinterpret_cast<int*>(smem_h + 2 * NP * (A_STAGE + B_STAGE) + 9 * BM * 8);   // [9][BM]
+    f32x4* const setw = reinterpret_cast<f32x4*>(smem_h + 2 * NP * A_STAGE + NBS * NP * B_STAGE);            // [9][BM]
+    int* const setp = reinterpret_cast<int*>(smem_h + 2 * NP * A_STAGE + NBS * NP * B_STAGE + 9 * BM * 8);   // [9][BM]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     };
     auto b_issue = [&](int chunk, int buf) {
         if (X6_KO & 4) return;
-        u16* dst = Bs + buf * NP * B_STAGE;
+        u16* dst = Bs + (NBS == 2 ? buf : 0) * NP * B_STAGE;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             const u16* src = wslab + (size_t)pl * plane_elems + (size_t)chunk * B_STAGE + lane * 8;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
-        if (more) {
+        if (NBS == 2 && more) {
             if (ch_tap == 0 && ch_c == 0) {
                 setups(ch_d);
                 __syncthreads();
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
             b_issue(ch + 1, buf ^ 1);
         }
         const u16* Ab = As + buf * NP * A_STAGE + wm * WTM * BKC + fo;
-        const u16* Bb = Bs + buf * NP * B_STAGE + wn * WTN * BKC + fo;
+        const u16* Bb = Bs + (NBS == 2 ? buf : 0) * NP * B_STAGE + wn * WTN * BKC + fo;
         bf16x8 af[NP][MT], bf[NP][NT];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
@@ -225,6 +231,17 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
             for (int i = 0; i < MT; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_STAGE + i * 16 * BKC);
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_STAGE + j * 16 * BKC);
+        }
+        if (NBS == 1 && more) {
+            // one weight buffer: every wave holds its fragments in registers before the next chunk's planes may land
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ch_tap == 0 && ch_c == 0) {
+                setups(ch_d);
+                __syncthreads();
+            }
+            gather_issue();
+            b_issue(ch + 1, 0);
         }
         // six products per fragment pair, smallest first (a: column planes, b: weight planes)
         if (!(X6_KO & 2))

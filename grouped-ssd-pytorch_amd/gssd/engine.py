@@ -34,8 +34,9 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
-# fp32 mode: the deformable conv on the bf16 matrix cores with three-plane operands (csrc/dcn_x6.hip; experiment, off by default: DESIGN 10)
-DCN_X6 = os.environ.get('GSSD_DCN_X6', '0') == '1'
+# fp32 mode: the deformable conv on the bf16 matrix cores with three-plane (fp32-equivalent) operands, csrc/dcn_x6.hip;
+# GSSD_DCN_X6=0: the fp32-MFMA kernel csrc/dcn_fused.hip
+DCN_X6 = os.environ.get('GSSD_DCN_X6', '1') != '0'
 # GSSD_NO_GRAPH=1 keeps every forward an eager list of launches (debugging / ablation)
 USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
 # GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
@@ -939,7 +940,7 @@ class _Plan(_PlanBase):
         esz = 2.0 if self.bf16 else 4.0
         self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_x6 if DCN_X6 else lib.gssd_dcn_forward_f32,
                   (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout),
-                  keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_x6<128x128>' if DCN_X6 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
+                  keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_x6<128x256>' if DCN_X6 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
                                     esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))

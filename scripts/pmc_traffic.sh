@@ -37,6 +37,7 @@ def short(n):
     if m: return f'flash_attn<{m.group(1)},{m.group(2)}>'
     if 'gemm_slot_kernel' in n: return 'gemm_slot<128x128>'
     if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
+    if 'dcn_x6_kernel' in n: return 'dcn_x6<128x256>'
     if 'dcn_bf16_kernel' in n: return 'dcn_bf16<128x256>'
     m = re.search(r'::(\w+_kernel)', n)
     return m.group(1) if m else n[:40]

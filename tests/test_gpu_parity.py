@@ -1173,7 +1173,19 @@ def test_constructor_flags(dev, golden, name):
     # the last source is a 1 x 1 map: with B = 2 its BatchNorms normalise TWO values per channel (+-1 wherever |x1 - x2| >> sqrt(eps),
     # a steep function of x1 - x2 elsewhere), so the last 4 priors and those layers' statistics amplify 1e-6 differences
     tail = 4 if args[0] else 0
-    assert rel(loc.detach()[:, :8732 - tail], lo[:, :8732 - tail]) < TOL and rel(conf.detach()[:, :8732 - tail], co[:, :8732 - tail]) < TOL
+    e_l, e_c = rel(loc.detach()[:, :8732 - tail], lo[:, :8732 - tail]), rel(conf.detach()[:, :8732 - tail], co[:, :8732 - tail])
+    if not (e_l < TOL and e_c < TOL):
+        # Two fp32 evaluations of a B = 2 train-mode graph can sit up to ~1.1e-4 apart (fs2pp: 2048-channel maps; measured with either
+        # deformable-conv kernel in the plan) while both are within 1e-4 of the exact result.  The arbiter of test_parity_margin_five_seeds:
+        # the same graph in float64 -- HIP must be within the gate of it and no farther from it than twice the fp32 oracle is (+ 2e-5).
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        with torch.no_grad():
+            l64, c64, _ = O.gssd_forward(sd64, x.double(), **flags)
+        n_ = 8732 - tail
+        h64 = max(rel(loc.detach()[:, :n_], l64[:, :n_]), rel(conf.detach()[:, :n_], c64[:, :n_]))
+        r64 = max(rel(lo[:, :n_], l64[:, :n_]), rel(co[:, :n_], c64[:, :n_]))
+        print(f'{name}: HIP vs fp32 oracle {max(e_l, e_c):.2e}; HIP vs float64 {h64:.2e}; fp32 oracle vs float64 {r64:.2e}')
+        assert h64 < TOL and h64 <= 2.0 * r64 + 2e-5, (name, e_l, e_c, h64, r64)
     assert rel(loc.detach(), lo) < 2e-2 and rel(conf.detach(), co) < 2e-2
     after = net.state_dict()
     for k, v in upd.items():
@@ -1842,7 +1854,7 @@ def test_graph_replay_equals_eager(dev, name):
         assert torch.equal(va, vb), k
     if name == 'gssdpp':
         class EL(list):
-            only = {'dcn_fused<128x256>'}
+            only = {'dcn_x6<128x256>', 'dcn_fused<128x256>'}
         ev = EL()
         net.__dict__['_events'] = ev
         with torch.no_grad():

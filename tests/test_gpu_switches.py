@@ -51,8 +51,8 @@ SWITCHES = [
     # (at this test's batch of 4 the deformable conv has 92 tiles for 256 CUs and keeps the one-tile form either way: the stream-K form
     # itself is tested at batch 32 by test_gpu_parity.py::test_dcn_fused_streamk)
     ('f32', {'GSSD_DCN_STREAMK': '0'}, lambda o, base: True),
-    # the deformable conv on the bf16 matrix cores with three-plane (fp32-equivalent) operands
-    ('f32', {'GSSD_DCN_X6': '1'}, lambda o, base: any(k.startswith('dcn_x6') for k in o['kernels']) and not any(k.startswith('dcn_x6') for k in base['kernels'])),
+    # the deformable conv on the fp32 matrix cores (csrc/dcn_fused.hip) instead of the three-plane bf16 form (csrc/dcn_x6.hip)
+    ('f32', {'GSSD_DCN_X6': '0'}, lambda o, base: any(k.startswith('dcn_fused') for k in o['kernels']) and any(k.startswith('dcn_x6') for k in base['kernels'])),
     ('bf16', {'GSSD_NO_CONV_FLAT': '1'}, lambda o, base: not any(k.startswith('conv_flat_bf16') for k in o['kernels'])
      and any(k.startswith('conv_flat_bf16') for k in base['kernels'])),
     ('bf16', {'GSSD_FLAT_BM': '128'}, lambda o, base: all(k.endswith(',128>') for k in o['kernels'] if k.startswith('conv_flat_bf16'))),
