@@ -83,6 +83,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 int gssd_try_conv_thin(const gssd_conv_desc& d, hipStream_t stream);
 // conv_wino.hip: returns 1 when the descriptor is not a Winograd shape / has no transformed weights
 int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream);
+int gssd_try_conv_x6(const gssd_conv_desc& d, hipStream_t stream);      // csrc/conv_x6.hip: 1 = not taken
 // conv_thin_wino.hip: conv1_2's shape class (4 x 16 -> 16 channels, large map) with Winograd weights; else returns 1
 int gssd_try_conv_thin_wino(const gssd_conv_desc& d, hipStream_t stream);
 int gssd_try_conv_thin_wgrad(const gssd_conv_desc& d, const float* dy, float* dw, hipStream_t stream);

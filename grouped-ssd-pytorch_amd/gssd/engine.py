@@ -33,6 +33,7 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
+USE_CONV_X6 = os.environ.get('GSSD_CONV_X6', '1') != '0'      # csrc/conv_x6.hip for the launches ops.x6_wanted names (fp32 mode)
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
 # fp32 mode: the deformable conv on the bf16 matrix cores with three-plane (fp32-equivalent) operands, csrc/dcn_x6.hip;
 # GSSD_DCN_X6=0: the fp32-MFMA kernel csrc/dcn_fused.hip
@@ -78,6 +79,10 @@ def conv_tag(d, real_cin_g=None, bf16=False):
             and not (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 64 != 0)):
         inst = '32x64' if (Mtot <= 512 or (d.m_per_image and Ms <= 128)) else '64x64'
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
+    if not bf16 and d.wgt_x6 and lib.gssd_conv_x6_takes(C.byref(d)) == 1:
+        M6 = d.B * d.Ho * d.Wo
+        flops = 2.0 * M6 * d.Cout * d.KH * d.KW * d.cin_g
+        return (f'conv_x6<{ops.x6_tile(cout_g, d.groups, M6)}>', flops, 4.0 * (d.B * d.H * d.W * d.cin_g * d.groups + M6 * d.Cout + d.Cout * d.KH * d.KW * d.cin_g))
     if bf16:
         if (d.groups == 4 and d.KH == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1 and d.H * d.W >= 75 * 75
                 and (d.cin_g, cout_g) in ((8, 16), (16, 16), (16, 32), (32, 32)) and not d.m_per_image and d.split_k == 1
@@ -570,6 +575,7 @@ class _Plan(_PlanBase):
 
     # ------------------------------------------------------------------------------------------------
     def _add(self, fn, args, keep=None, tag=None):
+        d = None
         if tag is None and fn in (lib.gssd_conv2d_nhwc_f32, lib.gssd_conv2d_nhwc_bf16):
             d = keep[0] if isinstance(keep, tuple) else keep
             tag = conv_tag(d, 3 if (d.cin_g in (4, 8) and d.groups == 4 and d.H == 300) else None,
@@ -577,6 +583,7 @@ class _Plan(_PlanBase):
         if tag is not None:
             tag = Tag(tag)
             tag.layer = getattr(self, '_layer', None)
+            tag.desc = d
         self.steps.append(_Step(fn, args, keep, tag, getattr(self, '_sid', 0), self.__dict__.pop('_pending_wait', None)))
 
     def _abuf(self, *shape):
@@ -658,6 +665,11 @@ class _Plan(_PlanBase):
                 return ops.winograd_weight(self.eng._packed[key], groups, cin_g, out)
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
+        X6 = None
+        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None):
+            def build_x6(out, key=name + '.w', groups=groups, cin_g=cin_g, taps=k * k, bn=ops.x6_tile(Cout // groups, groups, B * Ho * Ho)):
+                return ops.x6_weight(self.eng._packed[key], groups, cin_g, taps, bn, out)
+            X6 = self.eng._pack(name + '.x6', build_x6)       # (after '.w' as well)
         st = self.eng_stat(bn)
         srep = getattr(self, 'stat_rep', {}).get(id(bn), 0) if self.training else 0
         # Pooled trunk layers of a no-backward forward (conv1_2, conv2_2, conv3_3): max-pooling commutes with the monotone BatchNorm +
@@ -691,7 +703,7 @@ class _Plan(_PlanBase):
             return raw, Hp, Cout, (sc, sh, pd)
         raw, pd_tail = self._abuf_tail(Cout, B, Ho, Ho, Cout) if defer_bn else (self._abuf(B, Ho, Ho, Cout), None)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
-                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
+                                     stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U, wgt_x6=X6,
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None, stats_rep=srep)
@@ -841,12 +853,23 @@ class _Plan(_PlanBase):
         # fp32, N % 4 == 0 (38 x 38): all images as ONE M range -- 361 full row tiles instead of 12 per image with a ragged last one,
         # and the plain-GEMM dispatch (slot stream) instead of the per-image one
         flat = not self.bf16 and N % 4 == 0 and Np == N
-        d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg,
+        x6_tpg = None
+        if (not self.bf16 and USE_CONV_X6 and ops.x6_wanted(1, Cc, C4 + C2, 1, B * N) and C4 % ops.x6_tile(C4 + C2, 1, B * N) == 0):
+            def build_x6p(out, key=name + '.tpg.w', bn=ops.x6_tile(C4 + C2, 1, B * N)):
+                return ops.x6_weight(eng._packed[key], 1, Cc, 1, bn, out)
+            x6_tpg = eng._pack(name + '.tpg.x6', build_x6p)
+            gT.zero_()                         # csrc/conv_x6.hip never writes the row tails [N, Np) of g^T (conv_igemm zero-fills them)
+        d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg, wgt_x6=x6_tpg,
                       out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=not flat,
                       in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np,
                       flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else 0))
+        x6_o = None
+        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(1, C2, Cc, 1, B * N):
+            def build_x6o(out, bn=ops.x6_tile(Cc, 1, B * N)):
+                return ops.x6_weight(sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2), 1, C2, 1, bn, out)
+            x6_o = eng._pack(name + '.o.x6', build_x6o)
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
-                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2)
+                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2, wgt_x6=x6_o)
         fn = self.conv_fn
         if C4 % 64 == 0:
             self._add(fn, (C.byref(d1),), keep=(d1, w_tpg, b_tpg))

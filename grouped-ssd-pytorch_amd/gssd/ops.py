@@ -162,7 +162,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None, stats_rep=0):
+                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None, stats_rep=0, wgt_x6=None):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -178,6 +178,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.split_k = split_k
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.wgt_wino = _p(wgt_wino)
+    d.wgt_x6 = _p(wgt_x6)
     d.stats_rep = int(stats_rep)
     d.pool_sign = _p(pool_sign)
     d.out_b_stride = out_b_stride
@@ -207,6 +208,30 @@ def winograd_eligible(k, stride, pad, dil, cin_g, cout_g, groups=4):
     return cout_g % 32 == 0 or (groups == 1 and cout_g >= 24) or (groups == 4 and cin_g == 16 and cout_g == 16)
 
 
+def x6_tile(cout_g, groups, M):
+    """N tile (64 / 128 / 256) csrc/conv_x6.hip uses for this launch; the packed weights depend on it."""
+    return int(lib.gssd_conv_x6_tile(cout_g, groups, M))
+
+
+def x6_wanted(k, cin_g, cout_g, groups, M, winograd=False):
+    """Launches the engine hands to csrc/conv_x6.hip (fp32 mode): not the Winograd shapes (the same speed there), at least 128 output
+    channels per group and 256 k, M = B Ho Wo >= 4096 (19 x 19 maps at batch 32, 38 x 38 at batch 4) -- measured with scripts/bench_conv_x6.py: conv6 306 -> 174 us,
+    conv7 84 -> 56, the fuse convs 208 -> 166, the Self_Attn output convs 143-175 -> ~90."""
+    return (not winograd) and cin_g % 32 == 0 and cout_g >= 128 and cout_g % 8 == 0 and k * k * cin_g >= 256 and M >= 4096
+
+
+def x6_weight(w_packed, groups, cin_g, taps, bn, out=None):
+    """Packed K-major fp32 weights [Cout][taps*cin_g] -> the three bf16 planes of csrc/conv_x6.hip (uint16 tensor)."""
+    Cout = w_packed.shape[0]
+    if out is None:
+        n = int(lib.gssd_conv_x6_weight_elems(Cout, groups, cin_g, taps, bn))
+        if n <= 0:
+            raise _lib.GssdError(f'not a conv_x6 shape: Cout {Cout}, groups {groups}, cin_g {cin_g}, tile {bn}')
+        out = torch.empty(n, device=w_packed.device, dtype=torch.int16)
+    check(lib.gssd_conv_x6_pack_weight(_p(w_packed), _p(out), Cout, groups, cin_g, taps, w_packed.stride(0), bn, _stream()))
+    return out
+
+
 def winograd_weight(w_packed, groups, cin_g, out=None):
     """Packed K-major 3x3 weights [Cout][9*cin_g] -> U[g][16][cout_pad][cin_g] (G g G^T)."""
     Cout = w_packed.shape[0]
@@ -219,7 +244,7 @@ def winograd_weight(w_packed, groups, cin_g, out=None):
     return out
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None, winograd=False, **kw):
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None, winograd=False, x6=False, _keep=None, **kw):
     """Convenience one-shot conv for tests: x NHWC [B,H,W,Cin], weight OIHW; returns NHWC."""
     _need_cuda(x, w_oihw)
     B, H, W, Cin = x.shape
@@ -230,8 +255,14 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=Fal
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     U = winograd_weight(wp, groups, cin_g) if winograd else None
+    X6 = x6_weight(wp, groups, cin_g, k * k, x6_tile(Cout // groups, groups, B * Ho * Wo)) if x6 else None
     d, _, _ = make_conv_desc(x, wp, out, B=B, H=H, W=W, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
-                             stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats, wgt_wino=U, **kw)
+                             stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats, wgt_wino=U, wgt_x6=X6, **kw)
+    if x6 and lib.gssd_conv_x6_takes(C.byref(d)) != 1:
+        raise _lib.GssdError('conv2d_nhwc(x6=True): csrc/conv_x6.hip does not take this descriptor')
+    if _keep is not None:
+        _keep.extend([d, wp, U, X6, out])
+        return d
     run_conv(d)
     return out
 

@@ -109,6 +109,9 @@ typedef struct gssd_conv_desc {
                               convs of a Winograd shape (see gssd_winograd_weight_f32) then take the Winograd kernel; NULL = never */
     const float* pool_sign; /* flags & GSSD_CONV_POOL2 only: per-output-channel BatchNorm weight (gamma) of the layer's own BatchNorm;
                                only its SIGN is read (see GSSD_CONV_POOL2) */
+    const void* wgt_x6;    /* optional three-plane bf16 form of `wgt` (gssd_conv_x6_pack_weight, tile gssd_conv_x6_tile): plain-epilogue
+                              convs with cin_g % 32 == 0 then run csrc/conv_x6.hip (fp32-equivalent products on the bf16 matrix cores,
+                              see gssd_conv_x6_takes); NULL = never.  fp32 entry point only */
     int B, H, W;        /* input geometry */
     int in_stride;      /* floats between consecutive input pixels */
     int in_ch_off;      /* first input channel used */
@@ -140,6 +143,19 @@ typedef struct gssd_conv_desc {
 } gssd_conv_desc;
 
 int gssd_conv2d_nhwc_f32(const gssd_conv_desc* d, gssd_stream_t stream);
+
+/* fp32 convolution with fp32-equivalent products on the BF16 matrix cores (csrc/conv_x6.hip; nn.Conv2d of the reference's trunk,
+ * models/ssd_multiphase_custom_group.py vgg() / add_extras()): every operand is the exact sum of three bf16 planes, six
+ * v_mfma_f32_16x16x32_bf16 per product (all terms above 2^-24), fp32 accumulation.  gssd_conv_x6_tile: the N tile (64 / 128 / 256) the
+ * launch of a (cout_g, groups, M = B*Ho*Wo) conv uses -- the packed weights depend on it.  gssd_conv_x6_weight_elems: bf16 elements of
+ * the packed form (-1: not a shape the kernel takes).  gssd_conv_x6_pack_weight: K-major fp32 rows [Cout][row_stride] (gssd_pack_conv_weight)
+ * -> the three planes.  gssd_conv_x6_takes: 1 when gssd_conv2d_nhwc_f32 runs the descriptor on this kernel (wgt_x6 set, NHWC output,
+ * epilogue = bias / ReLU / batch sums only). */
+int gssd_conv_x6_tile(int cout_g, int groups, long long M);
+long long gssd_conv_x6_weight_elems(int Cout, int groups, int cin_g, int taps, int BN);
+int gssd_conv_x6_pack_weight(const float* w_packed, void* w_x6, int Cout, int groups, int cin_g, int taps, int row_stride, int BN,
+                             gssd_stream_t stream);
+int gssd_conv_x6_takes(const gssd_conv_desc* d);
 
 /* bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations, bf16 MFMA v_mfma_f32_16x16x32_bf16, fp32
  * accumulation).  Same descriptor; `in`, `wgt`, `resid`, `out`, `out2`, `in_pad` point to bf16 (uint16) data, element strides /

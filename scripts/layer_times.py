@@ -31,5 +31,10 @@ for i in range(n):
     ms = sum(ev[i + k * n][1].elapsed_time(ev[i + k * n][2]) for k in range(5)) / 5
     (tag, fl, by) = ev[i][0]
     tot += ms
-    print(f'{i:3d} {tag:24s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {by / ms / 1e6:7.0f} GB/s  {fl / 1e9:7.2f} GF  {by / 1e6:7.1f} MB')
+    d = getattr(ev[i][0], 'desc', None)
+    geo = ''
+    if d is not None and os.environ.get('LAYER_GEOMETRY'):
+        epi = ''.join(c for c, on in (('a', d.alpha), ('g', d.gate), ('r', d.resid), ('2', d.out2), ('x', d.in_scale), ('s', d.stats), ('R', d.relu), ('i', d.m_per_image)) if on)
+        geo = f'  {getattr(ev[i][0], "layer", None)} H{d.H} {d.cin_g * d.groups}>{d.Cout} g{d.groups} k{d.KH} s{d.stride} p{d.pad} d{d.dil} mode{d.out_mode} splitk{d.split_k} [{epi}]'
+    print(f'{i:3d} {tag:24s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {by / ms / 1e6:7.0f} GB/s  {fl / 1e9:7.2f} GF  {by / 1e6:7.1f} MB{geo}')
 print('total conv ms', tot)

@@ -2165,3 +2165,77 @@ def test_dcn_x6_matches_fused(dev, ops):
         e_x6, e_f = rel(nchw(got), r64), rel(nchw(ref), r64)
         print(f'dcn x6 vs float64 {e_x6:.2e}; fp32-MFMA kernel vs float64 {e_f:.2e}; x6 vs fp32-MFMA {rel(got, ref):.2e}')
         assert e_x6 < 2e-6 + 2 * e_f and rel(got, ref) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 19, 64, 64, 1, 3, 1, 1, 1), (3, 21, 128, 256, 4, 3, 1, 1, 1), (2, 19, 128, 512, 4, 3, 6, 6, 1),
+                                   (2, 17, 256, 216, 1, 3, 1, 1, 1), (2, 20, 256, 256, 4, 1, 0, 1, 1), (2, 23, 64, 96, 1, 3, 1, 1, 2),
+                                   (1, 9, 32, 40, 1, 5, 2, 1, 1)])
+def test_conv_x6_matches_float64(shape):
+    """csrc/conv_x6.hip: fp32 conv with three-plane bf16 operands (six MFMAs per product) is at least as close to a float64 convolution as
+    the fp32-MFMA kernel, for every tile width, with the fused input transform, bias, ReLU and the batch sums."""
+    import torch.nn.functional as F
+    from gssd import ops
+    B, H, Cin, Cout, g, k, pad, dil, stride = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, H + 3, Cin, generator=gen).to(dev)
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * 0.1).to(dev)
+    b = torch.randn(Cout, generator=gen).to(dev)
+    sc, sh = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)
+    pdv = -sh / sc - 1.0
+    for xf in (False, True):
+        kw = dict(in_scale=sc, in_shift=sh, in_pad=pdv) if xf else {}
+        xin = F.relu(x.double() * sc.double() + sh.double()) if xf else x.double()
+        ref = F.conv2d(xin.permute(0, 3, 1, 2), w.double(), b.double(), stride, pad, dil, g).permute(0, 2, 3, 1)
+        st6 = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)
+        y6 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, stats=st6, x6=True, **kw)
+        y32 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, **kw)
+        e6 = float((y6.double() - ref).abs().max() / ref.abs().max())
+        e32 = float((y32.double() - ref).abs().max() / ref.abs().max())
+        assert e6 < 2e-6 and e6 <= 1.5 * e32 + 1e-7, (xf, e6, e32)
+        n_px = ref.shape[0] * ref.shape[1] * ref.shape[2]           # fp32 partial sums per tile: errors relative to sum |v|, not to the sum
+        assert float((st6[:Cout] - ref.sum((0, 1, 2))).abs().max()) < 2e-7 * n_px * float(ref.abs().max())
+        assert float((st6[Cout:] - (ref * ref).sum((0, 1, 2))).abs().max()) < 2e-7 * n_px * float(ref.abs().max()) ** 2
+        yr = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, relu=True, x6=True, **kw)
+        torch.testing.assert_close(yr, torch.relu(y6), rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,Cc', [(3, 20, 512), (2, 19, 1024)])
+def test_conv_x6_epilogues_match_igemm(B, H, Cc):
+    """csrc/conv_x6.hip with the Self_Attn epilogues -- per-channel scale + gate + second output + residual, and the merged projection's
+    split-transposed store (flat and per-image descriptors) -- against conv_igemm / gemm_slot on the same descriptors."""
+    from gssd import ops, _lib
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    N, C4, C2 = H * H, Cc // 4, Cc // 2
+    Np = ops.round_up(N, 4)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    x, ag = rnd(B, H, H, Cc), rnd(B, H, H, C2)
+    w_o, w_p = rnd(Cc, C2) * 0.05, rnd(C4 + C2, Cc) * 0.05
+    bias_o, bias_p, alpha_o, alpha_p = rnd(Cc), rnd(C4 + C2), torch.rand(Cc, generator=gen).to(dev) + 0.5, torch.rand(C4 + C2, generator=gen).to(dev) + 0.5
+    gate = torch.tensor([0.37], device=dev)
+    M = B * N
+    res = {}
+    for tag in ('ref', 'x6'):
+        x6o = ops.x6_weight(w_o, 1, C2, 1, ops.x6_tile(Cc, 1, M)) if tag == 'x6' else None
+        x6p = ops.x6_weight(w_p, 1, Cc, 1, ops.x6_tile(C4 + C2, 1, M)) if tag == 'x6' else None
+        out, out2 = torch.empty(B, H, H, Cc, device=dev), torch.empty(B, H, H, Cc, device=dev)
+        d5, _, _ = ops.make_conv_desc(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=bias_o, alpha=alpha_o, gate=gate, resid=x,
+                                      out2=out2, wgt_x6=x6o)
+        assert _lib.lib.gssd_conv_x6_takes(ctypes.byref(d5)) == (1 if tag == 'x6' else 0)
+        ops.run_conv(d5)
+        outs = [out, out2]
+        for flat in ((True, False) if N % 4 == 0 else (False,)):
+            tp, gT = torch.empty(B, N, C4, device=dev), torch.zeros(B, C2, Np, device=dev)
+            d1, _, _ = ops.make_conv_desc(x, w_p, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=bias_p, alpha=alpha_p, wgt_x6=x6p,
+                                          out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=not flat,
+                                          in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np, flags=_lib.CONV_OUT_F32)
+            assert _lib.lib.gssd_conv_x6_takes(ctypes.byref(d1)) == (1 if tag == 'x6' else 0)
+            ops.run_conv(d1)
+            outs += [tp, gT]
+        res[tag] = outs
+    for a, b in zip(res['ref'], res['x6']):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
