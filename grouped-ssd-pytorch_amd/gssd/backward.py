@@ -371,6 +371,18 @@ class BackwardPlan:
             raise _lib.GssdError('this gradient map exists in bf16 only (a thin trunk layer): its one reader is the BatchNorm backward')
         return self.gbuf.get(t.data_ptr())
 
+    def _x6w(self, w, Cout, groups, cin_g, k, M, winograd=False):
+        """Three-plane bf16 form of the K-major fp32 weight rows ``w`` (re-derived inside the plan, right behind the launch that writes
+        ``w``) for the fp32 GEMMs csrc/conv_x6.hip takes (ops.x6_wanted); None otherwise."""
+        from .engine import USE_CONV_X6
+        if not USE_CONV_X6 or self.bf16_ops or not ops.x6_wanted(k, cin_g, Cout // groups, groups, M, winograd=winograd):
+            return None
+        bn = ops.x6_tile(Cout // groups, groups, M)
+        t = torch.empty(int(lib.gssd_conv_x6_weight_elems(Cout, groups, cin_g, k * k, bn)), device=self.dev, dtype=torch.int16)
+        self.keep.append(t)
+        self._add(lib.gssd_conv_x6_pack_weight, (w.data_ptr(), t.data_ptr(), Cout, groups, cin_g, k * k, w.stride(0), bn))
+        return t
+
     # gradient contribution of a conv to its input: dX (+)= conv(dY, flipped weights)
     def _dgrad(self, r, dy, x_in, conv, groups, Cin, H, Ho, Cout, k, stride, pad, dil):
         B = self.B
@@ -419,8 +431,9 @@ class BackwardPlan:
         if USE_WINOGRAD and ops.winograd_eligible(k, 1, pd, dil, Cout // groups, Cin // groups, groups):
             ud = self._buf(int(lib.gssd_winograd_weight_elems(Cin, groups, Cout // groups)))
             self._add(lib.gssd_winograd_weight_f32, (wd.data_ptr(), ud.data_ptr(), Cin, groups, Cout // groups, wd.stride(0)))
+        x6d = self._x6w(wd, Cin, groups, Cout // groups, k, B * H * H, winograd=ud is not None)
         d, Hout, _ = ops.make_conv_desc(src, wd, g, B=B, H=Hs, W=Hs, in_stride=Cout, cin_g=Cout // groups, Cout=Cin,
-                                        groups=groups, k=k, pad=pd, dil=dil, resid=existing, wgt_wino=ud)
+                                        groups=groups, k=k, pad=pd, dil=dil, resid=existing, wgt_wino=ud, wgt_x6=x6d)
         assert Hout == H, (Hout, H)
         self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d),), keep=d)
         self.gbuf[x_in.data_ptr()] = g
@@ -847,7 +860,7 @@ class BackwardPlan:
         if self.bf16_ops:             # the block's four dense GEMMs over the tokens on the bf16 matrix cores (fp32 accumulation)
             self._nt_bf16(T, wd_o, dag, B=B, H=H, in_stride=Cc, cin_g=Cc, Cout=C2)
         else:
-            d_dag, _, _ = mk(T, wd_o, dag, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2)
+            d_dag, _, _ = mk(T, wd_o, dag, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C2, wgt_x6=self._x6w(wd_o, C2, 1, Cc, 1, B * N))
             self._add(fn, (C.byref(d_dag),), keep=d_dag)
         # sigma, o bias, o weight
         dot = self._buf(1, dtype=torch.float64, zero_each_run=True)
@@ -964,7 +977,8 @@ class BackwardPlan:
             self._nt_bf16(dtpg, wd_p, gx, B=B, H=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
             self.keep.append(sig)
         else:
-            d_dx, _, _ = mk(dtpg, wd_p, gx, B=B, H=H, W=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid)
+            d_dx, _, _ = mk(dtpg, wd_p, gx, B=B, H=H, W=H, in_stride=CT, cin_g=CT, Cout=Cc, gate=sig.detach(), resid=resid,
+                            wgt_x6=self._x6w(wd_p, Cc, 1, CT, 1, B * H * H))
             self._add(fn, (C.byref(d_dx),), keep=(d_dx, sig))
 
     def _slice_cat(self, r):
@@ -1025,7 +1039,8 @@ class BackwardPlan:
         if self.bf16_ops:
             self._nt_bf16(dy, wt, dcols, B=B, H=H, in_stride=Cout, cin_g=Cout, Cout=Kc)      # 436 GFLOP: 3.4 ms in fp32
         else:
-            d_dc, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc)
+            d_dc, _, _ = ops.make_conv_desc(dy, wt, dcols, B=B, H=H, W=H, in_stride=Cout, cin_g=Cout, Cout=Kc,
+                                            wgt_x6=self._x6w(wt, Kc, 1, Cout, 1, B * H * H))
             self._add(lib.gssd_conv2d_nhwc_f32, (C.byref(d_dc),), keep=(d_dc, wt))
         # sampling backward: d(x) by atomics, d(offset / mask logits) per pixel
         gx = self._grad_of(x)
