@@ -1,5 +1,5 @@
-// fp32 fused modulated deformable 3x3 convolution on the BF16 matrix cores with fp32-equivalent products (round 4, experiment behind
-// GSSD_DCN_X6): the same algorithm and entry contract as dcn_fused.hip (fp32 x, fp32 offsets, fp32 blend, fp32 weights, fp32 output).
+// fp32 fused modulated deformable 3x3 convolution on the BF16 matrix cores with fp32-equivalent products (round 4; the fp32 mode's
+// deformable conv, GSSD_DCN_X6=0 runs dcn_fused.hip): the same algorithm and entry contract as dcn_fused.hip (fp32 x, fp32 offsets, fp32 blend, fp32 weights, fp32 output).
 // v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 matrix rate on gfx950.  An fp32 number is the exact sum of three bf16 numbers
 // (x = h + m + l, 8 + 8 + 8 mantissa bits, each rounded to nearest); a product x y is then h h' + (h m' + m h') + (h l' + l h' + m m') + terms
 // below 2^-24 |x y| -- six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to the last bit or two, and still cost 3/8 of the
