@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from .engine import GssdEngine, _Plan, _RecList, USE_WINOGRAD
+from .engine import GssdEngine, _Plan, _RecList, USE_WINOGRAD, USE_CONV_X6
 
 lib = _lib.lib
 
@@ -128,8 +128,13 @@ class _PlanPixelLink(_Plan):
             U = self.eng._pack(name + '.U', build_u)
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
         raw = self._buf(B, Ho, Ho, Cout)
+        X6 = None
+        if not getattr(self, "bf16", False) and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None):      # conv6 / conv7
+            def build_x6(out, key=name + '.w', groups=groups, cin_g=cin_g, taps=k * k, bn=ops.x6_tile(Cout // groups, groups, B * Ho * Ho)):
+                return ops.x6_weight(self.eng._packed[key], groups, cin_g, taps, bn, out)
+            X6 = self.eng._pack(name + '.x6', build_x6)
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k, stride=s,
-                                     pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
+                                     pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U, wgt_x6=X6,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None)
         self._add(self.conv_fn, (C.byref(d),), keep=(d, in_xf))
