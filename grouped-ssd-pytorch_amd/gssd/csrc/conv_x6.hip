@@ -185,9 +185,9 @@ __global__ __launch_bounds__(256, Cfg<BN>::OCC) void conv_x6_kernel(const gssd_c
         if (xf) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(xtab + fin_c * BKC + gq * 8 + 4 * hh);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(xtab + p.cin_g + fin_c * BKC + gq * 8 + 4 * hh);
-            v = v * sc + sh;
+            // (element by element: packed fp32 instructions do not run beside the MFMAs, scripts/ubench/mfma16_valu_overlap.hip)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
         }
         if (!gok[j]) v = zero4;
 #pragma unroll
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, Cfg<BN>::OCC) void conv_x6_kernel(const gssd_c
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[0], c, 0, 0, 0);
 #if X6_LOCAL_SUM
-                acc[i][j] += c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += c[e];
 #else
                 acc[i][j] = c;
 #endif

@@ -164,12 +164,14 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
             bf16x8 oh, om_, ol;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                // the blend of dcn_fused.hip: the same four products, the same order
-                const f32x4 v = gv[j][0][hh] * gw[j][0] + gv[j][1][hh] * gw[j][1] + gv[j][2][hh] * gw[j][2] + gv[j][3][hh] * gw[j][3];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    // the blend of dcn_fused.hip: the same four products, the same order -- element by element: the packed forms
+                    // (v_pk_mul_f32 / v_pk_fma_f32) do not run beside the MFMAs, a v_fma_f32 does (scripts/ubench/mfma16_valu_overlap.hip;
+                    // the file is built with -fno-slp-vectorize so that the compiler does not pair them up again)
+                    const float ve = gv[j][0][hh][e] * gw[j][0] + gv[j][1][hh][e] * gw[j][1] + gv[j][2][hh][e] * gw[j][2] + gv[j][3][hh][e] * gw[j][3];
                     __bf16 h, m, l;
-                    split3(v[e], h, m, l);
+                    split3(ve, h, m, l);
                     oh[4 * hh + e] = h;
                     om_[4 * hh + e] = m;
                     ol[4 * hh + e] = l;

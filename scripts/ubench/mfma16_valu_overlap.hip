@@ -1,0 +1,106 @@
+// Micro-benchmark (round 4, for csrc/conv_x6.hip / dcn_x6.hip): which vector instructions hide in the shadow of v_mfma_f32_16x16x32_bf16
+// (16 cycles per SIMD)?  Every wave issues [1 MFMA (four independent accumulators round robin), N independent fillers] x 64, unrolled,
+// 200 times; one or two waves per SIMD (256 / 512 threads, one workgroup per CU).  Reports shader cycles per MFMA of ONE wave: flat at 16
+// (one wave) or 32 (two waves sharing the pipe) while the fillers hide, rising by the filler's cost once they do not.
+//   hipcc --offload-arch=gfx950 -O3 mfma16_valu_overlap.hip -o mfma16_valu_overlap && ./mfma16_valu_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// FILL 0 v_fma_f32, 1 v_cvt_pk_bf16_f32, 2 v_pk_add_f32, 3 v_pk_fma_f32, 4 v_sub_f32, 5 v_lshlrev_b32, 6 v_and_b32, 7 v_cndmask_b32 (SGPR pair), 8 v_perm_b32
+template <int N, int FILL>
+__device__ __forceinline__ void fillers(f32x2 (&f)[8], float a, float b) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (FILL == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
+        if (FILL == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(f[i][1]) : "v"(f[i][0]), "v"(a));
+        if (FILL == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+        if (FILL == 3) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+        if (FILL == 4) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 5) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(f[i][1]) : "v"(f[i][0]));
+        if (FILL == 6) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(f[i][1]) : "v"(f[i][0]));
+        if (FILL == 7) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(f[i][0]) : "v"(a) : "s20", "s21");
+        if (FILL == 8) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(f[i][1]) : "v"(f[i][0]), "v"(a), "v"(b));
+    }
+}
+
+template <int N, int FILL, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void overlap_kernel(float* __restrict__ out, unsigned long long* __restrict__ cycles, int iters) {
+    const int lane = threadIdx.x & 63;
+    f32x2 f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = f32x2{(float)(lane + i), 1.f};
+    const float a = 1.0001f, b = 0.5f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 pa, pb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pa[e] = (__bf16)(float)(lane & 3), pb[e] = (__bf16)1.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k & 3]) : "v"(pa), "v"(pb));
+            fillers<N, FILL>(f, a, b);
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += f[i][0] + f[i][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0];
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+template <int N, int FILL, int THREADS>
+double run(float* out, unsigned long long* cyc, int blocks) {
+    const int iters = 200;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((overlap_kernel<N, FILL, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double s = 0;
+    for (auto v : h) s += (double)v;
+    return s / blocks / (iters * 64.0);
+}
+
+template <int FILL, int THREADS>
+void row(const char* name, float* out, unsigned long long* cyc, int cus) {
+    printf("  %-20s %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f\n", name, run<0, FILL, THREADS>(out, cyc, cus), run<1, FILL, THREADS>(out, cyc, cus),
+           run<2, FILL, THREADS>(out, cyc, cus), run<3, FILL, THREADS>(out, cyc, cus), run<4, FILL, THREADS>(out, cyc, cus), run<6, FILL, THREADS>(out, cyc, cus));
+}
+
+template <int THREADS>
+void table(float* out, unsigned long long* cyc, int cus) {
+    printf("%d wave(s) per SIMD: cycles per v_mfma_f32_16x16x32_bf16 of one wave with N = 0 1 2 3 4 6 fillers behind it\n", THREADS / 256);
+    row<0, THREADS>("v_fma_f32", out, cyc, cus);
+    row<1, THREADS>("v_cvt_pk_bf16_f32", out, cyc, cus);
+    row<2, THREADS>("v_pk_add_f32", out, cyc, cus);
+    row<3, THREADS>("v_pk_fma_f32", out, cyc, cus);
+    row<4, THREADS>("v_sub_f32", out, cyc, cus);
+    row<5, THREADS>("v_lshlrev_b32", out, cyc, cus);
+    row<6, THREADS>("v_and_b32", out, cyc, cus);
+    row<7, THREADS>("v_cndmask_b32 (sgpr)", out, cyc, cus);
+    row<8, THREADS>("v_perm_b32", out, cyc, cus);
+}
+
+int main() {
+    int dev = 0, cus = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)cus * 512 * sizeof(float));
+    hipMalloc(&cyc, (size_t)cus * sizeof(unsigned long long));
+    table<256>(out, cyc, cus);
+    table<512>(out, cyc, cus);
+    return 0;
+}
