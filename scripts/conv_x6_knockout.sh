@@ -8,7 +8,7 @@ KOS="${KOS:-0 1 2 4 8 16 32 3 18 19 27 59}"
 if [ "$1" = build ]; then
   mkdir -p build_ko
   for ko in $KOS; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$CS -munsafe-fp-atomics -DX6_KO=$ko $EXTRA -c $CS/conv_x6.hip -o build_ko/conv_x6_$ko.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$CS -munsafe-fp-atomics -fno-slp-vectorize -DX6_KO=$ko $EXTRA -c $CS/conv_x6.hip -o build_ko/conv_x6_$ko.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $CS/*.o | grep -v '/conv_x6.o$') build_ko/conv_x6_$ko.o -o build_ko/libgssd_ko$ko.so &
   done
   wait
