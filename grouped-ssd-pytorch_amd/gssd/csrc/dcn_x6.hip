@@ -5,6 +5,9 @@
 // below 2^-24 |x y| -- six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to the last bit or two, and still cost 3/8 of the
 // fp32 instruction's matrix-pipe time.  The sampled column is blended in fp32 exactly as before and split into its three planes when it is
 // written to LDS; the weights are split once, when they are packed.
+// K loop (end of round 4, X6_PIPE): the corner loads of chunk ch + 1 are requested first thing in chunk ch, and its blend + split + LDS writes
+// are dealt out behind the MFMAs of the chunk's last two fragment rows (one wave per SIMD: the vector work runs in the MFMAs' shadow instead of
+// after them): 2.60 -> 2.22 ms.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,6 +22,12 @@ namespace {
 
 #ifndef X6_BN
 #define X6_BN 256
+#endif
+#ifndef X6_SPLIT_ROWS
+#define X6_SPLIT_ROWS 2   // fragment rows of a chunk that carry the next chunk's blend + split: the last 2 (two quarters each), 3 (1, 1, 2) or all 4
+#endif
+#ifndef X6_PIPE
+#define X6_PIPE 1         // the pipelined K loop (value = vector instructions scheduled behind every MFMA); 0: the plain loop
 #endif
 // BN = 256: the sampled columns are computed for two output tiles instead of four (the kernel is bound by the fp32 corner loads); the three
 // weight planes of a chunk are then 48 KB, so they are staged in ONE buffer: fragments to registers, barrier, next chunk's DMA behind the MFMAs
@@ -205,6 +214,134 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
         }
     };
 
+#if X6_PIPE
+    // ---- the K loop as one instruction stream per chunk (one wave per SIMD: what overlaps must overlap inside the wave) -------------------
+    // chunk ch: weight fragments + the first activation row -> registers, barrier, DMA of chunk ch + 1's weight planes, corner loads of chunk
+    // ch + 2 (inline assembly: the compiler's wait-count pass would drain the DMA with them); then the MFMAs of chunk ch row by row, the next
+    // row's fragments read behind them and a quarter of chunk ch + 1's blend + split + LDS writes dealt out behind every row (its corners
+    // were loaded during chunk ch - 1: two register sets).  v_mfma_f32_16x16x32_bf16 hides one 8-cycle or two 4-cycle vector instructions
+    // (scripts/ubench/mfma16_valu_overlap.hip); the body is unconditional (past the end the last chunk is loaded again, the writes go to a
+    // stage nobody reads) so that it is one basic block.
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    f32x4 gw1[2];
+    f32x4 gv1[2][4][2];
+    auto issue = [&]() {
+        const int cb = ch_d * cpg + ch_c * BKC + gq * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = ch_tap * BM + gp + 64 * j;
+            gw1[j] = setw[e];
+            const int pos = setp[e];
+            const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
+            const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
+            const unsigned i10 = i00 + dyb * (unsigned)W;
+            const float* pc[4] = {x + (size_t)i00 * (unsigned)C + cb, x + (size_t)(i00 + dxb) * (unsigned)C + cb, x + (size_t)i10 * (unsigned)C + cb,
+                                  x + (size_t)(i10 + dxb) * (unsigned)C + cb};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gv1[j][k][0] = *reinterpret_cast<const f32x4*>(pc[k]);
+                gv1[j][k][1] = *reinterpret_cast<const f32x4*>(pc[k] + 4);
+            }
+        }
+    };
+    // quarter `part` (cell j = part >> 1, channel half hh = part & 1) of this thread's 16 column values: blend, split, three 8-byte LDS writes
+    auto finish_part = [&](int part, int buf) {
+        const int j = part >> 1, hh = part & 1;
+        bf16x4 oh, om_, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // the blend of dcn_fused.hip: the same four products, the same order (element by element, no packed fp32 instructions)
+            const float ve = gv1[j][0][hh][e] * gw1[j][0] + gv1[j][1][hh][e] * gw1[j][1] + gv1[j][2][hh][e] * gw1[j][2] + gv1[j][3][hh][e] * gw1[j][3];
+            __bf16 h, m, l;
+            split3(ve, h, m, l);
+            oh[e] = h;
+            om_[e] = m;
+            ol[e] = l;
+        }
+        u16* Ad = As + buf * NP * A_STAGE + a_wr0 + j * 64 * BKC + 4 * hh;
+        *reinterpret_cast<bf16x4*>(Ad) = oh;
+        *reinterpret_cast<bf16x4*>(Ad + A_STAGE) = om_;
+        *reinterpret_cast<bf16x4*>(Ad + 2 * A_STAGE) = ol;
+    };
+    static_assert(NBS == 1 && MT == 4, "the pipelined loop is written for one weight buffer and four fragment rows");
+
+    setups(0);
+    __syncthreads();
+    issue();                                       // chunk 0
+    b_issue(0, 0);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) finish_part(part, 0);
+    if (nchunks > 1) advance();
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks && ch_tap == 0 && ch_c == 0) {      // chunk ch + 1 opens a deformable group: its sampling table
+            setups(ch_d);
+            __syncthreads();
+        }
+        issue();             // corners of chunk ch + 1, first thing in the chunk (past the end: the last chunk again, written to a stage nobody reads)
+        __builtin_amdgcn_sched_barrier(0);
+        const u16* Ab = As + buf * NP * A_STAGE + wm * WTM * BKC + fo;
+        const u16* Bb = Bs + wn * WTN * BKC + fo;
+        bf16x8 afr[2][NP], bf[NP][NT];
+        auto a_row = [&](int i) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) afr[i & 1][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_STAGE + i * 16 * BKC);
+        };
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_STAGE + j * 16 * BKC);
+        a_row(0);
+        // one weight buffer: every wave holds its weight fragments in registers before the next chunk's planes may land
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        b_issue(min(ch + 1, nchunks - 1), 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (i + 1 < MT) a_row(i + 1);
+            const bf16x8 (&af)[NP] = afr[i & 1];
+            // six products per fragment pair, smallest first (a: column planes, b: weight planes)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][j], af[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2][j], af[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][j], af[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+            // the corners were requested in front of row 0: its 48 MFMAs (768 cycles) cover an L2 hit; rows 1 .. 3 carry the four quarters.
+            // Every row is its own scheduling region: [the next row's fragment reads] [MFMA, vector instructions]* [the quarter's planes]
+#if X6_SPLIT_ROWS == 2
+            constexpr int PARTS[4] = {0, 0, 2, 2};
+#elif X6_SPLIT_ROWS == 3
+            constexpr int PARTS[4] = {0, 1, 1, 2};
+#else
+            constexpr int PARTS[4] = {1, 1, 1, 1};
+#endif
+            constexpr int PFIRST[4] = {0, PARTS[0], PARTS[0] + PARTS[1], PARTS[0] + PARTS[1] + PARTS[2]};
+#pragma unroll
+            for (int q = 0; q < PARTS[i]; ++q) finish_part(PFIRST[i] + q, buf ^ 1);
+            if (i + 1 < MT) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+            for (int k = 0; k < NT * 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (PARTS[i] == 1) __builtin_amdgcn_sched_group_barrier(0x002, X6_PIPE, 0);
+                if (PARTS[i] == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2 * X6_PIPE, 0);
+            }
+            if (PARTS[i] == 1) __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);
+            if (PARTS[i] == 2) __builtin_amdgcn_sched_group_barrier(0x200, 2 * NP, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 2 < nchunks) advance();
+        __syncthreads();
+    }
+#else
     setups(0);
     __syncthreads();
     gather_issue();
@@ -266,6 +403,8 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
         }
         __syncthreads();
     }
+
+#endif
 
     // ---- epilogue: + bias, 16-byte NHWC fp32 stores (lane: pixel = lane & 15, 8 consecutive channels per tile pair) -----------
 #pragma unroll
