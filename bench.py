@@ -319,7 +319,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
                         alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
                         note=('fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product (everything above 2^-24), fp32 '
-                              'accumulation: fp32-equivalent results (tests/test_gpu_parity.py::test_dcn_x6_matches_fused); GSSD_DCN_X6=0 runs '
+                              'accumulation, the next chunk\'s blend + split in the MFMAs\' shadow: fp32-equivalent results (tests/test_gpu_parity.py::test_dcn_x6_matches_fused); GSSD_DCN_X6=0 runs '
                               'the fp32-MFMA kernel' if x6
                               else 'fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
                               else 'bf16 MFMA, fp32 accumulate')
