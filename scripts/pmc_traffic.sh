@@ -39,7 +39,6 @@ def short(n):
     if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
     if 'dcn_x6_kernel' in n: return 'dcn_x6<128x256>'
     if 'conv_x6_kernel' in n:
-        import re
         m6 = re.search(r'conv_x6_kernel<(\d+)', n)
         return f'conv_x6<{m6.group(1)}>' if m6 else 'conv_x6'
     if 'dcn_bf16_kernel' in n: return 'dcn_bf16<128x256>'
