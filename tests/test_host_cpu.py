@@ -37,6 +37,40 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.gssd_detect(None, None, None, 1, 8732, 2, 200, 0.01, 0.45, 0.1, 0.2, 0, 0, None, None, None, None) == -1
 
 
+def test_conv_x6_host_rules():
+    """Host side of csrc/conv_x6.hip (no device work): the tile rule, the size of the three-plane weight form, and which descriptors
+    gssd_conv2d_nhwc_f32 hands to the kernel (gssd_conv_x6_takes)."""
+    from gssd import _lib, ops
+    lib = _lib.lib
+    assert [lib.gssd_conv_x6_tile(c, 4, 46208) for c in (32, 64, 96, 128, 216, 256, 1024)] == [64, 64, 128, 128, 128, 128, 128]
+    # 3 planes x groups x ceil(cout_g / tile) x tile x taps x cin_g bf16 elements; -1 for shapes the kernel does not take
+    assert lib.gssd_conv_x6_weight_elems(1024, 4, 128, 9, 128) == 3 * 4 * 2 * 128 * 9 * 128
+    assert lib.gssd_conv_x6_weight_elems(216, 1, 512, 9, 128) == 3 * 1 * 2 * 128 * 9 * 512          # 216 -> two 128-column tiles, zero rows
+    assert lib.gssd_conv_x6_weight_elems(512, 1, 48, 1, 128) == -1                                    # cin_g % 32 != 0
+    assert lib.gssd_conv_x6_weight_elems(512, 1, 64, 1, 96) == -1                                     # not a tile width
+    assert ops.x6_wanted(1, 512, 512, 1, 46208) and ops.x6_wanted(3, 128, 256, 4, 11552)
+    assert not ops.x6_wanted(3, 128, 128, 4, 46208, winograd=True) and not ops.x6_wanted(1, 512, 64, 1, 46208) and not ops.x6_wanted(1, 512, 512, 1, 3200)
+    buf = torch.zeros(64, dtype=torch.float32)             # any 16-byte aligned host address: takes() only inspects the descriptor
+
+    def desc(**kw):
+        args = dict(B=2, H=19, W=19, in_stride=256, cin_g=256, Cout=512)
+        args.update(kw)
+        d, _, _ = ops.make_conv_desc(buf, buf, buf, wgt_x6=args.pop('x6', buf), **args)
+        return lib.gssd_conv_x6_takes(ctypes.byref(d))
+    assert desc() == 1
+    assert desc(x6=None) == 0                               # no three-plane weights: the fp32-MFMA kernels
+    assert desc(alpha=buf, gate=buf, resid=buf, out2=buf, relu=True, stats=torch.zeros(8, dtype=torch.float64)) == 1
+    assert desc(out2=buf) == 0                              # a second output only exists behind a gate
+    assert desc(split_k=2) == 0 and desc(out_mode=_lib.OUT_TRANSPOSED, m_per_image=True, out_stride=364) == 0
+    assert desc(cin_g=48, in_stride=48) == 0 and desc(Cout=24) == 0
+    # the merged Self_Attn projection: split-transposed store, whole tiles on either side of split_n, flat or contiguous per-image batches
+    sp = dict(Cout=384, out_mode=_lib.OUT_SPLIT_T, out_b=buf, split_n=128, out_stride=128, out_b_stride=364, flags=_lib.CONV_OUT_F32,
+              in_batch_stride=361 * 256, out_batch_stride=361 * 128, outb_batch_stride=256 * 364)
+    assert desc(**sp) == 1 and desc(m_per_image=True, **sp) == 1
+    assert desc(**dict(sp, split_n=64, out_stride=64, out_batch_stride=361 * 64)) == 0
+    assert desc(m_per_image=True, **dict(sp, in_batch_stride=400 * 256)) == 0
+
+
 def test_priorbox_bit_exact(golden):
     from layers.functions import PriorBox
     from data import v2, v2_512
