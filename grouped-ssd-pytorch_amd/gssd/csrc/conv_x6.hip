@@ -24,7 +24,9 @@ typedef unsigned short u16;
 namespace {
 
 #ifndef X6_SCHED
-#define X6_SCHED 2           // vector instructions scheduled behind every MFMA of the K loop (0: the compiler's own order)
+#define X6_SCHED 0           // N > 0: N (+1, +2 for the narrower tiles) vector instructions pinned behind every MFMA of the K loop by
+                             // sched_group_barrier; 0: the compiler's own order -- 5-6 % faster with two workgroups per CU (same-box sweep 0 / 1 / 2 / 3:
+                             // conv4_2 367 / 379 / 389 / 387 us, conv6 173 / 186 / 185 / 184), unlike dcn_x6 (one wave per SIMD) where the pinned order is the gain
 #endif
 #ifndef X6_KO
 #define X6_KO 0             // knock-outs (scripts/conv_x6_knockout.sh): 1 no transform / split, 2 no MFMAs, 4 no weight DMA, 8 no activation loads,
