@@ -52,6 +52,11 @@ CONFIGS = {
                dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4,
                     dcn_cat_sab=True), 39.4, 402.0),
 }
+WORKLOAD_SHORT = {
+    'gssd': 'gssd (BASELINE configs[1]): build_ssd(groups 4, BN, fuse) fwd + MultiBoxLoss, train-mode BN, batch 32, [B,12,300,300] slices',
+    'gssdpp': 'gssdpp (BASELINE configs[2], GSSD++: self-attention + SA-base + 1 DCN layer x 4 deformable groups, dcn_cat_sab) fwd + '
+              'MultiBoxLoss, train-mode BN, batch 32, [B,12,300,300] slices',
+}
 WORKLOAD = {
     'gssd': 'gssd (BASELINE configs[1]): build_ssd(groups 4, BN, fuse) forward + MultiBoxLoss, train-mode BN, '
             '[B,12,300,300] slices (4-phase 512x512 CT resized outside the timed region)',
@@ -62,6 +67,95 @@ WORKLOAD = {
 PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+
+
+LINE_LIMIT = 8192          # the driver keeps a bounded tail of stdout: r04's 21.6 KB line did not parse
+ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'launches_timed', 'ms_per_step',
+             'alg_flop_per_launch', 'alg_bytes_per_launch', 'fp32_equivalent_tflops', 'direct_conv_tflops')
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d} if isinstance(d, dict) else d
+
+
+def _roof(r, note=True):
+    if not isinstance(r, dict):
+        return r
+    out = _pick(r, ROOF_KEYS)
+    if note and r.get('note'):
+        out['note'] = str(r['note'])[:160]
+    if r.get('next'):
+        out['next'] = [_pick(q, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'ms_per_step', 'avg_launch_us')) for q in r['next']]
+    return out
+
+
+def _fstep(f):
+    return _pick(f, ('value', 'unit', 'steps', 'ms_per_step', 'host_enqueue_ms_per_step', 'grad_elems', 'rccl_ranks',
+                     'allreduce_exposed_ms', 'allreduce_overlapped', 'error'))
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line: the contract's fields + `roofline` + `cpu_baseline` + short summaries of the other legs, <= LINE_LIMIT
+    bytes.  Everything else (per-kernel tables, per-layer trunk table, notes) lives in the detail file."""
+    line = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                        'vs_baseline', 'dtype', 'data'))
+    cfg = full.get('config') or {}
+    line['config'] = dict(_pick(cfg, ('batch_per_gpu', 'global_batch', 'alg_gflop_per_img', 'alg_mb_per_img')),
+                          workload=str(cfg.get('workload_short') or cfg.get('workload', ''))[:200])
+    line.update(_pick(full, ('rccl_ranks', 'collective_backend', 'launcher', 'per_rank_ms_per_step', 'host_enqueue_ms_per_step',
+                             'steady', 'loss', 'first_step_loss')))
+    line['roofline'] = _roof(full.get('roofline'))
+    tr = full.get('trunk')
+    if isinstance(tr, dict):
+        line['trunk_roofline'] = dict(_pick(tr, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'ms_per_step', 'tflops')),
+                                      worst_layer=_pick(tr.get('worst_layer'), ('layer', 'us', 'gbs', 'tflops', 'frac')))
+    cb = full.get('cpu_baseline')
+    if isinstance(cb, dict):
+        line['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind', 'loss', 'passes_s', 'gpu_vs_cpu_loss_rel')),
+                                    sample=str(cb.get('sample', ''))[:240])
+    else:
+        line['cpu_baseline'] = cb
+    b = full.get('bf16')
+    if isinstance(b, dict):
+        r = b.get('roofline')
+        line['bf16'] = dict(_pick(b, ('value', 'unit', 'dtype', 'steps', 'ms_per_step', 'loss')),
+                            roofline=(dict(_pick(r, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'ms_per_step', 'tflops')),
+                                           binding_frac=r.get('binding_frac'),
+                                           worst_layer=_pick(r.get('worst_layer'), ('layer', 'us', 'gbs', 'tflops', 'frac')))
+                                      if isinstance(r, dict) else r),
+                            dominant_kernel=_roof(b.get('dominant_kernel'), note=False), full_step=_fstep(b.get('full_step')))
+    sec = full.get('secondary')
+    if isinstance(sec, dict):
+        line['secondary'] = dict(_pick(sec, ('value', 'unit', 'ms_per_step', 'loss')), workload=str(sec.get('workload', ''))[:60],
+                                 roofline=_roof(sec.get('roofline'), note=False))
+    pl = full.get('pixellink')
+    if isinstance(pl, dict):
+        line['pixellink'] = dict(_pick(pl, ('value', 'unit', 'ms_per_step', 'batch')), full_step=_pick(pl.get('full_step'), ('ms_per_step', 'value')))
+    line['full_step'] = _fstep(full.get('full_step'))
+    line['input_stage'] = _pick(full.get('input_stage'), ('ms_per_batch', 'alg_gbs', 'frac_hbm_peak', 'dtype'))
+    line['detail'] = detail_path
+    # belt and braces: drop optional summaries until the line fits
+    for k in ('pixellink', 'input_stage', 'secondary', 'trunk_roofline', 'first_step_loss', 'host_enqueue_ms_per_step'):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    if len(json.dumps(line)) > LINE_LIMIT:          # (8 ranks: per-rank lists are the only thing that grows)
+        line['roofline'] = _roof(full.get('roofline'), note=False)
+        if isinstance(line.get('bf16'), dict):
+            line['bf16'] = _pick(line['bf16'], ('value', 'unit', 'ms_per_step', 'roofline'))
+    assert len(json.dumps(line)) <= LINE_LIMIT, len(json.dumps(line))
+    return line
+
+
+def write_detail(full, path):
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(full, f, indent=1)
+        return path
+    except OSError as e:
+        print(f'bench.py: could not write {path}: {e}', file=sys.stderr)
+        return None
 
 
 def cpu_baseline(cfg_name, sample_b, seed):
@@ -149,6 +243,12 @@ def trunk_roofline(survey, n_pass, B, dtype):
     fl = sum(r[2] for r in lay.values())
     per = {k: dict(us=round(1e3 * r[0], 1), alg_mb=round(r[1] / 1e6, 1), gbs=round(r[1] / r[0] / 1e6, 1),
                    tflops=round(r[2] / r[0] / 1e9, 1), kernels=sorted(r[3])) for k, r in lay.items()}
+    # the BINDING roof per layer: max(bytes / t / HBM peak, FLOPs / t / matrix peak of the storage mode); the trunk's figure
+    # is the time-weighted mean of the layers'
+    pk = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
+    for v in per.values():
+        v['binding_frac'] = round(max(v['gbs'] / PEAK_HBM_GBS, v['tflops'] / pk), 4)
+    binding = sum(per[k]['binding_frac'] * lay[k][0] for k in lay) / ms
     big = {k: v for k, v in per.items() if v['alg_mb'] >= 0.02 * by / 1e6}
     worst = min(big, key=lambda k: big[k]['gbs'])
     survey_mb = SURVEY_TRUNK_MB_F32 * (0.5 if dtype == 'bf16' else 1.0)
@@ -159,6 +259,7 @@ def trunk_roofline(survey, n_pass, B, dtype):
     # accounting (the reference's pass structure, deleted passes counted as moved) is kept beside it under its own name.
     return dict(bound='hbm', achieved=round(built, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(built / PEAK_HBM_GBS, 4),
                 traffic=None, kernel='trunk conv1_1 .. conv5_3 (convs + BN/ReLU/pool passes)', ms_per_step=round(ms, 4),
+                binding_frac=round(binding, 4),
                 plan='nograd (torch.no_grad() forward: pooled trunk layers keep no full-resolution raw maps; a training step cannot use it)',
                 alg_mb_per_img=round(by / B / 1e6, 2), alg_bytes_per_step=round(by), tflops=round(fl / ms / 1e9, 1),
                 accounting='achieved = compulsory bytes of the launches as built (input + output + weights per launch) x images / '
@@ -227,15 +328,12 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             except (OSError, ValueError, KeyError):
                 pass
         events = EventList()
-        # the dominant KERNEL: the instance with the most time among those launched at most 12 times per step (a bucket of dozens
-        # of small-map launches of one tile shape is not one kernel, and bracketing it would cut the hipGraph into as many pieces)
-        cands = {k: v for k, v in sagg.items() if v[0] // 2 <= 12} or sagg
-        top = max(cands, key=lambda k: cands[k][1])
-        # a near-tie (within 10 %) between the single-launch deformable conv and a ten-launch instance goes to the single launch: one cut of
-        # the hipGraph instead of ten inside the timed region, and the kernel every earlier round reported
-        one = [k for k in cands if k.startswith('dcn_') and cands[k][1] >= 0.9 * cands[top][1]]
-        events.only = {one[0] if one else top}
-        runner_up = dict(kernel=top, ms_per_step=round(cands[top][1] / 2, 4)) if (one and one[0] != top) else None
+        # the dominant KERNEL: the template instance with the most time per step in the survey passes -- no launch-count cap, no
+        # tie-break; the next two instances are reported beside it from the same survey passes (`roofline_next`)
+        order = sorted(sagg, key=lambda k: -sagg[k][1])
+        top = order[0]
+        events.only = {top}
+        runner_up = order[1:3]
     # one more untimed step in exactly the timed region's launch mode (hipGraph segments around the bracketed kernel): the graph
     # capture of that mode happens here, not inside the K timed steps, whatever --warmup is
     for _ in range(3):
@@ -289,8 +387,8 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                                  alg_gbs=round(by / (ms * 1e-3) / 1e9, 1))
         agg = aggregate(events)
 
-        def make_roof(dom):
-            n, ms, fl, by = agg[dom]
+        def make_roof(dom, row, source):
+            n, ms, fl, by = row
             traffic = None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
             if os.path.exists(pmc):
@@ -299,37 +397,34 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                 except Exception:
                     traffic = None
             ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
-            wino = dom.startswith('conv_wino') or dom.startswith('conv_thin_wino')
-            x6 = dom.startswith('dcn_x6')
-            if ach_b / PEAK_HBM_GBS > ach_t / peak_t:
+            wino = dom.startswith(('conv_wino', 'conv_thin_wino'))
+            x6 = dom.startswith(('dcn_x6', 'conv_x6', 'conv_flat_x6', 'flash_attn_x'))
+            if x6:
+                # three-plane kernels: fp32-equivalent products as six bf16 MFMAs over operands split into three bf16 planes -- `achieved` /
+                # `frac` are the ISSUED bf16 FLOPs (6 x algorithmic) against the bf16 matrix peak; the algorithmic rate has its own name
+                roof = dict(bound='mfma', achieved=round(6 * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                            frac=round(6 * ach_t / PEAK_BF16_TFLOPS, 4), fp32_equivalent_tflops=round(ach_t, 2),
+                            fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
+                note = 'fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate: achieved = ISSUED bf16 FLOPs'
+            elif ach_b / PEAK_HBM_GBS > ach_t / peak_t:
                 roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
+                note = 'algorithmic bytes (in + out + weights) / launch time'
             elif wino:
                 # Winograd F(2x2,3x3) issues 2.25x fewer MFMA FLOPs than the direct convolution it computes: `achieved` / `frac` are the
                 # ISSUED FLOPs against the matrix pipe (what a roofline fraction means); the direct-convolution rate is reported under its own name
                 roof = dict(bound='mfma', achieved=round(ach_t / 2.25, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / 2.25 / peak_t, 4),
                             direct_conv_tflops=round(ach_t, 2), direct_conv_over_peak=round(ach_t / peak_t, 4))
-            elif x6:
-                # csrc/dcn_x6.hip: fp32-equivalent products as six bf16 MFMAs over three-plane operands -- `achieved` / `frac` are the ISSUED
-                # bf16 FLOPs (6 x algorithmic) against the bf16 matrix peak; the algorithmic (fp32-equivalent) rate has its own name
-                roof = dict(bound='mfma', achieved=round(6 * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                            frac=round(6 * ach_t / PEAK_BF16_TFLOPS, 4), fp32_equivalent_tflops=round(ach_t, 2),
-                            fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
+                note = 'Winograd F(2x2,3x3) on fp32 MFMA: achieved = ISSUED FLOPs (direct-conv FLOPs / 2.25)'
             else:
                 roof = dict(bound='mfma', achieved=round(ach_t, 2), peak=peak_t, unit='TFLOP/s', frac=round(ach_t / peak_t, 4))
+                note = 'fp32 MFMA (v_mfma_f32_16x16x4_f32)' if dtype == 'f32' else 'bf16 MFMA, fp32 accumulate'
             roof.update(traffic=traffic, kernel=dom, avg_launch_us=round(1e3 * ms / n, 2), launches_timed=n,
-                        alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n),
-                        note=('fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product (everything above 2^-24), fp32 '
-                              'accumulation, the next chunk\'s blend + split in the MFMAs\' shadow: fp32-equivalent results (tests/test_gpu_parity.py::test_dcn_x6_matches_fused); GSSD_DCN_X6=0 runs '
-                              'the fp32-MFMA kernel' if x6
-                              else 'fp32 MFMA (v_mfma_f32_16x16x4_f32); fp32 peak binds before HBM (AI >> 19.7 FLOP/B)' if dtype == 'f32'
-                              else 'bf16 MFMA, fp32 accumulate')
-                             + ('; Winograd F(2x2,3x3): achieved / frac = ISSUED MFMA FLOPs (direct-convolution FLOPs / 2.25) against the '
-                                'matrix pipe; direct_conv_tflops = the algorithmic (direct-convolution) rate' if wino else ''))
+                        ms_per_step=round(ms / n * (sagg[dom][0] // 2), 4),
+                        alg_flop_per_launch=round(fl / n), alg_bytes_per_launch=round(by / n), source=source, note=note)
             return roof
         dom = max(agg, key=lambda k: agg[k][1])
-        roof = make_roof(dom)
-        if runner_up:
-            roof['near_tie_with'] = runner_up
+        roof = make_roof(dom, agg[dom], 'HIP events around every launch of this instance inside the timed region')
+        roof['next'] = [make_roof(k, sagg[k], 'untimed survey passes') for k in (runner_up or []) if k in sagg]
     # the HBM-side companion of `roofline`: the heaviest of the byte-bound trunk layers (the patch-staged thin kernels of conv1_1 ..
     # conv2_2: arithmetic intensity below the ridge in both storage modes), from the untimed survey passes' per-launch HIP events
     roof_hbm = None
@@ -463,16 +558,25 @@ def self_launch(n):
     try:
         pending = set(range(n))
         while pending:
-            for r in sorted(pending):
-                try:
-                    c = procs[r].wait(timeout=0.5)
-                except subprocess.TimeoutExpired:
-                    continue
-                pending.discard(r)
-                if c != 0 and rc == 0:
-                    rc = c
-                    for q in pending:                     # one rank died: the others would wait in a collective forever
-                        procs[q].terminate()
+            time.sleep(0.05)
+            done = {r: procs[r].poll() for r in pending}
+            done = {r: c for r, c in done.items() if c is not None}
+            if not done:
+                continue
+            if any(c != 0 for c in done.values()) and rc == 0:
+                # one rank died: the others would wait in a collective forever.  Ranks that die BECAUSE a peer went away (a gloo / RCCL
+                # error -> exit code 1) can be seen in the same poll as the rank that caused it: give the rest a moment, then report
+                # the most specific code (anything but the generic 1 first)
+                time.sleep(0.3)
+                for r in pending - set(done):
+                    c = procs[r].poll()
+                    if c is not None:
+                        done[r] = c
+                bad = [c for _, c in sorted(done.items()) if c != 0]
+                rc = next((c for c in bad if c != 1), bad[0])
+                for q in pending - set(done):
+                    procs[q].terminate()
+            pending -= set(done)
     finally:
         for pr in procs:
             if pr.poll() is None:
@@ -545,10 +649,17 @@ def main():
     ap.add_argument('--no-input-stage', action='store_true', help='skip the separate timing of the device input stage')
     ap.add_argument('--no-bf16', action='store_true', help='skip the bf16 leg (BASELINE configs[4] on this workload)')
     ap.add_argument('--full-step-timeout', type=float, default=300.0, help='N > 1: seconds the full-step leg may take')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='where rank 0 writes the full record (kernels / trunk layers / notes); the stdout line stays <= 8 KB')
     ap.add_argument('--launch-probe', action='store_true',
                     help='rendezvous check only, no GPU: every rank joins a gloo group, rank 0 prints the ranks it saw '
                          '(tests/test_host_cpu.py drives the self-launcher with it on the CPU)')
+    ap.add_argument('--replay-detail', metavar='JSON', help='no GPU: read a full record (a detail file) and print the stdout line a run '
+                                                            'would print from it (tests/test_host_cpu.py checks its size)')
     a = ap.parse_args()
+    if a.replay_detail:
+        print(json.dumps(compact_line(json.load(open(a.replay_detail)), os.path.relpath(a.replay_detail, ROOT))), flush=True)
+        return
 
     from gssd import dist as gd
     world, rank, local = gd.env_world()
@@ -655,7 +766,8 @@ def main():
         'metric': '512x512 4-phase CT img/s (fwd+loss)', 'value': res['value'], 'unit': 'img/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': res['ms_per_step'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-        'config': {'workload': res['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
+        'config': {'workload': res['workload'], 'workload_short': WORKLOAD_SHORT[a.config] + (', bf16 storage' if a.dtype == 'bf16' else ''),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'priors': 8732,
                    'alg_gflop_per_img': res['alg_gflop_per_img'], 'alg_mb_per_img': res['alg_mb_per_img']},
         'rccl_ranks': gd.world_size(), 'collective_backend': backend if world > 1 else None,
         'per_rank_ms_per_step': res['per_rank_ms_per_step'], 'host_enqueue_ms_per_step': res['host_enqueue_ms_per_step'],
@@ -676,7 +788,9 @@ def main():
             if full_step is not None:
                 line['full_step'] = full_step
             if rank == 0:
-                print(json.dumps(line), flush=True)
+                # the full record (per-kernel tables, per-layer trunk table, notes) goes to the detail file; stdout carries ONE short line
+                dp = write_detail(line, a.detail)
+                print(json.dumps(compact_line(line, dp and os.path.relpath(dp, ROOT))), flush=True)
             if code is not None:
                 os._exit(code)
 

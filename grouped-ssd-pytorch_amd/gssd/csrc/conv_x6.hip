@@ -327,6 +327,12 @@ __global__ __launch_bounds__(256, Cfg<BN>::OCC) void conv_x6_kernel(const gssd_c
         chunk(ch, gvA, gokA, gvB, gokB);
         if (ch + 1 < nchunks) chunk(ch + 1, gvB, gokB, gvA, gokA);
     }
+    // The last chunk ends with `s_waitcnt vmcnt(4)`: its four look-ahead loads (the last chunk again) are still in flight, and they were
+    // issued from inline assembly, so the compiler's wait-count pass does not know about them.  gvA / gvB are dead from here on and their
+    // registers may be handed to epilogue temporaries: drain the loads before anything else can live there.  gvA / gvB are
+    // never copied between gather_issue() and the counted wait that names them as "+v" operands.
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gvA[0][0]), "+v"(gvA[0][1]), "+v"(gvA[1][0]), "+v"(gvA[1][1]),
+                                        "+v"(gvB[0][0]), "+v"(gvB[0][1]), "+v"(gvB[1][0]), "+v"(gvB[1][1]) : : "memory");
     __syncthreads();
 
     // ---- epilogue: + bias, batch sums of the pre-activation output, ReLU, 16-byte NHWC stores (lane: pixel r, 8 consecutive channels

@@ -185,3 +185,41 @@ def test_bench_self_launch_two_ranks_rendezvous():
     assert lines[0]['ranks'] == [0.0, 1.0] and lines[0]['rccl_ranks'] == 2 and lines[0]['launcher'] == 'self'
     rc, lines = _run_bench('--gpus', '2', '--launch-probe', env={'GSSD_PROBE_FAIL_RANK': '1'})
     assert rc == 7 and lines == []
+
+
+def test_bench_stdout_line_is_short_and_parses(tmp_path):
+    """the driver keeps a bounded tail of stdout -- the ONE JSON line must stay under 8 KB (r04's 21.6 KB line left
+    BENCH_r04.parsed = null).  Replays a full record of a real run (the committed round-4 detail, per-rank lists widened to 8 ranks)
+    through bench.py's own line builder and through the CLI, and checks the contract's fields + roofline + cpu_baseline survive."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r04_h_gssdpp_b32_bench.json')))
+    assert len(json.dumps(full)) > 2 * bench.LINE_LIMIT                      # the record itself is the long form
+    for world in (1, 8):
+        rec = json.loads(json.dumps(full))
+        rec['n_gpus'] = rec['rccl_ranks'] = world
+        rec['per_rank_ms_per_step'] = rec['per_rank_ms_per_step'] * world
+        rec['host_enqueue_ms_per_step'] = rec['host_enqueue_ms_per_step'] * world
+        rec['full_step']['host_enqueue_ms_per_step'] = rec['full_step']['host_enqueue_ms_per_step'] * world
+        line = bench.compact_line(rec, 'gpurun_out/bench_detail.json')
+        txt = json.dumps(line)
+        assert len(txt) < bench.LINE_LIMIT == 8192, len(txt)
+        back = json.loads(txt)
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                  'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+            assert k in back, k
+        assert 'workload' in back['config'] and 'model' not in back['config']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in back['roofline'], k
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in back['cpu_baseline'], k
+        assert 'kernels' not in back and 'trunk' not in back
+    p = tmp_path / 'detail.json'
+    p.write_text(json.dumps(full))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--replay-detail', str(p)], capture_output=True, text=True, timeout=300)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and len(r.stdout.strip().splitlines()) == 1 and len(last) < 8192
+    assert json.loads(last)['value'] == full['value']
