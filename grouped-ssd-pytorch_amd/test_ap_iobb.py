@@ -1,7 +1,11 @@
 """Drop-in for the reference's evaluation entry point (ssd_liverdet/test_ap_iobb.py:231-328 ``test_net``, :10-41
 ``voc_ap``): same call, but the images are transformed, run through the test-phase network and scored in batches on the
-MI355X (``gssd.input_stage`` -> HIP engine -> ``gssd.evaluator``).  Visualisation dumps and the PixelLink branch of the
-reference are out of scope."""
+MI355X (``gssd.input_stage`` -> HIP engine -> ``gssd.evaluator``).  ``visualize=True`` (:122, :157-179) runs the visualize plan
+(``net(x, visualize=True)`` -> detections, DCN offsets, base / fusion attention maps) and writes the reference's numpy dumps per
+image (``<idx>_x.npy``, ``_annotation.npy``, ``_all_offset.npy``, ``_all_fusion_attention.npy``, ``_all_base_attention.npy``); its two
+cv2 JPEG overlays are not written (no cv2 in the image: nothing to pin them against).  The PixelLink branch is out of scope."""
+import os
+
 import numpy as np
 import torch
 
@@ -27,8 +31,13 @@ def voc_ap(rec, prec, use_07_metric=True):
 def test_net(net, cuda, testset, transform, imsize=300, thresh=0.05, mode='v1', use_07_metric=True, ap_list=[0.5],
              iobb_list=[0.1], writer=None, iteration=None, visualize=False, output_path=None, model_name=None,
              use_pixel_link=False, batch_size=32):
-    if visualize or use_pixel_link:
-        raise NotImplementedError('visualisation dumps / PixelLink evaluation are not part of the hot path')
+    if use_pixel_link:
+        raise NotImplementedError('PixelLink evaluation (mask_to_box) is not part of the hot path')
+    vis_dir = None
+    if visualize:
+        assert output_path is not None and model_name is not None          # (test_ap_iobb.py:158)
+        vis_dir = os.path.join(output_path, 'visualize', model_name, testset.name)
+        os.makedirs(vis_dir, exist_ok=True)
     ev = DeviceEvaluator(thresh, ap_list, iobb_list, use_07_metric)
     n = len(testset)
     for start in range(0, n, batch_size):
@@ -39,7 +48,20 @@ def test_net(net, cuda, testset, transform, imsize=300, thresh=0.05, mode='v1', 
         x = torch.stack(xs).cuda().float().permute(0, 1, 4, 2, 3)
         x = x.reshape(x.shape[0], -1, x.shape[3], x.shape[4]).contiguous()      # [B, 12, s, s]
         with torch.no_grad():
-            y = net(x)
+            if visualize:
+                y, all_offset, all_attnb, all_attn = net(x, visualize=True)
+            else:
+                y = net(x)
+        if visualize:
+            for j, i in enumerate(idxs):                                         # the reference's per-image dumps (:163-179)
+                np.save(os.path.join(vis_dir, f'{i}_x.npy'), x[j:j + 1].cpu().numpy())
+                np.save(os.path.join(vis_dir, f'{i}_annotation.npy'), annos[j][None])
+                np.save(os.path.join(vis_dir, f'{i}_all_offset.npy'), np.array([o[j:j + 1].cpu().numpy() for o in all_offset], dtype=object),
+                        allow_pickle=True)
+                np.save(os.path.join(vis_dir, f'{i}_all_fusion_attention.npy'),
+                        {str(k): a[j:j + 1].cpu().numpy() for k, a in enumerate(all_attn)}, allow_pickle=True)
+                np.save(os.path.join(vis_dir, f'{i}_all_base_attention.npy'),
+                        {str(k): a[j:j + 1].cpu().numpy() for k, a in enumerate(all_attnb)}, allow_pickle=True)
         scales = [[im.shape[2], im.shape[1], im.shape[2], im.shape[1]] for im in imgs]
         if mode == 'v1':
             gts = [a[2:3, :-1] for a in annos]                                  # portal-phase box only (:206)

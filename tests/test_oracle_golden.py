@@ -195,6 +195,33 @@ def test_end_to_end_vs_reference(golden, name, flags):
     assert same_detections(det, g[f'{name}.det'], 2e-5)
 
 
+@pytest.mark.parametrize('name,flags', [
+    ('gssd', dict()),
+    ('gssdpp', dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True)),
+])
+def test_end_to_end_b32_vs_reference(golden, name, flags):
+    """The BENCHMARKED batch (B = 32, BASELINE configs[1] / configs[2]) against the imported reference's own outputs
+    (tests/golden/make_golden_b32.py: models/ssd_multiphase_custom_group.py:217-400 + multibox_loss.py:46-120): the oracle that
+    tests/test_gpu_parity.py::test_full_size_parity compares the HIP path with is pinned at this size too, incl. the 1 x 1 map's priors."""
+    g = golden('e2e_b32')
+    B = int(g['batch'])
+    shapes = {k: eval(s) for k, s in zip([str(k) for k in golden('e2e')[f'{name}.keys']], golden('e2e')[f'{name}.shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=int(g['wseed']))
+    x = synth.synth_images(B, seed=int(g['xseed']))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        loc, conf, upd = O.gssd_forward(sd, x, **flags)
+    l, c = loc.numpy(), conf.numpy()
+    assert np.abs(l.reshape(-1)[g[f'{name}.loc_idx']] - g[f'{name}.loc_val']).max() / g[f'{name}.loc_absmax'] < 1e-5
+    assert np.abs(c.reshape(-1)[g[f'{name}.conf_idx']] - g[f'{name}.conf_val']).max() / g[f'{name}.conf_absmax'] < 1e-5
+    assert np.abs(l[:, 8728:] - g[f'{name}.loc_1x1']).max() / g[f'{name}.loc_absmax'] < 1e-5
+    assert np.abs(c[:, 8728:] - g[f'{name}.conf_1x1']).max() / g[f'{name}.conf_absmax'] < 1e-5
+    ll, lc = O.multibox_loss(l, c, O.prior_box(), [t.numpy() for t in synth.synth_targets(B, int(g['xseed']))])[:2]
+    assert rel(ll, g[f'{name}.loss'][0]) < 1e-5 and rel(lc, g[f'{name}.loss'][1]) < 1e-5
+    for k in ('vgg.1.running_mean', 'vgg.41.running_var', 'bn_fuse_11.running_mean', 'extras.15.running_var'):
+        assert rel(upd[k].numpy(), g[f'{name}.after.{k}']) < 1e-5, k
+
+
 def same_detections(det, ref, atol):
     """Rows agree as a set: scores saturate so exact fp32 ties exist, and the reference's visiting order among
     ties is an accident of torch's unstable sort.  Every reference row must have its own partner within atol."""
