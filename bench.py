@@ -90,7 +90,7 @@ def _roof(r, note=True):
 
 
 def _fstep(f):
-    return _pick(f, ('value', 'unit', 'steps', 'ms_per_step', 'host_enqueue_ms_per_step', 'grad_elems', 'rccl_ranks',
+    return _pick(f, ('value', 'unit', 'steps', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_cpu_ms_per_step', 'grad_elems', 'rccl_ranks',
                      'allreduce_exposed_ms', 'allreduce_overlapped', 'error'))
 
 
@@ -613,18 +613,23 @@ def full_step_leg(a, net, crit, x, tg, dev, gd, world, B):
     for _ in range(4):                           # (the backward plan captures its hipGraphs on its third run)
         nred = train_step()
     gd.barrier(dev)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(a.full_step):
         train_step(True)
     host = time.perf_counter() - t0                 # every step enqueued, nothing waited for (beyond what the steps themselves wait for)
+    host_cpu = time.process_time() - c0             # CPU seconds of ALL threads of this rank (Python, autograd worker, HIP runtime)
     gd.barrier(dev)
     fdt = gd.max_over_ranks(time.perf_counter() - t0, dev)
     host_per_rank = [round(1e3 * t / a.full_step, 3) for t in gd.gather_over_ranks(host, dev)]
     exposed = (sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)) if ev else 0.0
     exposed = gd.max_over_ranks(exposed, dev)
     return dict(value=round(gd.aggregate_rate(world, B, a.full_step, fdt), 2), unit='img/s', steps=a.full_step,
-                ms_per_step=round(1e3 * fdt / a.full_step, 3), host_enqueue_ms_per_step=host_per_rank, grad_elems=int(nred), rccl_ranks=world,
+                ms_per_step=round(1e3 * fdt / a.full_step, 3), host_enqueue_ms_per_step=host_per_rank,
+                host_cpu_ms_per_step=round(1e3 * host_cpu / a.full_step, 3), grad_elems=int(nred), rccl_ranks=world,
                 allreduce_exposed_ms=round(exposed, 3), allreduce_overlapped=bool(red.overlapped_last),
+                host_note='host_enqueue = wall time to enqueue the K steps: the GPU step is longer than the host side, so it includes the time the '
+                          'HIP queues push back (scripts/host_profile.py at batch 2, where the host is the bound: 6.8 ms per step); host_cpu = CPU '
+                          'seconds of all threads of the rank per step',
                 note='fwd (HIP) + MultiBoxLoss (HIP fwd/bwd) + network backward (HIP: gssd/backward.py) + '
                      + (f'RCCL all-reduce of the flat fp32 gradient buffer over {world} ranks in 4 ranges started under the backward '
                         '(allreduce_exposed_ms = main-stream time from backward-enqueued to all ranges reduced + scaled, max over ranks)'

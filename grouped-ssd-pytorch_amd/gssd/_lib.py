@@ -39,6 +39,14 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PlanOp(C.Structure):
+    """struct gssd_plan_op (csrc/plan_run.hip): one LAUNCH / WAIT of a launch-plan segment."""
+    _fields_ = [('kind', c_i), ('fn', c_i), ('stream', c_i), ('nargs', c_i), ('args', C.c_uint64 * 24)]
+
+
+PLAN_LAUNCH, PLAN_WAIT = 0, 1
+
+
 class SnItem(C.Structure):
     """struct gssd_sn_item."""
     _fields_ = [('w', c_fp), ('u', c_fp), ('v', c_fp), ('inv_sigma', c_fp), ('rows', c_i), ('cols', c_i)]
@@ -62,6 +70,13 @@ SIGNATURES = {
     'gssd_conv_x6_weight_elems': (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     'gssd_conv_x6_pack_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
+    'gssd_conv_wino_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
+    'gssd_plan_fn_count': (c_i, []),
+    'gssd_plan_fn_name': (C.c_char_p, [c_i]),
+    'gssd_plan_fn_index': (c_i, [C.c_char_p]),
+    'gssd_plan_fn_nargs': (c_i, [c_i]),
+    'gssd_plan_op_size': (c_i, []),
+    'gssd_plan_run': (c_i, [C.POINTER(PlanOp), c_i, C.POINTER(c_fp), c_i, C.POINTER(c_i)]),
     'gssd_pack_conv_weight_bf16': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_cast_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_fp]),
     'gssd_cast_rows_f32_bf16': (c_i, [c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),
@@ -180,6 +195,9 @@ def _load():
             raise GssdError(f'{LIB_PATH} does not export {name}; rebuild it') from e
         fn.restype = res
         fn.argtypes = args
+    if lib.gssd_plan_op_size() != C.sizeof(PlanOp):
+        raise GssdError(f'{LIB_PATH}: struct gssd_plan_op is {lib.gssd_plan_op_size()} bytes in the library, {C.sizeof(PlanOp)} in this '
+                        f'binding; rebuild the library')
     if lib.gssd_conv_desc_size() != C.sizeof(ConvDesc):
         raise GssdError(f'{LIB_PATH}: struct gssd_conv_desc is {lib.gssd_conv_desc_size()} bytes in the library, '
                         f'{C.sizeof(ConvDesc)} in this binding; rebuild the library')

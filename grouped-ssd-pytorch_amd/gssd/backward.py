@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, planrun
 from ._lib import lib
 
 
@@ -1154,7 +1154,25 @@ class BackwardPlan:
 
     def _run_range(self, lo, hi, first, last):
         """Steps lo .. hi (inclusive) on the current stream and the plan's branch / leaf streams; every stream forked here is folded
-        back into the current stream before returning (a range ends where a gradient segment is handed out, or at the end)."""
+        back into the current stream before returning (a range ends where a gradient segment is handed out, or at the end).
+
+        The range is static, so its launches and stream forks / joins are recorded once (planrun.RecordSink) and replayed with one
+        gssd_plan_run call per run of launches (round 5: ~500 ctypes calls + ~100 torch stream calls per training step before); the
+        few steps that are torch code run on the host between the programs.  hipGraph capture and GSSD_NO_PLAN_RUN=1 execute the same
+        control flow directly (planrun.EagerSink)."""
+        if not planrun.USE_PLAN_RUN or torch.cuda.is_current_stream_capturing():
+            return self._emit_range(planrun.EagerSink(), lo, hi, first, last)
+        cache = self.__dict__.setdefault('_programs', {})
+        key = (lo, hi, first, last, bool(getattr(self, 'single_stream', False)), len(self.zero_list))
+        segs = cache.get(key)
+        if segs is None:
+            sink = planrun.RecordSink()
+            self._emit_range(sink, lo, hi, first, last)
+            segs = cache[key] = sink.finish()
+        planrun.replay(segs)
+
+    def _emit_range(self, sink, lo, hi, first, last):
+        MAIN = planrun.MAIN
         if first:
             if self.zero_list:
                 # one multi-tensor launch per dtype (a mixed fp32 / fp64 list takes _foreach_zero_'s slow path: ~180 fill launches a step)
@@ -1163,17 +1181,14 @@ class BackwardPlan:
                     for t in self.zero_list:
                         by.setdefault(t.dtype, []).append(t)
                     self._zero_groups = list(by.values())
-                for grp in self._zero_groups:
-                    torch._foreach_zero_(grp)
-            stream0 = torch.cuda.current_stream().cuda_stream
+                groups = self._zero_groups
+                sink.host(lambda: [torch._foreach_zero_(grp) for grp in groups])
             for fn, args in getattr(self.plan, 'pre', ()):      # bf16 forward plan: fp32 copies of what the forward stored (Bf16Shadow)
-                self._run_step(fn, args, stream0)
-        main = torch.cuda.current_stream()
-        stream = main.cuda_stream
+                self._emit_step(sink, fn, args, MAIN)
         if getattr(self, 'single_stream', False) or not (self.hoisted or any(x >= LEAF_SID for x in self.step_sid)):
             for si in range(lo, hi + 1):
                 fn, args = self.steps[si]
-                self._run_step(fn, args, stream)
+                self._emit_step(sink, fn, args, MAIN)
             return
         # branch chains on their own streams (forked behind everything enqueued so far), joined where the trunk needs them
         sides = {}
@@ -1181,7 +1196,7 @@ class BackwardPlan:
         def side(sid):
             if sid not in sides:
                 st = self.plan._side_stream(100 + sid)
-                st.wait_stream(main)
+                sink.wait(st, MAIN)
                 sides[sid] = st
             return sides[sid]
         if first:
@@ -1194,45 +1209,39 @@ class BackwardPlan:
             fn, args = self.steps[si]
             for w in self.step_wait.get(si, ()):
                 if w in sides:                               # (a branch whose steps all ran in an earlier range is already joined)
-                    main.wait_stream(sides[w])
+                    sink.wait(MAIN, sides[w])
             sid = self.step_sid[si]
             if sid == 0:
-                self._run_step(fn, args, stream)
+                self._emit_step(sink, fn, args, MAIN)
                 dirty = [True] * N_LEAF
             elif sid >= LEAF_SID:
                 k = sid - LEAF_SID
                 if dirty[k]:
-                    leaves[k].wait_stream(main)            # everything this launch reads was produced by earlier steps
+                    sink.wait(leaves[k], MAIN)             # everything this launch reads was produced by earlier steps
                     dirty[k] = False
                 used_leaf[k] = True
-                self._run_step(fn, args, leaves[k].cuda_stream)
+                self._emit_step(sink, fn, args, leaves[k])
             else:
-                st = side(sid)
-                if args is None or fn is _pack_dgrad_from_packed:
-                    with torch.cuda.stream(st):
-                        self._run_step(fn, args, st.cuda_stream)
-                else:
-                    self._run_step(fn, args, st.cuda_stream)
+                self._emit_step(sink, fn, args, side(sid))
         if last:
             for w in self.step_wait.get(len(self.steps), ()):
                 if w in sides:
-                    main.wait_stream(sides[w])
+                    sink.wait(MAIN, sides[w])
         # fold every stream that may have written gradients back into the main stream (a hook's all-reduce is ordered behind it)
         for st in sides.values():
-            main.wait_stream(st)
+            sink.wait(MAIN, st)
         for k, lf in enumerate(leaves):
             if used_leaf[k]:
-                main.wait_stream(lf)
+                sink.wait(MAIN, lf)
 
-    def _run_step(self, fn, args, stream):
+    @staticmethod
+    def _emit_step(sink, fn, args, key):
         if args is None:                         # host-side tensor bookkeeping (channel split of slice_and_cat's gradient)
-            fn()
+            sink.host(fn, key)
         elif fn is _pack_dgrad_from_packed:
-            fn(*args)
+            sink.host(lambda fn=fn, args=args: fn(*args), key)
         else:
-            rc = fn(*args, stream)
-            if rc != 0:
-                _lib.check(rc)
+            sink.launch(fn, args, key)
 
 
 class PixelLinkBackwardPlan(BackwardPlan):

@@ -561,6 +561,9 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 30);     // 32-bit BYTE offsets into the input
     if (!ok) return 1;
     if ((d.flags & GSSD_CONV_POOL2) && (d.resid || !d.pool_sign)) return 1;
+    // the same transforms with the 16 GEMMs on the bf16 matrix cores (three-plane operands, conv_wino_x6.hip): its U planes lie behind the fp32 U
+    if (gssd_wino_x6_enabled() && gssd_wino_x6_plane_elems(cout_g, d.groups, d.cin_g) > 0)
+        return gssd_launch_conv_wino_x6(d, d.wgt_wino + 16ll * d.groups * wino_u_rows(cout_g, d.groups) * d.cin_g, stream);
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
     // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent.  (Round 2: the persistent NB = 32
     // variant forced onto the 64 / 128-channel layers measures 15-30 % slower -- conv3_2 489 vs 415 us, conv4_2 436 vs 336 us: it
@@ -580,7 +583,18 @@ extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g)
     if (Cout <= 0 || groups <= 0 || Cout % groups || cin_g <= 0) return -1;
     const int rows = wino_u_rows(Cout / groups, groups);
     if (!rows) return -1;
-    return 16ll * groups * rows * cin_g;
+    // fp32 U, then (shapes conv_wino_x6.hip takes) its three bf16 planes in that kernel's staging order
+    return 16ll * groups * rows * cin_g + (wino_nb(Cout / groups, groups) ? gssd_wino_x6_plane_elems(Cout / groups, groups, cin_g) / 2 : 0);
+}
+
+extern "C" int gssd_conv_wino_x6_takes(const gssd_conv_desc* d) {
+    if (!d || !d->wgt_wino || !gssd_wino_x6_enabled()) return 0;
+    const int cout_g = d->Cout / d->groups;
+    const bool ok = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->cin_g % 16 == 0 && wino_nb(cout_g, d->groups) != 0 &&
+                    d->out_mode == GSSD_OUT_NHWC && !d->alpha && !d->gate && !d->out2 && !d->relu && d->split_k <= 1 && !d->m_per_image &&
+                    d->in_stride % 4 == 0 && d->in_ch_off % 4 == 0 && (long long)d->B * d->H * d->W * d->in_stride < (1ll << 30);
+    if (!ok || ((d->flags & GSSD_CONV_POOL2) && (d->resid || !d->pool_sign))) return 0;
+    return gssd_wino_x6_plane_elems(cout_g, d->groups, d->cin_g) > 0;
 }
 
 extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
@@ -592,5 +606,7 @@ extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cou
     hipLaunchKernelGGL(wino_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w_packed, U, groups, cout_g,
                        cout_pad, cin_g, row_stride);
     GSSD_CHECK_LAUNCH();
+    if (wino_nb(cout_g, groups) && gssd_wino_x6_plane_elems(cout_g, groups, cin_g) > 0)
+        return gssd_wino_x6_pack(w_packed, U + 16ll * groups * cout_pad * cin_g, Cout, groups, cin_g, row_stride, as_stream(stream));
     return GSSD_OK;
 }

@@ -637,6 +637,35 @@ int gssd_pixellink_loss_bwd_f32(const float* out1, const float* out2, const long
 int gssd_pixellink_decode_f32(const float* out1, const float* out2, int* labels, float* comps, int* ncomp, int B, int H, int W,
                               float pixel_thr, float link_thr, int max_comp, gssd_stream_t stream);
 
+/* ---- launch-plan runner (csrc/plan_run.hip) ----------------------------------------------------------------------------------------------
+ * The host side of the reference enqueues one kernel per Python call (nn.Module.__call__ -> ATen, train_lesion_multiphase_v2.py:242-253);
+ * this build's engine knows the whole static launch list of a step, so a SEGMENT of it (everything between two points where the host must
+ * act: a gradient-segment hook of the data-parallel reducer, a host-side tensor op) goes down in ONE call.
+ * An op is either a LAUNCH of any entry point of this header whose last parameter is the stream -- `fn` = gssd_plan_fn_index("gssd_..."),
+ * `args` = its other arguments in order as 64-bit words (pointers and integers by value, sign-extended; float as its 32 bits, double as its
+ * 64 bits), `stream` = index into the `streams` array of the call -- or a WAIT: streams[stream] waits for everything enqueued so far on
+ * streams[fn] (event record + hipStreamWaitEvent; fn == stream is a no-op).  Ops run in array order; the first failing op's index is stored
+ * in *failed_at (else -1) and its code returned.  Pointers inside args (descriptors included) must stay valid for the call only. */
+#define GSSD_PLAN_LAUNCH 0
+#define GSSD_PLAN_WAIT 1
+#define GSSD_PLAN_MAX_ARGS 24
+typedef struct gssd_plan_op {
+    int kind;   /* GSSD_PLAN_LAUNCH / GSSD_PLAN_WAIT */
+    int fn;     /* LAUNCH: function index; WAIT: index of the awaited stream */
+    int stream; /* index into `streams` */
+    int nargs;  /* LAUNCH: number of words used in args (checked against the function's parameter count) */
+    uint64_t args[GSSD_PLAN_MAX_ARGS];
+} gssd_plan_op;
+int gssd_plan_fn_count(void);
+const char* gssd_plan_fn_name(int index);
+int gssd_plan_fn_index(const char* name); /* -1: not an entry point the runner can launch */
+int gssd_plan_fn_nargs(int index);        /* parameters before the stream */
+int gssd_plan_op_size(void);              /* sizeof(gssd_plan_op) as built */
+int gssd_plan_run(const gssd_plan_op* ops, int n_ops, const gssd_stream_t* streams, int n_streams, int* failed_at);
+
+/* 1 when gssd_conv2d_nhwc_f32 runs the descriptor on the three-plane Winograd kernel (csrc/conv_wino_x6.hip; GSSD_WINO_X6=1 only) */
+int gssd_conv_wino_x6_takes(const gssd_conv_desc* d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,15 +17,55 @@ def test_abi_exports_match_header():
     from gssd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'gssd_hip.h')).read()
     declared = set(re.findall(r'\b(gssd_[a-z0-9_]+)\s*\(', hdr))
-    declared -= {'gssd_conv_desc', 'gssd_sn_item', 'gssd_stream_t'}
+    declared -= {'gssd_conv_desc', 'gssd_sn_item', 'gssd_stream_t', 'gssd_plan_op'}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.gssd_abi_version() == 5 and _lib.lib.gssd_build_arch() == b'gfx950'
+    assert _lib.lib.gssd_abi_version() == 6 and _lib.lib.gssd_build_arch() == b'gfx950'
     # struct layout agrees with the header's field order / C packing rules
     assert ctypes.sizeof(_lib.ConvDesc) == 16 * 8 + 27 * 4 + 4 + 6 * 8 == _lib.lib.gssd_conv_desc_size()   # (27 ints + 4 bytes of padding)
     assert ctypes.sizeof(_lib.SnItem) == 4 * 8 + 2 * 4
+
+
+def test_plan_runner_table_and_encoding():
+    """csrc/plan_run.hip: the runner's function table is exactly the header's `int gssd_*(..., gssd_stream_t stream)`
+    entry points, each with the parameter count of the binding; argument words are encoded as the header says; bad ops are refused with
+    their index before anything touches a device."""
+    import struct
+    from gssd import _lib, planrun
+    lib = _lib.lib
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'gssd_hip.h')).read(), flags=re.S)
+    want = {}
+    for name, args in re.findall(r'\bint\s+(gssd_\w+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S):
+        a = [x.strip() for x in args.replace('\n', ' ').split(',')]
+        if re.search(r'gssd_stream_t\s+\w+$', a[-1]):
+            want[name] = len(a) - 1
+    have = {lib.gssd_plan_fn_name(i).decode(): lib.gssd_plan_fn_nargs(i) for i in range(lib.gssd_plan_fn_count())}
+    assert have == want and len(have) >= 85
+    for name, n in have.items():
+        assert len(_lib.SIGNATURES[name][1]) == n + 1 and planrun.fn_info(getattr(lib, name))[0] == lib.gssd_plan_fn_index(name.encode())
+    assert lib.gssd_plan_fn_index(b'gssd_abi_version') == -1 and lib.gssd_plan_fn_nargs(10 ** 6) == -1
+    assert max(have.values()) <= 24 and ctypes.sizeof(_lib.PlanOp) == 16 + 24 * 8 == lib.gssd_plan_op_size()
+    # words: integers sign-extended, float / double as their bits, pointers by value, byref(struct) -> its address
+    assert planrun.word(_lib.c_i, -1) == 2 ** 64 - 1 and planrun.word(_lib.c_i64, 1 << 40) == 1 << 40
+    assert planrun.word(_lib.c_f, 0.5) == struct.unpack('<I', struct.pack('<f', 0.5))[0]
+    assert planrun.word(_lib.c_d, -2.25) == struct.unpack('<Q', struct.pack('<d', -2.25))[0]
+    d = _lib.ConvDesc()
+    assert planrun.word(ctypes.POINTER(_lib.ConvDesc), ctypes.byref(d)) == ctypes.addressof(d) and planrun.word(_lib.c_fp, None) == 0
+    # a program: a launch that the entry point itself refuses (null descriptor fields) -> its code and its index come back
+    prog = planrun.Program([('wait', planrun.MAIN, planrun.MAIN), ('launch', lib.gssd_conv2d_nhwc_f32, (ctypes.byref(d),), planrun.MAIN)])
+    with pytest.raises(_lib.GssdError, match=r'plan op 1 \(gssd_conv2d_nhwc_f32\)'):
+        prog.run(0)
+    ops_ = (_lib.PlanOp * 1)()
+    ops_[0].kind, ops_[0].fn, ops_[0].stream = _lib.PLAN_LAUNCH, 10 ** 6, 0
+    failed = ctypes.c_int(-7)
+    streams = (_lib.c_fp * 1)()
+    assert lib.gssd_plan_run(ops_, 1, streams, 1, ctypes.byref(failed)) == -1 and failed.value == 0
+    ops_[0].fn, ops_[0].nargs = lib.gssd_plan_fn_index(b'gssd_conv2d_nhwc_f32'), 3                       # wrong argument count
+    assert lib.gssd_plan_run(ops_, 1, streams, 1, ctypes.byref(failed)) == -1 and b'argument count' in lib.gssd_last_error()
+    ops_[0].stream = 5
+    assert lib.gssd_plan_run(ops_, 1, streams, 1, ctypes.byref(failed)) == -1 and b'stream index' in lib.gssd_last_error()
 
 
 def test_argument_validation_without_gpu():
