@@ -131,6 +131,9 @@ SIGNATURES = {
     'gssd_self_attn_flash_bwd_bf16': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_cast_split_f32_bf16': (c_i, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     'gssd_self_attn_flash_bwd_supported': (c_i, [c_i, c_i]),
+    'gssd_self_attn_core_x6_supported': (c_i, [c_i, c_i]),
+    'gssd_self_attn_core_x6_ws_bytes': (C.c_longlong, [c_i, c_i, c_i, c_i]),
+    'gssd_self_attn_core_x6_f32': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     'gssd_self_attn_core_bf16v': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     'gssd_softmax_rows_f32': (c_i, [c_fp, c_i64, c_i, c_i, c_fp]),
     'gssd_slice_and_cat_f32': (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_fp]),

@@ -101,6 +101,7 @@ const PlanFn g_plan_fns[] = {
     GSSD_PLAN_FN(gssd_sa_pool_kv_f32),
     GSSD_PLAN_FN(gssd_sa_unpool_f32),
     GSSD_PLAN_FN(gssd_self_attn_core_bf16v),
+    GSSD_PLAN_FN(gssd_self_attn_core_x6_f32),
     GSSD_PLAN_FN(gssd_self_attn_flash_bwd_bf16),
     GSSD_PLAN_FN(gssd_softmax_rows_f32),
     GSSD_PLAN_FN(gssd_slice_and_cat_f32),

@@ -40,6 +40,8 @@ USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
 DCN_X6 = os.environ.get('GSSD_DCN_X6', '1') != '0'
 # GSSD_NO_GRAPH=1 keeps every forward an eager list of launches (debugging / ablation)
 USE_GRAPH = os.environ.get('GSSD_NO_GRAPH', '0') != '1'
+# GSSD_FLASH_X6=0: the fp32-MFMA attention core (csrc/flash_attn.hip) keeps every launch of the fp32 mode (ablation / A-B)
+USE_FLASH_X6 = os.environ.get('GSSD_FLASH_X6', '1') != '0'
 # GSSD_NO_BRANCH_STREAMS=1 captures the plan as one serial chain (ablation)
 USE_BRANCH_STREAMS = os.environ.get('GSSD_NO_BRANCH_STREAMS', '0') != '1'
 SN_STREAM = 9               # stream id of the spectral-norm launch inside a captured graph
@@ -906,6 +908,13 @@ class _Plan(_PlanBase):
             self._add(lib.gssd_self_attn_core_bf16v, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2,
                                                       lse.data_ptr() if lse is not None else 0),
                       tag=(f'flash_attn_bf16v<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), B * (4.0 * N * C4 + 2.0 * C2 * Np + 2.0 * N * C2)))
+        elif USE_FLASH_X6 and N >= 1024 and C8 == 64 and lib.gssd_self_attn_core_x6_supported(C8, C2):
+            # both products of the core on the bf16 matrix cores over three-plane operands (csrc/flash_attn_x6.hip): fp32-equivalent results at
+            # 6 / 16 of the fp32 instruction's matrix-pipe time; the planes of theta | phi and g^T live in a scratch buffer of the plan
+            ws = self._buf(int(lib.gssd_self_attn_core_x6_ws_bytes(B, N, C8, C2)) // 4)
+            self._add(lib.gssd_self_attn_core_x6_f32, (tp.data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, Np, C8, C2, ws.data_ptr(),
+                                                       lse.data_ptr() if lse is not None else 0),
+                      tag=(f'flash_attn_x6<{C8},{C2}>', 2.0 * B * N * N * (C8 + C2), 4.0 * B * (N * C4 + C2 * Np + N * C2)))
         else:
             self._add(lib.gssd_self_attn_core_kv_f32, (tp.data_ptr(), tp[0, 0, C8:].data_ptr(), gT.data_ptr(), ag.data_ptr(), B, N, N, Np,
                                                        C8, C2, C4, 0, lse.data_ptr() if lse is not None else 0),

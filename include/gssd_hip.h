@@ -637,6 +637,16 @@ int gssd_pixellink_loss_bwd_f32(const float* out1, const float* out2, const long
 int gssd_pixellink_decode_f32(const float* out1, const float* out2, int* labels, float* comps, int* ncomp, int B, int H, int W,
                               float pixel_thr, float link_thr, int max_comp, gssd_stream_t stream);
 
+/* The fp32 Self_Attn core on the BF16 matrix cores with fp32-equivalent products (csrc/flash_attn_x6.hip; layers/self_attn.py:68-80): the
+ * contract of gssd_self_attn_core_f32 (tp [B][N][2D] fp32 theta | phi, gT [B][C2][Np] fp32, out [B][N][C2] fp32, optional lse [B][N]) with both
+ * products as six v_mfma_f32_16x16x32_bf16 over operands split into three bf16 planes.  `ws`: gssd_self_attn_core_x6_ws_bytes(B, N, D, C2) bytes
+ * of scratch (the planes of theta | phi and of g^T, written by a first pass of the call), 16-byte aligned.  (D, C2) = (64, 256) (the 38 x 38 maps):
+ * gssd_self_attn_core_x6_supported; anything else is GSSD_EINVAL (the caller keeps gssd_self_attn_core_f32). */
+int gssd_self_attn_core_x6_supported(int D, int C2);
+long long gssd_self_attn_core_x6_ws_bytes(int B, int N, int D, int C2);
+int gssd_self_attn_core_x6_f32(const float* tp, const float* gT, float* out, int B, int N, int Np, int D, int C2, void* ws, float* lse,
+                               gssd_stream_t stream);
+
 /* ---- launch-plan runner (csrc/plan_run.hip) ----------------------------------------------------------------------------------------------
  * The host side of the reference enqueues one kernel per Python call (nn.Module.__call__ -> ATen, train_lesion_multiphase_v2.py:242-253);
  * this build's engine knows the whole static launch list of a step, so a SEGMENT of it (everything between two points where the host must

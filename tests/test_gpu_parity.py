@@ -1588,6 +1588,41 @@ def test_full_size_parity(dev, name, golden):
     assert worst < TOL, lines
 
 
+@pytest.mark.parametrize('N,D,C2', [(1444, 64, 256), (1100, 64, 256), (300, 64, 256)])
+def test_self_attn_core_x6(dev, N, D, C2):
+    """csrc/flash_attn_x6.hip (the fp32 mode's attention core on the bf16 matrix cores, three-plane operands) against float64
+    softmax(theta phi^T) g (layers/self_attn.py:68-80) and against the fp32-MFMA core on the same inputs: fp32-equivalent means it
+    must be as close to float64 as the fp32 kernel is (and both within 3e-5 of the output scale at logits of +-200); the rows' log-sum-exp (what the
+    training step's backward reads) likewise.  Logits of magnitude ~30 (the detector's are ~50): a bf16-rounded logit would be off by
+    0.1; N = 300 leaves a ragged last key block and a ragged query tile."""
+    from gssd import _lib
+    lib = _lib.lib
+    B = 2
+    rng = np.random.default_rng(N + D)
+    Np = (N + 3) // 4 * 4
+    tp = torch.from_numpy(rng.normal(0, 1.9, size=(B, N, 2 * D)).astype(np.float32))
+    gT = torch.zeros(B, C2, Np)
+    gT[:, :, :N] = torch.from_numpy(rng.normal(0, 1.0, size=(B, C2, N)).astype(np.float32))
+    th, ph = tp[:, :, :D].double(), tp[:, :, D:].double()
+    logits = th @ ph.transpose(1, 2)
+    ref = torch.softmax(logits, -1) @ gT[:, :, :N].double().transpose(1, 2)
+    ref_lse = torch.logsumexp(logits, -1)
+    tpd, gTd = tp.to(dev), gT.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out6, lse6 = torch.empty(B, N, C2, device=dev), torch.empty(B, N, device=dev)
+    ws = torch.empty(int(lib.gssd_self_attn_core_x6_ws_bytes(B, N, D, C2)) // 4, device=dev)
+    assert lib.gssd_self_attn_core_x6_supported(D, C2) == 1 and lib.gssd_self_attn_core_x6_supported(128, 512) == 0
+    _lib.check(lib.gssd_self_attn_core_x6_f32(tpd.data_ptr(), gTd.data_ptr(), out6.data_ptr(), B, N, Np, D, C2, ws.data_ptr(), lse6.data_ptr(), st))
+    out4, lse4 = torch.empty(B, N, C2, device=dev), torch.empty(B, N, device=dev)
+    _lib.check(lib.gssd_self_attn_core_kv_f32(tpd.data_ptr(), tpd[0, 0, D:].data_ptr(), gTd.data_ptr(), out4.data_ptr(), B, N, N, Np, D, C2, 2 * D,
+                                              0, lse4.data_ptr(), st))
+    torch.cuda.synchronize()
+    e6, e4 = rel(out6, ref), rel(out4, ref)
+    l6, l4 = float((lse6.cpu().double() - ref_lse).abs().max()), float((lse4.cpu().double() - ref_lse).abs().max())
+    print(f'attention core N={N} D={D}: vs float64 three-plane {e6:.2e} fp32-MFMA {e4:.2e}; lse abs err {l6:.2e} / {l4:.2e}; max |logit| {float(logits.abs().max()):.1f}')
+    assert e6 < 3e-5 and e6 <= 1.5 * e4 + 1e-6 and l6 <= 1.5 * l4 + 1e-5
+
+
 def test_self_attn_op(dev, golden):
     """Self_Attn on its own (layers/self_attn.py:46-89) against the reference fixtures: out, sigma*o, the ATTENTION MAP, and
     (train) the spectral-norm u / v after-state; eval mode leaves u / v untouched."""
