@@ -222,6 +222,27 @@ def test_end_to_end_b32_vs_reference(golden, name, flags):
         assert rel(upd[k].numpy(), g[f'{name}.after.{k}']) < 1e-5, k
 
 
+def test_self_attn_gradients_vs_reference(golden):
+    """Gradient semantics of the Self_Attn restatement against the imported reference's own autograd (tests/golden/make_golden_grad.py:
+    layers/self_attn.py:46-89 through layers/spectral_norm.py:39-89, float64): d(x) and every parameter gradient, incl. the spectral-normed
+    weights -- the power iteration is outside the graph (torch.no_grad(), :74-81), sigma = u^T W v is differentiated through W only."""
+    g = golden('grad')
+    shapes = {k[5:]: g[k].shape for k in g.files if k.startswith('grad.')}
+    from gssd.modules import Self_Attn
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in Self_Attn(64).state_dict().items()}, seed=21)
+    sd64 = {k: (v.double().requires_grad_() if k in shapes else (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    pre = {'self_attn_list.0.' + k: v for k, v in sd64.items()}
+    x = torch.from_numpy(g['x']).requires_grad_()
+    out = O.self_attn(x, pre, 'self_attn_list.0', True)[0]
+    (out * torch.from_numpy(g['r'])).sum().backward()
+    assert rel(x.grad.numpy(), g['dx']) < 1e-10
+    for k in shapes:
+        if np.abs(g['grad.' + k]).max() < 1e-9:                  # phi's bias: softmax is shift invariant along the keys
+            assert sd64[k].grad.abs().max() < 1e-9
+            continue
+        assert rel(sd64[k].grad.numpy(), g['grad.' + k]) < 1e-10, k
+
+
 def same_detections(det, ref, atol):
     """Rows agree as a set: scores saturate so exact fp32 ties exist, and the reference's visiting order among
     ties is an accident of torch's unstable sort.  Every reference row must have its own partner within atol."""
