@@ -132,7 +132,7 @@ class _PlanPixelLink(_Plan):
         if not getattr(self, "bf16", False) and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None):      # conv6 / conv7
             def build_x6(out, key=name + '.w', groups=groups, cin_g=cin_g, taps=k * k, bn=ops.x6_tile(Cout // groups, groups, B * Ho * Ho)):
                 return ops.x6_weight(self.eng._packed[key], groups, cin_g, taps, bn, out)
-            X6 = self.eng._pack(name + '.x6', build_x6)
+            X6 = self.eng._pack(name + f'.x6@{ops.x6_tile(Cout // groups, groups, B * Ho * Ho)}', build_x6)       # the tile is part of the packed layout: part of the key
         d, _, _ = ops.make_conv_desc(x, wp, raw, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k, stride=s,
                                      pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U, wgt_x6=X6,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, 'grouped-ssd-pytorch_amd')); sys.path.inse
 import numpy as np, torch
 from oracle import gssd_oracle as O
 from gssd import synth
-from test_gpu_parity import NETS
+from gpu_common import NETS
 from models.ssd_multiphase_custom_group import build_ssd
 wseed, xseed = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (31337, 14)
 flags, args = NETS['gssdpp']

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (not part of the product): a differentiable ATen restatement of the GSSD / GSSD++ graph on the
-device (MIOpen convs, torch bmm / softmax, a gather-based deformable conv), used by tests/test_gpu_parity.py as a
+device (MIOpen convs, torch bmm / softmax, a gather-based deformable conv), used by tests/test_gpu_training.py / tests/test_gpu_parity.py as a
 second opinion on the HIP backward plan (gssd/backward.py) next to CPU autograd through the oracle.  Graph restated from
 models/ssd_multiphase_custom_group.py:217-400.  Nothing under grouped-ssd-pytorch_amd/ imports this file.
 """

@@ -2,7 +2,7 @@
 through the oracle graph (models/ssd_multiphase_custom_group.py:217-400 restated in oracle/gssd_oracle.py), with the graph's
 discontinuous decisions -- ReLU masks, max-pool arg-maxes and the deformable conv's sampling cells -- taken from the HIP path.
 
-tests/test_gpu_parity.py::test_backward_gradients lets both sides take their own decisions; a forward difference of 1e-7 then flips a
+tests/test_gpu_training.py::test_backward_gradients lets both sides take their own decisions; a forward difference of 1e-7 then flips a
 handful of ReLU / arg-max decisions between the two implementations and each flip moves single weight-gradient entries by ~1 % (seen
 equally between CPU fp32 and CPU float64), which is why that test can only hold 2e-2 on 11-15 tensors.  Here the float64 graph is
 evaluated with the decisions the HIP backward really took -- reconstructed exactly from what its kernel reads: the raw conv output the

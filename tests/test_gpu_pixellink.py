@@ -158,7 +158,7 @@ def test_loss_backward_vs_oracle_autograd(dev):
 def test_backward_gradients_vs_oracle(dev, tag):
     """Training step of the PixelLink++ row: HIP forward -> PixelLinkLoss -> loss.backward() (HIP loss backward + HIP backward plan)
     against CPU autograd through the oracle graph and the oracle loss, B = 2, relative L2 error per parameter tensor.  The bounds are
-    those of the detector's gradient test (tests/test_gpu_parity.py::test_backward_gradients): ReLU / max-pool decisions at |z| ~ 1e-6
+    those of the detector's gradient test (tests/test_gpu_training.py::test_backward_gradients): ReLU / max-pool decisions at |z| ~ 1e-6
     flip between two fp32 implementations and move single entries by ~1 %; parameters with no decision downstream match to 1e-4."""
     from pixel_link.criterion import PixelLinkLoss
     kw = FULL if tag == 'full' else PLAIN

@@ -2,7 +2,7 @@
 untested combination unless something runs it: one GSSD++ training step at batch 4 per switch, in a subprocess (the switches are read
 once per process), against the default configuration of the same process family.  The alternative paths compute the same function
 with a different kernel or schedule: fp32 results agree to 1e-4 of the tensor's scale (gradients 2e-2 relative L2: ReLU / max-pool
-decisions flip between fp32 summation orders, tests/test_gpu_parity.py::test_backward_gradients), bf16 results within the bf16
+decisions flip between fp32 summation orders, tests/test_gpu_training.py::test_backward_gradients), bf16 results within the bf16
 contract of tests/test_gpu_bf16.py (a few per cent after the trunk, loss 1e-2)."""
 import json
 import os
@@ -49,7 +49,7 @@ SWITCHES = [
     ('f32', {'GSSD_NO_WGRAD_SLOT': '1'}, lambda o, base: True),
     ('f32', {'GSSD_GEMM_SLOT_SWAP': '0'}, lambda o, base: True),
     # (at this test's batch of 4 the deformable conv has 92 tiles for 256 CUs and keeps the one-tile form either way: the stream-K form
-    # itself is tested at batch 32 by test_gpu_parity.py::test_dcn_fused_streamk)
+    # itself is tested at batch 32 by test_gpu_kernels.py::test_dcn_fused_streamk)
     ('f32', {'GSSD_DCN_STREAMK': '0'}, lambda o, base: True),
     # the deformable conv on the fp32 matrix cores (csrc/dcn_fused.hip) instead of the three-plane bf16 form (csrc/dcn_x6.hip)
     ('f32', {'GSSD_DCN_X6': '0'}, lambda o, base: any(k.startswith('dcn_fused') for k in o['kernels']) and any(k.startswith('dcn_x6') for k in base['kernels'])),
