@@ -596,10 +596,12 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
         if (mtot <= 512 || (d.m_per_image && mtot <= 4096 && M <= 128)) return launch_cfg<32, 64, 1, 4, 3>(d, M, images, s);
         if (mtot <= 4096) return launch_cfg<64, 64, 2, 2, 3>(d, M, images, s);
     }
-    // large plain GEMM-shaped launches (the 38 x 38 / 19 x 19 Self_Attn projections and output convs, the fuse convs): 256 x 128 tiles on eight
-    // waves -- these launches are bound by the L2 -> LDS traffic of re-reading the activation tile once per output tile (128 x 64 tiles: 566 MB
-    // per fuse_11 launch for 94 MB of operands), and a 256 x 128 tile moves 2.7 x less per MFMA.  GSSD_BF16_BIG_TILES=0: the 128-row tiles.
-    static const int big = [] { const char* e = getenv("GSSD_BF16_BIG_TILES"); return e ? atoi(e) : 1; }();
+    // Measured and rejected (round 5), kept behind GSSD_BF16_BIG_TILES=1: 256 x 128 tiles on eight waves for the large GEMM-shaped launches (the
+    // 38 x 38 / 19 x 19 Self_Attn projections and output convs, the fuse convs).  The idea: 128 x 64 tiles re-read the activation tile once per
+    // output tile (566 MB of L2 -> LDS traffic per fuse_11 launch for 94 MB of operands).  Result: 7 launches 74.5 us at 197 TFLOP/s against
+    // 58.9 us at 287 -- with K = 256 .. 1024 a tile runs 4 .. 16 K steps, so the launch is bound by the tiles' prologue / epilogue, not by the
+    // traffic of the main loop, and the larger tile only costs occupancy.
+    static const int big = [] { const char* e = getenv("GSSD_BF16_BIG_TILES"); return e ? atoi(e) : 0; }();
     if (big && !d.m_per_image && d.split_k == 1 && M >= 8192 && cout_g % 128 == 0 && d.K % BK == 0 && d.K >= 256 &&
         (d.out_mode == GSSD_OUT_NHWC || (d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 128 == 0))) {
         return launch_cfg<256, 128, 4, 2>(d, M, images, s);      // (256 x 256 on eight waves: 256 registers and 672 bytes of scratch per lane)

@@ -63,10 +63,10 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     if (cout_g > 32 and d.split_k == 1 and Mtot <= 4096 and os.environ.get('GSSD_NO_SMALL_TILES') is None
             and not (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 64 != 0)):
         inst = '32x64' if (Mtot <= 512 or (d.m_per_image and Ms <= 128)) else '64x64'
-    if (bf16 and os.environ.get('GSSD_BF16_BIG_TILES', '1') != '0' and not d.m_per_image and d.split_k == 1 and d.B * d.Ho * d.Wo >= 8192
+    if (bf16 and os.environ.get('GSSD_BF16_BIG_TILES', '0') == '1' and not d.m_per_image and d.split_k == 1 and d.B * d.Ho * d.Wo >= 8192
             and cout_g % 128 == 0 and d.K % 64 == 0 and d.K >= 256
             and (d.out_mode == _lib.OUT_NHWC or (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 128 == 0))):
-        inst = '256x128'                                 # csrc/conv_bf16.hip: the large GEMM-shaped launches (round 5)
+        inst = '256x128'                                 # csrc/conv_bf16.hip: opt-in experiment (measured slower, round 5)
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if not bf16 and d.wgt_x6 and lib.gssd_conv_x6_takes(C.byref(d)) == 1:
         M6 = d.B * d.Ho * d.Wo
