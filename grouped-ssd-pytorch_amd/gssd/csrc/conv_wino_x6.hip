@@ -4,20 +4,25 @@
 // conv_wino.hip runs the 16 Winograd-domain GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[co][ci]  on v_mfma_f32_16x16x4_f32 -- 1/16 of
 // the bf16 matrix rate of gfx950.  Here both operands are the exact sum of three bf16 planes (x = h + m + l, conv_x6.hip) and a product is six
 // v_mfma_f32_16x16x32_bf16 (every term above 2^-24), fp32 accumulation: 6 / 16 of the fp32 instruction's matrix-pipe time per product, on top
-// of Winograd's 2.25 x fewer products.  The transforms stay fp32 and are the ones of conv_wino.hip (V = B^T d B in registers straight from
-// global memory, Y = A^T M A in registers), so the result differs from that kernel only by the products' last bit.
+// of Winograd's 2.25 x fewer products.  The transforms stay fp32 and are the ones of conv_wino.hip (V = B^T d B straight from global memory,
+// Y = A^T M A in registers), so the result differs from that kernel only by the products' last bit.
 //
-// Work decomposition: a workgroup (4 waves, one per SIMD) is persistent and walks a contiguous range of items of one (group, 32-channel output
-// block); an item = 64 consecutive tiles of the linearised (image, tile_y, tile_x) list, 16 per wave.  K runs in chunks of 32 input channels: lane
-// (tile r, quad kq) owns channels 4 kq .. 4 kq + 3 of both 16-channel halves of the chunk -- the loads, the fused producer BatchNorm + ReLU and
-// the transform keep conv_wino.hip's layout (one 16-byte load per patch position and half) and the two halves fill slots 0-3 / 4-7 of the
-// lane's bf16x8 MFMA operand; U is packed in the same slot order (the MFMA only needs both operands to agree on which channel sits in which
-// k slot).  The vector ALU reaches only the 256 architectural registers and the accumulators take 128 more (16 xi x 2 x f32x4), so the planes of a
-// chunk (16 xi x 3 x 4 registers) never exist at once: the column transform t = B^T d is done in place in the patch registers, and the chunk then
-// runs ROW by row of the Winograd domain -- V_i. = t_i. B, its three-plane split (48 registers) and the 48 MFMAs of its four xi -- with row i + 1's
-// vector work in the same basic block as row i's MFMAs (the bf16 MFMA does not use the vector ALU's lanes: the two overlap).  A row is also the
-// LDS stage of the U planes (LDS-DMA, 4 xi = 24 KB, double buffered).  Rows of t die as they are consumed; the next step's patch loads are issued
-// into the freed registers (first half during row 1, second half during row 3).
+// What shapes the kernel: the vector ALU reaches only the 256 architectural registers and the split costs ~7 vector instructions per operand
+// element, so (a) the planes of all 16 xi of a K chunk (192 registers) plus 256 accumulators cannot exist at once, and (b) an output-channel block
+// must be as wide as possible (every block re-does the transform + split of the same patches).  Hence:
+//   * a workgroup (4 waves, one per SIMD) owns 64 consecutive tiles of the linearised (image, tile_y, tile_x) list -- 16 per wave -- and NB = 64
+//     (or 32) output channels of one group, and is persistent over a contiguous range of such items;
+//   * an item runs as FOUR PASSES, one per row i of the 4 x 4 Winograd domain: pass i needs only t_i. = (B^T d)_i. (two patch rows), V_i. = t_i. B
+//     (four xi), their three-plane split (48 registers) and 4 x NBT accumulators; after its K loop the pass is folded into the 2 x 2 outputs
+//     Y[a][b] += A[i][a] (M_i. A)[b] (Y = A^T M A is linear in M) and the accumulators are free again.  Patch rows are re-read by the passes that
+//     share them (from L1 / L2), U is streamed exactly once;
+//   * K runs in chunks of 32 input channels: lane (tile r, quad kq) owns channels 4 kq .. 4 kq + 3 of both 16-channel halves of the chunk (one
+//     16-byte load per patch position and half, conv_wino.hip's layout); the halves fill slots 0-3 / 4-7 of the lane's bf16x8 MFMA operand and U is
+//     packed in the same slot order (the MFMA only needs both operands to agree on which channel sits in which k slot);
+//   * a stage = (pass, chunk): U planes of its four xi by LDS-DMA (4 xi x 3 planes x NB x 32 bf16, double buffered); the stage body is ONE basic
+//     block -- the DMA of stage s + 1, the patch loads of stage s + 2, the vector work of stage s + 1 (producer BatchNorm + ReLU, t, V, split) and
+//     the 24 NBT MFMAs of stage s -- so that the vector work runs beside the MFMAs (the bf16 MFMA does not use the vector ALU's lanes).  Past
+//     the last stage the last one is prepared again (results unused): no branch in the body.
 #include "common.h"
 #include <cstdlib>
 
@@ -25,16 +30,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+#ifndef WX6_KO
+#define WX6_KO 0              // knock-outs (scripts/wino_x6_knockout.sh; results wrong by construction): 1 no vector work (transform / split), 2 no MFMAs,
+#endif                        // 4 no U DMA, 8 no patch loads, 16 no fragment reads
 #ifndef WX6_LOCAL_SUM
 #define WX6_LOCAL_SUM 1       // the six products of a chunk are summed from zero and added to the running sum by the vector ALU (the bf16 MFMA's
 #endif                        // adder truncates: conv_x6.hip)
 
 namespace {
 
-constexpr int NB = 32, NBT = 2, NP = 3, XG = 4;
-constexpr int TILE_ELEMS = 32 * 32;                 // bf16 per (xi, plane): 32 output channels x 32 k slots
-constexpr int STAGE_ELEMS = XG * NP * TILE_ELEMS;   // 24 KB
-constexpr int CHUNK_ELEMS = 16 * NP * TILE_ELEMS;   // 96 KB per (group, output block, 32-channel chunk)
+constexpr int NP = 3, XG = 4;
 
 __device__ __host__ __forceinline__ int swz(int row) { return (row & 8) ? 3 : 0; }       // 64-byte rows: conflict-free ds_read_b128 (conv_x6.hip)
 
@@ -52,7 +57,7 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 
 struct WinoX6Params {
     const float* in;
-    const u16* Ux;           // [groups][cout blocks][chunks][16 xi][3 planes][32 co][32 slots], slot groups swizzled (swz)
+    const u16* Ux;           // [groups][cout blocks][chunks][16 xi][3 planes][NB co][32 slots], slot groups swizzled (swz)
     const float* bias;
     float* out;
     const float* resid;
@@ -69,57 +74,23 @@ struct WinoX6Params {
     unsigned pad_off;
 };
 
-// one 16-channel half of a chunk, in place: producer BatchNorm + ReLU, padding, then the column transform raw[i * 4 + j] := (B^T d)[i][j]
-template <bool XF>
-__device__ __forceinline__ void xform_cols(f32x4 (&raw)[16], const f32x4& sc, const f32x4& sh, const f32x4& padq, const unsigned valid,
-                                           const bool select_pad) {
-    if (select_pad) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) raw[q][e] = (valid >> q) & 1 ? raw[q][e] : padq[e];
-    }
-    if (XF) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) raw[q][e] = fmaxf(raw[q][e] * sc[e] + sh[e], 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 d0 = raw[0 * 4 + j], d1 = raw[1 * 4 + j], d2 = raw[2 * 4 + j], d3 = raw[3 * 4 + j];
-        raw[0 * 4 + j] = d0 - d2;
-        raw[1 * 4 + j] = d1 + d2;
-        raw[2 * 4 + j] = d2 - d1;
-        raw[3 * 4 + j] = d1 - d3;
-    }
+// the patch rows pass i reads and how they combine: t_i. = d_ra + sg * d_rb   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+__device__ __forceinline__ void pass_rows(int i, int& ra, int& rb, float& sg) {
+    ra = i == 0 ? 0 : i == 2 ? 2 : 1;
+    rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+    sg = i == 1 ? 1.f : -1.f;
 }
 
-// row I of the Winograd domain: V[I][j] = (t[I][.] B)[j] for the lane's 8 channels (tA: slots 0-3, tB: slots 4-7), x = h + m + l
-template <int I>
-__device__ __forceinline__ void make_row(const f32x4 (&tA)[16], const f32x4 (&tB)[16], bf16x8 (&P)[4][NP]) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t0 = sub ? tB[I * 4 + 0][e] : tA[I * 4 + 0][e], t1 = sub ? tB[I * 4 + 1][e] : tA[I * 4 + 1][e];
-            const float t2 = sub ? tB[I * 4 + 2][e] : tA[I * 4 + 2][e], t3 = sub ? tB[I * 4 + 3][e] : tA[I * 4 + 3][e];
-            const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __bf16 h, m, l;
-                split3(v[j], h, m, l);
-                P[j][0][4 * sub + e] = h;
-                P[j][1][4 * sub + e] = m;
-                P[j][2][4 * sub + e] = l;
-            }
-        }
-    }
-}
+struct Stage {               // a stage = (item, pass, chunk) + the item's patch origin / validity mask of this lane's tile
+    int item, pass, c;
+    unsigned pix, valid;
+};
 
-template <bool XF, int EPI>      // EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
+// PSEL: out-of-image patch positions are replaced by the padding value with a select (else: the loads already fetched it, WinoX6Params::pad_off)
+template <int NBT, bool XF, int EPI, bool PSEL>      // NB = 16 NBT output channels per workgroup; EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
 __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params p) {
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];      // [2][STAGE_ELEMS]
+    constexpr int NB = 16 * NBT, TILE = NB * 32, STAGE = XG * NP * TILE, CHUNK = 16 * NP * TILE;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];      // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
@@ -130,12 +101,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
     const int pair = blockIdx.x % p.npairs, bx = blockIdx.x / p.npairs;
     const int g = pair / p.ncb, cb = pair - g * p.ncb;
     const int n0 = cb * NB;
-    int item = (int)(((long long)bx * nitems) / p.gx);
+    const int item_begin = (int)(((long long)bx * nitems) / p.gx);
     const int item_end = (int)(((long long)(bx + 1) * nitems) / p.gx);
-    if (item >= item_end) return;
+    if (item_begin >= item_end) return;
 
     const int cb_ld = p.in_ch_off + g * p.cin_g + kq * 4;            // + chunk * 32 + half * 16
-    const u16* Ug = p.Ux + (size_t)pair * p.nchunks * CHUNK_ELEMS + lane * 8;
+    const u16* Ug = p.Ux + (size_t)pair * p.nchunks * CHUNK + lane * 8;
+    const int nchunks = p.nchunks;
+    const bool tailB = (p.cin_g & 31) != 0;                           // the last chunk has one 16-channel half only
 
     auto decode = [&](int it, unsigned& pix_off, unsigned& valid) {
         const int t = (it * 4 + wv) * 16 + r;
@@ -154,274 +127,320 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         }
         pix_off = (unsigned)((pix0 * p.in_stride + cb_ld) * 4);        // may wrap for border tiles: only used where valid
     };
-    // patch position q of the lane's tile, channels cb_ld + ch16 * 16 .. + 3 (ch16 = 2 * chunk + half)
-    auto load_raw1 = [&](f32x4 (&raw)[16], unsigned pix_off, unsigned valid, int ch16, int q) {
-        const int i = q >> 2, j = q & 3;
-        const unsigned off = (valid >> q) & 1 ? pix_off + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
-                                              : (p.pad_off ? p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4) : 0u);
-        raw[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
+    auto advance = [&](Stage& s) {               // the stage after s; past the end: s again
+        Stage n = s;
+        if (++n.c == nchunks) {
+            n.c = 0;
+            if (++n.pass == 4) {
+                n.pass = 0;
+                ++n.item;
+                if (n.item >= item_end) return;  // (s stays the last stage)
+                decode(n.item, n.pix, n.valid);
+            }
+        }
+        s = n;
     };
-    // stage (chunk c, xi group xg) -> LDS slot: 24 pieces of 1 KB, wave w moves pieces w, w + 4, ..
-    auto stage_U = [&](int c, int xg, int slot) {
-        const u16* src = Ug + (size_t)c * CHUNK_ELEMS + xg * STAGE_ELEMS;
-        u16* dst = smem + slot * STAGE_ELEMS;
+    // the two patch rows of a stage, both 16-channel halves: raw[half][row a | row b][4 positions]
+    auto load_rows = [&](f32x4 (&raw)[2][2][4], const Stage& s) {
+        int ra, rb;
+        float sg;
+        pass_rows(s.pass, ra, rb, sg);
+        const bool hasB = !(tailB && s.c == nchunks - 1);
 #pragma unroll
-        for (int k = 0; k < STAGE_ELEMS / 512 / 4; ++k) {
+        for (int hf = 0; hf < 2; ++hf) {
+            const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);      // (a missing half re-reads the first one: its result is masked to zero)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int i = w ? rb : ra;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = i * 4 + j;
+                    const unsigned off = (s.valid >> q) & 1 ? s.pix + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
+                                                            : (PSEL ? 0u : p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4));
+                    if (WX6_KO & 8) continue;
+                    raw[hf][w][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
+                }
+            }
+        }
+    };
+    // vector work of a stage: padding, producer BatchNorm + ReLU, t = d_ra + sg d_rb, V = t B, three-plane split -> the operand planes of its 4 xi
+    auto make_planes = [&](f32x4 (&raw)[2][2][4], const Stage& s, bf16x8 (&P)[4][NP]) {
+        int ra, rb;
+        float sg;
+        pass_rows(s.pass, ra, rb, sg);
+        const bool hasB = !(tailB && s.c == nchunks - 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, padq = {0.f, 0.f, 0.f, 0.f};
+            if (XF) {
+                sc = *reinterpret_cast<const f32x4*>(p.in_scale + cb_ld + ch16 * 16);
+                sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_ld + ch16 * 16);
+                padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + ch16 * 16);
+            }
+            const float keep = (hf && !hasB) ? 0.f : 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float da = raw[hf][0][j][e], db = raw[hf][1][j][e];
+                    if (PSEL) {                               // out-of-image positions were fetched from offset 0: replace them by the padding value
+                        da = (s.valid >> (ra * 4 + j)) & 1 ? da : padq[e];
+                        db = (s.valid >> (rb * 4 + j)) & 1 ? db : padq[e];
+                    }
+                    if (XF) {
+                        da = fmaxf(da * sc[e] + sh[e], 0.f);
+                        db = fmaxf(db * sc[e] + sh[e], 0.f);
+                    }
+                    t[j] = (da + sg * db) * keep;
+                }
+                const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __bf16 h, m, l;
+                    split3(v[j], h, m, l);
+                    P[j][0][4 * hf + e] = h;
+                    P[j][1][4 * hf + e] = m;
+                    P[j][2][4 * hf + e] = l;
+                }
+            }
+        }
+    };
+    // U planes of a stage -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, wave w moves pieces w, w + 4, ..
+    auto stage_U = [&](const Stage& s, int slot) {
+        const u16* src = Ug + (size_t)s.c * CHUNK + s.pass * STAGE;
+        u16* dst = smem + slot * STAGE;
+#pragma unroll
+        for (int k = 0; k < STAGE / 512 / 4; ++k) {
             const int piece = 4 * k + wv;
             dma16(src + piece * 512, dst + piece * 512);
         }
     };
 
-    f32x4 acc[16][NBT];
+    f32x4 acc[XG][NBT], Y[2][2][NBT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int xl = 0; xl < XG; ++xl)
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = zero4;
+        for (int nb = 0; nb < NBT; ++nb) acc[xl][nb] = zero4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) Y[a][b][nb] = zero4;
     f32x4 ssum[NBT], ssq[NBT];
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = zero4;
     const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
+    const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row block of a tile
 
-    unsigned in_cur, valid_cur;
-    decode(item, in_cur, valid_cur);
-    stage_U(0, 0, 0);
-    f32x4 tA[16], tB[16];                                 // patch (raw), then t = B^T d in place; slots 0-3 / 4-7 of the operand
+    // ---- output transform's fold of a finished pass, and the epilogue of a finished item ------------------------------------------------------
+    auto fold = [&](int pass) {
+        // (M_i. A)[b]: b = 0: m0 + m1 + m2, b = 1: m1 - m2 - m3;  A^T column i: Y[0] += (i < 3) s, Y[1] += (i == 1) s - (i >= 2) s
+        const float c0 = pass < 3 ? 1.f : 0.f, c1 = pass == 1 ? 1.f : pass >= 2 ? -1.f : 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) load_raw1(tA, in_cur, valid_cur, 0, q);
-    if (p.cin_g > 16) {
+        for (int nb = 0; nb < NBT; ++nb) {
+            const f32x4 s0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
+            const f32x4 s1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) load_raw1(tB, in_cur, valid_cur, 1, q);
-    }
-    int slot = 0;
-    const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row half of a tile
+            for (int e = 0; e < 4; ++e) {
+                Y[0][0][nb][e] += c0 * s0[e];
+                Y[0][1][nb][e] += c0 * s1[e];
+                Y[1][0][nb][e] += c1 * s0[e];
+                Y[1][1][nb][e] += c1 * s1[e];
+            }
+#pragma unroll
+            for (int xl = 0; xl < XG; ++xl) acc[xl][nb] = zero4;
+        }
+    };
+    auto epilogue = [&](int item) {
+        // lane (r, kq) holds Y[a][b] of channels n0 + nb*16 + 4*kq + j of tile r (conv_wino.hip's epilogue)
+        const int t = (item * 4 + wv) * 16 + r;
+        if (t < p.ntiles) {
+            const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
+            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            const int y = 2 * ty, x = 2 * tx;
+            const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
+            const int ch0 = g * p.cout_g + n0 + kq * 4;
+            const size_t o00 = EPI == 2 ? ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch0
+                                        : ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + ch0;
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) {
+                const int nrem = p.cout_g - (n0 + nb * 16 + kq * 4);      // channels of this quad that exist (zero rows of U beyond)
+                if (nrem <= 0) continue;
+                f32x4 bia = zero4;
+                if (p.bias) {
+                    if (vec && nrem >= 4) bia = *reinterpret_cast<const f32x4*>(p.bias + ch0 + nb * 16);
+                    else
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < nrem) bia[j] = p.bias[ch0 + nb * 16 + j];
+                }
+                f32x4 v[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) v[a][c2] = Y[a][c2][nb] + bia;
+                auto put = [&](size_t o, const f32x4& val) {
+                    if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
+                    else
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < nrem) p.out[o + j] = val[j];
+                };
+                if (EPI == 2) {
+                    // GSSD_CONV_POOL2: a Winograd tile IS a pooling window; batch sums in the order of the unpooled epilogue
+                    f32x4 mx = v[0][0], mn = v[0][0];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                mx[j] = fmaxf(mx[j], v[a][c2][j]);
+                                mn[j] = fminf(mn[j], v[a][c2][j]);
+                                ssum[nb][j] += v[a][c2][j];
+                                ssq[nb][j] = __builtin_fmaf(v[a][c2][j], v[a][c2][j], ssq[nb][j]);
+                            }
+                        }
+                    f32x4 sgn = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (vec && nrem >= 4) sgn = *reinterpret_cast<const f32x4*>(p.pool_sign + ch0 + nb * 16);
+                    else
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < nrem) sgn[j] = p.pool_sign[ch0 + nb * 16 + j];
+                    f32x4 res;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) res[j] = sgn[j] >= 0.f ? mx[j] : mn[j];
+                    put(o00 + nb * 16, res);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+                            const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
+                            f32x4 val = v[a][c2];
+                            if (EPI == 1) {
+                                if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
+                                else
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (j < nrem) val[j] += p.resid[o + j];
+                            }
+                            put(o, val);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                ssum[nb][j] += val[j];
+                                ssq[nb][j] = __builtin_fmaf(val[j], val[j], ssq[nb][j]);
+                            }
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int nb = 0; nb < NBT; ++nb) Y[a][b2][nb] = zero4;
+    };
 
-    // the four xi of row `xg` (U planes from LDS slot `sl`) against the row's operand planes
-    auto mfma_row = [&](const int xg, const int sl, const bf16x8 (&P)[4][NP]) {
-        const u16* ub = smem + sl * STAGE_ELEMS + fo;
+    // ---- the stage stream ---------------------------------------------------------------------------------------------------------------------
+    // stage s: matrix work from planes Pc (made during stage s - 1) and LDS slot `slot`; the body also makes the planes of stage s + 1 from the
+    // patch rows loaded during stage s - 1 and loads the rows of stage s + 2
+    auto body = [&](const Stage& cur, const Stage& nxt, const Stage& nn, const bf16x8 (&Pc)[4][NP], bf16x8 (&Pn)[4][NP], f32x4 (&rawN)[2][2][4],
+                    f32x4 (&rawL)[2][2][4], const int slot) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA pieces of stage s have landed (and the patch rows of stage s + 1)
+        __syncthreads();                          // ... everyone's have; the other slot is free again
+        if (!(WX6_KO & 4)) stage_U(nxt, slot ^ 1);
+        load_rows(rawL, nn);
+        if (!(WX6_KO & 1)) make_planes(rawN, nxt, Pn);
+        const u16* ub = smem + slot * STAGE + fo;
 #pragma unroll
         for (int xl = 0; xl < XG; ++xl) {
-            const int xi = xg * XG + xl;
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
                 bf16x8 u[NP];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) u[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE_ELEMS + nb * 16 * 32);
-                // six products, smallest first (u: weight planes, P: activation planes)
+                for (int q = 0; q < NP; ++q) {
+                    if (WX6_KO & 16) asm volatile("" : "=v"(u[q]));
+                    else u[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+                }
+                if (WX6_KO & 2) continue;
+                // six products, smallest first (u: weight planes, Pc: activation planes)
 #if WX6_LOCAL_SUM
-                f32x4 s = zero4;
+                f32x4 s6 = zero4;
 #else
-                f32x4 s = acc[xi][nb];
+                f32x4 s6 = acc[xl][nb];
 #endif
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], P[xl][1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[2], P[xl][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], P[xl][2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], P[xl][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], P[xl][1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], P[xl][0], s, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], Pc[xl][1], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[2], Pc[xl][0], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][2], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], Pc[xl][0], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][1], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][0], s6, 0, 0, 0);
 #if WX6_LOCAL_SUM
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[xi][nb][e] += s[e];
+                for (int e = 0; e < 4; ++e) acc[xl][nb][e] += s6[e];
 #else
-                acc[xi][nb] = s;
+                acc[xl][nb] = s6;
 #endif
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur.c == nchunks - 1) {
+            fold(cur.pass);
+            if (cur.pass == 3) epilogue(cur.item);
         }
     };
-    // top of a stage: this wave's DMA pieces of the stage have landed (vmcnt(0): with them every patch load issued a stage ago), then
-    // everyone's have and everyone is done reading the other slot
-    auto stage_sync = [&]() {
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-    };
 
-    for (;;) {
-        const int item_next = item + 1;
-        const bool have_next = item_next < item_end;
-        unsigned in_next = in_cur, valid_next = 0;
-        if (have_next) decode(item_next, in_next, valid_next);
-        for (int c = 0; c < p.nchunks; ++c) {
-            const bool hasB = c * 32 + 16 < p.cin_g;
-            const bool last = c + 1 == p.nchunks;
-            const bool more = !last || have_next;
-            const unsigned ld_in = last ? in_next : in_cur;
-            const unsigned ld_valid = last ? valid_next : valid_cur;
-            const int ld_c = last ? 0 : c + 1;
-            const bool ld_hasB = ld_c * 32 + 16 < p.cin_g;
-            // ---- column transforms of both halves, in place ------------------------------------------------------------------------------
-            {
-                f32x4 sc = zero4, sh = zero4, padq = zero4;
-                if (XF) {
-                    sc = *reinterpret_cast<const f32x4*>(p.in_scale + cb_ld + c * 32);
-                    sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_ld + c * 32);
-                    padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + c * 32);
-                }
-                xform_cols<XF>(tA, sc, sh, padq, valid_cur, !p.pad_off);
-            }
-            if (hasB) {
-                f32x4 sc = zero4, sh = zero4, padq = zero4;
-                if (XF) {
-                    sc = *reinterpret_cast<const f32x4*>(p.in_scale + cb_ld + c * 32 + 16);
-                    sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_ld + c * 32 + 16);
-                    padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + c * 32 + 16);
-                }
-                xform_cols<XF>(tB, sc, sh, padq, valid_cur, !p.pad_off);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) tB[q] = zero4;          // a 16-channel tail: slots 4-7 are zero on both sides (U is zero-padded)
-            }
-            // ---- rows: vector work of row i + 1 beside the MFMAs of row i ------------------------------------------------------------------
-            bf16x8 P0[4][NP], P1[4][NP];
-            f32x4 nA[16], nB[16];                             // the next step's patch
-            make_row<0>(tA, tB, P0);
-            stage_sync();
-            stage_U(c, 1, slot ^ 1);
-            make_row<1>(tA, tB, P1);
-            mfma_row(0, slot, P0);
-            stage_sync();
-            stage_U(c, 2, slot);
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) load_raw1(nA, ld_in, ld_valid, 2 * ld_c, q);
-            }
-            make_row<2>(tA, tB, P0);
-            mfma_row(1, slot ^ 1, P1);
-            stage_sync();
-            stage_U(c, 3, slot ^ 1);
-            make_row<3>(tA, tB, P1);
-            mfma_row(2, slot, P0);
-            stage_sync();
-            if (more) {
-                stage_U(ld_c, 0, slot);
-                if (ld_hasB) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) load_raw1(nB, ld_in, ld_valid, 2 * ld_c + 1, q);
-                }
-            }
-            mfma_row(3, slot ^ 1, P1);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                tA[q] = nA[q];
-                tB[q] = nB[q];
-            }
-        }
-
-        // ---- output transform + epilogue (conv_wino.hip's): lane (r, kq) holds M[co n0 + nb*16 + 4*kq + j][tile r] for all 16 xi ------------
-        {
-            const int t = (item * 4 + wv) * 16 + r;
-            if (t < p.ntiles) {
-                const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
-                const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-                const int y = 2 * ty, x = 2 * tx;
-                const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
-                const int ch0 = g * p.cout_g + n0 + kq * 4;
-                const size_t o00 = EPI == 2 ? ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch0
-                                            : ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + ch0;
-#pragma unroll
-                for (int nb = 0; nb < NBT; ++nb) {
-                    const int nrem = p.cout_g - (n0 + nb * 16 + kq * 4);      // channels of this quad that exist (zero rows of U beyond)
-                    if (nrem <= 0) continue;
-                    f32x4 s0[4], s1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {             // A^T M, four channels at a time
-                        s0[j] = acc[0 * 4 + j][nb] + acc[1 * 4 + j][nb] + acc[2 * 4 + j][nb];
-                        s1[j] = acc[1 * 4 + j][nb] - acc[2 * 4 + j][nb] - acc[3 * 4 + j][nb];
-                    }
-                    f32x4 bia = zero4;
-                    if (p.bias) {
-                        if (vec && nrem >= 4) bia = *reinterpret_cast<const f32x4*>(p.bias + ch0 + nb * 16);
-                        else
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (j < nrem) bia[j] = p.bias[ch0 + nb * 16 + j];
-                    }
-                    f32x4 v[2][2];
-                    v[0][0] = s0[0] + s0[1] + s0[2] + bia;
-                    v[0][1] = s0[1] - s0[2] - s0[3] + bia;
-                    v[1][0] = s1[0] + s1[1] + s1[2] + bia;
-                    v[1][1] = s1[1] - s1[2] - s1[3] + bia;
-                    auto put = [&](size_t o, const f32x4& val) {
-                        if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
-                        else
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (j < nrem) p.out[o + j] = val[j];
-                    };
-                    if (EPI == 2) {
-                        // GSSD_CONV_POOL2: a Winograd tile IS a pooling window; batch sums in the order of the unpooled epilogue
-                        f32x4 mx = v[0][0], mn = v[0][0];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int c2 = 0; c2 < 2; ++c2) {
-                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    mx[j] = fmaxf(mx[j], v[a][c2][j]);
-                                    mn[j] = fminf(mn[j], v[a][c2][j]);
-                                    ssum[nb][j] += v[a][c2][j];
-                                    ssq[nb][j] = __builtin_fmaf(v[a][c2][j], v[a][c2][j], ssq[nb][j]);
-                                }
-                            }
-                        f32x4 sg = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (vec && nrem >= 4) sg = *reinterpret_cast<const f32x4*>(p.pool_sign + ch0 + nb * 16);
-                        else
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (j < nrem) sg[j] = p.pool_sign[ch0 + nb * 16 + j];
-                        f32x4 res;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) res[j] = sg[j] >= 0.f ? mx[j] : mn[j];
-                        put(o00 + nb * 16, res);
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int c2 = 0; c2 < 2; ++c2) {
-                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
-                                const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
-                                f32x4 val = v[a][c2];
-                                if (EPI == 1) {
-                                    if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
-                                    else
-#pragma unroll
-                                        for (int j = 0; j < 4; ++j)
-                                            if (j < nrem) val[j] += p.resid[o + j];
-                                }
-                                put(o, val);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    ssum[nb][j] += val[j];
-                                    ssq[nb][j] = __builtin_fmaf(val[j], val[j], ssq[nb][j]);
-                                }
-                            }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        if (!have_next) break;
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-            for (int nb = 0; nb < NBT; ++nb) acc[xi][nb] = zero4;
-        item = item_next;
-        in_cur = in_next;
-        valid_cur = valid_next;
+    Stage s0;
+    s0.item = item_begin;
+    s0.pass = 0;
+    s0.c = 0;
+    decode(s0.item, s0.pix, s0.valid);
+    Stage s1 = s0;
+    advance(s1);
+    Stage s2 = s1;
+    advance(s2);
+    bf16x8 PA[4][NP], PB[4][NP];
+    f32x4 rawA[2][2][4], rawB[2][2][4];
+    stage_U(s0, 0);
+    load_rows(rawA, s0);
+    load_rows(rawB, s1);
+    make_planes(rawA, s0, PA);
+    const int nstages = (item_end - item_begin) * 4 * nchunks;           // even
+    for (int s = 0; s < nstages; s += 2) {
+        // stage s: planes PA, makes PB from rawB (stage s + 1), loads rawA (stage s + 2)
+        body(s0, s1, s2, PA, PB, rawB, rawA, 0);
+        s0 = s1;
+        s1 = s2;
+        advance(s2);
+        // stage s + 1: planes PB, makes PA from rawA, loads rawB
+        body(s0, s1, s2, PB, PA, rawA, rawB, 1);
+        s0 = s1;
+        s1 = s2;
+        advance(s2);
     }
 
     if (p.stats) {                                        // one flush per workgroup: 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
-        __syncthreads();                                  // all waves are done with the U stages (no DMA in flight: the last step issued none)
+        __builtin_amdgcn_s_waitcnt(0x0f70);               // the last body's (unused) DMA has landed before LDS is reused
+        __syncthreads();
         float* red = reinterpret_cast<float*>(smem);      // [4 waves][NB][2]
-        float fs[8], fq[8];                               // value index i: channel n0 + 16 * (i >> 2) + 4 * kq + (i & 3)
+        float fs[4 * NBT], fq[4 * NBT];                   // value index i: channel n0 + 16 * (i >> 2) + 4 * kq + (i & 3)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * NBT; ++i) {
             fs[i] = ssum[i >> 2][i & 3];
             fq[i] = ssq[i >> 2][i & 3];
         }
-        // halving exchange over the 16 tile lanes: lane r ends with value index r & 7 (lanes r and r ^ 8 hold the same value, folded below)
+        // halving exchange over the 16 tile lanes: lane r ends with value index r & (4 NBT - 1)
 #pragma unroll
-        for (int w = 4; w >= 1; w >>= 1) {
+        for (int w = 8; w >= 1; w >>= 1) {
+            if (4 * NBT <= w) continue;
             const bool up = (r & w) != 0;
 #pragma unroll
             for (int i = 0; i < w; ++i) {
@@ -431,11 +450,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
                 fq[i] = kq2 + __shfl_xor(gq, w, 64);
             }
         }
-        fs[0] += __shfl_xor(fs[0], 8, 64);
-        fq[0] += __shfl_xor(fq[0], 8, 64);
-        if (r < 8) {
-            red[(wv * NB + (r >> 2) * 16 + kq * 4 + (r & 3)) * 2 + 0] = fs[0];
-            red[(wv * NB + (r >> 2) * 16 + kq * 4 + (r & 3)) * 2 + 1] = fq[0];
+        if (4 * NBT == 8) {                               // the two tile-lane halves both hold value index r & 7
+            fs[0] += __shfl_xor(fs[0], 8, 64);
+            fq[0] += __shfl_xor(fq[0], 8, 64);
+        }
+        {
+            const int vi = r & (4 * NBT - 1);
+            if (r < 4 * NBT) {
+                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 0] = fs[0];
+                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 1] = fq[0];
+            }
         }
         __syncthreads();
         if (tid < NB && n0 + tid < p.cout_g) {
@@ -453,10 +477,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
     }
 }
 
+// output-channel block of a layer
+inline int wx6_nb(int cout_g) { return cout_g > 32 ? 64 : 32; }
+
+// != 0: the padding vector lies this many bytes behind `in` (the layout the engine builds: directly behind the dense map, 32-bit reachable):
+// out-of-image patch positions then LOAD their padding value (address select) instead of a per-element select afterwards
+inline unsigned wx6_pad_off(const gssd_conv_desc& d) {
+    if (!(d.in_scale && d.in_pad && (uintptr_t)d.in_pad > (uintptr_t)d.in)) return 0;
+    const unsigned long long diff = (unsigned long long)((uintptr_t)d.in_pad - (uintptr_t)d.in);
+    if (diff == (unsigned long long)d.B * d.H * d.W * d.in_stride * sizeof(float) && diff + (unsigned long long)d.in_stride * 4 < (1ull << 32) &&
+        (diff & 15) == 0)
+        return (unsigned)diff;
+    return 0;
+}
+
 // packed K-major weights [Cout][tap * cin_g + ci] (row stride `ws`) -> the three bf16 planes of U = G g G^T in the kernel's staging order
-__global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restrict__ Ux, int groups, int cout_g, int ncb, int cin_g, int nchunks,
+__global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restrict__ Ux, int groups, int cout_g, int ncb, int NB, int cin_g, int nchunks,
                                       int ws) {
     const int cin_pad = nchunks * 32, cout_pad = ncb * NB;
+    const int TILE = NB * 32, CHUNK = 16 * NP * TILE;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= groups * cout_pad * cin_pad) return;
     const int ci = i % cin_pad, cop = i / cin_pad;
@@ -478,7 +517,7 @@ __global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restri
     const int cb = cg / NB, row = cg % NB;
     const int c = ci / 32, wi = ci % 32;
     const int sub = wi >> 4, kq = (wi & 15) >> 2, e = wi & 3;
-    const size_t base = ((size_t)(g * ncb + cb) * nchunks + c) * CHUNK_ELEMS + row * 32 + ((kq ^ swz(row & 15)) << 3) + 4 * sub + e;
+    const size_t base = ((size_t)(g * ncb + cb) * nchunks + c) * CHUNK + row * 32 + ((kq ^ swz(row & 15)) << 3) + 4 * sub + e;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {                         // (G g) G^T
         const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
@@ -486,16 +525,17 @@ __global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restri
         for (int b = 0; b < 4; ++b) {
             __bf16 h, m, l;
             split3(u[b], h, m, l);
-            u16* dst = Ux + base + (size_t)(a * 4 + b) * NP * TILE_ELEMS;
-            dst[0 * TILE_ELEMS] = __builtin_bit_cast(u16, h);
-            dst[1 * TILE_ELEMS] = __builtin_bit_cast(u16, m);
-            dst[2 * TILE_ELEMS] = __builtin_bit_cast(u16, l);
+            u16* dst = Ux + base + (size_t)(a * 4 + b) * NP * TILE;
+            dst[0 * TILE] = __builtin_bit_cast(u16, h);
+            dst[1 * TILE] = __builtin_bit_cast(u16, m);
+            dst[2 * TILE] = __builtin_bit_cast(u16, l);
         }
     }
 }
 
-template <bool XF, int EPI>
-int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
+template <int NBT, bool XF, int EPI, bool PSEL>
+int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
+    constexpr int NB = 16 * NBT;
     WinoX6Params p;
     p.in = d.in;
     p.Ux = Ux;
@@ -525,16 +565,9 @@ int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
     p.nchunks = (d.cin_g + 31) / 32;
     p.npairs = p.ncb * d.groups;
     p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
-    p.pad_off = 0;
-    if (XF && d.in_pad && (uintptr_t)d.in_pad > (uintptr_t)d.in) {
-        const unsigned long long diff = (unsigned long long)((uintptr_t)d.in_pad - (uintptr_t)d.in);
-        // only the layout the engine builds: the vector directly behind the dense map (so the 32-bit offsets of the kernel reach it)
-        if (diff == (unsigned long long)d.B * d.H * d.W * d.in_stride * sizeof(float) && diff + (unsigned long long)d.in_stride * 4 < (1ull << 32) &&
-            (diff & 15) == 0)
-            p.pad_off = (unsigned)diff;
-    }
-    constexpr size_t smem = 2 * (size_t)STAGE_ELEMS * sizeof(u16);
-    auto kern = conv_wino_x6_kernel<XF, EPI>;
+    p.pad_off = PSEL ? 0u : wx6_pad_off(d);
+    constexpr size_t smem = 2 * (size_t)XG * NP * NB * 32 * sizeof(u16);
+    auto kern = conv_wino_x6_kernel<NBT, XF, EPI, PSEL>;
     static unsigned attr_mask = 0;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
@@ -544,7 +577,7 @@ int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
     }
     gssd_attr_done(&attr_mask);
     const int nitems = (p.ntiles + 63) / 64;
-    int gx = 256 / p.npairs;                              // one workgroup per CU (448 registers per lane)
+    int gx = 256 / p.npairs;                              // one workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > nitems) gx = nitems;
     p.gx = gx;
@@ -553,26 +586,32 @@ int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
     return GSSD_OK;
 }
 
+template <int NBT, bool XF, int EPI>
+int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
+    if (XF && wx6_pad_off(d)) return launch_wino_x6_sel<NBT, XF, EPI, false>(d, Ux, stream);
+    return launch_wino_x6_sel<NBT, XF, EPI, true>(d, Ux, stream);
+}
+
 }  // namespace
 
 // bf16 elements of the three-plane U of a layer (0: not a shape this kernel takes)
 long long gssd_wino_x6_plane_elems(int cout_g, int groups, int cin_g) {
     if (cin_g % 16 != 0 || cout_g < 24) return 0;
-    const long long ncb = (cout_g + NB - 1) / NB, nchunks = (cin_g + 31) / 32;
-    return (long long)groups * ncb * nchunks * CHUNK_ELEMS;
+    const long long NB = wx6_nb(cout_g), ncb = (cout_g + NB - 1) / NB, nchunks = (cin_g + 31) / 32;
+    return (long long)groups * ncb * nchunks * 16 * NP * NB * 32;
 }
 
 int gssd_wino_x6_pack(const float* w_packed, void* Ux, int Cout, int groups, int cin_g, int row_stride, hipStream_t stream) {
     const int cout_g = Cout / groups;
-    const int ncb = (cout_g + NB - 1) / NB, nchunks = (cin_g + 31) / 32;
+    const int NB = wx6_nb(cout_g), ncb = (cout_g + NB - 1) / NB, nchunks = (cin_g + 31) / 32;
     const int n = groups * ncb * NB * nchunks * 32;
     hipLaunchKernelGGL(wino_x6_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, w_packed, reinterpret_cast<u16*>(Ux), groups, cout_g,
-                       ncb, cin_g, nchunks, row_stride);
+                       ncb, NB, cin_g, nchunks, row_stride);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
-// GSSD_WINO_X6=1 switches it on (default off: see DESIGN.md -- with one wave per SIMD the vector work of the three-plane split does not hide)
+// GSSD_WINO_X6=1 switches it on (opt-in while it is being measured)
 bool gssd_wino_x6_enabled() {
     static const bool on = [] {
         const char* e = getenv("GSSD_WINO_X6");
@@ -585,6 +624,12 @@ bool gssd_wino_x6_enabled() {
 int gssd_launch_conv_wino_x6(const gssd_conv_desc& d, const void* Ux, hipStream_t stream) {
     const u16* ux = reinterpret_cast<const u16*>(Ux);
     const int epi = (d.flags & GSSD_CONV_POOL2) ? 2 : d.resid ? 1 : 0;
-    if (d.in_scale) return epi == 2 ? launch_wino_x6<true, 2>(d, ux, stream) : epi == 1 ? launch_wino_x6<true, 1>(d, ux, stream) : launch_wino_x6<true, 0>(d, ux, stream);
-    return epi == 2 ? launch_wino_x6<false, 2>(d, ux, stream) : epi == 1 ? launch_wino_x6<false, 1>(d, ux, stream) : launch_wino_x6<false, 0>(d, ux, stream);
+    const bool wide = wx6_nb(d.Cout / d.groups) == 64;
+#define WX6_GO(NBT_)                                                                                                                        \
+    (d.in_scale ? (epi == 2 ? launch_wino_x6<NBT_, true, 2>(d, ux, stream) : epi == 1 ? launch_wino_x6<NBT_, true, 1>(d, ux, stream)       \
+                                                                                       : launch_wino_x6<NBT_, true, 0>(d, ux, stream))      \
+                : (epi == 2 ? launch_wino_x6<NBT_, false, 2>(d, ux, stream) : epi == 1 ? launch_wino_x6<NBT_, false, 1>(d, ux, stream)     \
+                                                                                        : launch_wino_x6<NBT_, false, 0>(d, ux, stream)))
+    return wide ? WX6_GO(4) : WX6_GO(2);
+#undef WX6_GO
 }
