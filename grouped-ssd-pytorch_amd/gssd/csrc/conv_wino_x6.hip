@@ -37,6 +37,20 @@ typedef unsigned short u16;
 #define WX6_LOCAL_SUM 1       // the six products of a chunk are summed from zero and added to the running sum by the vector ALU (the bf16 MFMA's
 #endif                        // adder truncates: conv_x6.hip)
 
+#ifdef WX6_TIMING
+// debug build (scripts/wino_x6_timing.py): wave 0 of every workgroup accumulates the shader clocks between its phase boundaries
+__device__ unsigned long long g_wx6_timing[8];
+extern "C" int gssd_wino_x6_timing_read(unsigned long long* out8) {
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wx6_timing), 64);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_wx6_timing), z, 64);
+    return 0;
+}
+#define WXSTAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; }
+#else
+#define WXSTAMP(k)
+#endif
+
 namespace {
 
 constexpr int NP = 3, XG = 4;
@@ -74,15 +88,8 @@ struct WinoX6Params {
     unsigned pad_off;
 };
 
-// the patch rows pass i reads and how they combine: t_i. = d_ra + sg * d_rb   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
-__device__ __forceinline__ void pass_rows(int i, int& ra, int& rb, float& sg) {
-    ra = i == 0 ? 0 : i == 2 ? 2 : 1;
-    rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
-    sg = i == 1 ? 1.f : -1.f;
-}
-
-struct Stage {               // a stage = (item, pass, chunk) + the item's patch origin / validity mask of this lane's tile
-    int item, pass, c;
+struct Step {                // a step = one 32-channel chunk of one item + the item's patch origin / validity mask of this lane's tile
+    int item, c;
     unsigned pix, valid;
 };
 
@@ -127,47 +134,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         }
         pix_off = (unsigned)((pix0 * p.in_stride + cb_ld) * 4);        // may wrap for border tiles: only used where valid
     };
-    auto advance = [&](Stage& s) {               // the stage after s; past the end: s again
-        Stage n = s;
+    auto advance = [&](Step& s) {                // the step after s; past the end: s again
+        Step n = s;
         if (++n.c == nchunks) {
             n.c = 0;
-            if (++n.pass == 4) {
-                n.pass = 0;
-                ++n.item;
-                if (n.item >= item_end) return;  // (s stays the last stage)
-                decode(n.item, n.pix, n.valid);
-            }
+            ++n.item;
+            if (n.item >= item_end) return;      // (s stays the last step)
+            decode(n.item, n.pix, n.valid);
         }
         s = n;
     };
-    // the two patch rows of a stage, both 16-channel halves: raw[half][row a | row b][4 positions]
-    auto load_rows = [&](f32x4 (&raw)[2][2][4], const Stage& s) {
-        int ra, rb;
-        float sg;
-        pass_rows(s.pass, ra, rb, sg);
+    // one patch row (4 positions, both 16-channel halves) of a step: row[half][position]
+    typedef f32x4 Row[2][4];
+    auto load_row = [&](Row& row, const Step& s, const int i) {
         const bool hasB = !(tailB && s.c == nchunks - 1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);      // (a missing half re-reads the first one: its result is masked to zero)
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int i = w ? rb : ra;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = i * 4 + j;
-                    const unsigned off = (s.valid >> q) & 1 ? s.pix + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
-                                                            : (PSEL ? 0u : p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4));
-                    if (WX6_KO & 8) continue;
-                    raw[hf][w][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int q = i * 4 + j;
+                const unsigned off = (s.valid >> q) & 1 ? s.pix + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
+                                                        : (PSEL ? 0u : p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4));
+                if (WX6_KO & 8) continue;
+                row[hf][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
             }
         }
     };
-    // vector work of a stage: padding, producer BatchNorm + ReLU, t = d_ra + sg d_rb, V = t B, three-plane split -> the operand planes of its 4 xi
-    auto make_planes = [&](f32x4 (&raw)[2][2][4], const Stage& s, bf16x8 (&P)[4][NP]) {
-        int ra, rb;
-        float sg;
-        pass_rows(s.pass, ra, rb, sg);
+    // padding + producer BatchNorm + ReLU of a row, in place, once (a row serves two passes)
+    auto activate_row = [&](Row& row, const Step& s, const int i) {
+        if (WX6_KO & 1) return;
         const bool hasB = !(tailB && s.c == nchunks - 1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -180,21 +176,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
             }
             const float keep = (hf && !hasB) ? 0.f : 1.f;
 #pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = row[hf][j][e];
+                    if (PSEL) d = (s.valid >> (i * 4 + j)) & 1 ? d : padq[e];      // (fetched from offset 0: replace by the padding value)
+                    if (XF) d = fmaxf(d * sc[e] + sh[e], 0.f);
+                    row[hf][j][e] = d * keep;
+                }
+        }
+    };
+    // Winograd row: t = ra + sg * rb, V = t B, three-plane split -> the operand planes of its four xi
+    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP]) {
+        if (WX6_KO & 1) return;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float da = raw[hf][0][j][e], db = raw[hf][1][j][e];
-                    if (PSEL) {                               // out-of-image positions were fetched from offset 0: replace them by the padding value
-                        da = (s.valid >> (ra * 4 + j)) & 1 ? da : padq[e];
-                        db = (s.valid >> (rb * 4 + j)) & 1 ? db : padq[e];
-                    }
-                    if (XF) {
-                        da = fmaxf(da * sc[e] + sh[e], 0.f);
-                        db = fmaxf(db * sc[e] + sh[e], 0.f);
-                    }
-                    t[j] = (da + sg * db) * keep;
-                }
+                for (int j = 0; j < 4; ++j) t[j] = ra[hf][j][e] + sg * rb[hf][j][e];
                 const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -205,11 +206,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
                     P[j][2][4 * hf + e] = l;
                 }
             }
-        }
     };
-    // U planes of a stage -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, wave w moves pieces w, w + 4, ..
-    auto stage_U = [&](const Stage& s, int slot) {
-        const u16* src = Ug + (size_t)s.c * CHUNK + s.pass * STAGE;
+    // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, wave w moves pieces w, w + 4, ..
+    auto stage_U = [&](const int c, const int i, const int slot) {
+        if (WX6_KO & 4) return;
+        const u16* src = Ug + (size_t)c * CHUNK + i * STAGE;
         u16* dst = smem + slot * STAGE;
 #pragma unroll
         for (int k = 0; k < STAGE / 512 / 4; ++k) {
@@ -218,12 +219,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         }
     };
 
-    f32x4 acc[XG][NBT], Y[2][2][NBT];
+    f32x4 Y[2][2][NBT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int xl = 0; xl < XG; ++xl)
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) acc[xl][nb] = zero4;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -236,25 +233,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
     const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
     const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row block of a tile
 
-    // ---- output transform's fold of a finished pass, and the epilogue of a finished item ------------------------------------------------------
-    auto fold = [&](int pass) {
-        // (M_i. A)[b]: b = 0: m0 + m1 + m2, b = 1: m1 - m2 - m3;  A^T column i: Y[0] += (i < 3) s, Y[1] += (i == 1) s - (i >= 2) s
-        const float c0 = pass < 3 ? 1.f : 0.f, c1 = pass == 1 ? 1.f : pass >= 2 ? -1.f : 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            const f32x4 s0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
-            const f32x4 s1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Y[0][0][nb][e] += c0 * s0[e];
-                Y[0][1][nb][e] += c0 * s1[e];
-                Y[1][0][nb][e] += c1 * s0[e];
-                Y[1][1][nb][e] += c1 * s1[e];
-            }
-#pragma unroll
-            for (int xl = 0; xl < XG; ++xl) acc[xl][nb] = zero4;
-        }
-    };
     auto epilogue = [&](int item) {
         // lane (r, kq) holds Y[a][b] of channels n0 + nb*16 + 4*kq + j of tile r (conv_wino.hip's epilogue)
         const int t = (item * 4 + wv) * 16 + r;
@@ -349,84 +327,144 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
                 for (int nb = 0; nb < NBT; ++nb) Y[a][b2][nb] = zero4;
     };
 
-    // ---- the stage stream ---------------------------------------------------------------------------------------------------------------------
-    // stage s: matrix work from planes Pc (made during stage s - 1) and LDS slot `slot`; the body also makes the planes of stage s + 1 from the
-    // patch rows loaded during stage s - 1 and loads the rows of stage s + 2
-    auto body = [&](const Stage& cur, const Stage& nxt, const Stage& nn, const bf16x8 (&Pc)[4][NP], bf16x8 (&Pn)[4][NP], f32x4 (&rawN)[2][2][4],
-                    f32x4 (&rawL)[2][2][4], const int slot) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA pieces of stage s have landed (and the patch rows of stage s + 1)
-        __syncthreads();                          // ... everyone's have; the other slot is free again
-        if (!(WX6_KO & 4)) stage_U(nxt, slot ^ 1);
-        load_rows(rawL, nn);
-        if (!(WX6_KO & 1)) make_planes(rawN, nxt, Pn);
+
+    // the four xi of Winograd row I: 24 NBT MFMAs from the row's planes and LDS slot `slot`, folded into the 2 x 2 outputs right away
+    // (Y = A^T M A is linear in M: Y[a][b] += A[I][a] (M_I. A)[b]; A^T = [1 1 1 0; 0 1 -1 -1])
+    auto mfma_row = [&](const int I, const bf16x8 (&Pc)[4][NP], const int slot) {
         const u16* ub = smem + slot * STAGE + fo;
+        // the weight fragments of group k + 1 are requested before the MFMAs of group k (one wave per SIMD: an LDS read issued right in front
+        // of its MFMA costs the wave the whole LDS latency -- 55 us of a 327 us conv3_2 launch by knock-out)
+        bf16x8 u[2][NP];
+        auto frags = [&](const int k, bf16x8 (&dst)[NP]) {
+            const int nb = k / XG, xl = k % XG;
 #pragma unroll
-        for (int xl = 0; xl < XG; ++xl) {
+            for (int q = 0; q < NP; ++q) {
+                if (WX6_KO & 16) asm volatile("" : "=v"(dst[q]));
+                else dst[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+            }
+        };
+        frags(0, u[0]);
+        f32x4 m[XG];
 #pragma unroll
-            for (int nb = 0; nb < NBT; ++nb) {
-                bf16x8 u[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    if (WX6_KO & 16) asm volatile("" : "=v"(u[q]));
-                    else u[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+        for (int k = 0; k < XG * NBT; ++k) {
+            const int nb = k / XG, xl = k % XG;
+            if (k + 1 < XG * NBT) frags(k + 1, u[(k + 1) & 1]);
+            const bf16x8 (&uc)[NP] = u[k & 1];
+            // six products, smallest first (uc: weight planes, Pc: activation planes), summed from zero
+            f32x4 s6 = zero4;
+            if (!(WX6_KO & 2)) {
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][1], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[2], Pc[xl][0], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][2], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][0], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][1], s6, 0, 0, 0);
+                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][0], s6, 0, 0, 0);
+            }
+            m[xl] = s6;
+            if (xl == XG - 1) {
+                const f32x4 s0 = m[0] + m[1] + m[2], s1 = m[1] - m[2] - m[3];
+                if (I < 3) {
+                    Y[0][0][nb] += s0;
+                    Y[0][1][nb] += s1;
                 }
-                if (WX6_KO & 2) continue;
-                // six products, smallest first (u: weight planes, Pc: activation planes)
-#if WX6_LOCAL_SUM
-                f32x4 s6 = zero4;
-#else
-                f32x4 s6 = acc[xl][nb];
-#endif
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], Pc[xl][1], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[2], Pc[xl][0], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][2], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[1], Pc[xl][0], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][1], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[0], Pc[xl][0], s6, 0, 0, 0);
-#if WX6_LOCAL_SUM
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[xl][nb][e] += s6[e];
-#else
-                acc[xl][nb] = s6;
-#endif
+                if (I == 1) {
+                    Y[1][0][nb] += s0;
+                    Y[1][1][nb] += s1;
+                }
+                if (I >= 2) {
+                    Y[1][0][nb] -= s0;
+                    Y[1][1][nb] -= s1;
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (cur.c == nchunks - 1) {
-            fold(cur.pass);
-            if (cur.pass == 3) epilogue(cur.item);
-        }
+    };
+#ifdef WX6_TIMING
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    auto stage_sync = [&]() {
+        WXSTAMP(3)                                // (the block that just ended: vector work + MFMAs)
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA pieces of the stage have landed (and the patch rows loaded a block ago)
+        WXSTAMP(0)
+        __syncthreads();                          // ... everyone's have; the other slot is free again
+        WXSTAMP(1)
     };
 
-    Stage s0;
-    s0.item = item_begin;
-    s0.pass = 0;
-    s0.c = 0;
-    decode(s0.item, s0.pix, s0.valid);
-    Stage s1 = s0;
-    advance(s1);
-    Stage s2 = s1;
-    advance(s2);
+    // ---- the step stream: a step = one chunk = four blocks in the row order 0, 3, 1, 2 (rows d0 and d3 die first: their registers take the next
+    // step's loads).  Block k: [sync] [DMA of the next block's U planes] [patch loads of the next step into rows that are dead] [vector work of the
+    // NEXT block's Winograd row] [MFMAs + fold of this block's row] -- one basic block, so the vector work runs beside the MFMAs.
+    Step cur;
+    cur.item = item_begin;
+    cur.c = 0;
+    decode(cur.item, cur.pix, cur.valid);
+    Step nxt = cur;
+    advance(nxt);
+    Row d0, d1, d2, d3, e2;                       // e2: the next step's row 2 (row 2 is the last to die)
     bf16x8 PA[4][NP], PB[4][NP];
-    f32x4 rawA[2][2][4], rawB[2][2][4];
-    stage_U(s0, 0);
-    load_rows(rawA, s0);
-    load_rows(rawB, s1);
-    make_planes(rawA, s0, PA);
-    const int nstages = (item_end - item_begin) * 4 * nchunks;           // even
-    for (int s = 0; s < nstages; s += 2) {
-        // stage s: planes PA, makes PB from rawB (stage s + 1), loads rawA (stage s + 2)
-        body(s0, s1, s2, PA, PB, rawB, rawA, 0);
-        s0 = s1;
-        s1 = s2;
-        advance(s2);
-        // stage s + 1: planes PB, makes PA from rawA, loads rawB
-        body(s0, s1, s2, PB, PA, rawA, rawB, 1);
-        s0 = s1;
-        s1 = s2;
-        advance(s2);
+    stage_U(cur.c, 0, 0);
+    load_row(d0, cur, 0);
+    load_row(d2, cur, 2);
+    load_row(d1, cur, 1);
+    load_row(d3, cur, 3);
+    activate_row(d0, cur, 0);
+    activate_row(d2, cur, 2);
+    make_planes(d0, d2, -1.f, PA);                // t0 = d0 - d2
+    const int nsteps = (item_end - item_begin) * nchunks;
+    WXSTAMP(5)
+    for (int s = 0; s < nsteps; ++s) {
+        // block 0: MFMA row 0 (PA, slot 0) | vector: row 3 (t3 = d1 - d3) -> PB | loads: next d0, next d2 (into e2)
+        stage_sync();
+        stage_U(cur.c, 3, 1);
+        load_row(d0, nxt, 0);
+        load_row(e2, nxt, 2);
+        WXSTAMP(2)
+        activate_row(d1, cur, 1);
+        activate_row(d3, cur, 3);
+        make_planes(d1, d3, -1.f, PB);
+        mfma_row(0, PA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // block 1: MFMA row 3 (PB, slot 1) | vector: row 1 (t1 = d1 + d2) -> PA | loads: next d3
+        stage_sync();
+        stage_U(cur.c, 1, 0);
+        load_row(d3, nxt, 3);
+        WXSTAMP(2)
+        make_planes(d1, d2, 1.f, PA);
+        mfma_row(3, PB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // block 2: MFMA row 1 (PA, slot 0) | vector: row 2 (t2 = d2 - d1) -> PB
+        stage_sync();
+        stage_U(cur.c, 2, 1);
+        WXSTAMP(2)
+        make_planes(d2, d1, -1.f, PB);
+        mfma_row(1, PA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // block 3: MFMA row 2 (PB, slot 1) | vector: the next step's row 0 -> PA | loads: next d1
+        stage_sync();
+        stage_U(nxt.c, 0, 0);
+        load_row(d1, nxt, 1);
+        WXSTAMP(2)
+        activate_row(d0, nxt, 0);
+        activate_row(e2, nxt, 2);
+        make_planes(d0, e2, -1.f, PA);
+        mfma_row(2, PB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d2[hf][j] = e2[hf][j];
+        WXSTAMP(3)
+        if (cur.c == nchunks - 1) epilogue(cur.item);
+        WXSTAMP(4)
+        cur = nxt;
+        advance(nxt);
     }
 
+#ifdef WX6_TIMING
+    if (tid == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_wx6_timing[k], tacc[k]);
+        atomicAdd(&g_wx6_timing[6], (unsigned long long)nsteps);
+        atomicAdd(&g_wx6_timing[7], 1ull);
+    }
+#endif
     if (p.stats) {                                        // one flush per workgroup: 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
         __builtin_amdgcn_s_waitcnt(0x0f70);               // the last body's (unused) DMA has landed before LDS is reused
         __syncthreads();
