@@ -33,6 +33,9 @@ typedef unsigned short u16;
 #ifndef WX6_KO
 #define WX6_KO 0              // knock-outs (scripts/wino_x6_knockout.sh; results wrong by construction): 1 no vector work (transform / split), 2 no MFMAs,
 #endif                        // 4 no U DMA, 8 no patch loads, 16 no fragment reads
+#ifndef WX6_SCHED
+#define WX6_SCHED 4           // vector instructions pinned behind every MFMA of a part (0: the compiler's own order)
+#endif
 #ifndef WX6_LOCAL_SUM
 #define WX6_LOCAL_SUM 1       // the six products of a chunk are summed from zero and added to the running sum by the vector ALU (the bf16 MFMA's
 #endif                        // adder truncates: conv_x6.hip)
@@ -144,80 +147,110 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         }
         s = n;
     };
-    // one patch row (4 positions, both 16-channel halves) of a step: row[half][position]
+    // one patch row (4 positions, both 16-channel halves) of a step: row[half][position].  Loads, activation and the plane construction are dealt
+    // out in QUARTERS (quarter q: half q >> 1; loads: positions 2 (q & 1), + 1; vector work: channels e = 2 (q & 1), + 1 of the lane's quad) so
+    // that a block can issue its memory instructions a few at a time between its MFMA groups: a burst of 12 DMA pieces + 16 loads in front of a
+    // block cost the wave ~80 cycles of issue time each (6.5 k cycles per step by scripts/wino_x6_timing.py)
     typedef f32x4 Row[2][4];
-    auto load_row = [&](Row& row, const Step& s, const int i) {
+    auto load_row_q = [&](Row& row, const Step& s, const int i, const int q) {
         const bool hasB = !(tailB && s.c == nchunks - 1);
+        const int hf = q >> 1;
+        const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);          // (a missing half re-reads the first one: its result is masked to zero)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);      // (a missing half re-reads the first one: its result is masked to zero)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = i * 4 + j;
-                const unsigned off = (s.valid >> q) & 1 ? s.pix + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
-                                                        : (PSEL ? 0u : p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4));
-                if (WX6_KO & 8) continue;
-                row[hf][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
-            }
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * (q & 1) + jj;
+            const int pos = i * 4 + j;
+            const unsigned off = (s.valid >> pos) & 1 ? s.pix + (unsigned)(((i * p.W + j) * p.in_stride + ch16 * 16) * 4)
+                                                      : (PSEL ? 0u : p.pad_off + (unsigned)((cb_ld + ch16 * 16) * 4));
+            if (WX6_KO & 8) continue;
+            row[hf][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in) + off);
         }
     };
-    // padding + producer BatchNorm + ReLU of a row, in place, once (a row serves two passes)
-    auto activate_row = [&](Row& row, const Step& s, const int i) {
-        if (WX6_KO & 1) return;
+    auto load_row = [&](Row& row, const Step& s, const int i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_row_q(row, s, i, q);
+    };
+    // producer BatchNorm scale / shift / padding value of a step's two 16-channel halves, in registers (loaded a step ahead: a load in front of its
+    // first use costs the single wave of a SIMD the whole L2 latency)
+    struct XfTab {
+        f32x4 sc[2], sh[2], pd[2];
+    };
+    auto load_xf = [&](XfTab& t, const Step& s) {
         const bool hasB = !(tailB && s.c == nchunks - 1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int ch16 = 2 * s.c + (hf && hasB ? 1 : 0);
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, padq = {0.f, 0.f, 0.f, 0.f};
             if (XF) {
-                sc = *reinterpret_cast<const f32x4*>(p.in_scale + cb_ld + ch16 * 16);
-                sh = *reinterpret_cast<const f32x4*>(p.in_shift + cb_ld + ch16 * 16);
-                padq = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + ch16 * 16);
+                t.sc[hf] = *reinterpret_cast<const f32x4*>(p.in_scale + cb_ld + ch16 * 16);
+                t.sh[hf] = *reinterpret_cast<const f32x4*>(p.in_shift + cb_ld + ch16 * 16);
+                t.pd[hf] = *reinterpret_cast<const f32x4*>(p.in_pad + cb_ld + ch16 * 16);
+            } else {
+                t.sc[hf] = f32x4{1.f, 1.f, 1.f, 1.f};
+                t.sh[hf] = t.pd[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const float keep = (hf && !hasB) ? 0.f : 1.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d = row[hf][j][e];
-                    if (PSEL) d = (s.valid >> (i * 4 + j)) & 1 ? d : padq[e];      // (fetched from offset 0: replace by the padding value)
-                    if (XF) d = fmaxf(d * sc[e] + sh[e], 0.f);
-                    row[hf][j][e] = d * keep;
-                }
         }
     };
-    // Winograd row: t = ra + sg * rb, V = t B, three-plane split -> the operand planes of its four xi
-    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP]) {
+    // padding + producer BatchNorm + ReLU of a row, in place, once (a row serves two passes): quarter q
+    auto activate_row_q = [&](Row& row, const Step& s, const XfTab& xt, const int i, const int q) {
         if (WX6_KO & 1) return;
+        const bool hasB = !(tailB && s.c == nchunks - 1);
+        const int hf = q >> 1;
+        const float keep = (hf && !hasB) ? 0.f : 1.f;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int ee = 0; ee < 2; ++ee) {
+            const int e = 2 * (q & 1) + ee;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = ra[hf][j][e] + sg * rb[hf][j][e];
-                const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    __bf16 h, m, l;
-                    split3(v[j], h, m, l);
-                    P[j][0][4 * hf + e] = h;
-                    P[j][1][4 * hf + e] = m;
-                    P[j][2][4 * hf + e] = l;
-                }
+            for (int j = 0; j < 4; ++j) {
+                float d = row[hf][j][e];
+                if (PSEL) d = (s.valid >> (i * 4 + j)) & 1 ? d : xt.pd[hf][e];      // (fetched from offset 0: replace by the padding value)
+                if (XF) d = fmaxf(d * xt.sc[hf][e] + xt.sh[hf][e], 0.f);
+                row[hf][j][e] = d * keep;
             }
+        }
+    };
+    auto activate_row = [&](Row& row, const Step& s, const XfTab& xt, const int i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) activate_row_q(row, s, xt, i, q);
+    };
+    // Winograd row: t = ra + sg * rb, V = t B, three-plane split -> the operand planes of its four xi: quarter q
+    auto make_planes_q = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP], const int q) {
+        if (WX6_KO & 1) return;
+        const int hf = q >> 1;
+#pragma unroll
+        for (int ee = 0; ee < 2; ++ee) {
+            const int e = 2 * (q & 1) + ee;
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = ra[hf][j][e] + sg * rb[hf][j][e];
+            const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 h, m, l;
+                split3(v[j], h, m, l);
+                P[j][0][4 * hf + e] = h;
+                P[j][1][4 * hf + e] = m;
+                P[j][2][4 * hf + e] = l;
+            }
+        }
+    };
+    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) make_planes_q(ra, rb, sg, P, q);
     };
     // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, wave w moves pieces w, w + 4, ..
-    auto stage_U = [&](const int c, const int i, const int slot) {
+    auto stage_U_q = [&](const int c, const int i, const int slot, const int q, const int nq) {      // part q of nq
         if (WX6_KO & 4) return;
         const u16* src = Ug + (size_t)c * CHUNK + i * STAGE;
         u16* dst = smem + slot * STAGE;
+        constexpr int PW = STAGE / 512 / 4;       // pieces per wave
 #pragma unroll
-        for (int k = 0; k < STAGE / 512 / 4; ++k) {
+        for (int k = 0; k < PW; ++k) {
+            if (k * nq / PW != q) continue;
             const int piece = 4 * k + wv;
             dma16(src + piece * 512, dst + piece * 512);
         }
     };
+    auto stage_U = [&](const int c, const int i, const int slot) { stage_U_q(c, i, slot, 0, 1); };
 
     f32x4 Y[2][2][NBT];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -330,26 +363,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
 
     // the four xi of Winograd row I: 24 NBT MFMAs from the row's planes and LDS slot `slot`, folded into the 2 x 2 outputs right away
     // (Y = A^T M A is linear in M: Y[a][b] += A[I][a] (M_I. A)[b]; A^T = [1 1 1 0; 0 1 -1 -1])
-    auto mfma_row = [&](const int I, const bf16x8 (&Pc)[4][NP], const int slot) {
-        const u16* ub = smem + slot * STAGE + fo;
-        // the weight fragments of group k + 1 are requested before the MFMAs of group k (one wave per SIMD: an LDS read issued right in front
-        // of its MFMA costs the wave the whole LDS latency -- 55 us of a 327 us conv3_2 launch by knock-out)
+    // one 16-channel output tile of Winograd row I: the weight fragments of xi k + 1 are requested before the MFMAs of xi k (one wave per SIMD:
+    // an LDS read issued right in front of its MFMA costs the wave the whole LDS latency); VPM vector instructions are pinned behind every MFMA
+    auto mfma_row_nb = [&](const int I, const bf16x8 (&Pc)[4][NP], const int slot, const int nb) {
+        const u16* ub = smem + slot * STAGE + fo + nb * 16 * 32;
         bf16x8 u[2][NP];
-        auto frags = [&](const int k, bf16x8 (&dst)[NP]) {
-            const int nb = k / XG, xl = k % XG;
+        auto frags = [&](const int xl, bf16x8 (&dst)[NP]) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 if (WX6_KO & 16) asm volatile("" : "=v"(dst[q]));
-                else dst[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+                else dst[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE);
             }
         };
         frags(0, u[0]);
         f32x4 m[XG];
 #pragma unroll
-        for (int k = 0; k < XG * NBT; ++k) {
-            const int nb = k / XG, xl = k % XG;
-            if (k + 1 < XG * NBT) frags(k + 1, u[(k + 1) & 1]);
-            const bf16x8 (&uc)[NP] = u[k & 1];
+        for (int xl = 0; xl < XG; ++xl) {
+            if (xl + 1 < XG) frags(xl + 1, u[(xl + 1) & 1]);
+            const bf16x8 (&uc)[NP] = u[xl & 1];
             // six products, smallest first (uc: weight planes, Pc: activation planes), summed from zero
             f32x4 s6 = zero4;
             if (!(WX6_KO & 2)) {
@@ -361,22 +392,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
                 s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][0], s6, 0, 0, 0);
             }
             m[xl] = s6;
-            if (xl == XG - 1) {
-                const f32x4 s0 = m[0] + m[1] + m[2], s1 = m[1] - m[2] - m[3];
-                if (I < 3) {
-                    Y[0][0][nb] += s0;
-                    Y[0][1][nb] += s1;
-                }
-                if (I == 1) {
-                    Y[1][0][nb] += s0;
-                    Y[1][1][nb] += s1;
-                }
-                if (I >= 2) {
-                    Y[1][0][nb] -= s0;
-                    Y[1][1][nb] -= s1;
-                }
+        }
+        // fold, element by element (a packed fp32 add beside MFMAs costs the wave an MFMA slot: scripts/ubench/mfma16_valu_overlap.hip)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s0 = m[0][e] + m[1][e] + m[2][e], s1 = m[1][e] - m[2][e] - m[3][e];
+            if (I < 3) {
+                Y[0][0][nb][e] += s0;
+                Y[0][1][nb][e] += s1;
+            }
+            if (I == 1) {
+                Y[1][0][nb][e] += s0;
+                Y[1][1][nb][e] += s1;
+            }
+            if (I >= 2) {
+                Y[1][0][nb][e] -= s0;
+                Y[1][1][nb][e] -= s1;
             }
         }
+#if WX6_SCHED
+        // [3 LDS reads of the next xi] then (MFMA, WX6_SCHED vector instructions) x 6, four times
+#pragma unroll
+        for (int xl = 0; xl < XG; ++xl) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, WX6_SCHED, 0);
+            }
+        }
+#endif
     };
 #ifdef WX6_TIMING
     unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -405,48 +450,72 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
     load_row(d2, cur, 2);
     load_row(d1, cur, 1);
     load_row(d3, cur, 3);
-    activate_row(d0, cur, 0);
-    activate_row(d2, cur, 2);
+    XfTab xc, xn;                                 // this step's / the next step's activation parameters
+    load_xf(xc, cur);
+    load_xf(xn, nxt);
+    activate_row(d0, cur, xc, 0);
+    activate_row(d2, cur, xc, 2);
     make_planes(d0, d2, -1.f, PA);                // t0 = d0 - d2
     const int nsteps = (item_end - item_begin) * nchunks;
     WXSTAMP(5)
     for (int s = 0; s < nsteps; ++s) {
-        // block 0: MFMA row 0 (PA, slot 0) | vector: row 3 (t3 = d1 - d3) -> PB | loads: next d0, next d2 (into e2)
+        // Each block runs in NBT parts (one 16-channel output tile's MFMAs each); the block's memory instructions and vector work are dealt out
+        // over the parts, every part a scheduling region of its own.
+        constexpr int QP = 4 / NBT;               // vector / load quarters per part
+        // block 0: MFMA row 0 (PA, slot 0) | vector: row 3 (t3 = d1 - d3) -> PB | loads: next d0, next d2 (into e2) | DMA: row 3 -> slot 1
         stage_sync();
-        stage_U(cur.c, 3, 1);
-        load_row(d0, nxt, 0);
-        load_row(e2, nxt, 2);
-        WXSTAMP(2)
-        activate_row(d1, cur, 1);
-        activate_row(d3, cur, 3);
-        make_planes(d1, d3, -1.f, PB);
-        mfma_row(0, PA, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // block 1: MFMA row 3 (PB, slot 1) | vector: row 1 (t1 = d1 + d2) -> PA | loads: next d3
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            stage_U_q(cur.c, 3, 1, nb, NBT);
+#pragma unroll
+            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
+                load_row_q(d0, nxt, 0, q);
+                load_row_q(e2, nxt, 2, q);
+                activate_row_q(d1, cur, xc, 1, q);
+                activate_row_q(d3, cur, xc, 3, q);
+                make_planes_q(d1, d3, -1.f, PB, q);
+            }
+            mfma_row_nb(0, PA, 0, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // block 1: MFMA row 3 (PB, slot 1) | vector: row 1 (t1 = d1 + d2) -> PA | loads: next d3 | DMA: row 1 -> slot 0
         stage_sync();
-        stage_U(cur.c, 1, 0);
-        load_row(d3, nxt, 3);
-        WXSTAMP(2)
-        make_planes(d1, d2, 1.f, PA);
-        mfma_row(3, PB, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // block 2: MFMA row 1 (PA, slot 0) | vector: row 2 (t2 = d2 - d1) -> PB
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            stage_U_q(cur.c, 1, 0, nb, NBT);
+#pragma unroll
+            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
+                load_row_q(d3, nxt, 3, q);
+                make_planes_q(d1, d2, 1.f, PA, q);
+            }
+            mfma_row_nb(3, PB, 1, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // block 2: MFMA row 1 (PA, slot 0) | vector: row 2 (t2 = d2 - d1) -> PB | DMA: row 2 -> slot 1
         stage_sync();
-        stage_U(cur.c, 2, 1);
-        WXSTAMP(2)
-        make_planes(d2, d1, -1.f, PB);
-        mfma_row(1, PA, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // block 3: MFMA row 2 (PB, slot 1) | vector: the next step's row 0 -> PA | loads: next d1
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            stage_U_q(cur.c, 2, 1, nb, NBT);
+#pragma unroll
+            for (int q = nb * QP; q < (nb + 1) * QP; ++q) make_planes_q(d2, d1, -1.f, PB, q);
+            mfma_row_nb(1, PA, 0, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // block 3: MFMA row 2 (PB, slot 1) | vector: the next step's row 0 -> PA | loads: next d1 | DMA: the next step's row 0 -> slot 0
         stage_sync();
-        stage_U(nxt.c, 0, 0);
-        load_row(d1, nxt, 1);
-        WXSTAMP(2)
-        activate_row(d0, nxt, 0);
-        activate_row(e2, nxt, 2);
-        make_planes(d0, e2, -1.f, PA);
-        mfma_row(2, PB, 1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            stage_U_q(nxt.c, 0, 0, nb, NBT);
+#pragma unroll
+            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
+                load_row_q(d1, nxt, 1, q);
+                activate_row_q(d0, nxt, xn, 0, q);
+                activate_row_q(e2, nxt, xn, 2, q);
+                make_planes_q(d0, e2, -1.f, PA, q);
+            }
+            mfma_row_nb(2, PB, 1, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -455,7 +524,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         if (cur.c == nchunks - 1) epilogue(cur.item);
         WXSTAMP(4)
         cur = nxt;
+        xc = xn;
         advance(nxt);
+        load_xf(xn, nxt);                         // (used from block 3 of the coming step on)
     }
 
 #ifdef WX6_TIMING
