@@ -398,8 +398,15 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                     traffic = None
             ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
             wino = dom.startswith(('conv_wino', 'conv_thin_wino'))
-            x6 = dom.startswith(('dcn_x6', 'conv_x6', 'conv_flat_x6', 'flash_attn_x'))
-            if x6:
+            x6 = dom.startswith(("dcn_x6", "conv_x6", "conv_wino_x6", "flash_attn_x"))
+            if dom.startswith('conv_wino_x6'):
+                # Winograd F(2x2,3x3) with three-plane operands: 2.25 x fewer products than the direct conv, six bf16 MFMAs each -- `achieved` /
+                # `frac` are the ISSUED bf16 FLOPs (direct-conv FLOPs x 6 / 2.25) against the bf16 matrix peak
+                iss = ach_t * 6 / 2.25
+                roof = dict(bound='mfma', achieved=round(iss, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(iss / PEAK_BF16_TFLOPS, 4),
+                            direct_conv_tflops=round(ach_t, 2), fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
+                note = 'Winograd F(2x2,3x3), operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product: achieved = ISSUED bf16 FLOPs'
+            elif x6:
                 # three-plane kernels: fp32-equivalent products as six bf16 MFMAs over operands split into three bf16 planes -- `achieved` /
                 # `frac` are the ISSUED bf16 FLOPs (6 x algorithmic) against the bf16 matrix peak; the algorithmic rate has its own name
                 roof = dict(bound='mfma', achieved=round(6 * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',

@@ -562,7 +562,7 @@ int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
     if (!ok) return 1;
     if ((d.flags & GSSD_CONV_POOL2) && (d.resid || !d.pool_sign)) return 1;
     // the same transforms with the 16 GEMMs on the bf16 matrix cores (three-plane operands, conv_wino_x6.hip): its U planes lie behind the fp32 U
-    if (gssd_wino_x6_enabled() && gssd_wino_x6_plane_elems(cout_g, d.groups, d.cin_g) > 0)
+    if (gssd_wino_x6_plane_elems(cout_g, d.groups, d.cin_g) > 0 && gssd_wino_x6_wanted(d))
         return gssd_launch_conv_wino_x6(d, d.wgt_wino + 16ll * d.groups * wino_u_rows(cout_g, d.groups) * d.cin_g, stream);
     // NB = 64 holds 256 accumulators per lane and has no registers left for a prefetched patch across the epilogue: one item
     // per workgroup there; the NB = 32 variant (conv2_2: two chunks per item) runs persistent.  (Round 2: the persistent NB = 32
@@ -594,7 +594,7 @@ extern "C" int gssd_conv_wino_x6_takes(const gssd_conv_desc* d) {
                     d->out_mode == GSSD_OUT_NHWC && !d->alpha && !d->gate && !d->out2 && !d->relu && d->split_k <= 1 && !d->m_per_image &&
                     d->in_stride % 4 == 0 && d->in_ch_off % 4 == 0 && (long long)d->B * d->H * d->W * d->in_stride < (1ll << 30);
     if (!ok || ((d->flags & GSSD_CONV_POOL2) && (d->resid || !d->pool_sign))) return 0;
-    return gssd_wino_x6_plane_elems(cout_g, d->groups, d->cin_g) > 0;
+    return gssd_wino_x6_plane_elems(cout_g, d->groups, d->cin_g) > 0 && gssd_wino_x6_wanted(*d);
 }
 
 extern "C" int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,

@@ -7,22 +7,23 @@
 // of Winograd's 2.25 x fewer products.  The transforms stay fp32 and are the ones of conv_wino.hip (V = B^T d B straight from global memory,
 // Y = A^T M A in registers), so the result differs from that kernel only by the products' last bit.
 //
-// What shapes the kernel: the vector ALU reaches only the 256 architectural registers and the split costs ~7 vector instructions per operand
-// element, so (a) the planes of all 16 xi of a K chunk (192 registers) plus 256 accumulators cannot exist at once, and (b) an output-channel block
-// must be as wide as possible (every block re-does the transform + split of the same patches).  Hence:
-//   * a workgroup (4 waves, one per SIMD) owns 64 consecutive tiles of the linearised (image, tile_y, tile_x) list -- 16 per wave -- and NB = 64
-//     (or 32) output channels of one group, and is persistent over a contiguous range of such items;
-//   * an item runs as FOUR PASSES, one per row i of the 4 x 4 Winograd domain: pass i needs only t_i. = (B^T d)_i. (two patch rows), V_i. = t_i. B
-//     (four xi), their three-plane split (48 registers) and 4 x NBT accumulators; after its K loop the pass is folded into the 2 x 2 outputs
-//     Y[a][b] += A[i][a] (M_i. A)[b] (Y = A^T M A is linear in M) and the accumulators are free again.  Patch rows are re-read by the passes that
-//     share them (from L1 / L2), U is streamed exactly once;
+// What shapes the kernel: with one wave per SIMD a wave issues a vector instruction every ~8 cycles, and the transform + three-plane split cost
+// ~2000 of them per 32-channel chunk of 16 tiles against 384 MFMAs (6.1 k cycles) -- a single instruction stream that does both runs at 27 k
+// cycles per chunk whatever the order (measured: scripts/wino_x6_timing.py, profiles/r05_e_*).  Hence TWO ROLES, one wave of each per SIMD:
+//   * a workgroup = 8 waves owns 64 consecutive tiles of the linearised (image, tile_y, tile_x) list and NB = 64 (or 32) output channels of one
+//     group, persistent over a contiguous range of such items.  Waves 0-3 are PRODUCERS (tile group w: 16 tiles): patch loads, producer BatchNorm
+//     + ReLU, the Winograd input transform, the split, operand planes -> LDS in MFMA-operand order (lane-linear: 16 bytes per lane, xi and plane).
+//     Waves 4-7 are CONSUMERS (tile group w - 4): U planes by LDS-DMA, fragment reads, the MFMAs, the output transform and the epilogue.
+//     Waves w and w + 4 share a SIMD: its matrix pipe and its vector issue slots are used by different instruction streams;
 //   * K runs in chunks of 32 input channels: lane (tile r, quad kq) owns channels 4 kq .. 4 kq + 3 of both 16-channel halves of the chunk (one
 //     16-byte load per patch position and half, conv_wino.hip's layout); the halves fill slots 0-3 / 4-7 of the lane's bf16x8 MFMA operand and U is
 //     packed in the same slot order (the MFMA only needs both operands to agree on which channel sits in which k slot);
-//   * a stage = (pass, chunk): U planes of its four xi by LDS-DMA (4 xi x 3 planes x NB x 32 bf16, double buffered); the stage body is ONE basic
-//     block -- the DMA of stage s + 1, the patch loads of stage s + 2, the vector work of stage s + 1 (producer BatchNorm + ReLU, t, V, split) and
-//     the 24 NBT MFMAs of stage s -- so that the vector work runs beside the MFMAs (the bf16 MFMA does not use the vector ALU's lanes).  Past
-//     the last stage the last one is prepared again (results unused): no branch in the body.
+//   * a chunk runs as four BLOCKS, one per row i of the 4 x 4 Winograd domain, in the order 0, 3, 1, 2: block i needs t_i. = (B^T d)_i. (two patch
+//     rows, loaded ONCE per chunk and kept in the producer's registers), V_i. = t_i. B (four xi) and their planes; the consumer folds the block's
+//     products into the 2 x 2 outputs right away, Y[a][b] += A[i][a] (M_i. A)[b] (Y = A^T M A is linear in M), so it keeps 16 NBT output
+//     registers instead of 64 NBT accumulators;
+//   * per block two barriers: A -- the block's planes are in LDS and its U planes have landed; B -- the consumers hold the planes in registers,
+//     the producers may write the next block's.  U stages (4 xi x 3 planes x NB x 32 bf16) are double buffered.
 #include "common.h"
 #include <cstdlib>
 
@@ -33,26 +34,9 @@ typedef unsigned short u16;
 #ifndef WX6_KO
 #define WX6_KO 0              // knock-outs (scripts/wino_x6_knockout.sh; results wrong by construction): 1 no vector work (transform / split), 2 no MFMAs,
 #endif                        // 4 no U DMA, 8 no patch loads, 16 no fragment reads
-#ifndef WX6_SCHED
-#define WX6_SCHED 4           // vector instructions pinned behind every MFMA of a part (0: the compiler's own order)
-#endif
 #ifndef WX6_LOCAL_SUM
 #define WX6_LOCAL_SUM 1       // the six products of a chunk are summed from zero and added to the running sum by the vector ALU (the bf16 MFMA's
 #endif                        // adder truncates: conv_x6.hip)
-
-#ifdef WX6_TIMING
-// debug build (scripts/wino_x6_timing.py): wave 0 of every workgroup accumulates the shader clocks between its phase boundaries
-__device__ unsigned long long g_wx6_timing[8];
-extern "C" int gssd_wino_x6_timing_read(unsigned long long* out8) {
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wx6_timing), 64);
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_wx6_timing), z, 64);
-    return 0;
-}
-#define WXSTAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; }
-#else
-#define WXSTAMP(k)
-#endif
 
 namespace {
 
@@ -98,11 +82,15 @@ struct Step {                // a step = one 32-channel chunk of one item + the 
 
 // PSEL: out-of-image patch positions are replaced by the padding value with a select (else: the loads already fetched it, WinoX6Params::pad_off)
 template <int NBT, bool XF, int EPI, bool PSEL>      // NB = 16 NBT output channels per workgroup; EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
-__global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params p) {
+__global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params p) {
     constexpr int NB = 16 * NBT, TILE = NB * 32, STAGE = XG * NP * TILE, CHUNK = 16 * NP * TILE;
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];      // [2][STAGE]
+    constexpr int PWAVE = XG * NP * 512;                             // u16 elements of one tile group's planes of a block: [xi][plane][lane][8]
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];      // U [2][STAGE] | P [4 tile groups][PWAVE]
+    u16* const Pl = smem + 2 * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    const int wv = wave & 3;                                         // tile group
     const int r = lane & 15, kq = lane >> 4;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int nitems = (p.ntiles + 63) >> 6;
@@ -119,6 +107,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
     const u16* Ug = p.Ux + (size_t)pair * p.nchunks * CHUNK + lane * 8;
     const int nchunks = p.nchunks;
     const bool tailB = (p.cin_g & 31) != 0;                           // the last chunk has one 16-channel half only
+    const int nsteps = (item_end - item_begin) * nchunks;            // a step = one 32-channel chunk of one item = four blocks
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto decode = [&](int it, unsigned& pix_off, unsigned& valid) {
         const int t = (it * 4 + wv) * 16 + r;
@@ -147,6 +137,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
         }
         s = n;
     };
+
+    if (producer) {
+        // =============================== producer: patch rows -> activated -> Winograd row -> three planes -> LDS ===============================
     // one patch row (4 positions, both 16-channel halves) of a step: row[half][position].  Loads, activation and the plane construction are dealt
     // out in QUARTERS (quarter q: half q >> 1; loads: positions 2 (q & 1), + 1; vector work: channels e = 2 (q & 1), + 1 of the lane's quad) so
     // that a block can issue its memory instructions a few at a time between its MFMA groups: a burst of 12 DMA pieces + 16 loads in front of a
@@ -222,14 +215,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
             float t[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] = ra[hf][j][e] + sg * rb[hf][j][e];
-            const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+            // the four V of the channel as one 4-vector: the split's dependent chain (convert, subtract, convert, subtract, convert) runs on four
+            // independent values side by side
+            const f32x4 v = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+            __bf16 h[4], m[4], l[4];
+            f32x4 r1, r2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r1[j] = v[j] - (float)h[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = (__bf16)r1[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r2[j] = r1[j] - (float)m[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) l[j] = (__bf16)r2[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                __bf16 h, m, l;
-                split3(v[j], h, m, l);
-                P[j][0][4 * hf + e] = h;
-                P[j][1][4 * hf + e] = m;
-                P[j][2][4 * hf + e] = l;
+                P[j][0][4 * hf + e] = h[j];
+                P[j][1][4 * hf + e] = m[j];
+                P[j][2][4 * hf + e] = l[j];
             }
         }
     };
@@ -237,351 +242,328 @@ __global__ __launch_bounds__(256, 1) void conv_wino_x6_kernel(const WinoX6Params
 #pragma unroll
         for (int q = 0; q < 4; ++q) make_planes_q(ra, rb, sg, P, q);
     };
-    // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, wave w moves pieces w, w + 4, ..
-    auto stage_U_q = [&](const int c, const int i, const int slot, const int q, const int nq) {      // part q of nq
-        if (WX6_KO & 4) return;
-        const u16* src = Ug + (size_t)c * CHUNK + i * STAGE;
-        u16* dst = smem + slot * STAGE;
-        constexpr int PW = STAGE / 512 / 4;       // pieces per wave
+        u16* const Pw = Pl + wv * PWAVE + lane * 8;
+        auto put_planes = [&](const bf16x8 (&P)[4][NP]) {
 #pragma unroll
-        for (int k = 0; k < PW; ++k) {
-            if (k * nq / PW != q) continue;
-            const int piece = 4 * k + wv;
-            dma16(src + piece * 512, dst + piece * 512);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(Pw + (j * NP + q) * 512) = P[j][q];
+        };
+        // barrier B of the block that is running (its planes are in the consumers' registers), the next block's planes -> LDS, barrier A of the next
+        auto hand_over = [&](const bf16x8 (&P)[4][NP]) {
+            __builtin_amdgcn_s_barrier();                 // B
+            put_planes(P);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // A
+        };
+        Step cur;
+        cur.item = item_begin;
+        cur.c = 0;
+        decode(cur.item, cur.pix, cur.valid);
+        Step nxt = cur;
+        advance(nxt);
+        Row d0, d1, d2, d3, e2;                       // e2: the next step's row 2 (row 2 is the last to die)
+        bf16x8 P[4][NP];
+        XfTab xc, xn;
+        load_xf(xc, cur);
+        load_xf(xn, nxt);
+        load_row(d0, cur, 0);
+        load_row(d2, cur, 2);
+        load_row(d1, cur, 1);
+        load_row(d3, cur, 3);
+        activate_row(d0, cur, xc, 0);
+        activate_row(d2, cur, xc, 2);
+        make_planes(d0, d2, -1.f, P);                 // row 0: t0 = d0 - d2
+        put_planes(P);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // A of block 0
+        for (int s = 0; s < nsteps; ++s) {
+            // while the consumers run row 0: row 3 (t3 = d1 - d3); rows d0 / (next) d2 reload
+            load_row(d0, nxt, 0);
+            load_row(e2, nxt, 2);
+            activate_row(d1, cur, xc, 1);
+            activate_row(d3, cur, xc, 3);
+            make_planes(d1, d3, -1.f, P);
+            hand_over(P);
+            // while they run row 3: row 1 (t1 = d1 + d2)
+            load_row(d3, nxt, 3);
+            make_planes(d1, d2, 1.f, P);
+            hand_over(P);
+            // while they run row 1: row 2 (t2 = d2 - d1)
+            make_planes(d2, d1, -1.f, P);
+            hand_over(P);
+            // while they run row 2: the next step's row 0 (past the end: this step's again, unused)
+            load_row(d1, nxt, 1);
+            activate_row(d0, nxt, xn, 0);
+            activate_row(e2, nxt, xn, 2);
+            make_planes(d0, e2, -1.f, P);
+            hand_over(P);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d2[hf][j] = e2[hf][j];
+            cur = nxt;
+            xc = xn;
+            advance(nxt);
+            load_xf(xn, nxt);
         }
-    };
-    auto stage_U = [&](const int c, const int i, const int slot) { stage_U_q(c, i, slot, 0, 1); };
-
-    f32x4 Y[2][2][NBT];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int nb = 0; nb < NBT; ++nb) Y[a][b][nb] = zero4;
-    f32x4 ssum[NBT], ssq[NBT];
-#pragma unroll
-    for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = zero4;
-    const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
-    const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row block of a tile
-
-    auto epilogue = [&](int item) {
-        // lane (r, kq) holds Y[a][b] of channels n0 + nb*16 + 4*kq + j of tile r (conv_wino.hip's epilogue)
-        const int t = (item * 4 + wv) * 16 + r;
-        if (t < p.ntiles) {
-            const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
-            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-            const int y = 2 * ty, x = 2 * tx;
-            const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
-            const int ch0 = g * p.cout_g + n0 + kq * 4;
-            const size_t o00 = EPI == 2 ? ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch0
-                                        : ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + ch0;
-#pragma unroll
-            for (int nb = 0; nb < NBT; ++nb) {
-                const int nrem = p.cout_g - (n0 + nb * 16 + kq * 4);      // channels of this quad that exist (zero rows of U beyond)
-                if (nrem <= 0) continue;
-                f32x4 bia = zero4;
-                if (p.bias) {
-                    if (vec && nrem >= 4) bia = *reinterpret_cast<const f32x4*>(p.bias + ch0 + nb * 16);
-                    else
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < nrem) bia[j] = p.bias[ch0 + nb * 16 + j];
-                }
-                f32x4 v[2][2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) v[a][c2] = Y[a][c2][nb] + bia;
-                auto put = [&](size_t o, const f32x4& val) {
-                    if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
-                    else
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < nrem) p.out[o + j] = val[j];
-                };
-                if (EPI == 2) {
-                    // GSSD_CONV_POOL2: a Winograd tile IS a pooling window; batch sums in the order of the unpooled epilogue
-                    f32x4 mx = v[0][0], mn = v[0][0];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) {
-                            if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                mx[j] = fmaxf(mx[j], v[a][c2][j]);
-                                mn[j] = fminf(mn[j], v[a][c2][j]);
-                                ssum[nb][j] += v[a][c2][j];
-                                ssq[nb][j] = __builtin_fmaf(v[a][c2][j], v[a][c2][j], ssq[nb][j]);
-                            }
-                        }
-                    f32x4 sgn = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (vec && nrem >= 4) sgn = *reinterpret_cast<const f32x4*>(p.pool_sign + ch0 + nb * 16);
-                    else
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < nrem) sgn[j] = p.pool_sign[ch0 + nb * 16 + j];
-                    f32x4 res;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) res[j] = sgn[j] >= 0.f ? mx[j] : mn[j];
-                    put(o00 + nb * 16, res);
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) {
-                            if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
-                            const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
-                            f32x4 val = v[a][c2];
-                            if (EPI == 1) {
-                                if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
-                                else
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        if (j < nrem) val[j] += p.resid[o + j];
-                            }
-                            put(o, val);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                ssum[nb][j] += val[j];
-                                ssq[nb][j] = __builtin_fmaf(val[j], val[j], ssq[nb][j]);
-                            }
-                        }
-                }
-            }
-        }
+    } else {
+        // =============================== consumer: U planes by LDS-DMA, MFMAs, output transform, epilogue =========================================
+        f32x4 Y[2][2][NBT];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int nb = 0; nb < NBT; ++nb) Y[a][b2][nb] = zero4;
-    };
-
-
-    // the four xi of Winograd row I: 24 NBT MFMAs from the row's planes and LDS slot `slot`, folded into the 2 x 2 outputs right away
-    // (Y = A^T M A is linear in M: Y[a][b] += A[I][a] (M_I. A)[b]; A^T = [1 1 1 0; 0 1 -1 -1])
-    // one 16-channel output tile of Winograd row I: the weight fragments of xi k + 1 are requested before the MFMAs of xi k (one wave per SIMD:
-    // an LDS read issued right in front of its MFMA costs the wave the whole LDS latency); VPM vector instructions are pinned behind every MFMA
-    auto mfma_row_nb = [&](const int I, const bf16x8 (&Pc)[4][NP], const int slot, const int nb) {
-        const u16* ub = smem + slot * STAGE + fo + nb * 16 * 32;
-        bf16x8 u[2][NP];
-        auto frags = [&](const int xl, bf16x8 (&dst)[NP]) {
+                for (int nb = 0; nb < NBT; ++nb) Y[a][b][nb] = zero4;
+        f32x4 ssum[NBT], ssq[NBT];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                if (WX6_KO & 16) asm volatile("" : "=v"(dst[q]));
-                else dst[q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE);
+        for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = zero4;
+        const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
+        const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row block of a tile
+        // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, consumer wave w moves pieces w, w + 4, ..
+        auto stage_U_part = [&](const int c, const int i, const int slot, const int part) {      // part of NBT (-1: all)
+            if (WX6_KO & 4) return;
+            const u16* src = Ug + (size_t)c * CHUNK + i * STAGE;
+            u16* dst = smem + slot * STAGE;
+            constexpr int PW = STAGE / 512 / 4;       // pieces per consumer wave
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                if (part >= 0 && k * NBT / PW != part) continue;
+                const int piece = 4 * k + wv;
+                dma16(src + piece * 512, dst + piece * 512);
             }
         };
-        frags(0, u[0]);
-        f32x4 m[XG];
+        auto stage_U = [&](const int c, const int i, const int slot) { stage_U_part(c, i, slot, -1); };
+    auto epilogue = [&](int item) {
+            // lane (r, kq) holds Y[a][b] of channels n0 + nb*16 + 4*kq + j of tile r (conv_wino.hip's epilogue)
+            const int t = (item * 4 + wv) * 16 + r;
+            if (t < p.ntiles) {
+                const int b = t / tiles_per_img, rem = t - b * tiles_per_img;
+                const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+                const int y = 2 * ty, x = 2 * tx;
+                const bool y1 = y + 1 < p.H, x1 = x + 1 < p.W;
+                const int ch0 = g * p.cout_g + n0 + kq * 4;
+                const size_t o00 = EPI == 2 ? ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * p.out_stride + p.out_ch_off + ch0
+                                            : ((size_t)(b * p.H + y) * p.W + x) * p.out_stride + p.out_ch_off + ch0;
 #pragma unroll
-        for (int xl = 0; xl < XG; ++xl) {
-            if (xl + 1 < XG) frags(xl + 1, u[(xl + 1) & 1]);
-            const bf16x8 (&uc)[NP] = u[xl & 1];
-            // six products, smallest first (uc: weight planes, Pc: activation planes), summed from zero
-            f32x4 s6 = zero4;
-            if (!(WX6_KO & 2)) {
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][1], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[2], Pc[xl][0], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][2], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][0], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][1], s6, 0, 0, 0);
-                s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][0], s6, 0, 0, 0);
-            }
-            m[xl] = s6;
-        }
-        // fold, element by element (a packed fp32 add beside MFMAs costs the wave an MFMA slot: scripts/ubench/mfma16_valu_overlap.hip)
+                for (int nb = 0; nb < NBT; ++nb) {
+                    const int nrem = p.cout_g - (n0 + nb * 16 + kq * 4);      // channels of this quad that exist (zero rows of U beyond)
+                    if (nrem <= 0) continue;
+                    f32x4 bia = zero4;
+                    if (p.bias) {
+                        if (vec && nrem >= 4) bia = *reinterpret_cast<const f32x4*>(p.bias + ch0 + nb * 16);
+                        else
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float s0 = m[0][e] + m[1][e] + m[2][e], s1 = m[1][e] - m[2][e] - m[3][e];
-            if (I < 3) {
-                Y[0][0][nb][e] += s0;
-                Y[0][1][nb][e] += s1;
-            }
-            if (I == 1) {
-                Y[1][0][nb][e] += s0;
-                Y[1][1][nb][e] += s1;
-            }
-            if (I >= 2) {
-                Y[1][0][nb][e] -= s0;
-                Y[1][1][nb][e] -= s1;
-            }
-        }
-#if WX6_SCHED
-        // [3 LDS reads of the next xi] then (MFMA, WX6_SCHED vector instructions) x 6, four times
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) bia[j] = p.bias[ch0 + nb * 16 + j];
+                    }
+                    f32x4 v[2][2];
 #pragma unroll
-        for (int xl = 0; xl < XG; ++xl) {
-            __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, WX6_SCHED, 0);
+                        for (int c2 = 0; c2 < 2; ++c2) v[a][c2] = Y[a][c2][nb] + bia;
+                    auto put = [&](size_t o, const f32x4& val) {
+                        if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
+                        else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) p.out[o + j] = val[j];
+                    };
+                    if (EPI == 2) {
+                        // GSSD_CONV_POOL2: a Winograd tile IS a pooling window; batch sums in the order of the unpooled epilogue
+                        f32x4 mx = v[0][0], mn = v[0][0];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    mx[j] = fmaxf(mx[j], v[a][c2][j]);
+                                    mn[j] = fminf(mn[j], v[a][c2][j]);
+                                    ssum[nb][j] += v[a][c2][j];
+                                    ssq[nb][j] = __builtin_fmaf(v[a][c2][j], v[a][c2][j], ssq[nb][j]);
+                                }
+                            }
+                        f32x4 sgn = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (vec && nrem >= 4) sgn = *reinterpret_cast<const f32x4*>(p.pool_sign + ch0 + nb * 16);
+                        else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nrem) sgn[j] = p.pool_sign[ch0 + nb * 16 + j];
+                        f32x4 res;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) res[j] = sgn[j] >= 0.f ? mx[j] : mn[j];
+                        put(o00 + nb * 16, res);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
+                                const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
+                                f32x4 val = v[a][c2];
+                                if (EPI == 1) {
+                                    if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
+                                    else
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            if (j < nrem) val[j] += p.resid[o + j];
+                                }
+                                put(o, val);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    ssum[nb][j] += val[j];
+                                    ssq[nb][j] = __builtin_fmaf(val[j], val[j], ssq[nb][j]);
+                                }
+                            }
+                    }
+                }
             }
-        }
-#endif
-    };
-#ifdef WX6_TIMING
-    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
-    auto stage_sync = [&]() {
-        WXSTAMP(3)                                // (the block that just ended: vector work + MFMAs)
-        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's DMA pieces of the stage have landed (and the patch rows loaded a block ago)
-        WXSTAMP(0)
-        __syncthreads();                          // ... everyone's have; the other slot is free again
-        WXSTAMP(1)
-    };
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; ++nb) Y[a][b2][nb] = zero4;
+        };
 
-    // ---- the step stream: a step = one chunk = four blocks in the row order 0, 3, 1, 2 (rows d0 and d3 die first: their registers take the next
-    // step's loads).  Block k: [sync] [DMA of the next block's U planes] [patch loads of the next step into rows that are dead] [vector work of the
-    // NEXT block's Winograd row] [MFMAs + fold of this block's row] -- one basic block, so the vector work runs beside the MFMAs.
-    Step cur;
-    cur.item = item_begin;
-    cur.c = 0;
-    decode(cur.item, cur.pix, cur.valid);
-    Step nxt = cur;
-    advance(nxt);
-    Row d0, d1, d2, d3, e2;                       // e2: the next step's row 2 (row 2 is the last to die)
-    bf16x8 PA[4][NP], PB[4][NP];
-    stage_U(cur.c, 0, 0);
-    load_row(d0, cur, 0);
-    load_row(d2, cur, 2);
-    load_row(d1, cur, 1);
-    load_row(d3, cur, 3);
-    XfTab xc, xn;                                 // this step's / the next step's activation parameters
-    load_xf(xc, cur);
-    load_xf(xn, nxt);
-    activate_row(d0, cur, xc, 0);
-    activate_row(d2, cur, xc, 2);
-    make_planes(d0, d2, -1.f, PA);                // t0 = d0 - d2
-    const int nsteps = (item_end - item_begin) * nchunks;
-    WXSTAMP(5)
-    for (int s = 0; s < nsteps; ++s) {
-        // Each block runs in NBT parts (one 16-channel output tile's MFMAs each); the block's memory instructions and vector work are dealt out
-        // over the parts, every part a scheduling region of its own.
-        constexpr int QP = 4 / NBT;               // vector / load quarters per part
-        // block 0: MFMA row 0 (PA, slot 0) | vector: row 3 (t3 = d1 - d3) -> PB | loads: next d0, next d2 (into e2) | DMA: row 3 -> slot 1
-        stage_sync();
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            stage_U_q(cur.c, 3, 1, nb, NBT);
-#pragma unroll
-            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
-                load_row_q(d0, nxt, 0, q);
-                load_row_q(e2, nxt, 2, q);
-                activate_row_q(d1, cur, xc, 1, q);
-                activate_row_q(d3, cur, xc, 3, q);
-                make_planes_q(d1, d3, -1.f, PB, q);
-            }
-            mfma_row_nb(0, PA, 0, nb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // block 1: MFMA row 3 (PB, slot 1) | vector: row 1 (t1 = d1 + d2) -> PA | loads: next d3 | DMA: row 1 -> slot 0
-        stage_sync();
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            stage_U_q(cur.c, 1, 0, nb, NBT);
-#pragma unroll
-            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
-                load_row_q(d3, nxt, 3, q);
-                make_planes_q(d1, d2, 1.f, PA, q);
-            }
-            mfma_row_nb(3, PB, 1, nb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // block 2: MFMA row 1 (PA, slot 0) | vector: row 2 (t2 = d2 - d1) -> PB | DMA: row 2 -> slot 1
-        stage_sync();
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            stage_U_q(cur.c, 2, 1, nb, NBT);
-#pragma unroll
-            for (int q = nb * QP; q < (nb + 1) * QP; ++q) make_planes_q(d2, d1, -1.f, PB, q);
-            mfma_row_nb(1, PA, 0, nb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // block 3: MFMA row 2 (PB, slot 1) | vector: the next step's row 0 -> PA | loads: next d1 | DMA: the next step's row 0 -> slot 0
-        stage_sync();
-#pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            stage_U_q(nxt.c, 0, 0, nb, NBT);
-#pragma unroll
-            for (int q = nb * QP; q < (nb + 1) * QP; ++q) {
-                load_row_q(d1, nxt, 1, q);
-                activate_row_q(d0, nxt, xn, 0, q);
-                activate_row_q(e2, nxt, xn, 2, q);
-                make_planes_q(d0, e2, -1.f, PA, q);
-            }
-            mfma_row_nb(2, PB, 1, nb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d2[hf][j] = e2[hf][j];
-        WXSTAMP(3)
-        if (cur.c == nchunks - 1) epilogue(cur.item);
-        WXSTAMP(4)
-        cur = nxt;
-        xc = xn;
-        advance(nxt);
-        load_xf(xn, nxt);                         // (used from block 3 of the coming step on)
-    }
 
-#ifdef WX6_TIMING
-    if (tid == 0) {
-        for (int k = 0; k < 6; ++k) atomicAdd(&g_wx6_timing[k], tacc[k]);
-        atomicAdd(&g_wx6_timing[6], (unsigned long long)nsteps);
-        atomicAdd(&g_wx6_timing[7], 1ull);
-    }
-#endif
-    if (p.stats) {                                        // one flush per workgroup: 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
-        __builtin_amdgcn_s_waitcnt(0x0f70);               // the last body's (unused) DMA has landed before LDS is reused
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 waves][NB][2]
-        float fs[4 * NBT], fq[4 * NBT];                   // value index i: channel n0 + 16 * (i >> 2) + 4 * kq + (i & 3)
+        // the four xi of Winograd row I: 24 NBT MFMAs from the row's planes and LDS slot `slot`, folded into the 2 x 2 outputs right away
+        // (Y = A^T M A is linear in M: Y[a][b] += A[I][a] (M_I. A)[b]; A^T = [1 1 1 0; 0 1 -1 -1])
+
+        // Winograd row I: the planes of its four xi (LDS -> registers, then barrier B), 24 NBT MFMAs against the U planes of LDS slot `slot`, folded
+        // into the 2 x 2 outputs right away (Y[a][b] += A[I][a] (M_I. A)[b]; A^T = [1 1 1 0; 0 1 -1 -1])
+        const u16* const Pr = Pl + wv * PWAVE + lane * 8;
+        auto run_row = [&](const int I, const int slot, const int c_next, const int i_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the block's U planes have landed
+            __builtin_amdgcn_s_barrier();                 // A: everyone's have, the producers' planes are in LDS
+            bf16x8 Pc[4][NP];
 #pragma unroll
-        for (int i = 0; i < 4 * NBT; ++i) {
-            fs[i] = ssum[i >> 2][i & 3];
-            fq[i] = ssq[i >> 2][i & 3];
-        }
-        // halving exchange over the 16 tile lanes: lane r ends with value index r & (4 NBT - 1)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int w = 8; w >= 1; w >>= 1) {
-            if (4 * NBT <= w) continue;
-            const bool up = (r & w) != 0;
+                for (int q = 0; q < NP; ++q) Pc[j][q] = *reinterpret_cast<const bf16x8*>(Pr + (j * NP + q) * 512);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // B: the plane buffer is free for the next block
+            const u16* ub = smem + slot * STAGE + fo;
+            // the 12 weight fragments of output tile nb + 1 are requested before the 24 MFMAs of tile nb (an LDS read issued right in front of
+            // its MFMA costs the wave the LDS latency: 64 such waits per step were ~10 k of the consumer's 23 k cycles); the next block's DMA pieces
+            // go out a few per tile
+            bf16x8 u[2][XG][NP];
+            auto frags = [&](const int nb, bf16x8 (&dst)[XG][NP]) {
 #pragma unroll
-            for (int i = 0; i < w; ++i) {
-                const float ks = up ? fs[i + w] : fs[i], gs = up ? fs[i] : fs[i + w];
-                const float kq2 = up ? fq[i + w] : fq[i], gq = up ? fq[i] : fq[i + w];
-                fs[i] = ks + __shfl_xor(gs, w, 64);
-                fq[i] = kq2 + __shfl_xor(gq, w, 64);
+                for (int xl = 0; xl < XG; ++xl)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        if (WX6_KO & 16) asm volatile("" : "=v"(dst[xl][q]));
+                        else dst[xl][q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+                    }
+            };
+            frags(0, u[0]);
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) {
+                if (nb + 1 < NBT) frags(nb + 1, u[(nb + 1) & 1]);
+                stage_U_part(c_next, i_next, slot ^ 1, nb);
+                f32x4 m[XG];
+#pragma unroll
+                for (int xl = 0; xl < XG; ++xl) {
+                    const bf16x8 (&uc)[NP] = u[nb & 1][xl];
+                    // six products, smallest first (uc: weight planes, Pc: activation planes), summed from zero
+                    f32x4 s6 = zero4;
+                    if (!(WX6_KO & 2)) {
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][1], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[2], Pc[xl][0], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][2], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][0], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][1], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][0], s6, 0, 0, 0);
+                    }
+                    m[xl] = s6;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s0 = m[0][e] + m[1][e] + m[2][e], s1 = m[1][e] - m[2][e] - m[3][e];
+                    if (I < 3) {
+                        Y[0][0][nb][e] += s0;
+                        Y[0][1][nb][e] += s1;
+                    }
+                    if (I == 1) {
+                        Y[1][0][nb][e] += s0;
+                        Y[1][1][nb][e] += s1;
+                    }
+                    if (I >= 2) {
+                        Y[1][0][nb][e] -= s0;
+                        Y[1][1][nb][e] -= s1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (4 * NBT == 8) {                               // the two tile-lane halves both hold value index r & 7
-            fs[0] += __shfl_xor(fs[0], 8, 64);
-            fq[0] += __shfl_xor(fq[0], 8, 64);
-        }
-        {
-            const int vi = r & (4 * NBT - 1);
-            if (r < 4 * NBT) {
-                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 0] = fs[0];
-                red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 1] = fq[0];
+        };
+        int item = item_begin, c = 0;
+        stage_U(0, 0, 0);
+        for (int s = 0; s < nsteps; ++s) {
+            const int cn = c + 1 == nchunks ? 0 : c + 1;          // the next step's chunk (past the end: harmless)
+            run_row(0, 0, c, 3);
+            run_row(3, 1, c, 1);
+            run_row(1, 0, c, 2);
+            run_row(2, 1, cn, 0);
+            if (c == nchunks - 1) {
+                epilogue(item);
+                ++item;
             }
+            c = cn;
         }
-        __syncthreads();
-        if (tid < NB && n0 + tid < p.cout_g) {
-            double s = 0.0, q = 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA past the end)
+        __builtin_amdgcn_s_barrier();                         // A of the block past the end (the producers' last hand-over); they exit behind it
+        if (p.stats) {                                        // one flush per workgroup: 16 tile lanes of a kq -> LDS over waves -> fp64 atomics
+            // (only the four consumer waves are left: the barriers below count the waves that have not ended)
+            float* red = reinterpret_cast<float*>(smem);      // [4 waves][NB][2]
+            float fs[4 * NBT], fq[4 * NBT];                   // value index i: channel n0 + 16 * (i >> 2) + 4 * kq + (i & 3)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                s += (double)red[(w * NB + tid) * 2 + 0];
-                q += (double)red[(w * NB + tid) * 2 + 1];
+            for (int i = 0; i < 4 * NBT; ++i) {
+                fs[i] = ssum[i >> 2][i & 3];
+                fq[i] = ssq[i >> 2][i & 3];
             }
-            const int n = g * p.cout_g + n0 + tid;
-            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
-            unsafeAtomicAdd(st + n, s);
-            unsafeAtomicAdd(st + p.Cout + n, q);
+            // halving exchange over the 16 tile lanes: lane r ends with value index r & (4 NBT - 1)
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1) {
+                if (4 * NBT <= w) continue;
+                const bool up = (r & w) != 0;
+#pragma unroll
+                for (int i = 0; i < w; ++i) {
+                    const float ks = up ? fs[i + w] : fs[i], gs = up ? fs[i] : fs[i + w];
+                    const float kq2 = up ? fq[i + w] : fq[i], gq = up ? fq[i] : fq[i + w];
+                    fs[i] = ks + __shfl_xor(gs, w, 64);
+                    fq[i] = kq2 + __shfl_xor(gq, w, 64);
+                }
+            }
+            if (4 * NBT == 8) {                               // the two tile-lane halves both hold value index r & 7
+                fs[0] += __shfl_xor(fs[0], 8, 64);
+                fq[0] += __shfl_xor(fq[0], 8, 64);
+            }
+            {
+                const int vi = r & (4 * NBT - 1);
+                if (r < 4 * NBT) {
+                    red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 0] = fs[0];
+                    red[(wv * NB + (vi >> 2) * 16 + kq * 4 + (vi & 3)) * 2 + 1] = fq[0];
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            const int ct = tid - 256;
+            if (ct < NB && n0 + ct < p.cout_g) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s += (double)red[(w * NB + ct) * 2 + 0];
+                    q += (double)red[(w * NB + ct) * 2 + 1];
+                }
+                const int n = g * p.cout_g + n0 + ct;
+                double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+                unsafeAtomicAdd(st + n, s);
+                unsafeAtomicAdd(st + p.Cout + n, q);
+            }
         }
     }
 }
@@ -675,7 +657,7 @@ int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t strea
     p.npairs = p.ncb * d.groups;
     p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
     p.pad_off = PSEL ? 0u : wx6_pad_off(d);
-    constexpr size_t smem = 2 * (size_t)XG * NP * NB * 32 * sizeof(u16);
+    constexpr size_t smem = (2 * (size_t)XG * NP * NB * 32 + 4 * (size_t)XG * NP * 512) * sizeof(u16);      // two U stages + the planes of a block
     auto kern = conv_wino_x6_kernel<NBT, XF, EPI, PSEL>;
     static unsigned attr_mask = 0;
     if (gssd_attr_needed(&attr_mask)) {
@@ -690,7 +672,7 @@ int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t strea
     if (gx < 1) gx = 1;
     if (gx > nitems) gx = nitems;
     p.gx = gx;
-    hipLaunchKernelGGL(kern, dim3(gx * p.npairs), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(gx * p.npairs), dim3(512), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -720,13 +702,25 @@ int gssd_wino_x6_pack(const float* w_packed, void* Ux, int Cout, int groups, int
     return GSSD_OK;
 }
 
-// GSSD_WINO_X6=1 switches it on (opt-in while it is being measured)
-bool gssd_wino_x6_enabled() {
-    static const bool on = [] {
+// GSSD_WINO_X6=0: the fp32-MFMA Winograd kernel (conv_wino.hip) keeps every launch (ablation / A-B); =2: every shape the kernel takes
+int gssd_wino_x6_mode() {
+    static const int mode = [] {
         const char* e = getenv("GSSD_WINO_X6");
-        return e && e[0] == '1';
+        return e ? atoi(e) : 1;
     }();
-    return on;
+    return mode;
+}
+bool gssd_wino_x6_enabled() { return gssd_wino_x6_mode() != 0; }
+
+// the shapes it is used for by default: where it beat conv_wino.hip in a same-box A/B at batch 32 (scripts/wino_x6_ab.sh, round 5: conv3_1 176 vs
+// 238 us, conv3_2 303 vs 353, conv4_1 145 vs 166, conv4_2 260 vs 273; 19 x 19 maps: 90 vs 91; 32-channel blocks (conv2_2) and 16-channel groups
+// (conv2_1) lose: the vector work per output channel doubles / half of every MFMA's k slots are padding)
+bool gssd_wino_x6_wanted(const gssd_conv_desc& d) {
+    const int mode = gssd_wino_x6_mode();
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    const int cout_g = d.Cout / d.groups;
+    return cout_g >= 64 && d.cin_g >= 32 && (long long)d.B * ((d.H + 1) / 2) * ((d.W + 1) / 2) >= 8192;
 }
 
 // called by gssd_try_conv_wino() once the descriptor is known to be a Winograd shape: `Ux` = the three-plane U behind the fp32 U
