@@ -709,7 +709,7 @@ def main():
         gd.init('gloo')
         seen = gd.gather_over_ranks(rank)
         if os.environ.get('GSSD_PROBE_FAIL_RANK') == str(rank):
-            sys.exit(7)                    # a rank that dies: the launcher must end the others and return its code
+            os._exit(7)                    # a rank that dies (no interpreter teardown: gloo's destructor may abort there and replace the code)
         gd.barrier()
         if rank == 0:
             print(json.dumps({'probe': True, 'n_gpus': world, 'ranks': seen, 'rccl_ranks': gd.world_size(),
