@@ -148,6 +148,7 @@ SIGNATURES = {
     'gssd_dcn_streamk': (c_i, [c_i]),
     'gssd_dcn_streamk_status': (c_i, [c_fp]),
     'gssd_dcn_streamk_reset': (c_i, [c_fp]),
+    'gssd_dcn_streamk_release': (c_i, [c_fp]),
     'gssd_dcn_forward_f32': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_resample_ksize': (c_i, [c_i, c_i, c_i]),
     'gssd_resample_coeffs': (c_i, [c_i, c_i, c_i, c_fp, c_fp]),

@@ -56,6 +56,20 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// the split of TWO values at once, planes as packed bf16 pairs (a in the low half): one v_cvt_pk_bf16_f32 per plane and pair (the element-wise
+// form costs one per element: the compiler does not pair the converts of two chains), and the packed result IS the operand dword
+__device__ __forceinline__ void split3_pair(const float a, const float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, ph << 16), rb = b - __builtin_bit_cast(float, ph & 0xffff0000u);
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, pm << 16), sb = rb - __builtin_bit_cast(float, pm & 0xffff0000u);
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
+
 struct WinoX6Params {
     const float* in;
     const u16* Ux;           // [groups][cout blocks][chunks][16 xi][3 planes][NB co][32 slots], slot groups swizzled (swz)
@@ -206,51 +220,40 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         for (int q = 0; q < 4; ++q) activate_row_q(row, s, xt, i, q);
     };
     // Winograd row: t = ra + sg * rb, V = t B, three-plane split -> the operand planes of its four xi: quarter q
-    auto make_planes_q = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP], const int q) {
+    // planes of a block as operand dwords: P[xi][plane] = 4 dwords = the lane's 8 k slots (dword 2 * half + e / 2 holds channels e, e + 1)
+    auto make_planes_q = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NP], const int q) {
         if (WX6_KO & 1) return;
-        const int hf = q >> 1;
+        const int hf = q >> 1, e = 2 * (q & 1);
+        float t0[4], t1[4];
 #pragma unroll
-        for (int ee = 0; ee < 2; ++ee) {
-            const int e = 2 * (q & 1) + ee;
-            float t[4];
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = ra[hf][j][e] + sg * rb[hf][j][e];
+            t1[j] = ra[hf][j][e + 1] + sg * rb[hf][j][e + 1];
+        }
+        const float v0[4] = {t0[0] - t0[2], t0[1] + t0[2], t0[2] - t0[1], t0[1] - t0[3]};
+        const float v1[4] = {t1[0] - t1[2], t1[1] + t1[2], t1[2] - t1[1], t1[1] - t1[3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = ra[hf][j][e] + sg * rb[hf][j][e];
-            // the four V of the channel as one 4-vector: the split's dependent chain (convert, subtract, convert, subtract, convert) runs on four
-            // independent values side by side
-            const f32x4 v = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
-            __bf16 h[4], m[4], l[4];
-            f32x4 r1, r2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r1[j] = v[j] - (float)h[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m[j] = (__bf16)r1[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r2[j] = r1[j] - (float)m[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) l[j] = (__bf16)r2[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                P[j][0][4 * hf + e] = h[j];
-                P[j][1][4 * hf + e] = m[j];
-                P[j][2][4 * hf + e] = l[j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            unsigned ph, pm, pl;
+            split3_pair(v0[j], v1[j], ph, pm, pl);
+            P[j][0][2 * hf + (q & 1)] = ph;
+            P[j][1][2 * hf + (q & 1)] = pm;
+            P[j][2][2 * hf + (q & 1)] = pl;
         }
     };
-    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, bf16x8 (&P)[4][NP]) {
+    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NP]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) make_planes_q(ra, rb, sg, P, q);
     };
         u16* const Pw = Pl + wv * PWAVE + lane * 8;
-        auto put_planes = [&](const bf16x8 (&P)[4][NP]) {
+        auto put_planes = [&](const u32x4 (&P)[4][NP]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(Pw + (j * NP + q) * 512) = P[j][q];
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(Pw + (j * NP + q) * 512) = P[j][q];
         };
         // barrier B of the block that is running (its planes are in the consumers' registers), the next block's planes -> LDS, barrier A of the next
-        auto hand_over = [&](const bf16x8 (&P)[4][NP]) {
+        auto hand_over = [&](const u32x4 (&P)[4][NP]) {
             __builtin_amdgcn_s_barrier();                 // B
             put_planes(P);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         Step nxt = cur;
         advance(nxt);
         Row d0, d1, d2, d3, e2;                       // e2: the next step's row 2 (row 2 is the last to die)
-        bf16x8 P[4][NP];
+        u32x4 P[4][NP];
         XfTab xc, xn;
         load_xf(xc, cur);
         load_xf(xn, nxt);

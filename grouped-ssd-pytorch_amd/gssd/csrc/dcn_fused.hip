@@ -552,7 +552,17 @@ void sk_init(SkDev& s, int dev) {
 SkRegion* sk_region(SkDev& s, const void* out, int ints, bool may_alloc) {
     for (int i = 0; i < s.nregions; ++i)
         if (s.regions[i].out == out && s.regions[i].ints >= ints) return &s.regions[i];
-    if (!may_alloc || s.nregions == SK_MAX_REGIONS) return nullptr;
+    if (!may_alloc) return nullptr;
+    // a smaller region of the same output buffer (the address served a smaller launch before) is replaced, not kept beside the new one
+    for (int i = 0; i < s.nregions; ++i)
+        if (s.regions[i].out == out) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(s.regions[i].flags);
+            (void)hipFree(s.regions[i].ws);
+            s.regions[i] = s.regions[--s.nregions];
+            break;
+        }
+    if (s.nregions == SK_MAX_REGIONS) return nullptr;
     int* fl = nullptr;
     float* ws = nullptr;
     const size_t fbytes = (size_t)((ints + 31) & ~31) * sizeof(int);
@@ -596,6 +606,29 @@ extern "C" int gssd_dcn_streamk_reset(gssd_stream_t stream) {
             return GSSD_ELAUNCH;
         }
     return GSSD_OK;
+}
+
+// frees the flag / slab region of the launches that write `out` (NULL: every region of the current device).  A region is ~32 MB on a 256-CU
+// device and is created by the first stream-K launch for an output: a caller that drops or reallocates its outputs releases theirs (ADVICE r4;
+// gssd/plan_ops.py does when a forward plan is destroyed).  hipFree synchronises: not to be called while a stream is capturing.
+extern "C" int gssd_dcn_streamk_release(const void* out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) return GSSD_OK;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    SkDev& s = g_sk[dev];
+    int kept = 0;
+    for (int i = 0; i < s.nregions; ++i) {
+        if (out == nullptr || s.regions[i].out == out) {
+            (void)hipFree(s.regions[i].flags);
+            (void)hipFree(s.regions[i].ws);
+        } else {
+            s.regions[kept++] = s.regions[i];
+        }
+    }
+    const int freed = s.nregions - kept;
+    s.nregions = kept;
+    return freed;
 }
 
 extern "C" int gssd_dcn_forward_f32(const float* x, const float* om, const float* w_packed, const float* bias, float* out, int B,

@@ -193,6 +193,15 @@ class _PlanBase:
 class _Plan(_PlanBase, PlanGraphMixin, PlanOpsMixin, PlanExecMixin):
     """The launch plan of one (batch size, mode) of the detector.  The graph walk lives in plan_graph.PlanGraphMixin, the per-op emitters in
     plan_ops.PlanOpsMixin, eager / hipGraph execution in plan_exec.PlanExecMixin; this class keeps construction and the buffer / step helpers."""
+
+    def __del__(self):
+        # csrc/dcn_fused.hip's stream-K regions belong to this plan's deformable-conv outputs (GSSD_DCN_X6=0 only)
+        try:
+            for ptr in self.__dict__.get('_sk_outs', ()):
+                lib.gssd_dcn_streamk_release(ptr)
+        except Exception:        # noqa: BLE001 -- interpreter teardown
+            pass
+
     def __init__(self, eng, B, training, dev, want_maps=False, nograd=False):
         self.eng, self.B, self.training, self.dev = eng, B, training, dev
         self.nograd = nograd                       # no backward will read this plan's activations

@@ -5,7 +5,8 @@ import os
 import torch
 from . import _lib, ops
 from ._lib import lib
-from .plan_common import ALL_STREAMS, USE_BRANCH_STREAMS, USE_GRAPH
+from . import plan_common
+from .plan_common import ALL_STREAMS, USE_BRANCH_STREAMS
 
 
 class PlanExecMixin:
@@ -22,7 +23,7 @@ class PlanExecMixin:
         x = x.contiguous().float()
         only = getattr(events, 'only', None) if events is not None else None
         self._runs = getattr(self, '_runs', 0) + 1
-        if USE_GRAPH and (events is None or only) and self._runs > 2:
+        if plan_common.USE_GRAPH and (events is None or only) and self._runs > 2:
             return self._run_graphs(x, events, only)
         return self._run_eager(x, events, only)
 

@@ -374,6 +374,9 @@ class PlanOpsMixin:
                   (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout),
                   keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_x6<128x256>' if DCN_X6 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
                                     esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
+        if not self.bf16 and not DCN_X6:
+            # the stream-K form keeps a flag / slab region per output buffer: released with the plan (engine._Plan.__del__)
+            self.__dict__.setdefault('_sk_outs', []).append(out.data_ptr())
         self.offsets = getattr(self, 'offsets', [])
         self.offsets.append((om, H, dg))
         self.rec.append(('dcn', dict(mod=m, x_in=x, out=out, H=H, Cin=Cin, Cout=Cout, om=om, d_om=d1, dg=dg, li=li, omc=OMC)))

@@ -431,6 +431,9 @@ int gssd_dcn_streamk(int mode);
 #define GSSD_DCN_SK_TIMEOUT 4     /* a workgroup gave up waiting for a partial sum: stream-K is off */
 int gssd_dcn_streamk_status(unsigned* xcc_map);
 int gssd_dcn_streamk_reset(gssd_stream_t stream);
+/* frees the stream-K flag / slab region (~32 MB) of the launches writing `out` (NULL: all regions of the current device); returns the number of
+ * regions freed.  Synchronises (hipFree): call it when an output buffer is dropped, never under stream capture. */
+int gssd_dcn_streamk_release(const void* out);
 
 /* bf16 storage variant (configs[4]): x, w_packed, out bf16; om, bias fp32; fp32 blend and accumulation */
 /* The fp32 deformable conv on the bf16 matrix cores with fp32-equivalent products (csrc/dcn_x6.hip): every operand as the exact sum of

@@ -884,6 +884,12 @@ def test_dcn_fused_streamk(dev, ops, B, Cc, Cout, dg):
     assert torch.equal(a, b)
     # usable, no wait timed out (bit 2 = "id & 7 is not the XCD here" is information: the hand-over is placement independent)
     assert lib.gssd_dcn_streamk_status(None) & ~2 == 0
+    # the flag / slab regions belong to OUTPUT buffers: releasing one frees exactly its region, NULL frees the rest, a launch afterwards
+    # makes its own again (regions used to accumulate for the life of the process)
+    # (one region per output ADDRESS: the caching allocator may hand sk1 / sk2 / sk3 the same or different blocks)
+    assert lib.gssd_dcn_streamk_release(sk3.data_ptr()) == 1 and lib.gssd_dcn_streamk_release(sk3.data_ptr()) == 0
+    assert lib.gssd_dcn_streamk_release(None) >= 0 and lib.gssd_dcn_streamk_release(None) == 0
+    assert torch.equal(run(1), sk1)
 
 
 def test_dcn_streamk_is_placement_independent(dev, ops):

@@ -573,7 +573,7 @@ def test_graph_replay_equals_eager(dev, name):
     plan = net._engine._last_plan
     assert plan._runs == 5 and len(plan._graphs) == 1                 # runs 3..5 were graph replays
     # the twin runs the same five training forwards eagerly
-    import gssd.engine as E
+    import gssd.plan_common as E          # (plan_exec.run reads the switch through this module)
     E.USE_GRAPH = False
     try:
         with torch.no_grad():
