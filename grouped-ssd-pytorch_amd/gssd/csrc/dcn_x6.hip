@@ -58,6 +58,20 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// the same split of TWO values at once, planes as packed bf16 pairs (a in the low half): one v_cvt_pk_bf16_f32 per plane and PAIR, and the
+// packed result is the operand dword (the element-wise form converts every element alone and then once more to pack: 7 converts per pair)
+__device__ __forceinline__ void split3_pair(const float a, const float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, ph << 16), rb = b - __builtin_bit_cast(float, ph & 0xffff0000u);
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, pm << 16), sb = rb - __builtin_bit_cast(float, pm & 0xffff0000u);
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
+
 // wp: [3 planes][n_tiles][chunks][BN rows in staging order][32] bf16 (slot-swizzled), chunk = (d * cpg/32 + c32) * 9 + tap
 __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                        const u16* __restrict__ wp, const float* __restrict__ bias,
@@ -223,9 +237,10 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     // (scripts/ubench/mfma16_valu_overlap.hip); the body is unconditional (past the end the last chunk is loaded again, the writes go to a
     // stage nobody reads) so that it is one basic block.
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    f32x4 gw1[2];
-    f32x4 gv1[2][4][2];
+    f32x4 gw1[2] = {};
+    f32x4 gv1[2][4][2] = {};
     auto issue = [&]() {
+        if (X6_KO & 8) return;
         const int cb = ch_d * cpg + ch_c * BKC + gq * 8;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -246,22 +261,21 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     };
     // quarter `part` (cell j = part >> 1, channel half hh = part & 1) of this thread's 16 column values: blend, split, three 8-byte LDS writes
     auto finish_part = [&](int part, int buf) {
+        if (X6_KO & 1) return;
         const int j = part >> 1, hh = part & 1;
-        bf16x4 oh, om_, ol;
+        float ve[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
             // the blend of dcn_fused.hip: the same four products, the same order (element by element, no packed fp32 instructions)
-            const float ve = gv1[j][0][hh][e] * gw1[j][0] + gv1[j][1][hh][e] * gw1[j][1] + gv1[j][2][hh][e] * gw1[j][2] + gv1[j][3][hh][e] * gw1[j][3];
-            __bf16 h, m, l;
-            split3(ve, h, m, l);
-            oh[e] = h;
-            om_[e] = m;
-            ol[e] = l;
-        }
+            ve[e] = gv1[j][0][hh][e] * gw1[j][0] + gv1[j][1][hh][e] * gw1[j][1] + gv1[j][2][hh][e] * gw1[j][2] + gv1[j][3][hh][e] * gw1[j][3];
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pair(ve[0], ve[1], h0, m0, l0);
+        split3_pair(ve[2], ve[3], h1, m1, l1);
+        const u32x2 oh = {h0, h1}, om_ = {m0, m1}, ol = {l0, l1};
         u16* Ad = As + buf * NP * A_STAGE + a_wr0 + j * 64 * BKC + 4 * hh;
-        *reinterpret_cast<bf16x4*>(Ad) = oh;
-        *reinterpret_cast<bf16x4*>(Ad + A_STAGE) = om_;
-        *reinterpret_cast<bf16x4*>(Ad + 2 * A_STAGE) = ol;
+        *reinterpret_cast<u32x2*>(Ad) = oh;
+        *reinterpret_cast<u32x2*>(Ad + A_STAGE) = om_;
+        *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = ol;
     };
     static_assert(NBS == 1 && MT == 4, "the pipelined loop is written for one weight buffer and four fragment rows");
 
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
             if (i + 1 < MT) a_row(i + 1);
             const bf16x8 (&af)[NP] = afr[i & 1];
             // six products per fragment pair, smallest first (a: column planes, b: weight planes)
+            if (!(X6_KO & 2))
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 f32x4 c = acc[i][j];

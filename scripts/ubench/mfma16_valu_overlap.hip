@@ -25,6 +25,20 @@ __device__ __forceinline__ void fillers(f32x2 (&f)[8], float a, float b) {
         if (FILL == 6) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(f[i][1]) : "v"(f[i][0]));
         if (FILL == 7) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(f[i][0]) : "v"(a) : "s20", "s21");
         if (FILL == 8) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(f[i][1]) : "v"(f[i][0]), "v"(a), "v"(b));
+        // round 5: is the 8-cycle cost of the bit / convert rows the instruction or the out-of-place destination of this test?
+        if (FILL == 9) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(f[i][0]));
+        if (FILL == 10) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(f[i][1]) : "v"(f[i][0]), "v"(a));
+        if (FILL == 11) asm volatile("v_and_b32 %0, %1, %0" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 12) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(f[i][0]) : "v"(a), "v"(b));
+        if (FILL == 13) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(f[i][1]) : "v"(f[i][0]));
+        if (FILL == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 16) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(f[i][0]) : "v"(a), "v"(b));
+        if (FILL == 17) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 18) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 19) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
+        if (FILL == 20) asm volatile("v_fma_mix_f32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
+        if (FILL == 21) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
     }
 }
 
@@ -90,9 +104,73 @@ void table(float* out, unsigned long long* cyc, int cus) {
     row<6, THREADS>("v_and_b32", out, cyc, cus);
     row<7, THREADS>("v_cndmask_b32 (sgpr)", out, cyc, cus);
     row<8, THREADS>("v_perm_b32", out, cyc, cus);
+    row<9, THREADS>("v_lshlrev_b32 inplace", out, cyc, cus);
+    row<10, THREADS>("v_sub_f32 outofplace", out, cyc, cus);
+    row<11, THREADS>("v_and_b32 inplace", out, cyc, cus);
+    row<12, THREADS>("v_dot2c_f32_bf16", out, cyc, cus);
+    row<13, THREADS>("v_cvt_pk inplace", out, cyc, cus);
+    row<14, THREADS>("v_mov_b32", out, cyc, cus);
+    row<15, THREADS>("v_add_u32", out, cyc, cus);
+    row<16, THREADS>("v_and_or_b32", out, cyc, cus);
+    row<17, THREADS>("v_xor_b32", out, cyc, cus);
+    row<18, THREADS>("v_max_f32", out, cyc, cus);
+    row<19, THREADS>("v_mul_f32", out, cyc, cus);
+    row<20, THREADS>("v_fma_mix_f32", out, cyc, cus);
+    row<21, THREADS>("v_bfi_b32", out, cyc, cus);
+}
+
+// round 5: is v - float(bf16(v)) through v_dot2c_f32_bf16 (acc = v; acc += h * -1 + h' * 0) the exact residual the shift + subtract gives?
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__global__ void dot2_exact_kernel(const float* __restrict__ v, unsigned* __restrict__ bad, int n, unsigned ca, unsigned cb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i + 1 >= n) return;
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, ph << 16), rb = b - __builtin_bit_cast(float, ph & 0xffff0000u);
+    float da = a, db = b;
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(da) : "v"(ph), "v"(ca));
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(db) : "v"(ph), "v"(cb));
+    if (__builtin_bit_cast(unsigned, da) != __builtin_bit_cast(unsigned, ra)) atomicAdd(&bad[0], 1u);
+    if (__builtin_bit_cast(unsigned, db) != __builtin_bit_cast(unsigned, rb)) atomicAdd(&bad[1], 1u);
+    // second level: the residual of the residual
+    const unsigned pm = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, pm << 16), sb = rb - __builtin_bit_cast(float, pm & 0xffff0000u);
+    float ea = ra, eb = rb;
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(ea) : "v"(pm), "v"(ca));
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(eb) : "v"(pm), "v"(cb));
+    if (__builtin_bit_cast(unsigned, ea) != __builtin_bit_cast(unsigned, sa)) atomicAdd(&bad[2], 1u);
+    if (__builtin_bit_cast(unsigned, eb) != __builtin_bit_cast(unsigned, sb)) atomicAdd(&bad[3], 1u);
+}
+
+void dot2_exact() {
+    const int n = 1 << 24;
+    std::vector<float> h(n);
+    unsigned long long s = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < n; ++i) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        unsigned bits = (unsigned)(s >> 32);
+        if (i % 3 == 0) {                                    // any finite bit pattern incl. subnormals
+            if (((bits >> 23) & 0xff) == 0xff) bits &= ~(1u << 30);
+            h[i] = __builtin_bit_cast(float, bits);
+        } else {                                             // activations: ~N(0, 1) scale values
+            h[i] = ((int)(bits >> 8) - (1 << 23)) * (4.0f / (1 << 23)) * ((i % 3 == 1) ? 1.f : 1e-3f);
+        }
+    }
+    float* d;
+    unsigned* bad;
+    hipMalloc(&d, (size_t)n * sizeof(float));
+    hipMalloc(&bad, 4 * sizeof(unsigned));
+    hipMemset(bad, 0, 4 * sizeof(unsigned));
+    hipMemcpy(d, h.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(dot2_exact_kernel, dim3(n / 2 / 256), dim3(256), 0, 0, d, bad, n, 0x0000BF80u, 0xBF800000u);
+    unsigned hb[4];
+    hipMemcpy(hb, bad, sizeof(hb), hipMemcpyDeviceToHost);
+    printf("v_dot2c_f32_bf16 residual vs shift + v_sub_f32 on %d values (1/3 arbitrary bit patterns): mismatches level 1 lo %u hi %u, level 2 lo %u hi %u\n", n, hb[0],
+           hb[1], hb[2], hb[3]);
 }
 
 int main() {
+    dot2_exact();
     int dev = 0, cus = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
