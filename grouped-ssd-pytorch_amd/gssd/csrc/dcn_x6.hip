@@ -9,13 +9,14 @@
 // are dealt out behind the MFMAs of the chunk's last two fragment rows (one wave per SIMD: the vector work runs in the MFMAs' shadow instead of
 // after them): 2.60 -> 2.22 ms.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 #ifndef X6_KO
-#define X6_KO 0        // knock-outs (scripts/dcn_x6_knockout.sh): 1 no blend / split VALU, 2 no MFMAs, 4 no weight DMA, 8 no x loads
+#define X6_KO 0        // knock-outs (scripts/dcn_x6_knockout.sh): 1 no blend / split VALU, 2 no MFMAs, 4 no weight DMA, 8 no x loads, 16 no fragment reads, 32 no barrier
 #endif
 
 namespace {
@@ -25,6 +26,9 @@ namespace {
 #endif
 #ifndef X6_SPLIT_ROWS
 #define X6_SPLIT_ROWS 2   // fragment rows of a chunk that carry the next chunk's blend + split: the last 2 (two quarters each), 3 (1, 1, 2) or all 4
+#endif
+#ifndef X6_V2
+#define X6_V2 1        // round 5's K loop (v2::dcn_x6_v2_kernel); 0: round 4's kernel (chunk order tap-fastest)
 #endif
 #ifndef X6_PIPE
 #define X6_PIPE 1         // the pipelined K loop (value = vector instructions scheduled behind every MFMA); 0: the plain loop
@@ -446,6 +450,383 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
     }
 }
 
+
+#if X6_V2
+// ---- round 5: the K loop as a software pipeline without an exposed fragment phase, memory instructions dealt out between the MFMAs ------------
+// Round 4's loop (below, X6_V2 = 0) held all 24 weight fragments of a chunk in registers because the three weight planes (48 KB) had a single
+// LDS buffer: every chunk began with 27 ds_read_b128 per wave + a barrier before its first MFMA, then 12 DMA + 16 corner requests in a row --
+// knock-outs: MFMAs alone 1.12 ms, + fragment reads 1.28, + DMA 1.60, everything 2.12.  What the measurements of this round say
+// (scripts/ubench/vmem_rates.hip, mfma_rates.hip, scripts/dcn_x6_knockout.sh):
+//   * a CU gets 52 B / clk of contiguous 1-KiB pieces and ~40 B / clk of 128-byte corner segments out of L2, as plain loads or LDS DMA alike:
+//     the 112 KB a chunk needs are ~2 600 cycles of the vector memory path beside 3 072 cycles of MFMAs -- requests issued in a burst stall the
+//     wave (and its matrix pipe) while the queue drains, so every request sits behind its own group of six MFMAs here;
+//   * the DMA's cost is issue, not latency (the same eight chunks over and over: no change);
+//   * the channel-block-fastest chunk order (one tap's table instead of nine: room for everything) costs the corner loads their L2 hits --
+//     the next tap revisits a pixel's line 8 chunks = 4 MB of traffic later -- so the order stays tap-fastest, and LDS is found elsewhere:
+// 24 KB ONE activation stage (the four rows' fragments are reloaded IN PLACE, behind the last column tile's MFMAs, from the stage the previous
+// iteration wrote; a second barrier in mid-iteration lets the next chunk's planes overwrite it) + 96 KB weight planes in four half buffers +
+// 23 KB sampling table of a group = 143 KB.  The loop is rotated by half a chunk: iteration `it` runs the column tiles j = 4..7 of chunk it - 1
+// (part A), then j = 0..3 of chunk it (part B).  What an iteration reads (Y half of chunk it - 1, X half of chunk it) was DMA'd during the
+// previous iteration; what it DMAs (Y of chunk it, X of chunk it + 1) goes to the halves the previous iteration read.  Column tile outer,
+// fragment row inner: the weight fragments of one tile are prefetched behind the previous tile's MFMAs (2 x 12 VGPRs instead of 96).
+// Part A carries the 16 corner requests of chunk it + 1 (inline assembly, counted waits) and the 12 DMA pieces, one per group of six MFMAs;
+// part B carries the blend + split + plane writes of chunk it + 1, one pair of values per group.
+namespace v2 {
+constexpr int HB_ROWS = BN / 2;                       // rows of a half buffer: (wave column, j & 3, r)
+constexpr int HB_PLANE = HB_ROWS * BKC;               // u16 elements per plane of a half
+constexpr int HB_ELEMS = NP * HB_PLANE;               // 24 KB
+constexpr int NTH = NT / 2;                           // column tiles per half
+constexpr int TAB_N = 9 * BM;
+constexpr int LDS_BYTES = (NP * A_STAGE + 4 * HB_ELEMS) * 2 + TAB_N * 16 + TAB_N * 4;
+constexpr int TPT = (TAB_N + 255) / 256;              // table entries per thread
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+static_assert(MT == 4 && NT == 8 && BN == 256, "written for 128 x 256 tiles on four waves");
+#ifndef X6_D0
+#define X6_D0 4          // part-A group (0..15) behind which the first DMA piece is issued; one piece per group from there (past 15: part B)
+#endif
+// vmcnt is counted in issue order: a cell's 8 requests have landed when at most W younger operations of the wave are outstanding.
+// Issue order of an iteration: [G0] .. [G15] with piece D(g - X6_D0) behind G(g); cell 0 = G0..G7 is awaited in front of part B's group 0,
+// cell 1 = G8..G15 in front of its group 8.
+#if X6_D0 == 0
+#define X6_W0 13         // G8..G15 + D7..D11
+#define X6_W1 0
+#elif X6_D0 == 4
+#define X6_W0 17         // G8..G15 + D3..D11
+#define X6_W1 1          // D11
+#elif X6_D0 == 8
+#define X6_W0 16         // G8..G15 + D0..D7 (D8..D11 follow in part B)
+#define X6_W1 5          // D7 + D8..D11
+#else
+#error "X6_D0: 0, 4 or 8"
+#endif
+#define X6_STR2(x) #x
+#define X6_STR(x) X6_STR2(x)
+
+__global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restrict__ x, const float* __restrict__ om,
+                                                          const u16* __restrict__ wp, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
+                                                          int Cout, int ntn, int mtiles, long long plane_elems) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
+    u16* const As = smem_h;                                   // [3][BM][32]
+    u16* const Bh = smem_h + NP * A_STAGE;                    // [X | Y][2][3][BN / 2][32]
+    f32x4* const tabw = reinterpret_cast<f32x4*>(smem_h + NP * A_STAGE + 4 * HB_ELEMS);      // [9][BM] corner weights (x mask)
+    int* const tabp = reinterpret_cast<int*>(tabw + TAB_N);                                   // [9][BM] corner position + step flags
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    int mt, nt;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        if (8 % ntn == 0) {
+            nt = xcd % ntn;
+            mt = slot * (8 / ntn) + xcd / ntn;
+        } else {
+            const int id = slot * 8 + xcd;
+            nt = id % ntn;
+            mt = id / ntn;
+        }
+    }
+    if (mt >= mtiles) return;
+    const int m0 = mt * BM;
+    const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;
+    const int nchunks = dg * cpc * 9;
+    const u16* wslab = wp + (size_t)nt * nchunks * B_STAGE;      // plane 0; plane p at + p * plane_elems
+
+    f32x4 acc[MT][NT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
+
+    // gather roles: thread -> (pixel rows gp and gp + 64, 8-channel slot gq)
+    const int gq = tid & 3, gp = tid >> 2;
+    const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
+    const int fo = r * BKC + ((kq ^ swz(r)) << 3);
+
+    // ---- sampling table of one deformable group (9 taps x BM rows): the om values are requested at the top of an iteration, the entries are
+    // made and written behind its second barrier (nobody reads the old table any more), the next iteration's corner requests read them ----------
+    float t_dy[TPT], t_dx[TPT], t_ml[TPT];
+    auto tab_load = [&](int d) {
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int e = tid + 256 * u;
+            const int tap = e / BM, m = m0 + (e - tap * BM);
+            t_dy[u] = t_dx[u] = t_ml[u] = 0.f;
+            if (e < TAB_N && m < M) {
+                const float* omp = om + (size_t)m * om_stride;
+                t_dy[u] = omp[d * 18 + 2 * tap];
+                t_dx[u] = omp[d * 18 + 2 * tap + 1];
+                t_ml[u] = omp[dg * 18 + d * 9 + tap];
+            }
+        }
+    };
+    auto tab_finish = [&]() {                            // the arithmetic of dcn_fused.hip
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int e = tid + 256 * u;
+            if (e >= TAB_N) continue;
+            const int tap = e / BM, m = m0 + (e - tap * BM);
+            f32x4 wv = zero4;
+            int pos = 0;
+            if (m < M) {
+                const int b = m / HW, pix = m - b * HW;
+                const int h = pix / W, w = pix - h * W;
+                const float msk = 1.f / (1.f + expf(-t_ml[u]));
+                const float py = (float)(h - 1 + tap / 3) + t_dy[u];
+                const float px = (float)(w - 1 + tap % 3) + t_dx[u];
+                if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
+                    const float y0f = floorf(py), x0f = floorf(px);
+                    const int y0 = (int)y0f, x0 = (int)x0f;
+                    const float ly = py - y0f, lx = px - x0f, hy = 1.f - ly, hx = 1.f - lx;
+                    const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+                    wv[0] = (y0ok && x0ok) ? hy * hx * msk : 0.f;
+                    wv[1] = (y0ok && x1ok) ? hy * lx * msk : 0.f;
+                    wv[2] = (y1ok && x0ok) ? ly * hx * msk : 0.f;
+                    wv[3] = (y1ok && x1ok) ? ly * lx * msk : 0.f;
+                    const int ya = y0ok ? y0 : 0, xa = x0ok ? x0 : 0;
+                    const int yb = y1ok ? y0 + 1 : H - 1, xb = x1ok ? x0 + 1 : W - 1;
+                    pos = (int)((unsigned)(b * HW + ya * W + xa) | ((unsigned)(xb - xa) << 30) | ((unsigned)(yb - ya) << 31));
+                }
+            }
+            tabw[e] = wv;
+            tabp[e] = pos;
+        }
+    };
+
+    // ---- corner requests of one chunk: 2 cells x 4 corners x 2 halves of 4 fp32 channels per thread, by inline assembly ------------------------
+    f32x4 gw[2];
+    f32x4 gv[2][4][2];
+    const float* pc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        gw[j] = zero4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[j][k][0] = gv[j][k][1] = zero4, pc[j][k] = x;
+    }
+    int ld_tap = 0, ld_cc = 0, ld_d = 0;                    // the chunk the next corner requests are for
+    auto corner_addr = [&](int j) {                          // cell j: weights + the four corner addresses from the table
+        const int cb = ld_d * cpg + ld_cc * BKC + gq * 8;
+        const int e = ld_tap * BM + gp + 64 * j;
+        gw[j] = tabw[e];
+        const int pos = tabp[e];
+        const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
+        const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
+        const unsigned i10 = i00 + dyb * (unsigned)W;
+        pc[j][0] = x + (size_t)i00 * (unsigned)C + cb;
+        pc[j][1] = x + (size_t)(i00 + dxb) * (unsigned)C + cb;
+        pc[j][2] = x + (size_t)i10 * (unsigned)C + cb;
+        pc[j][3] = x + (size_t)(i10 + dxb) * (unsigned)C + cb;
+    };
+    auto corner_req = [&](int q) {                           // request q = (cell, corner, half): 16 bytes per lane
+        if (X6_KO & 8) return;
+        const int j = q >> 3, k = (q >> 1) & 3;
+        if (q & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gv[j][k][1]) : "v"(pc[j][k]) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[j][k][0]) : "v"(pc[j][k]) : "memory");
+    };
+    // the 8 requests of cell J have landed; N younger requests / DMA pieces of this wave may still be in flight
+#define X6_CELL_WAIT(J, N)                                                                                                              \
+    if (!(X6_KO & 8))                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(" X6_STR(N) ")"                                                                                       \
+                 : "+v"(gv[J][0][0]), "+v"(gv[J][0][1]), "+v"(gv[J][1][0]), "+v"(gv[J][1][1]), "+v"(gv[J][2][0]), "+v"(gv[J][2][1]),    \
+                   "+v"(gv[J][3][0]), "+v"(gv[J][3][1]))
+    auto advance_ld = [&]() {
+        if (++ld_tap == 9) {
+            ld_tap = 0;
+            if (++ld_cc == cpc) {
+                ld_cc = 0;
+                ++ld_d;
+            }
+        }
+    };
+    // pair `p` (cell p >> 2, channels 2 (p & 3), + 1) of this thread's 16 column values: blend, split, one dword per plane
+    auto blend_pair = [&](int p) {
+        if (X6_KO & 1) return;
+        const int j = p >> 2, hh = (p >> 1) & 1, e0 = 2 * (p & 1);
+        // the blend of dcn_fused.hip: the same four products, the same order (element by element, no packed fp32 instructions)
+        const float va = gv[j][0][hh][e0] * gw[j][0] + gv[j][1][hh][e0] * gw[j][1] + gv[j][2][hh][e0] * gw[j][2] + gv[j][3][hh][e0] * gw[j][3];
+        const float vb = gv[j][0][hh][e0 + 1] * gw[j][0] + gv[j][1][hh][e0 + 1] * gw[j][1] + gv[j][2][hh][e0 + 1] * gw[j][2] +
+                         gv[j][3][hh][e0 + 1] * gw[j][3];
+        unsigned ph, pm, pl;
+        split3_pair(va, vb, ph, pm, pl);
+        unsigned* Ad = reinterpret_cast<unsigned*>(As + a_wr0 + j * 64 * BKC + 4 * hh + e0);
+        Ad[0] = ph;
+        Ad[A_STAGE / 2] = pm;
+        Ad[A_STAGE] = pl;
+    };
+    // weight planes of (chunk, half) -> half buffer (half, parity): 24 1-KiB pieces (plane, wave column, j & 3), six per wave
+    auto dma_piece = [&](int chunk, int half, int parity, int q) {
+        if (X6_KO & 4) return;
+        if (X6_KO & 64) chunk &= 7;                           // experiment: always the same eight chunks
+        u16* dst = Bh + (half * 2 + parity) * HB_ELEMS;
+        const u16* src = wslab + (size_t)chunk * B_STAGE + lane * 8;
+        const int p = q * 4 + wave;                          // piece 0..23
+        const int pl = p >> 3, g8 = p & 7;
+        const int G = (g8 >> 2) * NT + half * NTH + (g8 & 3);      // 16-row group of the plane's [BN][32] tile
+        dma16(src + (size_t)pl * plane_elems + G * 512, dst + pl * HB_PLANE + g8 * 512);
+    };
+
+    bf16x8 areg[MT][NP], breg[2][NP];
+    auto a_load_row = [&](int i) {
+        const u16* Ab = As + (wm * WTM + i * 16) * BKC + fo;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (X6_KO & 16) asm volatile("" : "=v"(areg[i][pl]));
+            else areg[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_STAGE);
+        }
+    };
+    auto b_load = [&](int which, int half, int parity, int jj) {
+        const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * (HB_ROWS / 2) + jj * 16) * BKC + fo;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (X6_KO & 16) asm volatile("" : "=v"(breg[which][pl]));
+            else breg[which][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * HB_PLANE);
+        }
+    };
+    // the six products of one fragment pair, smallest first (first operand: weight planes, second: column planes)
+    auto mma_row = [&](int i, int j, int which) {
+        if (X6_KO & 2) return;
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+        acc[i][j] = c;
+    };
+
+    // ---- prologue: table of group 0, corners + planes of chunk 0, X half of chunk 0's weights ---------------------------------------------------
+    tab_load(0);
+    tab_finish();
+    __syncthreads();
+    corner_addr(0);
+    corner_addr(1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) corner_req(q);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dma_piece(0, 0, 0, q);
+    X6_CELL_WAIT(0, 14);
+    X6_CELL_WAIT(1, 6);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) blend_pair(p);
+    advance_ld();                                            // nchunks >= 9
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    int tb_next = cpc * 9, tb_d = 1;                         // first chunk of the next group, and the group
+
+    // ---- iteration `it`: [part A: j = 4..7 of chunk it - 1] [part B: j = 0..3 of chunk it]; FIRST has no chunk behind it, LAST none in front ----
+    auto iteration = [&](int it, auto first_c, auto last_c) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        const int par = it & 1;
+        const int cy = min(it, nchunks - 1), cx = min(it + 1, nchunks - 1);
+        bool make_tab = false;
+        if (!LAST) {
+            make_tab = it + 2 == tb_next && it + 2 < nchunks;
+            if (make_tab) tab_load(tb_d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- part A ----
+        if (!FIRST) {
+            b_load(0, 1, par ^ 1, 0);                        // Y of chunk it - 1, landed during the previous iteration
+#pragma unroll
+            for (int jj = 0; jj < NTH; ++jj) {
+                if (jj + 1 < NTH) b_load((jj + 1) & 1, 1, par ^ 1, jj + 1);
+                else if (!LAST) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int g = jj * MT + i;               // group 0..15: six MFMAs, one corner request, one DMA piece
+                    if (!LAST) {
+                        if (g == 0) corner_addr(0);
+                        if (g == 8) corner_addr(1);
+                    }
+                    mma_row(i, NTH + jj, jj & 1);
+                    if (!LAST) {
+                        corner_req(g);
+                        if (g >= X6_D0 && g < X6_D0 + 12) {
+                            const int q = g - X6_D0;
+                            dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
+                        }
+                        if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            corner_addr(0);
+            corner_addr(1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) corner_req(q);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_load_row(i);
+            b_load(0, 0, par, 0);
+        }
+        if (!LAST) {
+            // every wave holds chunk it's fragments: the stage may take chunk it + 1's planes (and the table a new group's entries)
+            if (X6_KO & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // ---- part B ----
+#pragma unroll
+            for (int jj = 0; jj < NTH; ++jj) {
+                if (jj + 1 < NTH) b_load((jj + 1) & 1, 0, par, jj + 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int g = jj * MT + i;               // group 0..15: six MFMAs + one pair of column values on every second group
+                    if (g == 0) X6_CELL_WAIT(0, X6_W0);
+                    if (g == 8) X6_CELL_WAIT(1, X6_W1);
+                    mma_row(i, jj, jj & 1);
+                    if (X6_D0 + 12 > 16 && g < X6_D0 + 12 - 16) {
+                        const int q = g + 16 - X6_D0;
+                        dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
+                    }
+                    if (!(g & 1)) blend_pair(g >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (make_tab) {
+                tab_finish();
+                tb_next += cpc * 9;
+                ++tb_d;
+            }
+            if (it + 2 < nchunks) advance_ld();
+            if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    };
+    iteration(0, std::true_type{}, std::false_type{});
+    for (int it = 1; it < nchunks; ++it) iteration(it, std::false_type{}, std::false_type{});
+    iteration(nchunks, std::false_type{}, std::true_type{});
+
+    // ---- epilogue: + bias, 16-byte NHWC fp32 stores (lane: pixel = lane & 15, 8 consecutive channels per tile pair) -----------
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+        const int n0 = nt * BN + wn * WTN + 32 * u + 8 * kq;
+        float bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = (bias && n0 + c < Cout) ? bias[n0 + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r;
+            if (m >= M) continue;
+            float* dst = out + (size_t)m * Cout + n0;
+            if (n0 + 8 <= Cout) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][2 * u][0] + bv[0], acc[i][2 * u][1] + bv[1], acc[i][2 * u][2] + bv[2], acc[i][2 * u][3] + bv[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) =
+                    f32x4{acc[i][2 * u + 1][0] + bv[4], acc[i][2 * u + 1][1] + bv[5], acc[i][2 * u + 1][2] + bv[6], acc[i][2 * u + 1][3] + bv[7]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (n0 + c < Cout) dst[c] = acc[i][2 * u + (c >> 2)][c & 3] + bv[c];
+            }
+        }
+    }
+}
+}  // namespace v2
+#endif
+
 // OIHW fp32 [Cout][C][3][3] -> three bf16 planes, each [n_tiles][chunks][BN staging rows][32] with the slot swizzle; rows beyond Cout zero
 __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int C, int dg, long long total) {
     const int cpg = C / dg, cpc = cpg / BKC, nchunks = dg * cpc * 9;
@@ -457,7 +838,7 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
         const int chunk = (int)(t % nchunks);
         const int nt = (int)(t / nchunks);
         const int q = slot ^ swz(row);
-        const int tap = chunk % 9, cc = chunk / 9;
+        const int tap = chunk % 9, cc = chunk / 9;                                // chunk = ((group * cpc + channel block) * 9 + tap)
         const int c = cc * BKC + q * 8 + e;
         const int n = nt * BN + chan_of_row(row);
         __bf16 h, m, l;
@@ -494,8 +875,14 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
     static unsigned attr_mask = 0;
+#if X6_V2
+    const auto kernel = v2::dcn_x6_v2_kernel;
+    constexpr int LDS_BYTES = v2::LDS_BYTES;
+#else
+    const auto kernel = dcn_x6_kernel;
+#endif
     if (gssd_attr_needed(&attr_mask)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", LDS_BYTES);
             return GSSD_ELAUNCH;
@@ -509,7 +896,7 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     } else {
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
-    hipLaunchKernelGGL(dcn_x6_kernel, dim3(blocks), dim3(256), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
                        out, M, H, W, C, dg, om_stride, Cout, ntn, mtiles, gssd_dcn_packed_weight_elems_x6(Cout, C) / 3);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
