@@ -472,37 +472,29 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
 // Part A carries the 16 corner requests of chunk it + 1 (inline assembly, counted waits) and the 12 DMA pieces, one per group of six MFMAs;
 // part B carries the blend + split + plane writes of chunk it + 1, one pair of values per group.
 namespace v2 {
-constexpr int HB_ROWS = BN / 2;                       // rows of a half buffer: (wave column, j & 3, r)
+// eight waves (two per SIMD: with one, every scalar / vector / LDS instruction of the wave takes one of the 768 issue slots the 192 MFMAs of a
+// chunk leave it -- the four-wave form of this loop ran 1.96 ms, every knock-out paid) on 64 x 64 wave tiles: 2 (rows) x 4 (columns)
+constexpr int THREADS = 512, NWAVES = THREADS / 64;
+constexpr int WTN = 64, NT = WTN / 16;                // shadows the four-wave constants of the file
+constexpr int HB_ROWS = BN / 2;                       // rows of a half buffer: (wave column, j & 1, r)
 constexpr int HB_PLANE = HB_ROWS * BKC;               // u16 elements per plane of a half
 constexpr int HB_ELEMS = NP * HB_PLANE;               // 24 KB
 constexpr int NTH = NT / 2;                           // column tiles per half
+constexpr int NG = NTH * MT;                          // groups of six MFMAs per part
 constexpr int TAB_N = 9 * BM;
 constexpr int LDS_BYTES = (NP * A_STAGE + 4 * HB_ELEMS) * 2 + TAB_N * 16 + TAB_N * 4;
-constexpr int TPT = (TAB_N + 255) / 256;              // table entries per thread
+constexpr int TPT = (TAB_N + THREADS - 1) / THREADS;  // table entries per thread
+constexpr int DPW = 24 / NWAVES;                      // DMA pieces per wave and half
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(MT == 4 && NT == 8 && BN == 256, "written for 128 x 256 tiles on four waves");
-#ifndef X6_D0
-#define X6_D0 4          // part-A group (0..15) behind which the first DMA piece is issued; one piece per group from there (past 15: part B)
-#endif
-// vmcnt is counted in issue order: a cell's 8 requests have landed when at most W younger operations of the wave are outstanding.
-// Issue order of an iteration: [G0] .. [G15] with piece D(g - X6_D0) behind G(g); cell 0 = G0..G7 is awaited in front of part B's group 0,
-// cell 1 = G8..G15 in front of its group 8.
-#if X6_D0 == 0
-#define X6_W0 13         // G8..G15 + D7..D11
-#define X6_W1 0
-#elif X6_D0 == 4
-#define X6_W0 17         // G8..G15 + D3..D11
-#define X6_W1 1          // D11
-#elif X6_D0 == 8
-#define X6_W0 16         // G8..G15 + D0..D7 (D8..D11 follow in part B)
-#define X6_W1 5          // D7 + D8..D11
-#else
-#error "X6_D0: 0, 4 or 8"
-#endif
+static_assert(MT == 4 && NT == 4 && BN == 256 && NG == 8, "written for 128 x 256 tiles on eight waves");
+// vmcnt is counted in issue order: the thread's 8 corner requests have landed when at most X6_W younger operations of the wave are
+// outstanding.  Issue order of an iteration's part A (groups 0..7): two requests behind each of the groups 0..3, one DMA piece behind each of
+// the groups 2..7 -> younger than the last request: D1..D5.
+#define X6_W 5
 #define X6_STR2(x) #x
 #define X6_STR(x) X6_STR2(x)
 
-__global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const u16* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
                                                           int Cout, int ntn, int mtiles, long long plane_elems) {
@@ -513,7 +505,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
     int* const tabp = reinterpret_cast<int*>(tabw + TAB_N);                                   // [9][BM] corner position + step flags
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 15, kq = lane >> 4;
     int mt, nt;
     {
@@ -540,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
 
-    // gather roles: thread -> (pixel rows gp and gp + 64, 8-channel slot gq)
+    // gather roles: thread -> (pixel row gp, 8-channel slot gq)
     const int gq = tid & 3, gp = tid >> 2;
     const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
     const int fo = r * BKC + ((kq ^ swz(r)) << 3);
@@ -551,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
     auto tab_load = [&](int d) {
 #pragma unroll
         for (int u = 0; u < TPT; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + THREADS * u;
             const int tap = e / BM, m = m0 + (e - tap * BM);
             t_dy[u] = t_dx[u] = t_ml[u] = 0.f;
             if (e < TAB_N && m < M) {
@@ -565,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
     auto tab_finish = [&]() {                            // the arithmetic of dcn_fused.hip
 #pragma unroll
         for (int u = 0; u < TPT; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + THREADS * u;
             if (e >= TAB_N) continue;
             const int tap = e / BM, m = m0 + (e - tap * BM);
             f32x4 wv = zero4;
@@ -595,42 +587,40 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
         }
     };
 
-    // ---- corner requests of one chunk: 2 cells x 4 corners x 2 halves of 4 fp32 channels per thread, by inline assembly ------------------------
-    f32x4 gw[2];
-    f32x4 gv[2][4][2];
-    const float* pc[2][4];
+    // ---- corner requests of one chunk: 4 corners x 2 halves of 4 fp32 channels per thread, by inline assembly ------------------------------------
+    f32x4 gw = zero4;
+    f32x4 gv[4][2];
+    const float* pc[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        gw[j] = zero4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gv[j][k][0] = gv[j][k][1] = zero4, pc[j][k] = x;
-    }
+    for (int k = 0; k < 4; ++k) gv[k][0] = gv[k][1] = zero4, pc[k] = x;
     int ld_tap = 0, ld_cc = 0, ld_d = 0;                    // the chunk the next corner requests are for
-    auto corner_addr = [&](int j) {                          // cell j: weights + the four corner addresses from the table
+    auto corner_addr = [&]() {                               // weights + the four corner addresses from the table
         const int cb = ld_d * cpg + ld_cc * BKC + gq * 8;
-        const int e = ld_tap * BM + gp + 64 * j;
-        gw[j] = tabw[e];
-        const int pos = tabp[e];
+        const int e = ld_tap * BM + gp;
+        gw = tabw[e];
+        int pos = tabp[e];
+        if (X6_KO & 128) pos = (pos & 0xC0000000) | gp;       // experiment: every tile reads the same 128 pixels (cache hits)
+        if (X6_KO & 256) pos = (pos & 0xC0000000) | min(m0 + gp, M - 2);      // experiment: no offsets (own pixel, dense lines)
         const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
         const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
         const unsigned i10 = i00 + dyb * (unsigned)W;
-        pc[j][0] = x + (size_t)i00 * (unsigned)C + cb;
-        pc[j][1] = x + (size_t)(i00 + dxb) * (unsigned)C + cb;
-        pc[j][2] = x + (size_t)i10 * (unsigned)C + cb;
-        pc[j][3] = x + (size_t)(i10 + dxb) * (unsigned)C + cb;
+        pc[0] = x + (size_t)i00 * (unsigned)C + cb;
+        pc[1] = x + (size_t)(i00 + dxb) * (unsigned)C + cb;
+        pc[2] = x + (size_t)i10 * (unsigned)C + cb;
+        pc[3] = x + (size_t)(i10 + dxb) * (unsigned)C + cb;
     };
-    auto corner_req = [&](int q) {                           // request q = (cell, corner, half): 16 bytes per lane
+    auto corner_req = [&](int q) {                           // request q = (corner, half): 16 bytes per lane
         if (X6_KO & 8) return;
-        const int j = q >> 3, k = (q >> 1) & 3;
-        if (q & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gv[j][k][1]) : "v"(pc[j][k]) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[j][k][0]) : "v"(pc[j][k]) : "memory");
+        const int k = q >> 1;
+        if (q & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gv[k][1]) : "v"(pc[k]) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[k][0]) : "v"(pc[k]) : "memory");
     };
-    // the 8 requests of cell J have landed; N younger requests / DMA pieces of this wave may still be in flight
-#define X6_CELL_WAIT(J, N)                                                                                                              \
-    if (!(X6_KO & 8))                                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(" X6_STR(N) ")"                                                                                       \
-                 : "+v"(gv[J][0][0]), "+v"(gv[J][0][1]), "+v"(gv[J][1][0]), "+v"(gv[J][1][1]), "+v"(gv[J][2][0]), "+v"(gv[J][2][1]),    \
-                   "+v"(gv[J][3][0]), "+v"(gv[J][3][1]))
+    // the 8 requests have landed; N younger DMA pieces of this wave may still be in flight
+#define X6_CELL_WAIT(N)                                                                                                     \
+    if (!(X6_KO & 8))                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" X6_STR(N) ")"                                                                           \
+                 : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[1][0]), "+v"(gv[1][1]), "+v"(gv[2][0]), "+v"(gv[2][1]), "+v"(gv[3][0]), \
+                   "+v"(gv[3][1]))
     auto advance_ld = [&]() {
         if (++ld_tap == 9) {
             ld_tap = 0;
@@ -640,30 +630,31 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
             }
         }
     };
-    // pair `p` (cell p >> 2, channels 2 (p & 3), + 1) of this thread's 16 column values: blend, split, one dword per plane
-    auto blend_pair = [&](int p) {
+    // half `hh` (channels 4 hh .. 4 hh + 3) of this thread's 8 column values: blend, split, one 8-byte write per plane
+    auto blend_half = [&](int hh) {
         if (X6_KO & 1) return;
-        const int j = p >> 2, hh = (p >> 1) & 1, e0 = 2 * (p & 1);
-        // the blend of dcn_fused.hip: the same four products, the same order (element by element, no packed fp32 instructions)
-        const float va = gv[j][0][hh][e0] * gw[j][0] + gv[j][1][hh][e0] * gw[j][1] + gv[j][2][hh][e0] * gw[j][2] + gv[j][3][hh][e0] * gw[j][3];
-        const float vb = gv[j][0][hh][e0 + 1] * gw[j][0] + gv[j][1][hh][e0 + 1] * gw[j][1] + gv[j][2][hh][e0 + 1] * gw[j][2] +
-                         gv[j][3][hh][e0 + 1] * gw[j][3];
-        unsigned ph, pm, pl;
-        split3_pair(va, vb, ph, pm, pl);
-        unsigned* Ad = reinterpret_cast<unsigned*>(As + a_wr0 + j * 64 * BKC + 4 * hh + e0);
-        Ad[0] = ph;
-        Ad[A_STAGE / 2] = pm;
-        Ad[A_STAGE] = pl;
+        float ve[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            // the blend of dcn_fused.hip: the same four products, the same order (element by element, no packed fp32 instructions)
+            ve[e] = gv[0][hh][e] * gw[0] + gv[1][hh][e] * gw[1] + gv[2][hh][e] * gw[2] + gv[3][hh][e] * gw[3];
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(ve[0], ve[1], h0, m0_, l0);
+        split3_pair(ve[2], ve[3], h1, m1, l1);
+        u16* Ad = As + a_wr0 + 4 * hh;
+        *reinterpret_cast<u32x2*>(Ad) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(Ad + A_STAGE) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = u32x2{l0, l1};
     };
-    // weight planes of (chunk, half) -> half buffer (half, parity): 24 1-KiB pieces (plane, wave column, j & 3), six per wave
+    // weight planes of (chunk, half) -> half buffer (half, parity): 24 1-KiB pieces (plane, wave column, j & 1), three per wave
     auto dma_piece = [&](int chunk, int half, int parity, int q) {
         if (X6_KO & 4) return;
         if (X6_KO & 64) chunk &= 7;                           // experiment: always the same eight chunks
         u16* dst = Bh + (half * 2 + parity) * HB_ELEMS;
         const u16* src = wslab + (size_t)chunk * B_STAGE + lane * 8;
-        const int p = q * 4 + wave;                          // piece 0..23
+        const int p = q * NWAVES + wave;                     // piece 0..23
         const int pl = p >> 3, g8 = p & 7;
-        const int G = (g8 >> 2) * NT + half * NTH + (g8 & 3);      // 16-row group of the plane's [BN][32] tile
+        const int G = (g8 >> 1) * NT + half * NTH + (g8 & 1);      // 16-row group of the plane's [BN][32] tile
         dma16(src + (size_t)pl * plane_elems + G * 512, dst + pl * HB_PLANE + g8 * 512);
     };
 
@@ -677,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
         }
     };
     auto b_load = [&](int which, int half, int parity, int jj) {
-        const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * (HB_ROWS / 2) + jj * 16) * BKC + fo;
+        const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * NTH * 16 + jj * 16) * BKC + fo;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             if (X6_KO & 16) asm volatile("" : "=v"(breg[which][pl]));
@@ -701,22 +692,20 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
     tab_load(0);
     tab_finish();
     __syncthreads();
-    corner_addr(0);
-    corner_addr(1);
+    corner_addr();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) corner_req(q);
+    for (int q = 0; q < 8; ++q) corner_req(q);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) dma_piece(0, 0, 0, q);
-    X6_CELL_WAIT(0, 14);
-    X6_CELL_WAIT(1, 6);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) blend_pair(p);
+    for (int q = 0; q < DPW; ++q) dma_piece(0, 0, 0, q);
+    X6_CELL_WAIT(3);
+    blend_half(0);
+    blend_half(1);
     advance_ld();                                            // nchunks >= 9
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     int tb_next = cpc * 9, tb_d = 1;                         // first chunk of the next group, and the group
 
-    // ---- iteration `it`: [part A: j = 4..7 of chunk it - 1] [part B: j = 0..3 of chunk it]; FIRST has no chunk behind it, LAST none in front ----
+    // ---- iteration `it`: [part A: j = 2, 3 of chunk it - 1] [part B: j = 0, 1 of chunk it]; FIRST has no chunk behind it, LAST none in front ----
     auto iteration = [&](int it, auto first_c, auto last_c) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const int par = it & 1;
@@ -726,6 +715,7 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
             make_tab = it + 2 == tb_next && it + 2 < nchunks;
             if (make_tab) tab_load(tb_d);
         }
+        auto dma_q = [&](int q) { dma_piece(q < DPW ? cy : cx, q < DPW ? 1 : 0, q < DPW ? par : par ^ 1, q % DPW); };      // q = 0 .. 2 DPW - 1
         __builtin_amdgcn_sched_barrier(0);
         // ---- part A ----
         if (!FIRST) {
@@ -736,30 +726,26 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
                 else if (!LAST) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int g = jj * MT + i;               // group 0..15: six MFMAs, one corner request, one DMA piece
-                    if (!LAST) {
-                        if (g == 0) corner_addr(0);
-                        if (g == 8) corner_addr(1);
-                    }
+                    const int g = jj * MT + i;               // group 0..7: six MFMAs; two corner requests (groups 0..3), one DMA piece (2..7)
+                    if (!LAST && g == 0) corner_addr();
                     mma_row(i, NTH + jj, jj & 1);
                     if (!LAST) {
-                        corner_req(g);
-                        if (g >= X6_D0 && g < X6_D0 + 12) {
-                            const int q = g - X6_D0;
-                            dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
+                        if (g < 4) {
+                            corner_req(2 * g);
+                            corner_req(2 * g + 1);
                         }
+                        if (g >= 2) dma_q(g - 2);
                         if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
-            corner_addr(0);
-            corner_addr(1);
+            corner_addr();
 #pragma unroll
-            for (int q = 0; q < 16; ++q) corner_req(q);
+            for (int q = 0; q < 8; ++q) corner_req(q);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
+            for (int q = 0; q < 2 * DPW; ++q) dma_q(q);
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_load_row(i);
             b_load(0, 0, par, 0);
@@ -774,16 +760,12 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_v2_kernel(const float* __restri
                 if (jj + 1 < NTH) b_load((jj + 1) & 1, 0, par, jj + 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int g = jj * MT + i;               // group 0..15: six MFMAs + one pair of column values on every second group
-                    if (g == 0) X6_CELL_WAIT(0, X6_W0);
-                    if (g == 8) X6_CELL_WAIT(1, X6_W1);
+                    const int g = jj * MT + i;               // group 0..7: six MFMAs; the two halves of the thread's column values ride on 1..3 and 4..6
+                    if (g == 1) X6_CELL_WAIT(X6_W);
                     mma_row(i, jj, jj & 1);
-                    if (X6_D0 + 12 > 16 && g < X6_D0 + 12 - 16) {
-                        const int q = g + 16 - X6_D0;
-                        dma_piece(q < 6 ? cy : cx, q < 6 ? 1 : 0, q < 6 ? par : par ^ 1, q % 6);
-                    }
-                    if (!(g & 1)) blend_pair(g >> 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 1) blend_half(0);
+                    if (g == 4) blend_half(1);
+                    if (g == 0 || g == 3 || g == 6 || g == 7) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (make_tab) {
@@ -896,7 +878,7 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     } else {
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(X6_V2 ? 512 : 256), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
                        out, M, H, W, C, dg, om_stride, Cout, ntn, mtiles, gssd_dcn_packed_weight_elems_x6(Cout, C) / 3);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;

@@ -13,7 +13,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // FILL 0 v_fma_f32, 1 v_cvt_pk_bf16_f32, 2 v_pk_add_f32, 3 v_pk_fma_f32, 4 v_sub_f32, 5 v_lshlrev_b32, 6 v_and_b32, 7 v_cndmask_b32 (SGPR pair), 8 v_perm_b32
 template <int N, int FILL>
-__device__ __forceinline__ void fillers(f32x2 (&f)[8], float a, float b) {
+__device__ __forceinline__ void fillers(f32x2 (&f)[8], float a, float b, f32x4 (&g_ld)[4], const float* g_ptr, const float* g_ptr2, unsigned g_lds) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (FILL == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
@@ -39,10 +39,16 @@ __device__ __forceinline__ void fillers(f32x2 (&f)[8], float a, float b) {
         if (FILL == 19) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i][0]) : "v"(a));
         if (FILL == 20) asm volatile("v_fma_mix_f32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
         if (FILL == 21) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(f[i][0]) : "v"(a), "v"(b));
+        // round 5 (dcn_x6): memory instructions behind an MFMA -- an L1-resident 1-KiB load / LDS DMA piece per wave, LDS reads / writes
+        if (FILL == 22) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g_ld[i & 3]) : "v"(g_ptr) : "memory");
+        if (FILL == 23) asm volatile("ds_read_b128 %0, %1" : "=v"(g_ld[i & 3]) : "v"(g_lds) : "memory");
+        if (FILL == 24) asm volatile("ds_write_b64 %0, %1" : : "v"(g_lds), "v"(f[i]) : "memory");
+        if (FILL == 25) asm volatile("global_load_lds_dwordx4 %0, off" : : "v"(g_ptr) : "memory");
+        if (FILL == 26) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g_ld[i & 3]) : "v"(g_ptr2) : "memory");
     }
 }
 
-template <int N, int FILL, int THREADS>
+template <int N, int FILL, int THREADS, int EVERY = 1, int ACCS = 4>
 __global__ __launch_bounds__(THREADS, 1) void overlap_kernel(float* __restrict__ out, unsigned long long* __restrict__ cycles, int iters) {
     const int lane = threadIdx.x & 63;
     f32x2 f[8];
@@ -55,17 +61,23 @@ __global__ __launch_bounds__(THREADS, 1) void overlap_kernel(float* __restrict__
     bf16x8 pa, pb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) pa[e] = (__bf16)(float)(lane & 3), pb[e] = (__bf16)1.f;
+    f32x4 g_ld[4];
+    __shared__ __attribute__((aligned(16))) float lds_buf[8 * 64 * 4 * 2];
+    const float* g_ptr = out + (size_t)(blockIdx.x * THREADS + threadIdx.x) * 4;                         // 1 KiB contiguous per wave
+    const float* g_ptr2 = out + (size_t)blockIdx.x * THREADS * 4 + (threadIdx.x >> 6) * 8192 + (lane >> 2) * 1024 + (lane & 3) * 8;   // 128 B per quad, 4 KiB apart
+    const unsigned g_lds = (unsigned)(size_t)(lds_buf) + threadIdx.x * 16;
+    asm volatile("s_mov_b32 m0, %0" : : "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_buf + (threadIdx.x >> 6) * 1024)));
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 64; ++k) {
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k & 3]) : "v"(pa), "v"(pb));
-            fillers<N, FILL>(f, a, b);
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ACCS == 6 ? (k / 6) & 3 : k & (ACCS - 1)]) : "v"(pa), "v"(pb));
+            if (k % EVERY == 0) fillers<N, FILL>(f, a, b, g_ld, g_ptr, g_ptr2, g_lds);
         }
     }
-    asm volatile("s_nop 7\n\ts_nop 7");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(g_ld[0]), "+v"(g_ld[1]), "+v"(g_ld[2]), "+v"(g_ld[3]));
     const unsigned long long t1 = __builtin_readcyclecounter();
-    float s = 0.f;
+    float s = (FILL >= 22 && FILL != 24 && FILL != 25) ? g_ld[0][0] + g_ld[1][0] + g_ld[2][0] + g_ld[3][0] : 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += f[i][0] + f[i][1];
 #pragma unroll
@@ -74,10 +86,10 @@ __global__ __launch_bounds__(THREADS, 1) void overlap_kernel(float* __restrict__
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
-template <int N, int FILL, int THREADS>
+template <int N, int FILL, int THREADS, int EVERY = 1, int ACCS = 4>
 double run(float* out, unsigned long long* cyc, int blocks) {
     const int iters = 200;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((overlap_kernel<N, FILL, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, out, cyc, iters);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((overlap_kernel<N, FILL, THREADS, EVERY, ACCS>), dim3(blocks), dim3(THREADS), 0, 0, out, cyc, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(blocks);
     hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -117,6 +129,11 @@ void table(float* out, unsigned long long* cyc, int cus) {
     row<19, THREADS>("v_mul_f32", out, cyc, cus);
     row<20, THREADS>("v_fma_mix_f32", out, cyc, cus);
     row<21, THREADS>("v_bfi_b32", out, cyc, cus);
+    row<22, THREADS>("global_load_dwordx4 1KiB", out, cyc, cus);
+    row<26, THREADS>("global_load_dwordx4 quad", out, cyc, cus);
+    row<25, THREADS>("global_load_lds_dwordx4", out, cyc, cus);
+    row<23, THREADS>("ds_read_b128", out, cyc, cus);
+    row<24, THREADS>("ds_write_b64", out, cyc, cus);
 }
 
 // round 5: is v - float(bf16(v)) through v_dot2c_f32_bf16 (acc = v; acc += h * -1 + h' * 0) the exact residual the shift + subtract gives?
@@ -169,6 +186,18 @@ void dot2_exact() {
            hb[1], hb[2], hb[3]);
 }
 
+template <int FILL, int THREADS>
+void sparse_row(const char* name, float* out, unsigned long long* cyc, int cus) {
+    printf("  %-26s %6.1f %6.1f %6.1f %6.1f %6.1f\n", name, run<1, FILL, THREADS, 2>(out, cyc, cus), run<1, FILL, THREADS, 4>(out, cyc, cus),
+           run<1, FILL, THREADS, 8>(out, cyc, cus), run<2, FILL, THREADS, 8>(out, cyc, cus), run<1, FILL, THREADS, 16>(out, cyc, cus));
+}
+
+template <int FILL, int ACCS>
+void chain_row(const char* name, float* out, unsigned long long* cyc, int cus) {
+    printf("  %-40s %6.1f %6.1f %6.1f %6.1f %6.1f\n", name, run<0, FILL, 256, 1, ACCS>(out, cyc, cus), run<1, FILL, 256, 1, ACCS>(out, cyc, cus),
+           run<2, FILL, 256, 1, ACCS>(out, cyc, cus), run<3, FILL, 256, 1, ACCS>(out, cyc, cus), run<4, FILL, 256, 1, ACCS>(out, cyc, cus));
+}
+
 int main() {
     dot2_exact();
     int dev = 0, cus = 0;
@@ -176,9 +205,24 @@ int main() {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     float* out;
     unsigned long long* cyc;
-    hipMalloc(&out, (size_t)cus * 512 * sizeof(float));
+    hipMalloc(&out, (size_t)cus * 512 * 64 * sizeof(float));
+    hipMemset(out, 0, (size_t)cus * 512 * 64 * sizeof(float));
     hipMalloc(&cyc, (size_t)cus * sizeof(unsigned long long));
     table<256>(out, cyc, cus);
     table<512>(out, cyc, cus);
+    printf("one wave per SIMD, N = 0 1 2 3 4 fillers behind every MFMA, by how the MFMAs use their accumulators: cycles per MFMA\n");
+    chain_row<0, 1>("v_fma_f32, ONE accumulator", out, cyc, cus);
+    chain_row<0, 2>("v_fma_f32, two alternating", out, cyc, cus);
+    chain_row<0, 6>("v_fma_f32, chains of six", out, cyc, cus);
+    chain_row<0, 4>("v_fma_f32, four round robin", out, cyc, cus);
+    chain_row<13, 1>("v_cvt_pk_bf16_f32, ONE accumulator", out, cyc, cus);
+    chain_row<13, 6>("v_cvt_pk_bf16_f32, chains of six", out, cyc, cus);
+    chain_row<23, 6>("ds_read_b128, chains of six", out, cyc, cus);
+    printf("one wave per SIMD, memory instructions behind every 2nd / 4th / 8th / (two behind every) 8th / 16th MFMA: cycles per MFMA (16.2 = hidden)\n");
+    sparse_row<22, 256>("global_load_dwordx4 1KiB", out, cyc, cus);
+    sparse_row<26, 256>("global_load_dwordx4 quad", out, cyc, cus);
+    sparse_row<25, 256>("global_load_lds_dwordx4", out, cyc, cus);
+    sparse_row<23, 256>("ds_read_b128", out, cyc, cus);
+    sparse_row<24, 256>("ds_write_b64", out, cyc, cus);
     return 0;
 }
