@@ -706,6 +706,14 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
     int tb_next = cpc * 9, tb_d = 1;                         // first chunk of the next group, and the group
 
     // ---- iteration `it`: [part A: j = 2, 3 of chunk it - 1] [part B: j = 0, 1 of chunk it]; FIRST has no chunk behind it, LAST none in front ----
+    // Two barriers, both with slack.  B1 (behind part A's first column tile): the previous iteration's planes and X pieces are in LDS, its
+    // table is read -> the stage / the X half may be read, the X half the previous part B used may be overwritten, the table rewritten.
+    // B2 (behind part B's first group): every wave holds chunk it's activation fragments and has its corner data and Y pieces -> the stage
+    // may take chunk it + 1's planes, the Y half may be read (its first fragments are prefetched behind part B's last group).
+    // Issue order of a wave's memory operations: g0: D0 G0 G1, g1: D1 G2 G3, g2: D2 G4 G5, g3: G6 G7 | B1 | g4: D3, g5: D4, g6: D5
+    // (D0..D2: Y pieces of chunk it, D3..D5: X pieces of chunk it + 1); vmcnt counts in issue order:
+    //   B1: vmcnt(11) = the previous iteration's X pieces have landed;   B2: vmcnt(3) = G0..G7 and D0..D2 have landed.
+    constexpr int K_B2 = (X6_KO & 4) ? 0 : DPW, K_B1 = K_B2 + ((X6_KO & 8) ? 0 : 8);
     auto iteration = [&](int it, auto first_c, auto last_c) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const int par = it & 1;
@@ -719,41 +727,49 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
         __builtin_amdgcn_sched_barrier(0);
         // ---- part A ----
         if (!FIRST) {
-            b_load(0, 1, par ^ 1, 0);                        // Y of chunk it - 1, landed during the previous iteration
 #pragma unroll
             for (int jj = 0; jj < NTH; ++jj) {
                 if (jj + 1 < NTH) b_load((jj + 1) & 1, 1, par ^ 1, jj + 1);
-                else if (!LAST) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int g = jj * MT + i;               // group 0..7: six MFMAs; two corner requests (groups 0..3), one DMA piece (2..7)
+                    const int g = jj * MT + i;               // group 0..7: six MFMAs
                     if (!LAST && g == 0) corner_addr();
+                    if (jj + 1 == NTH && !LAST && i == 0) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it (behind B1)
                     mma_row(i, NTH + jj, jj & 1);
                     if (!LAST) {
+                        if (g < 3) dma_q(g);
                         if (g < 4) {
                             corner_req(2 * g);
                             corner_req(2 * g + 1);
                         }
-                        if (g >= 2) dma_q(g - 2);
+                        if (g >= 4 && g < 7) dma_q(g - 1);
                         if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if (jj == 0 && !LAST) {
+                    if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B1) : "memory");          // B1
+                    if (make_tab) {
+                        tab_finish();
+                        tb_next += cpc * 9;
+                        ++tb_d;
+                    }
                 }
             }
         } else {
             corner_addr();
 #pragma unroll
+            for (int q = 0; q < DPW; ++q) dma_q(q);
+#pragma unroll
             for (int q = 0; q < 8; ++q) corner_req(q);
 #pragma unroll
-            for (int q = 0; q < 2 * DPW; ++q) dma_q(q);
+            for (int q = DPW; q < 2 * DPW; ++q) dma_q(q);
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_load_row(i);
             b_load(0, 0, par, 0);
         }
         if (!LAST) {
-            // every wave holds chunk it's fragments: the stage may take chunk it + 1's planes (and the table a new group's entries)
-            if (X6_KO & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // ---- part B ----
 #pragma unroll
             for (int jj = 0; jj < NTH; ++jj) {
@@ -761,21 +777,20 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int g = jj * MT + i;               // group 0..7: six MFMAs; the two halves of the thread's column values ride on 1..3 and 4..6
-                    if (g == 1) X6_CELL_WAIT(X6_W);
                     mma_row(i, jj, jj & 1);
+                    if (g == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B2) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B2) : "memory");          // B2
+                        X6_CELL_WAIT(3);                     // (already true: ties the corner registers to the wait for the compiler)
+                    }
                     if (g == 1) blend_half(0);
                     if (g == 4) blend_half(1);
+                    if (g == NG - 1) b_load(0, 1, par, 0);   // Y of chunk it for the next iteration's first column tile
                     if (g == 0 || g == 3 || g == 6 || g == 7) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (make_tab) {
-                tab_finish();
-                tb_next += cpc * 9;
-                ++tb_d;
-            }
             if (it + 2 < nchunks) advance_ld();
-            if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     };
     iteration(0, std::true_type{}, std::false_type{});
