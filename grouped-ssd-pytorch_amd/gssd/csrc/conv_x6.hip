@@ -15,6 +15,7 @@
 //
 // Replaces the cuDNN kernels behind nn.Conv2d of the reference's trunk (layers/..., models/ssd_multiphase_custom_group.py: vgg()).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,6 +57,23 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     m = (__bf16)r1;
     l = (__bf16)(r1 - (float)m);
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// the same split of TWO values at once, planes as packed bf16 pairs (a in the low half): one v_cvt_pk_bf16_f32 per plane and pair
+__device__ __forceinline__ void split3_pair(const float a, const float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, ph << 16), rb = b - __builtin_bit_cast(float, ph & 0xffff0000u);
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, pm << 16), sb = rb - __builtin_bit_cast(float, pm & 0xffff0000u);
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
+
+#ifndef X6_V2
+#define X6_V2 1             // round 5's K loop for the 64- / 128-column tiles (conv_x6_v2_kernel); 0: round 4's (conv_x6_kernel, also the 256-column sweep instance)
+#endif
 
 template <int BN>
 struct Cfg {
@@ -427,6 +445,423 @@ __global__ __launch_bounds__(256, Cfg<BN>::OCC) void conv_x6_kernel(const gssd_c
     }
 }
 
+#if X6_V2
+// ---- round 5: the K loop of dcn_x6.hip's v2 kernel for the plain convolution ---------------------------------------------------------------
+// Round 4's loop read all weight fragments of a chunk (+ the first activation row) in front of a barrier, then issued the weight DMA and the
+// activation loads in a burst; "feeding" and MFMAs added up (profiles/r04_f_conv_x6_knockout.txt).  Here, as in dcn_x6.hip (see there):
+//   * iteration `it` = [part A: the column tiles of the second half of chunk it - 1] [part B: the first half of chunk it];
+//   * ONE activation stage (the four rows' fragments are reloaded in place behind the last column tile's MFMAs), the weight planes in four
+//     half buffers (X: first half of the wave's column tiles, Y: second half; two of each): what an iteration reads was DMA'd during the
+//     previous one -- 24 + 48 KB for 128 columns as before, 24 + 24 KB for 64;
+//   * column tile outer, fragment row inner; the weight fragments of the next tile are prefetched behind the current tile's MFMAs;
+//   * every memory request sits behind its own group of six MFMAs; waits are counted (vmcnt is in issue order);
+//   * two barriers per iteration: B1 in front of part A's last column tile (the previous iteration's planes and X pieces are in LDS),
+//     B2 behind part B's first group (every wave holds its fragments, its loads and Y pieces have landed).
+template <int BN>
+struct Cfg2 {
+    static constexpr int WTN = BN / 2, NT = WTN / 16, NTH = NT / 2, MT = 4;
+    static constexpr int NG = NTH * MT;                   // groups of six MFMAs per part: 8 / 4
+    static constexpr int HB_ROWS = BN / 2, HB_PLANE = HB_ROWS * BKC, HB_ELEMS = NP * HB_PLANE;
+    static constexpr int PH = NP * HB_ROWS / 16;          // 1-KiB pieces per half: 12 / 6
+    static constexpr int DPW = 2 * PH / 4;                // pieces per wave and iteration: 6 / 3
+    static constexpr int NY = (PH + 3) / 4;               // the wave's first NY pieces cover its share of the Y half: 3 / 2
+    static constexpr int LDS_BYTES = (NP * A_STAGE + 4 * HB_ELEMS) * 2;      // + the scale / shift table
+    static_assert(BN == 64 || BN == 128, "tiles");
+};
+
+template <int BN, bool XF>
+__global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles,
+                                                           const long long plane_elems) {
+    using K = Cfg2<BN>;
+    constexpr int WTM = 64, WTN = K::WTN, MT = K::MT, NT = K::NT, NTH = K::NTH, NG = K::NG, DPW = K::DPW, NY = K::NY, PH = K::PH;
+    constexpr int HB_PLANE = K::HB_PLANE, HB_ELEMS = K::HB_ELEMS, B_STAGE = BN * BKC;
+    extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
+    u16* const As = smem_h;                                   // [3][BM][32]
+    u16* const Bh = smem_h + NP * A_STAGE;                    // [X | Y][2][3][BN / 2][32]
+    float* const xtab = reinterpret_cast<float*>(smem_h + NP * A_STAGE + 4 * HB_ELEMS);      // [2][cin_g] scale | shift
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    // flat XCD-aware grid: the slots of an XCD run through all (group, N tile) pairs of one M tile before the next M tile
+    const int ny = p.groups * ntn;
+    const int slot = blockIdx.x >> 3;
+    const int mt = (slot / ny) * 8 + (blockIdx.x & 7);
+    const int by = slot % ny;
+    if (mt >= mtiles) return;
+    const int g = by / ntn, nt = by - g * ntn;
+    const int cout_g = p.Cout / p.groups;
+    const int n0g = nt * BN;
+    const int m0 = mt * BM;
+    const int HoWo = p.Ho * p.Wo;
+    const int taps = p.KH * p.KW;
+    const int cpc = p.cin_g / BKC;
+    const int nchunks = cpc * taps;
+    const float* __restrict__ in = p.in + p.in_ch_off + g * p.cin_g;
+    const u16* wslab = reinterpret_cast<const u16*>(p.wgt_x6) + (size_t)by * nchunks * B_STAGE;      // plane 0; plane q at + q * plane_elems
+    constexpr bool xf = XF;
+
+    f32x4 acc[MT][NT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
+
+    // gather roles: thread -> (pixel rows gp and gp + 64, 8-channel slot gq)
+    const int gq = tid & 3, gp = tid >> 2;
+    const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
+    const int fo = r * BKC + ((kq ^ swz(r)) << 3);
+    int g_iy0[2], g_ix0[2], g_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + gp + 64 * j;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HoWo, pix = mm - b * HoWo;
+        const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+        g_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 20);
+        g_ix0[j] = ox * p.stride - p.pad;
+        g_off[j] = ((b * p.H + oy * p.stride - p.pad) * p.W + g_ix0[j]) * p.in_stride + gq * 8;
+    }
+    if (xf) {
+        const float* xsc = p.in_scale + p.in_ch_off + g * p.cin_g;
+        const float* xsh = p.in_shift + p.in_ch_off + g * p.cin_g;
+        for (int c = tid; c < p.cin_g; c += 256) {
+            xtab[c] = xsc[c];
+            xtab[p.cin_g + c] = xsh[c];
+        }
+    }
+
+    // ---- activation loads of one chunk: 2 pixels x 2 halves of 4 fp32 channels per thread, by inline assembly (counted waits) ----------------
+    int ld_ty = 0, ld_tx = 0, ld_c = 0, ld_tap = 0;          // the chunk the next loads are for = the chunk split next
+    f32x4 gv[2][2];
+    bool gok[2] = {false, false};
+    const float* src[2] = {in, in};
+    gv[0][0] = gv[0][1] = gv[1][0] = gv[1][1] = zero4;
+    auto load_addr = [&]() {
+        const int dy = ld_ty * p.dil, dx = ld_tx * p.dil;
+        const int toff = (dy * p.W + dx) * p.in_stride + ld_c * BKC;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gok[j] = (unsigned)(g_iy0[j] + dy) < (unsigned)p.H && (unsigned)(g_ix0[j] + dx) < (unsigned)p.W;
+            src[j] = in + (gok[j] ? g_off[j] + toff : gq * 8);
+        }
+    };
+    auto load_req = [&](int q) {                             // request q = (pixel, half): 16 bytes per lane
+        if (X6_KO & 8) return;
+        const int j = q >> 1;
+        if (q & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gv[j][1]) : "v"(src[j]) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[j][0]) : "v"(src[j]) : "memory");
+    };
+    int fin_c = 0;                                           // 32-channel block of the chunk in gv (for the scale / shift table)
+    auto advance_ld = [&]() {
+        ++ld_tap;
+        if (++ld_tx == p.KW) {
+            ld_tx = 0;
+            ++ld_ty;
+        }
+        if (ld_tap == taps) {
+            ld_tap = ld_ty = ld_tx = 0;
+            ++ld_c;
+        }
+    };
+    // quarter `part` (pixel part >> 1, channel half part & 1) of this thread's 16 values: deferred BatchNorm + ReLU, split, 8 bytes per plane
+    auto finish_part = [&](int part) {
+        if (X6_KO & 1) return;
+        const int j = part >> 1, hh = part & 1;
+        f32x4 v = gv[j][hh];
+        if (xf) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(xtab + fin_c * BKC + gq * 8 + 4 * hh);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(xtab + p.cin_g + fin_c * BKC + gq * 8 + 4 * hh);
+            // (element by element: packed fp32 instructions do not run beside the MFMAs, scripts/ubench/mfma16_valu_overlap.hip)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+        }
+        if (!gok[j]) v = zero4;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(v[0], v[1], h0, m0_, l0);
+        split3_pair(v[2], v[3], h1, m1, l1);
+        if (X6_KO & 32) return;
+        u16* Ad = As + a_wr0 + j * 64 * BKC + 4 * hh;
+        *reinterpret_cast<u32x2*>(Ad) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(Ad + A_STAGE) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = u32x2{l0, l1};
+    };
+    // piece q (0 .. DPW - 1) of this wave in an iteration: the first PH pieces of the iteration's list are the Y half of chunk cy, the rest the
+    // X half of chunk cx; piece = (plane, wave column, column tile inside the half)
+    auto dma_piece = [&](int q, int cy, int cx, int par) {
+        if (X6_KO & 4) return;
+        const int idx = q * 4 + wave;
+        const bool isx = idx >= PH;
+        const int pc = isx ? idx - PH : idx;
+        const int pl = pc / (2 * NTH), g8 = pc - pl * (2 * NTH);
+        const int half = isx ? 0 : 1, parity = isx ? par ^ 1 : par;
+        const int G = (g8 / NTH) * NT + half * NTH + (g8 % NTH);       // 16-row group of the plane's [BN][32] tile
+        const u16* s = wslab + (size_t)(isx ? cx : cy) * B_STAGE + (size_t)pl * plane_elems + G * 512 + lane * 8;
+        dma16(s, Bh + (half * 2 + parity) * HB_ELEMS + pl * HB_PLANE + g8 * 512);
+    };
+
+    bf16x8 areg[MT][NP], breg[2][NP];
+    auto a_load_row = [&](int i) {
+        const u16* Ab = As + (wm * WTM + i * 16) * BKC + fo;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (X6_KO & 16) asm volatile("" : "=v"(areg[i][pl]));
+            else areg[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_STAGE);
+        }
+    };
+    auto b_load = [&](int which, int half, int parity, int jj) {
+        const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * NTH * 16 + jj * 16) * BKC + fo;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (X6_KO & 16) asm volatile("" : "=v"(breg[which][pl]));
+            else breg[which][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * HB_PLANE);
+        }
+    };
+    // six products per fragment pair, smallest first (first operand: weight planes).  The bf16 MFMA's adder truncates: summing the six products
+    // of a chunk from zero and adding the chunk's sum to the running sum with the vector ALU (round to nearest) keeps the result closer to
+    // float64 than the fp32-MFMA kernels (3-4 x closer than accumulating in place: scripts/bench_conv_x6.py)
+    auto mma_row = [&](int i, int j, int which) {
+        if (X6_KO & 2) return;
+#if X6_LOCAL_SUM
+        f32x4 c = zero4;
+#else
+        f32x4 c = acc[i][j];
+#endif
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+#if X6_LOCAL_SUM
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] += c[e];
+#else
+        acc[i][j] = c;
+#endif
+    };
+    constexpr int NGQ = (X6_KO & 8) ? 0 : 4, NDQ = (X6_KO & 4) ? 0 : DPW, NYQ = (X6_KO & 4) ? 0 : NY;
+    // all four loads have landed; N younger DMA pieces of this wave may still be in flight
+#define X6_LOADS_WAIT(N) \
+    if (!(X6_KO & 8)) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[1][0]), "+v"(gv[1][1]) : "n"(N))
+
+    // ---- prologue: planes of chunk 0, X half of chunk 0's weights --------------------------------------------------------------------------------
+    load_addr();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_req(q);
+    if (xf) __syncthreads();                       // the scale / shift table
+    if (!(X6_KO & 4)) {
+        // X half of chunk 0: PH pieces over four waves (the counts differ by wave when PH = 6: everything is awaited)
+        for (int pc = wave; pc < PH; pc += 4) {
+            const int pl = pc / (2 * NTH), g8 = pc - pl * (2 * NTH);
+            const int G = (g8 / NTH) * NT + (g8 % NTH);
+            dma16(wslab + (size_t)pl * plane_elems + G * 512 + lane * 8, Bh + pl * HB_PLANE + g8 * 512);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[1][0]), "+v"(gv[1][1]));
+#pragma unroll
+    for (int part = 0; part < 4; ++part) finish_part(part);
+    if (nchunks > 1) {
+        advance_ld();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // Issue order of a wave's memory operations in an iteration (128 columns: 8 groups per part, 6 pieces; 64 columns: 4 groups, 3 pieces):
+    //   128: g0: D0 L0, g1: D1 L1, g2: D2 L2, g3: L3 | B1 | g4: D3, g5: D4, g6: D5      B1: vmcnt(NY + 4), B2: vmcnt(DPW - NY)
+    //    64: | B1 | g0: D0 L0 L1, g1: D1 L2 L3, g2: D2                                   B1: vmcnt(0),      B2: vmcnt(DPW - NY)
+    // (D0 .. D(NY-1) cover the wave's share of the Y half; L = activation load)
+    auto iteration = [&](int it, auto first_c, auto last_c) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        const int par = it & 1;
+        const int cy = min(it, nchunks - 1), cx = min(it + 1, nchunks - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- part A ----
+        if (!FIRST) {
+#pragma unroll
+            for (int jj = 0; jj < NTH; ++jj) {
+                if (jj + 1 == NTH && !LAST) {
+                    // B1: the previous iteration's planes and X pieces are in LDS (every wave waited for its own), its table reads are done
+                    constexpr int K_B1 = NTH == 1 ? 0 : NYQ + NGQ;
+                    if (X6_KO & 64) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B1) : "memory");
+                }
+                if (jj + 1 < NTH) b_load((jj + 1) & 1, 1, par ^ 1, jj + 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int gidx = jj * MT + i;            // group 0 .. NG - 1: six MFMAs
+                    if (!LAST && gidx == 0) load_addr();
+                    if (jj + 1 == NTH && !LAST && i == 0) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it (behind B1)
+                    mma_row(i, NTH + jj, jj & 1);
+                    if (!LAST) {
+                        if (NTH == 2) {
+                            if (gidx < 3) dma_piece(gidx, cy, cx, par);
+                            if (gidx < 4) load_req(gidx);
+                            if (gidx >= 4 && gidx < 7) dma_piece(gidx - 1, cy, cx, par);
+                        } else {
+                            if (gidx < 3) dma_piece(gidx, cy, cx, par);
+                            if (gidx < 2) {
+                                load_req(2 * gidx);
+                                load_req(2 * gidx + 1);
+                            }
+                        }
+                        if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            load_addr();
+#pragma unroll
+            for (int q = 0; q < NY; ++q) dma_piece(q, cy, cx, par);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_req(q);
+#pragma unroll
+            for (int q = NY; q < DPW; ++q) dma_piece(q, cy, cx, par);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_load_row(i);
+            b_load(NTH & 1, 0, par, 0);
+        }
+        if (!LAST) {
+            // ---- part B (weight fragments of tile jj in breg[(NTH + jj) & 1]: part A's last tile left X's first tile in breg[NTH & 1]) ----
+#pragma unroll
+            for (int jj = 0; jj < NTH; ++jj) {
+                if (jj + 1 < NTH) b_load((NTH + jj + 1) & 1, 0, par, jj + 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int gidx = jj * MT + i;            // group 0 .. NG - 1: six MFMAs; the four quarters of the thread's values ride behind
+                    mma_row(i, jj, (NTH + jj) & 1);
+                    if (gidx == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        // B2: every wave holds chunk it's activation fragments; this wave's loads and Y pieces have landed
+                        constexpr int K_B2 = NDQ - NYQ;
+                        if (X6_KO & 64) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B2) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B2) : "memory");
+                        X6_LOADS_WAIT(DPW - NY);             // (already true: ties the load registers to the wait for the compiler)
+                    }
+                    if (NTH == 2) {
+                        if (gidx == 1) finish_part(0);
+                        if (gidx == 2) finish_part(1);
+                        if (gidx == 4) finish_part(2);
+                        if (gidx == 5) finish_part(3);
+                    } else {
+                        if (gidx == 1) finish_part(0), finish_part(1);
+                        if (gidx == 2) finish_part(2);
+                        if (gidx == 3) finish_part(3);
+                    }
+                    if (gidx == NG - 1) b_load(0, 1, par, 0);   // Y of chunk it for the next iteration's first column tile
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (it + 2 < nchunks) advance_ld();
+            fin_c = ld_c;                                    // block of the chunk the next iteration requests (and splits in its part B)
+        }
+    };
+    // fin_c: block of the chunk whose values sit in gv while part B runs = the chunk requested in this iteration's part A (ld_c at that time)
+    fin_c = ld_c;
+    iteration(0, std::true_type{}, std::false_type{});
+    for (int it = 1; it < nchunks; ++it) iteration(it, std::false_type{}, std::false_type{});
+    iteration(nchunks, std::false_type{}, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[1][0]), "+v"(gv[1][1]) : : "memory");
+    __syncthreads();
+#undef X6_LOADS_WAIT
+
+    // ---- epilogue: + bias, batch sums of the pre-activation output, ReLU, 16-byte NHWC stores (lane: pixel r, 8 consecutive channels
+    //      per tile pair) ------------------------------------------------------------------------------------------------------------
+    float* red = reinterpret_cast<float*>(smem_h);          // [2 wm][BN][2]
+    const float gate = p.gate ? *p.gate : 0.f;
+    const bool split_t = p.out_mode == GSSD_OUT_SPLIT_T && n0g >= p.split_n;      // workgroup-uniform: split_n is a multiple of the tile
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+        const int nl = wn * WTN + 32 * u + 8 * kq;            // channel inside the tile
+        const int ng = n0g + nl;                              // ... inside the group
+        const bool n_ok = ng + 8 <= cout_g;
+        const int n = g * cout_g + ng;
+        float bv[8], av[8], ssum[8], ssq[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bv[c] = (p.bias && n_ok) ? p.bias[n + c] : 0.f;
+            av[c] = (p.alpha && n_ok) ? p.alpha[n + c] : 1.f;
+            ssum[c] = ssq[c] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r;
+            if (m >= M || !n_ok) continue;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v[c] = acc[i][2 * u + (c >> 2)][c & 3] * av[c] + bv[c];
+                ssum[c] += v[c];
+                ssq[c] += v[c] * v[c];
+            }
+            if (split_t) {
+                // second column range of a merged projection: per image [n - split_n][pixel] (the row tails up to out_b_stride are never
+                // written: the caller zero-fills the buffer once)
+                const int bi = m / HoWo, ml = m - bi * HoWo;
+                float* dst = p.out_b + (size_t)bi * p.outb_batch_stride + (size_t)(n - p.split_n) * p.out_b_stride + ml;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) dst[(size_t)c * p.out_b_stride] = v[c];
+                continue;
+            }
+            // conv_igemm's epilogue order: gate, second output, residual, ReLU
+            const size_t o = (size_t)m * p.out_stride + p.out_ch_off + n;
+            if (p.gate) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] *= gate;
+                if (p.out2) {
+                    *reinterpret_cast<f32x4*>(p.out2 + o) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(p.out2 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+            if (p.resid) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.resid + o), r1 = *reinterpret_cast<const f32x4*>(p.resid + o + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] += r0[c];
+                    v[4 + c] += r1[c];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p.out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float s = ssum[c], q = ssq[c];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (r == 0) {
+                    red[(wm * BN + nl + c) * 2 + 0] = s;
+                    red[(wm * BN + nl + c) * 2 + 1] = q;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < BN && n0g + tid < cout_g) {
+            const double s = (double)red[tid * 2 + 0] + (double)red[(BN + tid) * 2 + 0];
+            const double q = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+            const int n = g * cout_g + n0g + tid;
+            double* st = gssd_stats_replica(p.stats, p.stats_rep, p.Cout);
+            unsafeAtomicAdd(st + n, s);
+            unsafeAtomicAdd(st + p.Cout + n, q);
+        }
+    }
+}
+
+#endif
+
 // packed fp32 rows [Cout][row_stride] (k = tap * cin_g + c) -> three bf16 planes in the kernel's DMA order; rows beyond cout_g zero
 __global__ void conv_x6_pack_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int groups, int cin_g, int taps, int row_stride,
                                     int BN, long long total) {
@@ -469,6 +904,28 @@ int launch(const gssd_conv_desc& d, int M, hipStream_t stream) {
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
+
+#if X6_V2
+template <int BN, bool XF>
+int launch2(const gssd_conv_desc& d, int M, hipStream_t stream) {
+    static unsigned attr_mask = 0;
+    auto kern = conv_x6_v2_kernel<BN, XF>;
+    constexpr int lds = Cfg2<BN>::LDS_BYTES;
+    if (gssd_attr_needed(&attr_mask)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 4096) != hipSuccess) {
+            gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds + 4096);
+            return GSSD_ELAUNCH;
+        }
+        gssd_attr_done(&attr_mask);
+    }
+    const int cout_g = d.Cout / d.groups;
+    const int ntn = (cout_g + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
+    const long long plane = (long long)d.groups * ntn * BN * d.KH * d.KW * d.cin_g;
+    hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * d.groups * ntn), dim3(256), lds + (d.in_scale ? 8 * d.cin_g : 0), stream, d, M, ntn, mtiles, plane);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+#endif
 
 bool shape_ok(int cin_g, int cout_g, int groups) {
     return cin_g > 0 && cin_g % BKC == 0 && cout_g >= 32 && cout_g % 8 == 0 && groups > 0;
@@ -538,8 +995,13 @@ int gssd_try_conv_x6(const gssd_conv_desc& d, hipStream_t stream) {
     const long long Mll = (long long)d.B * d.Ho * d.Wo;
     const int M = (int)Mll;
     switch (gssd_conv_x6_tile(d.Cout / d.groups, d.groups, Mll)) {
+#if X6_V2
+        case 64: return d.in_scale ? launch2<64, true>(d, M, stream) : launch2<64, false>(d, M, stream);
+        case 128: return d.in_scale ? launch2<128, true>(d, M, stream) : launch2<128, false>(d, M, stream);
+#else
         case 64: return d.in_scale ? launch<64, true>(d, M, stream) : launch<64, false>(d, M, stream);
         case 128: return d.in_scale ? launch<128, true>(d, M, stream) : launch<128, false>(d, M, stream);
+#endif
         default: return d.in_scale ? launch<256, true>(d, M, stream) : launch<256, false>(d, M, stream);
     }
 }
