@@ -472,6 +472,18 @@ __global__ __launch_bounds__(256, 1) void dcn_x6_kernel(const float* __restrict_
 // Part A carries the 16 corner requests of chunk it + 1 (inline assembly, counted waits) and the 12 DMA pieces, one per group of six MFMAs;
 // part B carries the blend + split + plane writes of chunk it + 1, one pair of values per group.
 namespace v2 {
+#ifdef X6_TIMING
+// debug build (scripts/dcn_x6_timing.sh): wave 0 of every workgroup accumulates the 100-MHz real-time ticks between its phase boundaries
+__device__ unsigned long long g_x6_timing[8];
+#define X6_T(k)                                                   \
+    if (X6_TIMING_ON) {                                           \
+        const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+        t_acc[k] += t_now - t_last;                               \
+        t_last = t_now;                                           \
+    }
+#else
+#define X6_T(k)
+#endif
 // eight waves (two per SIMD: with one, every scalar / vector / LDS instruction of the wave takes one of the 768 issue slots the 192 MFMAs of a
 // chunk leave it -- the four-wave form of this loop ran 1.96 ms, every knock-out paid) on 64 x 64 wave tiles: 2 (rows) x 4 (columns)
 constexpr int THREADS = 512, NWAVES = THREADS / 64;
@@ -532,6 +544,13 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
 
+#ifdef X6_TIMING
+#ifndef X6_TWAVE
+#define X6_TWAVE 0
+#endif
+    const bool X6_TIMING_ON = wave == X6_TWAVE;
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memrealtime();
+#endif
     // gather roles: thread -> (pixel row gp, 8-channel slot gq)
     const int gq = tid & 3, gp = tid >> 2;
     const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
@@ -615,12 +634,12 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
         if (q & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gv[k][1]) : "v"(pc[k]) : "memory");
         else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[k][0]) : "v"(pc[k]) : "memory");
     };
-    // the 8 requests have landed; N younger DMA pieces of this wave may still be in flight
-#define X6_CELL_WAIT(N)                                                                                                     \
-    if (!(X6_KO & 8))                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" X6_STR(N) ")"                                                                           \
-                 : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[1][0]), "+v"(gv[1][1]), "+v"(gv[2][0]), "+v"(gv[2][1]), "+v"(gv[3][0]), \
-                   "+v"(gv[3][1]))
+    // the four requests of channel half HH (or all eight: X6_CELL_WAIT) have landed; N younger requests of this wave may still be in flight
+#define X6_HALF_WAIT(HH, N) \
+    if (!(X6_KO & 8)) asm volatile("s_waitcnt vmcnt(" X6_STR(N) ")" : "+v"(gv[0][HH]), "+v"(gv[1][HH]), "+v"(gv[2][HH]), "+v"(gv[3][HH]))
+#define X6_CELL_WAIT(N)    \
+    X6_HALF_WAIT(0, N);    \
+    X6_HALF_WAIT(1, N)
     auto advance_ld = [&]() {
         if (++ld_tap == 9) {
             ld_tap = 0;
@@ -708,12 +727,25 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
     // ---- iteration `it`: [part A: j = 2, 3 of chunk it - 1] [part B: j = 0, 1 of chunk it]; FIRST has no chunk behind it, LAST none in front ----
     // Two barriers, both with slack.  B1 (behind part A's first column tile): the previous iteration's planes and X pieces are in LDS, its
     // table is read -> the stage / the X half may be read, the X half the previous part B used may be overwritten, the table rewritten.
-    // B2 (behind part B's first group): every wave holds chunk it's activation fragments and has its corner data and Y pieces -> the stage
-    // may take chunk it + 1's planes, the Y half may be read (its first fragments are prefetched behind part B's last group).
-    // Issue order of a wave's memory operations: g0: D0 G0 G1, g1: D1 G2 G3, g2: D2 G4 G5, g3: G6 G7 | B1 | g4: D3, g5: D4, g6: D5
-    // (D0..D2: Y pieces of chunk it, D3..D5: X pieces of chunk it + 1); vmcnt counts in issue order:
-    //   B1: vmcnt(11) = the previous iteration's X pieces have landed;   B2: vmcnt(3) = G0..G7 and D0..D2 have landed.
-    constexpr int K_B2 = (X6_KO & 4) ? 0 : DPW, K_B1 = K_B2 + ((X6_KO & 8) ? 0 : 8);
+    // B2 (behind part B's first group): every wave holds chunk it's activation fragments and its Y pieces have landed -> the stage may take
+    // chunk it + 1's planes, the Y half may be read (its first fragments are prefetched behind part B's last group).
+    // ONE memory request per group of six MFMAs: the vector memory path takes one wave-wide 16-byte request per 16 cycles, so eight waves can
+    // issue one each per 128 cycles; a denser stretch stalls the waves IN ORDER in front of their next MFMAs (the timing build showed the
+    // first column tile of part A, carrying 11 of the 14 requests, at 1.6 x its MFMA time and a 550-ns wait at B1 behind it).
+    // Slots (A0..A7, B0..B7): D0 D1 D2 (Y pieces of chunk it) | L0 | B1 | L1 L2 L3 L4 | L5 | B2 | L6 L7 | D3 D4 D5 (X pieces of chunk it + 1);
+    // L0..L3 = the first channel half of the four corners, L4..L7 the second.  vmcnt counts in issue order:
+    //   B1: vmcnt(4) = the previous iteration's D5 has landed;   B2: vmcnt(6) = D0..D2 have landed;
+    //   first half of the column values (B3, in front of D3): vmcnt(4) = L0..L3;   second half (B6): vmcnt(3) = L4..L7.
+    constexpr int NDH = (X6_KO & 4) ? 0 : DPW, NLQ = (X6_KO & 8) ? 0 : 1;
+    constexpr int K_B1 = NDH + NLQ, K_B2 = 6 * NLQ;
+    auto vm_slot = [&](int sl, int cy, int cx, int par) {    // the memory request of slot sl = 0..15 (A0..A7, B0..B7)
+        auto dma_q = [&](int q) { dma_piece(q < DPW ? cy : cx, q < DPW ? 1 : 0, q < DPW ? par : par ^ 1, q % DPW); };
+        if (sl < 3) dma_q(sl);
+        else if (sl < 11) {
+            const int l = sl - 3;                            // L0..L7: corner l & 3, channel half l >> 2
+            corner_req(2 * (l & 3) + (l >> 2));
+        } else if (sl < 14) dma_q(sl - 8);
+    };
     auto iteration = [&](int it, auto first_c, auto last_c) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const int par = it & 1;
@@ -723,7 +755,6 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
             make_tab = it + 2 == tb_next && it + 2 < nchunks;
             if (make_tab) tab_load(tb_d);
         }
-        auto dma_q = [&](int q) { dma_piece(q < DPW ? cy : cx, q < DPW ? 1 : 0, q < DPW ? par : par ^ 1, q % DPW); };      // q = 0 .. 2 DPW - 1
         __builtin_amdgcn_sched_barrier(0);
         // ---- part A ----
         if (!FIRST) {
@@ -733,23 +764,20 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int g = jj * MT + i;               // group 0..7: six MFMAs
-                    if (!LAST && g == 0) corner_addr();
+                    if (!LAST && g == 3) corner_addr();
                     if (jj + 1 == NTH && !LAST && i == 0) b_load((jj + 1) & 1, 0, par, 0);          // X of chunk it (behind B1)
                     mma_row(i, NTH + jj, jj & 1);
                     if (!LAST) {
-                        if (g < 3) dma_q(g);
-                        if (g < 4) {
-                            corner_req(2 * g);
-                            corner_req(2 * g + 1);
-                        }
-                        if (g >= 4 && g < 7) dma_q(g - 1);
+                        vm_slot(g, cy, cx, par);
                         if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (jj == 0 && !LAST) {
+                    X6_T(0)
                     if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B1) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B1) : "memory");          // B1
+                    X6_T(1)
                     if (make_tab) {
                         tab_finish();
                         tb_next += cpc * 9;
@@ -760,11 +788,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
         } else {
             corner_addr();
 #pragma unroll
-            for (int q = 0; q < DPW; ++q) dma_q(q);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) corner_req(q);
-#pragma unroll
-            for (int q = DPW; q < 2 * DPW; ++q) dma_q(q);
+            for (int sl = 0; sl < 8; ++sl) vm_slot(sl, cy, cx, par);
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_load_row(i);
             b_load(0, 0, par, 0);
@@ -776,27 +800,34 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
                 if (jj + 1 < NTH) b_load((jj + 1) & 1, 0, par, jj + 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int g = jj * MT + i;               // group 0..7: six MFMAs; the two halves of the thread's column values ride on 1..3 and 4..6
+                    const int g = jj * MT + i;               // group 0..7: six MFMAs; the two halves of the thread's column values ride on 3..4 and 6..7
+                    if (g == 3) X6_HALF_WAIT(0, 4);
+                    if (g == 6) X6_HALF_WAIT(1, 3);
                     mma_row(i, jj, jj & 1);
+                    vm_slot(8 + g, cy, cx, par);
                     if (g == 0) {
                         __builtin_amdgcn_sched_barrier(0);
+                        X6_T(2)
                         if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K_B2) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B2) : "memory");          // B2
-                        X6_CELL_WAIT(3);                     // (already true: ties the corner registers to the wait for the compiler)
+                        X6_T(4)
                     }
-                    if (g == 1) blend_half(0);
-                    if (g == 4) blend_half(1);
+                    if (g == 3) blend_half(0);
+                    if (g == 6) blend_half(1);
                     if (g == NG - 1) b_load(0, 1, par, 0);   // Y of chunk it for the next iteration's first column tile
-                    if (g == 0 || g == 3 || g == 6 || g == 7) __builtin_amdgcn_sched_barrier(0);
+                    if (g != 3 && g != 6) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (it + 2 < nchunks) advance_ld();
+            X6_T(5)
         }
     };
+    X6_T(6)
     iteration(0, std::true_type{}, std::false_type{});
     for (int it = 1; it < nchunks; ++it) iteration(it, std::false_type{}, std::false_type{});
     iteration(nchunks, std::false_type{}, std::true_type{});
 
+    X6_T(0)
     // ---- epilogue: + bias, 16-byte NHWC fp32 stores (lane: pixel = lane & 15, 8 consecutive channels per tile pair) -----------
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
@@ -820,6 +851,13 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v2_kernel(const float* __re
             }
         }
     }
+#ifdef X6_TIMING
+    X6_T(7)
+    if (tid == X6_TWAVE * 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_x6_timing[k], t_acc[k]);
+    }
+#endif
 }
 }  // namespace v2
 #endif
@@ -847,6 +885,15 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
 }
 
 }  // namespace
+
+#ifdef X6_TIMING
+extern "C" int gssd_dcn_x6_timing_read(unsigned long long* out8) {       // debug build only: read and clear
+    unsigned long long z[8] = {};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(v2::g_x6_timing), sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(v2::g_x6_timing), z, sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
+    return GSSD_OK;
+}
+#endif
 
 extern "C" long long gssd_dcn_packed_weight_elems_x6(int Cout, int C) {          // bf16 elements (three planes)
     if (Cout <= 0 || C <= 0 || C % BKC != 0) return -1;
