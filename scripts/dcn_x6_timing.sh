@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R/grouped-ssd-pytorch_amd/gssd/csrc
 OBJS=$(ls *.o | grep -v '^dcn_x6.o$')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../../include -I. -munsafe-fp-atomics -Wno-unused-result -fno-slp-vectorize -DX6_TIMING $EXTRA -c dcn_x6.hip -o /tmp/x6_t.o &&
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../../include -I. -munsafe-fp-atomics -Wno-unused-result -fno-slp-vectorize -DX6_TIMING -DX6_TWAVE=${TWAVE:-0} $EXTRA -c dcn_x6.hip -o /tmp/x6_t.o &&
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/x6_t.o -o /tmp/libgssd_x6_t.so &&
 GSSD_LIB_PATH=/tmp/libgssd_x6_t.so python3 - <<'PY'
 import os, sys, ctypes as C
@@ -29,11 +29,14 @@ for _ in range(n): ops.dcn_forward_x6(x, om, w, bias, dg)
 e1.record(); torch.cuda.synchronize(); rd(buf)
 t = [v / n for v in buf]
 wgs, its = 722, 288
-names = ['part A, first column tile (+ epilogue share)', 'B1: wait vmcnt / lgkmcnt + barrier', 'part A second tile + part B first group', 'B2: own LDS reads done (lgkmcnt 0)',
-         'B2: wait vmcnt + barrier', 'part B groups 1..7', 'prologue', 'epilogue']
-print(f'dcn_x6 (timing build): {e0.elapsed_time(e1) / n:.3f} ms per launch incl. the weight split; wave 0 of {wgs} workgroups, {its} iterations each')
+tw = int(os.environ.get('TWAVE', '0'))
+if tw < 8:
+    names = ['part A + first group of part B', 'M: wait lgkmcnt + barrier', 'part B groups 1..7', 'E: barrier', '-', '-', '-', '-']
+else:
+    names = ['DMA issue, wait corners, blend + split', 'M: wait Y pieces + barrier', 'plane writes, corner requests', 'E: wait X pieces, LDS writes + barrier', '-', '-', '-', '-']
+print(f'dcn_x6 (timing build): {e0.elapsed_time(e1) / n:.3f} ms per launch incl. the weight split; wave {tw} of {wgs} workgroups, {its} iterations each')
 tot = sum(t)
 for k in range(8):
     per = t[k] / wgs * 10.0          # ns per workgroup
-    print(f'  {names[k]:48s} {100 * t[k] / tot:5.1f} %   {per / (its if k < 6 else 1):9.1f} ns per ' + ('iteration' if k < 6 else 'workgroup'))
+    if t[k]: print(f'  {names[k]:48s} {100 * t[k] / tot:5.1f} %   {per / its:9.1f} ns per iteration')
 PY

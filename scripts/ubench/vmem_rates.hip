@@ -2,7 +2,7 @@
 //   mode 0  global_load_dwordx4, a wave reads 1 KiB contiguous (the weight planes' pieces as plain loads)
 //   mode 1  global_load_lds_dwordx4 of the same pieces (LDS DMA, the way the x6 kernels stage their weight planes)
 //   mode 2  global_load_dwordx4, quads of lanes read 128 contiguous bytes at scattered 4 KiB-strided pixels (dcn_x6's corner loads: 2 x 16 B per lane)
-//   mode 3  global_load_dwordx2 pairs ... not used
+//   mode 3  as mode 2 with the quad's pieces contiguous: 64 B per quad and instruction (lane & 3) * 16, second instruction + 64
 // Every wave issues `batch` loads, waits for all of them, repeats; the footprint per CU is `span` bytes (default 96 KiB: L2 hits, beyond the 32 KiB L1).
 //   hipcc --offload-arch=gfx950 -O3 vmem_rates.hip -o vmem_rates && ./vmem_rates
 #include <hip/hip_runtime.h>
@@ -34,6 +34,12 @@ __global__ __launch_bounds__(512, 1) void vmem_kernel(const float* __restrict__ 
                 const char* p = base + o + lane * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                  (__attribute__((address_space(3))) void*)(lds + (wave * BATCH + b) * 256), 16, 0, 0);
+            } else if (MODE == 3) {
+                // the same 16 pixels per instruction, but the quad's four 16-byte pieces are CONTIGUOUS (64 B; b odd: the line's second half)
+                unsigned pix = (o >> 11) + (unsigned)(lane >> 2) * 7u;
+                unsigned a = (pix * 4096u) % span + (unsigned)(lane & 3) * 16u + (unsigned)(b & 1) * 64u;
+                const char* p = base + a;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[b]) : "v"(p) : "memory");
             } else {
                 // 16 pixels per instruction (lane >> 2), 4 KiB apart, 32 B per lane in two instructions (b even / odd)
                 unsigned pix = (o >> 11) + (unsigned)(lane >> 2) * 7u;
@@ -91,6 +97,7 @@ int main() {
                 run<0, 12>("global_load_dwordx4 contiguous", src, out, cus, threads, span, shared_src, ghz);
                 run<1, 12>("global_load_lds_dwordx4 contiguous", src, out, cus, threads, span, shared_src, ghz);
                 run<2, 16>("global_load_dwordx4 128 B per quad, scattered", src, out, cus, threads, span, shared_src, ghz);
+                run<3, 16>("global_load_dwordx4 64 B contiguous per quad", src, out, cus, threads, span, shared_src, ghz);
             }
         }
     run<0, 4>("global_load_dwordx4 contiguous", src, out, cus, 256, 96 * 1024, 0, ghz);
