@@ -961,7 +961,8 @@ def test_dcn_x6_matches_fused(dev, ops):
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 19, 64, 64, 1, 3, 1, 1, 1), (3, 21, 128, 256, 4, 3, 1, 1, 1), (2, 19, 128, 512, 4, 3, 6, 6, 1),
                                    (2, 17, 256, 216, 1, 3, 1, 1, 1), (2, 20, 256, 256, 4, 1, 0, 1, 1), (2, 23, 64, 96, 1, 3, 1, 1, 2),
-                                   (1, 9, 32, 40, 1, 5, 2, 1, 1)])
+                                   (1, 9, 32, 40, 1, 5, 2, 1, 1), (2, 19, 32, 64, 1, 1, 0, 1, 1), (1, 11, 32, 128, 1, 1, 0, 1, 1),
+                                   (1, 13, 64, 136, 1, 1, 0, 1, 1)])          # (the last three: K loops of one and two chunks)
 def test_conv_x6_matches_float64(shape):
     """csrc/conv_x6.hip: fp32 conv with three-plane bf16 operands (six MFMAs per product) is at least as close to a float64 convolution as
     the fp32-MFMA kernel, for every tile width, with the fused input transform, bias, ReLU and the batch sums."""
