@@ -29,4 +29,5 @@ for B in (11, 22, 32):
     ms = e0.elapsed_time(e1) / 20
     tiles = ((B * H * H + 127) // 128) * 2
     fl = 2.0 * B * H * H * Cout * 9 * C
-    print(f'dcn_bf16 B={B}: {tiles} tiles, {ms * 1e3:.0f} us, {fl / ms / 1e9:.0f} TFLOP/s')
+    print(f'dcn_bf16 B={B}: {tiles} tiles, {ms * 1e3:.0f} us, {fl / ms / 1e9:.0f} TFLOP/s, checksum {float(out.float().double().sum()):.6f} {float(out.float().double().abs().sum()):.6f}')
+    if os.environ.get('DUMP'): torch.save(out.cpu(), os.environ['DUMP'] + f'_{B}.pt')

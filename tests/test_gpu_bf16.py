@@ -296,6 +296,46 @@ def test_dcn_bf16(dev, B, Cc, H, dg, Cout):
     assert rel(nchw(out.float()), ref) < 3 * BF_ULP and l2rel(nchw(out.float()), ref) < BF_ULP
 
 
+def test_dcn_bf16_loader_wave_kernel_is_bit_identical(dev, tmp_path):
+    """csrc/dcn_bf16.hip's opt-in round-5 kernel (GSSD_DCN_BF16_V3=1: eight matrix + four loader waves; the switch is read once per process,
+    so it runs in a child process) against the default kernel: the same blend arithmetic and K order -> the same bits."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(sys.argv[1], 'grouped-ssd-pytorch_amd'))
+from gssd._lib import lib, check
+dev = torch.device('cuda:0')
+res = {}
+for (B, H, Cc, dg, Cout) in ((3, 13, 128, 1, 296), (2, 19, 256, 4, 512), (1, 11, 128, 2, 40)):
+    g = torch.Generator().manual_seed(B * 1000 + Cc)
+    x = torch.randn(B, H, H, Cc, generator=g).to(dev).to(torch.bfloat16)
+    om = (torch.randn(B, H, H, 27 * dg, generator=g) * 1.5).to(dev)
+    w = (torch.randn(Cout, Cc, 3, 3, generator=g) * 0.05).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    wp = torch.empty(int(lib.gssd_dcn_packed_weight_elems_bf16(Cout, Cc)), device=dev, dtype=torch.bfloat16)
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib.gssd_dcn_pack_weight_bf16(w.data_ptr(), wp.data_ptr(), Cout, Cc, dg, s))
+    out = torch.full((B, H, H, Cout), float('nan'), device=dev, dtype=torch.bfloat16)
+    check(lib.gssd_dcn_forward_bf16(x.data_ptr(), om.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, Cc, dg, 27 * dg, Cout, s))
+    torch.cuda.synchronize()
+    res[(B, H, Cc, dg, Cout)] = out.cpu()
+torch.save(res, sys.argv[2])
+"""
+    outs = []
+    for v in ('0', '1'):
+        f = str(tmp_path / f'dcnb_{v}.pt')
+        env = dict(os.environ, GSSD_DCN_BF16_V3=v)
+        r = subprocess.run([sys.executable, '-c', code, ROOT, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k].float()).all()
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 NETS = {
     'gssd': (dict(), (True, 4, 4, 1, True, False, False, 0, 1, False, False, 1)),
     'gssdpp': (dict(use_self_attention=True, use_self_attention_base=True, num_dcn_layers=1, groups_dcn=4, dcn_cat_sab=True),
