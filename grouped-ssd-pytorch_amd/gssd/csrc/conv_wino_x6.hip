@@ -447,8 +447,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Pc[j][q] = *reinterpret_cast<const bf16x8*>(Pr + (j * NP + q) * 512);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // B: the plane buffer is free for the next block
             const u16* ub = smem + slot * STAGE + fo;
             // the 12 weight fragments of output tile nb + 1 are requested before the 24 MFMAs of tile nb (an LDS read issued right in front of
             // its MFMA costs the wave the LDS latency: 64 such waits per step were ~10 k of the consumer's 23 k cycles); the next block's DMA pieces
@@ -463,7 +461,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
                         else dst[xl][q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
                     }
             };
+            // the first tile's weight fragments are requested behind the planes' reads (the block's U planes are in LDS since barrier A): LDS
+            // returns in order, so the planes are in registers when at most these XG * NP reads are outstanding -- barrier B does not wait
+            // for them, and their round trip runs beside it instead of behind it
             frags(0, u[0]);
+            if (WX6_KO & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XG * NP) : "memory");
+            __builtin_amdgcn_s_barrier();                 // B: the plane buffer is free for the next block
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
                 if (nb + 1 < NBT) frags(nb + 1, u[(nb + 1) & 1]);

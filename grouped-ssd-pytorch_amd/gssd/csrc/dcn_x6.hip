@@ -84,7 +84,6 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
 }
 
 // wp: [3 planes][n_tiles][chunks][BN rows in staging order][32] bf16 (slot-swizzled), chunk = (d * cpg / 32 + c32) * 9 + tap
-namespace v3 {
 constexpr int MW = 8, LW = 4, THREADS = 64 * (MW + LW), LTHREADS = 64 * LW;
 constexpr int WTN = 64, NT = WTN / 16;                // matrix waves: 2 (rows) x 4 (columns) of 64 x 64
 constexpr int HB_ROWS = BN / 2, HB_PLANE = HB_ROWS * BKC, HB_ELEMS = NP * HB_PLANE;
@@ -113,7 +112,7 @@ __device__ unsigned long long g_x6_timing[8];
     if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(VM), "n"(LGKM) : "memory");           \
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(VM), "n"(LGKM) : "memory")
 
-__global__ __launch_bounds__(THREADS, 1) void dcn_x6_v3_kernel(const float* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const u16* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
                                                           int Cout, int ntn, int mtiles, long long plane_elems) {
@@ -509,7 +508,6 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_v3_kernel(const float* __re
 }
 #undef X6_T
 #undef X6_BARRIER
-}  // namespace v3
 
 // OIHW fp32 [Cout][C][3][3] -> three bf16 planes, each [n_tiles][chunks][BN staging rows][32] with the slot swizzle; rows beyond Cout zero
 __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int C, int dg, long long total) {
@@ -538,8 +536,8 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
 #ifdef X6_TIMING
 extern "C" int gssd_dcn_x6_timing_read(unsigned long long* out8) {       // debug build only: read and clear
     unsigned long long z[8] = {};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(v3::g_x6_timing), sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(v3::g_x6_timing), z, sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6_timing), sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_x6_timing), z, sizeof(z)) != hipSuccess) return GSSD_ELAUNCH;
     return GSSD_OK;
 }
 #endif
@@ -568,8 +566,8 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
     static unsigned attr_mask = 0;
-    const auto kernel = v3::dcn_x6_v3_kernel;
-    constexpr int LDS_BYTES = v3::LDS_BYTES, NTHREADS = v3::THREADS;
+    const auto kernel = dcn_x6_kernel;
+    constexpr int NTHREADS = THREADS;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {

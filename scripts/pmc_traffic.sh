@@ -42,8 +42,8 @@ def short(n):
     if 'gemm_slot_kernel' in n: return 'gemm_slot<128x128>'
     if 'dcn_fused_kernel' in n: return 'dcn_fused<128x256>'
     if 'dcn_x6_kernel' in n: return 'dcn_x6<128x256>'
-    if 'conv_x6_kernel' in n:
-        m6 = re.search(r'conv_x6_kernel<(\d+)', n)
+    if 'conv_x6_kernel' in n or 'conv_x6_v2_kernel' in n:
+        m6 = re.search(r'conv_x6(?:_v2)?_kernel<(\d+)', n)
         return f'conv_x6<{m6.group(1)}>' if m6 else 'conv_x6'
     if 'dcn_bf16_kernel' in n: return 'dcn_bf16<128x256>'
     m = re.search(r'::(\w+_kernel)', n)
