@@ -84,8 +84,11 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
 }
 
 // wp: [3 planes][n_tiles][chunks][BN rows in staging order][32] bf16 (slot-swizzled), chunk = (d * cpg / 32 + c32) * 9 + tap
-constexpr int MW = 8, LW = 4, THREADS = 64 * (MW + LW), LTHREADS = 64 * LW;
-constexpr int WTN = 64, NT = WTN / 16;                // matrix waves: 2 (rows) x 4 (columns) of 64 x 64
+#ifndef X6_MW
+#define X6_MW 8          // matrix waves: 8 = 2 (rows) x 4 (columns) of 64 x 64; 4 = 2 x 2 of 64 x 128 (experiment)
+#endif
+constexpr int MW = X6_MW, LW = 4, THREADS = 64 * (MW + LW), LTHREADS = 64 * LW;
+constexpr int WCOLS = MW / 2, WTN = BN / WCOLS, NT = WTN / 16;
 constexpr int HB_ROWS = BN / 2, HB_PLANE = HB_ROWS * BKC, HB_ELEMS = NP * HB_PLANE;
 constexpr int NTH = NT / 2, NG = NTH * MT;
 constexpr int TAB_N = 9 * BM;
@@ -93,7 +96,7 @@ constexpr int LDS_BYTES = (NP * A_STAGE + 4 * HB_ELEMS) * 2 + TAB_N * 16 + TAB_N
 constexpr int TPT = (TAB_N + LTHREADS - 1) / LTHREADS;
 constexpr int DPH = 24 / LW;                          // DMA pieces per loader wave and half
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(MT == 4 && NT == 4 && BN == 256 && NG == 8, "written for 128 x 256 tiles, eight MFMA waves");
+static_assert(MT == 4 && (NT == 4 || NT == 8) && BN == 256, "written for 128 x 256 tiles, eight or four matrix waves");
 #ifdef X6_TIMING
 __device__ unsigned long long g_x6_timing[8];
 #ifndef X6_TWAVE
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
             for (int q = 0; q < DPH; ++q) {
                 const int p = q * LW + lwave;                // piece 0..23
                 const int pl = p >> 3, g8 = p & 7;
-                const int G = (g8 >> 1) * NT + half * NTH + (g8 & 1);      // 16-row group of the plane's [BN][32] tile
+                const int G = (g8 / NTH) * NT + half * NTH + (g8 % NTH);   // 16-row group of the plane's [BN][32] tile
                 dma16(src + (size_t)pl * plane_elems + G * 512, dst + pl * HB_PLANE + g8 * 512);
             }
         };
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
 #undef X6_CORNERS_WAIT
     } else {
         // ================================================ the matrix side: eight waves ===================================================
-        const int wm = wave >> 2, wn = wave & 3;
+        const int wm = wave / WCOLS, wn = wave % WCOLS;
         const int r = lane & 15, kq = lane >> 4;
         const int fo = r * BKC + ((kq ^ swz(r)) << 3);
         f32x4 acc[MT][NT];
