@@ -727,8 +727,11 @@ bool gssd_wino_x6_wanted(const gssd_conv_desc& d) {
     if (mode == 0) return false;
     if (mode == 2) return true;
     const int cout_g = d.Cout / d.groups;
-    // (the dense DCN offset conv -- 1024 -> 108 channels, two blocks of 64 with 20 padding rows -- loses: 651 vs 601 us)
-    return cout_g % 64 == 0 && d.cin_g >= 32 && (long long)d.B * ((d.H + 1) / 2) * ((d.W + 1) / 2) >= 8192;
+    // whole 64-channel blocks, or at least 80 % of the padded ones: the dense DCN offset conv (1024 -> 108 channels = two blocks with 20 padding
+    // rows) lost with the first producers (651 vs 601 us) and wins since the pair-wise split: 527 vs 575 us (512 -> 108: 277 vs 316)
+    const int padded = (cout_g + 63) / 64 * 64;
+    const bool blocks_ok = cout_g % 64 == 0 || (cout_g > 64 && 5 * cout_g >= 4 * padded);
+    return blocks_ok && d.cin_g >= 32 && (long long)d.B * ((d.H + 1) / 2) * ((d.W + 1) / 2) >= 8192;
 }
 
 // called by gssd_try_conv_wino() once the descriptor is known to be a Winograd shape: `Ux` = the three-plane U behind the fp32 U

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'grouped-ssd-py
 import torch
 from gssd import ops
 dev = torch.device('cuda:0')
-B, G = int(os.environ.get('B', 32)), 4
+B, G = int(os.environ.get('B', 32)), int(os.environ.get('G', 4))
 shapes = [('conv1_2', 300, 16, 16), ('conv2_1', 150, 16, 32), ('conv2_2', 150, 32, 32), ('conv3_1', 75, 32, 64), ('conv3_2', 75, 64, 64),
           ('conv4_1', 38, 64, 128), ('conv4_2', 38, 128, 128), ('conv5_x', 19, 128, 128)]
 if os.environ.get('SHAPES'):
