@@ -944,7 +944,8 @@ def test_dcn_x6_matches_fused(dev, ops):
     bf16 MFMAs per product -- fp32-equivalent: it must agree with the fp32-MFMA kernel to fp32 summation-order noise and with the
     float64 evaluation as well as that kernel does.  Shapes with a ragged last pixel tile and a masked channel tile."""
     rng = np.random.default_rng(77)
-    for (B, Cc, H, dg, Cout) in ((2, 128, 13, 4, 136), (1, 256, 19, 1, 512), (3, 128, 11, 2, 264), (1, 192, 9, 2, 40)):     # 1, 8, 2, 3 channel blocks per tap
+    for (B, Cc, H, dg, Cout) in ((2, 128, 13, 4, 136), (1, 256, 19, 1, 512), (3, 128, 11, 2, 264), (1, 192, 9, 2, 40),
+                                  (1, 32, 7, 1, 8)):     # 1, 8, 2, 3, 1 channel blocks per tap; the last: nine chunks in all
         x = torch.from_numpy(rng.normal(size=(B, H, H, Cc)).astype(np.float32)).to(dev)
         om = torch.from_numpy(rng.normal(0, 1.5, size=(B, H, H, 27 * dg)).astype(np.float32)).to(dev)
         w = torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cc, 3, 3)).astype(np.float32)).to(dev)
