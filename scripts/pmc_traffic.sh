@@ -23,12 +23,12 @@ def short(n):
     m = re.search(r'conv_thin_kernel<(\d+), (\d+)', n)
     if m: return f'conv_thin<{m.group(1)},{m.group(2)}>'
     if 'conv_thin_wino_kernel' in n: return 'conv_thin_wino<16,16>'
-    m = re.search(r'conv_wino_x6_kernel<(\d+)', n)
-    if m: return f'conv_wino_x6<{16 * int(m.group(1))}>'
+    m = re.search(r'conv_wino_x6_kernel<(\d+), (true|false), (\d+)', n)      # <NBT, fused input transform, epilogue (2: pooled), ..>
+    if m: return f'conv_wino_x6<{16 * int(m.group(1))}>' + ('' if m.group(2) == 'true' else '/plain') + ('/pool2' if m.group(3) == '2' else '')
     m = re.search(r'flash_attn_x6_kernel<(\d+), (\d+)', n)
     if m: return f'flash_attn_x6<{m.group(1)},{m.group(2)}>'
-    m = re.search(r'conv_wino_kernel<(\d+)', n)
-    if m: return f'conv_wino<{m.group(1)}>'
+    m = re.search(r'conv_wino_kernel<(\d+), (true|false), (?:true|false), (\d+)', n)      # <NB, fused input transform, .., epilogue (2: pooled)>
+    if m: return f'conv_wino<{m.group(1)}>' + ('' if m.group(2) == 'true' else '/plain') + ('/pool2' if m.group(3) == '2' else '')
     m = re.search(r'conv_bf16_kernel<(\d+), (\d+)', n)
     if m: return f'conv_bf16<{m.group(1)}x{m.group(2)}>'
     m = re.search(r'conv_flat_bf16_kernel<(\d+), (\d+), (?:true|false), (\d+), (\d+)', n)
