@@ -741,18 +741,28 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
                         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K_B2) : "memory");
                         X6_LOADS_WAIT(DPW - NY);             // (already true: ties the load registers to the wait for the compiler)
                     }
+#ifndef X6_FIN
+#define X6_FIN 1        // 1: a quarter rides on TWO groups of MFMAs (scheduling region = groups 2k - 1, 2k); 0: on one
+#endif
                     if (NTH == 2) {
-                        if (gidx == 1) finish_part(0);
-                        if (gidx == 2) finish_part(1);
-                        if (gidx == 4) finish_part(2);
-                        if (gidx == 5) finish_part(3);
+                        if (X6_FIN) {
+                            if (gidx == 1) finish_part(0);
+                            if (gidx == 3) finish_part(1);
+                            if (gidx == 5) finish_part(2);
+                            if (gidx == 7) finish_part(3);
+                        } else {
+                            if (gidx == 1) finish_part(0);
+                            if (gidx == 2) finish_part(1);
+                            if (gidx == 4) finish_part(2);
+                            if (gidx == 5) finish_part(3);
+                        }
                     } else {
                         if (gidx == 1) finish_part(0), finish_part(1);
                         if (gidx == 2) finish_part(2);
                         if (gidx == 3) finish_part(3);
                     }
                     if (gidx == NG - 1) b_load(0, 1, par, 0);   // Y of chunk it for the next iteration's first column tile
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(X6_FIN && NTH == 2) || (gidx & 1) == 0 || gidx == NG - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (it + 2 < nchunks) advance_ld();
