@@ -206,7 +206,10 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
                 tabp[e] = pos;
             }
         };
-        // corner requests of one chunk: 2 cells x 4 corners x 2 halves of 4 fp32 channels per thread, by inline assembly (counted waits)
+        // corner requests of one chunk: 2 cells x 4 corners x 2 halves of 4 fp32 channels per thread, by inline assembly (counted waits).
+        // Contract of the inline-assembly loads (as csrc/conv_x6.hip): gv is written ONLY by corner_reqs() and read only behind
+        // X6_CORNERS_WAIT, which names all sixteen registers as "+v" operands -- nothing may copy or reuse them in between (the compiler's
+        // wait-count pass does not know the loads; the loop ends with s_waitcnt vmcnt(0) before the registers can die)
         f32x4 gw[2];
         f32x4 gv[2][4][2];
 #pragma unroll
