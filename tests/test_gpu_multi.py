@@ -49,11 +49,18 @@ def test_bench_eight_ranks_code_path_on_one_gpu():
     the same on this host (host_enqueue_ms_per_step: fwd + loss graph replay, and the eager full training step) -- the quantity that
     bounds weak scaling on one node, since the data path has no collective (train_lesion_multiphase_v2.py:593's DataParallel replaced by
     one process per GPU).  Not a throughput measurement: the eight ranks share one GPU."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '2', '--steady', '0',
-                        '--no-bf16', '--no-events', '--full-step', '2', '--batch', '4'], capture_output=True, text=True, timeout=2400,
-                       env=dict(os.environ, GSSD_DIST_SAME_DEVICE='1', GSSD_DIST_BACKEND='gloo'))
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    # (nine processes share one GPU and one loopback rendezvous port picked just before the launch: one failure in ~5 full-suite runs was seen
+    # in round 5 and never alone -- a second attempt is allowed, and the first one's stderr is reported if both fail)
+    errs = []
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '2', '--steady', '0',
+                            '--no-bf16', '--no-events', '--full-step', '2', '--batch', '4'], capture_output=True, text=True, timeout=2400,
+                           env=dict(os.environ, GSSD_DIST_SAME_DEVICE='1', GSSD_DIST_BACKEND='gloo'))
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode == 0 and len(lines) == 1 and 'error' not in lines[0].get('full_step', {}):
+            break
+        errs.append(f'attempt {attempt}: rc {r.returncode}\n' + r.stderr[-3000:])
+    assert r.returncode == 0 and len(lines) == 1, '\n'.join(errs)
     ln = lines[0]
     assert ln['n_gpus'] == 8 and ln['rccl_ranks'] == 8 and ln['collective_backend'] == 'gloo' and len(ln['per_rank_ms_per_step']) == 8
     assert ln['config']['global_batch'] == 32 and ln['launcher'].startswith('self')
