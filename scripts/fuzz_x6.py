@@ -1,0 +1,73 @@
+"""Randomised shape sweep of the round-5 K loops: dcn_x6 against dcn_fused, conv_x6 against the fp32-MFMA implicit GEMM (both fp32-equivalent:
+agreement to fp32 summation-order noise).  usage (GPU box): python scripts/fuzz_x6.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'grouped-ssd-pytorch_amd'))
+import numpy as np
+import torch
+from gssd import ops
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+worst = 0.0
+for it in range(n_cases):
+    dg = int(rng.choice([1, 2, 4]))
+    cpc = int(rng.choice([1, 2, 3, 4]))
+    Cc = 32 * cpc * dg
+    H, W = int(rng.integers(3, 23)), int(rng.integers(3, 23))
+    B = int(rng.integers(1, 4))
+    Cout = int(rng.choice([8, 24, 40, 128, 136, 256, 264, 520]))
+    x = torch.from_numpy(rng.normal(size=(B, H, W, Cc)).astype(np.float32)).to(dev)
+    om = torch.from_numpy(rng.normal(0, float(rng.choice([0.3, 1.5, 4.0])), size=(B, H, W, 27 * dg)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cc, 3, 3)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.normal(size=Cout).astype(np.float32)).to(dev)
+    if H != W:
+        # ops.dcn_forward takes square maps only through its convenience wrapper: use the C ABI for both
+        from gssd._lib import lib, check
+        s = torch.cuda.current_stream().cuda_stream
+        wp = ops.dcn_pack_weight(w, dg)
+        n6 = int(lib.gssd_dcn_packed_weight_elems_x6(Cout, Cc))
+        wp6 = torch.empty(n6, device=dev, dtype=torch.bfloat16)
+        check(lib.gssd_dcn_pack_weight_x6(w.contiguous().data_ptr(), wp6.data_ptr(), Cout, Cc, dg, s))
+        ref = torch.full((B, H, W, Cout), float('nan'), device=dev)
+        got = torch.full((B, H, W, Cout), float('nan'), device=dev)
+        check(lib.gssd_dcn_forward_f32(x.data_ptr(), om.data_ptr(), wp.data_ptr(), b.data_ptr(), ref.data_ptr(), B, H, W, Cc, dg, 27 * dg, Cout, s))
+        check(lib.gssd_dcn_forward_x6(x.data_ptr(), om.data_ptr(), wp6.data_ptr(), b.data_ptr(), got.data_ptr(), B, H, W, Cc, dg, 27 * dg, Cout, s))
+    else:
+        ref = ops.dcn_forward(x, om, w, b, dg)
+        got = ops.dcn_forward_x6(x, om, w, b, dg)
+    torch.cuda.synchronize()
+    e = float((got - ref).abs().max() / ref.abs().max())
+    worst = max(worst, e)
+    ok = torch.isfinite(got).all() and e < 2e-5
+    print(f'dcn  B {B} {H}x{W} C {Cc} dg {dg} Cout {Cout}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
+    assert ok
+print(f'dcn_x6: {n_cases} shapes, worst rel {worst:.2e}')
+worst = 0.0
+for it in range(n_cases):
+    g = int(rng.choice([1, 1, 4]))
+    cin_g = 32 * int(rng.integers(1, 5))
+    cout_g = int(rng.choice([32, 40, 64, 72, 128, 136, 256]))
+    k = int(rng.choice([1, 3, 3, 5]))
+    dil = int(rng.choice([1, 1, 2])) if k == 3 else 1
+    pad = dil * (k // 2) if rng.random() < 0.8 else 0
+    stride = int(rng.choice([1, 1, 2]))
+    H, W = int(rng.integers(max(3, k * dil), 26)), int(rng.integers(max(3, k * dil), 26))
+    B = int(rng.integers(1, 4))
+    x = torch.from_numpy(rng.normal(size=(B, H, W, g * cin_g)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(g * cout_g, cin_g, k, k)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.normal(size=g * cout_g).astype(np.float32)).to(dev)
+    xf = rng.random() < 0.5
+    kw = {}
+    if xf:
+        sc = torch.from_numpy((rng.random(g * cin_g) + 0.5).astype(np.float32)).to(dev)
+        sh = torch.from_numpy((rng.normal(size=g * cin_g) * 0.3).astype(np.float32)).to(dev)
+        kw = dict(in_scale=sc, in_shift=sh, in_pad=-sh / sc - 1.0)
+    y6 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, x6=True, **kw)
+    y32 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, **kw)
+    torch.cuda.synchronize()
+    e = float((y6 - y32).abs().max() / y32.abs().max())
+    worst = max(worst, e)
+    ok = torch.isfinite(y6).all() and e < 2e-5
+    print(f'conv B {B} {H}x{W} cin_g {cin_g} cout_g {cout_g} g {g} k {k} pad {pad} dil {dil} stride {stride} xf {xf}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
+    assert ok
+print(f'conv_x6: {n_cases} shapes, worst rel {worst:.2e}')

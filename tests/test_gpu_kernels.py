@@ -1032,3 +1032,15 @@ def test_conv_x6_epilogues_match_igemm(B, H, Cc):
     for a, b in zip(res['ref'], res['x6']):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
+@pytest.mark.gpu
+def test_x6_kernels_random_shapes():
+    """scripts/fuzz_x6.py: dcn_x6 against dcn_fused and conv_x6 against the fp32-MFMA implicit GEMM on random shapes (non-square maps, every
+    tile tail, 1 .. 4 channel blocks per tap, strides / dilations / 1x1 .. 5x5, with and without the fused input transform): the rotated
+    K loops, their half buffers and counted waits must not depend on the shape."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_x6.py'), '12', '11'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'conv_x6: 12 shapes' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
