@@ -236,7 +236,11 @@ namespace v3 {
 // The loop and the wave roles of csrc/dcn_x6.hip's kernel (see there) with ONE bf16 plane: x is bf16 (one 16-byte request per corner and 8
 // channels), the blend is fp32 and rounds to bf16 once, one MFMA per fragment pair.  With a sixth of the MFMAs the kernel is bound by the
 // vector memory path alone: 32 KB of corner segments + 16 KB of weights per chunk.
-constexpr int MW = 8, LW = 4, THREADS = 64 * (MW + LW), LTHREADS = 64 * LW;
+#ifndef DCNB_LW
+#define DCNB_LW 8         // loader waves: 8 = one cell (8 channels of one pixel row) per thread, 4 = two
+#endif
+constexpr int MW = 8, LW = DCNB_LW, THREADS = 64 * (MW + LW), LTHREADS = 64 * LW;
+constexpr int NC = 512 / LTHREADS;                    // cells per loader thread
 constexpr int WTN = 64, NT = WTN / 16;                // matrix waves: 2 (rows) x 4 (columns) of 64 x 64
 constexpr int NP = 1;
 constexpr int HB_ROWS = BN / 2, HB_PLANE = HB_ROWS * BKC, HB_ELEMS = NP * HB_PLANE;
@@ -305,8 +309,9 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
 #define X6_LPRIO 3
 #endif
         __builtin_amdgcn_s_setprio(X6_LPRIO);                // the youngest waves of the SIMD would otherwise issue last
-        // gather roles: thread -> (pixel rows gp and gp + 64, 8-channel slot gq)
+        // gather roles: thread -> (pixel rows gp (+ 64 with four loader waves), 8-channel slot gq)
         const int gq = lt & 3, gp = lt >> 2;
+        constexpr int CSTEP = BM / NC;                       // row distance of a thread's cells
         const int a_wr0 = gp * BKC + ((gq ^ swz(gp)) << 3);
         // sampling table of one deformable group (9 taps x BM rows)
         float t_dy[TPT], t_dx[TPT], t_ml[TPT];
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         f32x4 gw[2];
         bf16x8 gv[2][4];                                     // [cell][corner]: 8 bf16 channels
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NC; ++j) {
             gw[j] = zero4;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -372,23 +377,23 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         int pos_next[2] = {0, 0};
         auto table_read = [&]() {                            // the table entries of the chunk requested next (LDS reads: issued early)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int e = ld_tap * BM + gp + 64 * j;
+            for (int j = 0; j < NC; ++j) {
+                const int e = ld_tap * BM + gp + CSTEP * j;
                 gw_next[j] = tabw[e];
                 pos_next[j] = tabp[e];
             }
         };
         const u16* pc[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NC; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) pc[j][k] = x;
         auto corner_addr = [&]() {                           // the eight corner addresses of the chunk requested next
             const int cb = ld_d * cpg + ld_cc * BKC + gq * 8;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NC; ++j) {
                 int pos = pos_next[j];
-                if (X6_KO & 128) pos = (pos & 0xC0000000) | (gp + 64 * j);       // experiment: every tile reads the same 128 pixels (cache hits)
+                if (X6_KO & 128) pos = (pos & 0xC0000000) | (gp + CSTEP * j);       // experiment: every tile reads the same 128 pixels (cache hits)
                 const unsigned i00 = (unsigned)(pos & 0x3FFFFFFF);
                 const unsigned dxb = ((unsigned)pos >> 30) & 1u, dyb = (unsigned)pos >> 31;
                 const unsigned i10 = i00 + dyb * (unsigned)W;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
                 pc[j][3] = x + (size_t)(i10 + dxb) * (unsigned)C + cb;
             }
         };
-        auto corner_reqs = [&](int q0, int q1) {             // requests q0 .. q1 - 1 of the 8: (cell, corner), 16 bytes = 8 channels per lane
+        auto corner_reqs = [&](int q0, int q1) {             // requests q0 .. q1 - 1 of the 4 NC: (cell, corner), 16 bytes = 8 channels per lane
             if (X6_KO & 8) return;
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
@@ -408,15 +413,19 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         };
         auto corners = [&]() {
             corner_addr();
-            corner_reqs(0, 8);
+            corner_reqs(0, 4 * NC);
         };
         // all 16 requests of this wave have landed; N younger DMA pieces may still be in flight
 #define X6_CORNERS_WAIT(N)                                                                                                            \
-    if (!(X6_KO & 8))                                                                                                                 \
-    asm volatile("s_waitcnt vmcnt(%8)"                                                                                                \
-                 : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[0][2]), "+v"(gv[0][3]), "+v"(gv[1][0]), "+v"(gv[1][1]), "+v"(gv[1][2]),     \
-                   "+v"(gv[1][3])                                                                                                      \
-                 : "n"(N))
+    if (!(X6_KO & 8)) {                                                                                                               \
+        if (NC == 2)                                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(%8)"                                                                                        \
+                         : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[0][2]), "+v"(gv[0][3]), "+v"(gv[1][0]), "+v"(gv[1][1]),             \
+                           "+v"(gv[1][2]), "+v"(gv[1][3])                                                                              \
+                         : "n"(N));                                                                                                    \
+        else                                                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gv[0][0]), "+v"(gv[0][1]), "+v"(gv[0][2]), "+v"(gv[0][3]) : "n"(N));            \
+    }
         auto advance_ld = [&]() {
             if (++ld_tap == 9) {
                 ld_tap = 0;
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         auto blend_all = [&]() {
             if (X6_KO & 1) return;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NC; ++j)
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     pln[j][e] = (__bf16)((float)gv[j][0][e] * gw[j][0] + (float)gv[j][1][e] * gw[j][1] + (float)gv[j][2][e] * gw[j][2] +
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         auto write_planes = [&]() {
             if (X6_KO & 1) return;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(As + a_wr0 + j * 64 * BKC) = pln[j];
+            for (int j = 0; j < NC; ++j) *reinterpret_cast<bf16x8*>(As + a_wr0 + j * CSTEP * BKC) = pln[j];
         };
         // weights of (chunk, half) -> half buffer (half, parity): 8 1-KiB pieces (wave column, j & 1), two per loader wave
         auto dma_half = [&](int chunk, int half, int parity) {
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
                 dma16(src + G * 512, dst + g8 * 512);
             }
         };
-        constexpr int ND = (X6_KO & 4) ? 0 : DPH, NL = (X6_KO & 8) ? 0 : 8;
+        constexpr int ND = (X6_KO & 4) ? 0 : DPH, NL = (X6_KO & 8) ? 0 : 4 * NC;
 
         // prologue: table of group 0; corners of chunk 0 -> planes -> stage; X half of chunk 0; corners of chunk 1 requested
         tab_load(0);
@@ -463,8 +472,8 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         table_read();
         corners();
         dma_half(0, 0, 0);
-        gw[0] = gw_next[0];
-        gw[1] = gw_next[1];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) gw[j] = gw_next[j];
         X6_CORNERS_WAIT(ND);
         blend_all();
         write_planes();
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
         // segments with four waves) beside 1.33 us of MFMAs on the other waves: they are dealt out over both halves of the iteration.
         // vmcnt, in issue order: corners of chunk it + 1 -> vmcnt(12); Y pieces -> vmcnt(6 + GPRE) at M; X pieces -> vmcnt(16) at E.
 #ifndef X6_GPRE
-#define X6_GPRE 4        // corner requests of chunk it + 2 issued in front of M(it), the rest behind it (same-box sweep 0 / 4 / 8 / 12 / 16: 1.92 / 1.90 / 1.98 / 1.98 / 2.06 ms)
+#define X6_GPRE (2 * NC)  // corner requests of chunk it + 2 issued in front of M(it), the rest behind it (same-box sweep 0 / 4 / 8 / 12 / 16: 1.92 / 1.90 / 1.98 / 1.98 / 2.06 ms)
 #endif
         constexpr int GPRE = X6_GPRE, NPRE = (X6_KO & 8) ? 0 : GPRE;
         for (int it = 0; it < nchunks; ++it) {
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
             if (make_tab) tab_load(tb_d);
             dma_half(min(it, nchunks - 1), 1, par);          // Y of chunk it
             dma_half(min(it + 1, nchunks - 1), 0, par ^ 1);  // X of chunk it + 1
-            gw[0] = gw_next[0];
-            gw[1] = gw_next[1];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) gw[j] = gw_next[j];
             if (!make_tab) table_read();                     // chunk it + 2's entries: the LDS round trip runs beside the blend
             X6_CORNERS_WAIT(2 * ND);                         // chunk it + 1's corners
             blend_all();
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_bf16_v3_kernel(const u16* __re
                 X6_BARRIER(ND + NPRE, 0);                    // M(it)
                 X6_T(1)
                 write_planes();
-                corner_reqs(GPRE, 8);
+                corner_reqs(GPRE, 4 * NC);
             }
             if (it + 3 < nchunks) advance_ld();
             X6_T(2)
@@ -694,7 +703,8 @@ extern "C" int gssd_dcn_forward_bf16(const void* x, const float* om, const void*
     static unsigned attr_mask = 0;
     // GSSD_DCN_BF16_V3=1: the loader / matrix-wave kernel (opt-in experiment, round 5: bit-identical output; 749 vs 779 us at B = 32,
     // 277 vs 346 at B = 11, 528 vs 487 at B = 22 -- with a sixth of the MFMAs per chunk the loaders' serial chain per chunk [table read ->
-    // corner wait -> blend -> addresses -> requests] is the bound, 510-560 of 850 ns; scripts/dcn_bf16_ab.sh, scripts/dcn_bf16_timing.sh)
+    // corner wait -> blend -> addresses -> requests] is the bound, 510-560 of 850 ns; eight loader waves with one cell per thread instead of
+    // four with two: the same 746 us -- the memory side alone takes 0.68 ms; scripts/dcn_bf16_ab.sh, scripts/dcn_bf16_timing.sh)
     static const bool use_v3 = getenv("GSSD_DCN_BF16_V3") && atoi(getenv("GSSD_DCN_BF16_V3")) == 1;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
