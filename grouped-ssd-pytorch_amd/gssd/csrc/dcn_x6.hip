@@ -133,7 +133,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
 #define X6_MAP 1         // 1: the column tiles of a row tile on the SAME XCD (consecutive slots: its x lines come out of one L2; same-box A/B
                          // 1.856 vs 1.882 - 1.894 ms); 0: on neighbouring XCDs (each XCD streams one column tile's weight planes)
 #endif
-        if (X6_MAP) {
+        if (X6_MAP) {                                        // (a contiguous range of row tiles per XCD -- neighbours share halo rows -- measured the same)
             nt = slot % ntn;
             mt = (slot / ntn) * 8 + xcd;
         } else if (8 % ntn == 0) {
