@@ -113,42 +113,46 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
 
     const int ntiles = (N + BKV - 1) / BKV;
     constexpr int STAGE = NP * (K_PLANE + V_PLANE);           // u16 elements per stage; two stages: the next tile lands under this tile's MFMAs
-    auto stage = [&](const int t, const int buf) {
+    // the DMA pieces of a tile, one at a time: piece slot j of this wave = K pieces first (KW per wave), then V pieces (VW per wave).  In the
+    // loop they are dealt out between the MFMA groups of the running tile (round 5: a wave issues in order, and the vector memory path takes
+    // one 1-KiB piece per 16 cycles per CU -- a burst of 60 pieces at the top of a tile held back every wave's MFMAs for up to ~1 000 cycles)
+    constexpr int K_RPP = 64 / UK, K_PIECES = NP * BKV / K_RPP, V_RPP = 64 / UV, V_PIECES = NP * C2 / V_RPP;
+    constexpr int KW = (K_PIECES + NW - 1) / NW, VW = (V_PIECES + NW - 1) / NW;
+    auto stage_piece = [&](const int t, const int buf, const int j) {
         const int key0 = t * BKV;
         u16* const Kd = smem + buf * STAGE;
         u16* const Vd = Kd + NP * K_PLANE;
-        {   // K tile: BKV rows of D bf16 per plane; piece = 1 KiB = 64 / UK rows
-            constexpr int RPP = 64 / UK, PIECES = NP * BKV / RPP;
+        if (j < KW) {   // K tile: BKV rows of D bf16 per plane; piece = 1 KiB = 64 / UK rows
             const int row_in = lane / UK, slot = lane % UK;
-#pragma unroll
-            for (int p0 = 0; p0 < PIECES; p0 += NW) {
-                const int piece = p0 + wave;
-                if (PIECES % NW != 0 && piece >= PIECES) break;
-                const int pl = piece / (BKV / RPP), row = (piece - pl * (BKV / RPP)) * RPP + row_in;
-                const int unit = slot ^ (row & SWK);
-                const u16* src = key0 + row < N ? tpb + pl * tp_plane + (size_t)(key0 + row) * (2 * D) + D + 8 * unit : g_zero16_x6;
-                dma16(src, Kd + piece * 512);
-            }
-        }
-        {   // V tile: C2 rows of BKV bf16 per plane
-            constexpr int RPP = 64 / UV, PIECES = NP * C2 / RPP;
+            const int piece = j * NW + wave;
+            if (K_PIECES % NW != 0 && piece >= K_PIECES) return;
+            const int pl = piece / (BKV / K_RPP), row = (piece - pl * (BKV / K_RPP)) * K_RPP + row_in;
+            const int unit = slot ^ (row & SWK);
+            const u16* src = key0 + row < N ? tpb + pl * tp_plane + (size_t)(key0 + row) * (2 * D) + D + 8 * unit : g_zero16_x6;
+            dma16(src, Kd + piece * 512);
+        } else {        // V tile: C2 rows of BKV bf16 per plane
             const int row_in = lane / UV, slot = lane % UV;
-#pragma unroll
-            for (int p0 = 0; p0 < PIECES; p0 += NW) {
-                const int piece = p0 + wave;
-                if (PIECES % NW != 0 && piece >= PIECES) break;
-                const int pl = piece / (C2 / RPP), row = (piece - pl * (C2 / RPP)) * RPP + row_in;
-                const int unit = slot ^ (BKV == 32 ? ((row & 8) ? 3 : 0) : (row & 7));
-                const u16* src = key0 + 8 * unit < Np32 ? gb + pl * g_plane + (size_t)row * Np32 + key0 + 8 * unit : g_zero16_x6;
-                dma16(src, Vd + piece * 512);
-            }
+            const int piece = (j - KW) * NW + wave;
+            if (V_PIECES % NW != 0 && piece >= V_PIECES) return;
+            const int pl = piece / (C2 / V_RPP), row = (piece - pl * (C2 / V_RPP)) * V_RPP + row_in;
+            const int unit = slot ^ (BKV == 32 ? ((row & 8) ? 3 : 0) : (row & 7));
+            const u16* src = key0 + 8 * unit < Np32 ? gb + pl * g_plane + (size_t)row * Np32 + key0 + 8 * unit : g_zero16_x6;
+            dma16(src, Vd + piece * 512);
         }
     };
+    auto stage = [&](const int t, const int buf) {
+#pragma unroll
+        for (int j = 0; j < KW + VW; ++j) stage_piece(t, buf, j);
+    };
+#ifndef FX6_SPREAD
+#define FX6_SPREAD 1         // 1: the next tile's pieces between the MFMA groups of this tile; 0: all of them at the tile's top
+#endif
     stage(0, 0);
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * BKV, buf = t & 1;
         __syncthreads();                                          // (vmcnt(0) + barrier) tile t has landed; everyone is done with tile t - 1
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        const int tn = t + 1 < ntiles ? t + 1 : t;             // past the end: the last tile again, into the stage nobody reads any more
+        if (!FX6_SPREAD && t + 1 < ntiles) stage(t + 1, buf ^ 1);
         const u16* const Ks = smem + buf * STAGE;
         const u16* const Vs = Ks + NP * K_PLANE;
 
@@ -172,6 +176,15 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], acc, 0, 0, 0);
             }
             s[kt] = acc;
+            // K pieces of the next tile behind the logits of this one
+            if (FX6_SPREAD)
+#pragma unroll
+                for (int j = 0; j < KW; ++j)
+                    if (j * KT / KW == kt) {
+                        __builtin_amdgcn_sched_barrier(0);       // (keeps the piece's address arithmetic here: hoisted, it costs registers the 12-wave form does not have)
+                        stage_piece(tn, buf ^ 1, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
         }
         // ---- online softmax over the keys of this tile (fp32, as flash_attn.hip) ----------------------------------------------------
         float mx = -INFINITY;
@@ -226,6 +239,15 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[c][e] += acc[e];
+            // V pieces of the next tile: VW of them dealt out over the first three quarters of the value tiles
+            if (FX6_SPREAD)
+#pragma unroll
+                for (int j = 0; j < VW; ++j)
+                    if (j * (3 * CT / 4) / VW == c) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_piece(tn, buf ^ 1, KW + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);
