@@ -175,6 +175,7 @@ SIGNATURES = {
     'gssd_reduce_max_f32': (c_i, [c_fp, c_i64, c_fp, c_i, c_fp]),
     'gssd_hnm_loss': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     'gssd_loss_finalize': (c_i, [c_fp, c_i, c_fp, c_fp, c_fp]),
+    'gssd_loss_finalize_global': (c_i, [c_fp, c_i, c_fp, c_i, c_fp, c_fp, c_fp]),
     'gssd_loss_backward': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     'gssd_detect': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     'gssd_softmax_lastdim_f32': (c_i, [c_fp, c_fp, c_i64, c_i, c_fp]),

@@ -492,6 +492,8 @@ struct SkDev {
     unsigned* err_dev = nullptr;
     SkRegion regions[SK_MAX_REGIONS];
     int nregions = 0;
+    SkRegion retired[SK_MAX_REGIONS];   // replaced inside a launch call; freed by gssd_dcn_streamk_release
+    int nretired = 0;
 };
 SkDev g_sk[16];
 std::mutex g_sk_mu;              // (first launches may come from two host threads: forward on the caller's, backward on autograd's)
@@ -554,11 +556,12 @@ SkRegion* sk_region(SkDev& s, const void* out, int ints, bool may_alloc) {
         if (s.regions[i].out == out && s.regions[i].ints >= ints) return &s.regions[i];
     if (!may_alloc) return nullptr;
     // a smaller region of the same output buffer (the address served a smaller launch before) is replaced, not kept beside the new one
+    // -- RETIRED, not freed: this runs inside a launch call (no device synchronisation, no hipFree there: another thread may hold a capture
+    // open); gssd_dcn_streamk_release frees the retired regions
     for (int i = 0; i < s.nregions; ++i)
         if (s.regions[i].out == out) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(s.regions[i].flags);
-            (void)hipFree(s.regions[i].ws);
+            if (s.nretired == SK_MAX_REGIONS) return nullptr;
+            s.retired[s.nretired++] = s.regions[i];
             s.regions[i] = s.regions[--s.nregions];
             break;
         }
@@ -628,6 +631,11 @@ extern "C" int gssd_dcn_streamk_release(const void* out) {
     }
     const int freed = s.nregions - kept;
     s.nregions = kept;
+    for (int i = 0; i < s.nretired; ++i) {               // regions replaced inside a launch call (sk_region)
+        (void)hipFree(s.retired[i].flags);
+        (void)hipFree(s.retired[i].ws);
+    }
+    s.nretired = 0;
     return freed;
 }
 

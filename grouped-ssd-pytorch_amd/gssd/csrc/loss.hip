@@ -300,6 +300,25 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partial, int B, 
     }
 }
 
+// the normaliser of multibox_loss.py:117 taken over ALL ranks' images ("for exact equivalence to a single 256-image batch,
+// all-reduce N (one int) and scale"): n_global = sum over ranks of the local N (the caller's all-reduce).  The rank's losses come out as
+// world * local sum / n_global and *n_total as n_global / world, so that the data-parallel MEAN over ranks of the losses / of the gradients
+// gssd_loss_backward forms with this n_total is exactly the loss / gradient of the one big batch.
+__global__ void loss_finalize_global_kernel(const double* __restrict__ partial, int B, const double* __restrict__ n_global, int world,
+                                            float* __restrict__ losses, double* __restrict__ n_total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double l = 0.0, c = 0.0;
+        for (int b = 0; b < B; ++b) {
+            l += partial[b * 4 + 0];
+            c += partial[b * 4 + 1];
+        }
+        const double n = *n_global / (double)world;
+        losses[0] = (float)(l / n);
+        losses[1] = (float)(c / n);
+        *n_total = n;
+    }
+}
+
 __global__ void loss_backward_kernel(const float* __restrict__ loc, const float* __restrict__ conf,
                                      const float* __restrict__ loc_t, const int64_t* __restrict__ conf_t,
                                      const uint8_t* __restrict__ sel, const double* __restrict__ n_total,
@@ -370,6 +389,14 @@ extern "C" int gssd_hnm_loss(const float* loc, const float* conf, const float* l
 extern "C" int gssd_loss_finalize(const double* partial, int B, float* losses, double* n_total, gssd_stream_t stream) {
     GSSD_CHECK_ARG(partial && losses && B > 0);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, B, losses, n_total);
+    GSSD_CHECK_LAUNCH();
+    return GSSD_OK;
+}
+
+extern "C" int gssd_loss_finalize_global(const double* partial, int B, const double* n_global, int world, float* losses, double* n_total,
+                                         gssd_stream_t stream) {
+    GSSD_CHECK_ARG(partial && losses && n_global && n_total && B > 0 && world > 0);
+    hipLaunchKernelGGL(loss_finalize_global_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, B, n_global, world, losses, n_total);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

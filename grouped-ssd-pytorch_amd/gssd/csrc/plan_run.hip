@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -136,6 +137,7 @@ const PlanFn g_plan_fns[] = {
     GSSD_PLAN_FN(gssd_reduce_max_f32),
     GSSD_PLAN_FN(gssd_hnm_loss),
     GSSD_PLAN_FN(gssd_loss_finalize),
+    GSSD_PLAN_FN(gssd_loss_finalize_global),
     GSSD_PLAN_FN(gssd_loss_backward),
     GSSD_PLAN_FN(gssd_detect),
     GSSD_PLAN_FN(gssd_softmax_lastdim_f32),
@@ -154,31 +156,40 @@ const PlanFn g_plan_fns[] = {
 constexpr int N_PLAN_FNS = (int)(sizeof(g_plan_fns) / sizeof(g_plan_fns[0]));
 
 // events for the WAIT ops: a ring per device (a wait captures the record made just before it, so a slot can be re-recorded as soon as the
-// hipStreamWaitEvent that names it has been enqueued)
+// hipStreamWaitEvent that names it has been enqueued).  Threading contract (gssd_hip.h): gssd_plan_run may be called from several host
+// threads; a ring's slot is handed out, recorded and waited on under the ring's mutex, so two threads never share a record / wait pair.  The
+// ring is chosen by the device that OWNS the awaited stream (hipStreamGetDevice), not by the caller's current device, and its events are
+// created with that device current.
 constexpr int N_EVENTS = 64;
 struct EventRing {
     hipEvent_t ev[N_EVENTS];
     int next = 0;
     bool ready = false;
+    std::mutex mu;
 };
 EventRing g_rings[32];
 
-hipEvent_t next_event(int& err) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 32) dev = 0;
+// dst waits for everything enqueued on src so far; 0 on success
+int record_and_wait(hipStream_t src, hipStream_t dst) {
+    int cur = 0, dev = -1;
+    (void)hipGetDevice(&cur);
+    hipDevice_t sdev;
+    if (src && hipStreamGetDevice(src, &sdev) == hipSuccess) dev = (int)sdev;
+    if (dev < 0) dev = cur;                               // the null stream: the current device's
+    if (dev < 0 || dev >= 32) return 1;
     EventRing& r = g_rings[dev];
+    std::lock_guard<std::mutex> lock(r.mu);
     if (!r.ready) {
-        for (int i = 0; i < N_EVENTS; ++i)
-            if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {
-                err = 1;
-                return nullptr;
-            }
+        if (dev != cur && hipSetDevice(dev) != hipSuccess) return 1;
+        bool ok = true;
+        for (int i = 0; i < N_EVENTS && ok; ++i) ok = hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) == hipSuccess;
+        if (dev != cur) (void)hipSetDevice(cur);
+        if (!ok) return 1;
         r.ready = true;
     }
     hipEvent_t e = r.ev[r.next];
     r.next = (r.next + 1) % N_EVENTS;
-    return e;
+    return (hipEventRecord(e, src) != hipSuccess || hipStreamWaitEvent(dst, e, 0) != hipSuccess) ? 1 : 0;
 }
 
 }  // namespace
@@ -222,10 +233,7 @@ extern "C" int gssd_plan_run(const gssd_plan_op* ops, int n_ops, const gssd_stre
                 gssd_set_error("gssd_plan_run: awaited stream index out of range");
                 rc = GSSD_EINVAL;
             } else if (op.fn != op.stream) {
-                int err = 0;
-                hipEvent_t e = next_event(err);
-                if (err || hipEventRecord(e, as_stream(streams[op.fn])) != hipSuccess ||
-                    hipStreamWaitEvent(as_stream(streams[op.stream]), e, 0) != hipSuccess) {
+                if (record_and_wait(as_stream(streams[op.fn]), as_stream(streams[op.stream]))) {
                     gssd_set_error("gssd_plan_run: event record / stream wait failed");
                     rc = GSSD_ELAUNCH;
                 }

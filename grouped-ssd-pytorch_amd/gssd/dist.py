@@ -16,6 +16,11 @@ def init(backend, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         kw = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
+        rdzv = os.environ.get('GSSD_DIST_INIT_FILE')
+        if rdzv:
+            # bench.py's self-launcher: a file-store rendezvous in a directory the parent owns -- no TCP port is picked ahead of the bind, so
+            # nothing on the host can take it in between (the loopback-port race ADVICE r5 names; torch.distributed.run keeps env://)
+            kw.update(init_method='file://' + rdzv, world_size=world, rank=rank)
         dist.init_process_group(backend, **kw)
     return world, rank
 
@@ -61,6 +66,18 @@ def aggregate_rate(world, per_rank_units, steps, seconds):
     return world * per_rank_units * steps / seconds
 
 
+def _scale_(t, world):
+    """t *= 1 / world in place.  Device tensors: one gssd_axpby_f32 launch on the current stream (the product path keeps its math in the
+    HIP library); CPU tensors (the gloo tests): torch."""
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        from . import _lib
+        _lib.check(_lib.lib.gssd_axpby_f32(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.numel(), 1.0 / world, 0.0,
+                                           torch.cuda.current_stream(t.device).cuda_stream))
+    else:
+        t.div_(world)
+    return t
+
+
 def allreduce_grads(params, world=None):
     """Data-parallel gradient averaging: ONE flat buffer (33 MB GSSD / 74 MB GSSD++ in fp32), one all-reduce (RCCL ring
     over xGMI on the GPUs), then scatter back -- replaces nn.DataParallel's reduce-to-device-0
@@ -75,11 +92,11 @@ def allreduce_grads(params, world=None):
     if base is not None and base.dim() == 1 and all(g._base is base for g in grads):
         # the HIP backward plan keeps all gradients as slices of one flat tensor: reduce it in place, no copies
         dist.all_reduce(base, op=dist.ReduceOp.SUM)
-        base.div_(world)
+        _scale_(base, world)
         return base.numel()
     flat = torch._utils._flatten_dense_tensors(grads)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(world)
+    _scale_(flat, world)
     for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
         g.copy_(f)
     return flat.numel()
@@ -126,7 +143,7 @@ class OverlappedGradReducer:
         n = 0
         for w, t in zip(self.works, self.ranges):
             w.wait()
-            t.div_(self.world)
+            _scale_(t, self.world)
             n += t.numel()
         self.overlapped_last = bool(self.works)
         skipped = eng is not None and getattr(eng, 'grad_segment_skipped', False)

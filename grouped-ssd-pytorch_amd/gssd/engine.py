@@ -157,9 +157,25 @@ class GssdEngine:
             job()
 
     def _build(self, B, training, dev, want_maps=False, nograd=False):
+        drain_sk_releases()
         if getattr(self.net, 'vanilla', False):
             return _PlanVanilla(self, B, training, dev)
         return _Plan(self, B, training, dev, want_maps, nograd)
+
+
+_SK_PENDING = []          # (device index, output pointer) of dropped plans whose stream-K regions await their release
+
+
+def drain_sk_releases():
+    """Free the stream-K regions queued by _Plan.__del__: only when no stream of this thread is capturing, each on its own device."""
+    if not _SK_PENDING or torch.cuda.is_current_stream_capturing():
+        return 0
+    n = 0
+    while _SK_PENDING:
+        di, ptr = _SK_PENDING.pop()
+        with torch.cuda.device(di):
+            n += max(0, int(lib.gssd_dcn_streamk_release(ptr)))
+    return n
 
 
 class _RecList(list):
@@ -195,10 +211,14 @@ class _Plan(_PlanBase, PlanGraphMixin, PlanOpsMixin, PlanExecMixin):
     plan_ops.PlanOpsMixin, eager / hipGraph execution in plan_exec.PlanExecMixin; this class keeps construction and the buffer / step helpers."""
 
     def __del__(self):
-        # csrc/dcn_fused.hip's stream-K regions belong to this plan's deformable-conv outputs (GSSD_DCN_X6=0 only)
+        # csrc/dcn_fused.hip's stream-K regions belong to this plan's deformable-conv outputs (GSSD_DCN_X6=0 only).  The release frees device
+        # memory (it synchronises) and the collector may drop a plan at any time -- inside another plan's open hipGraph capture, or with another
+        # device current -- so the pointers are only QUEUED here, with their device; drain_sk_releases() frees them at the next plan build
+        # that finds no capture open (ADVICE r5).
         try:
-            for ptr in self.__dict__.get('_sk_outs', ()):
-                lib.gssd_dcn_streamk_release(ptr)
+            outs = self.__dict__.get('_sk_outs', ())
+            if outs:
+                _SK_PENDING.extend((self.dev.index if self.dev.index is not None else torch.cuda.current_device(), ptr) for ptr in outs)
         except Exception:        # noqa: BLE001 -- interpreter teardown
             pass
 

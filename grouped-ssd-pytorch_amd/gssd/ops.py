@@ -455,8 +455,9 @@ def match_batch(tg, gt_off, priors, threshold=0.5, variance=(0.1, 0.2)):
 
 
 def multibox_loss_forward(loc, conf, priors, tg, n_gt, threshold=0.5, negpos_ratio=3, variance=(0.1, 0.2),
-                          want_scores=False):
-    """Returns dict(losses[2], loc_t, conf_t, sel, n_total, loss_c_all?)."""
+                          want_scores=False, global_n=False):
+    """Returns dict(losses[2], loc_t, conf_t, sel, n_total, loss_c_all?).  ``global_n``: the normaliser N of multibox_loss.py:117 over every
+    rank's images (one all-reduce of one double) instead of this rank's -- SURVEY.md 8e's exact equivalence to the single big batch."""
     _need_cuda(loc, conf, priors)
     loc = loc.contiguous()
     conf = conf.contiguous()
@@ -476,6 +477,12 @@ def multibox_loss_forward(loc, conf, priors, tg, n_gt, threshold=0.5, negpos_rat
     losses = torch.empty(2, device=dev, dtype=torch.float32)
     n_total = torch.empty(1, device=dev, dtype=torch.float64)
     check(lib.gssd_loss_finalize(_p(partial), B, _p(losses), _p(n_total), _stream()))
+    if global_n:
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            n_glob = n_total.clone()
+            dist.all_reduce(n_glob, op=dist.ReduceOp.SUM)
+            check(lib.gssd_loss_finalize_global(_p(partial), B, _p(n_glob), dist.get_world_size(), _p(losses), _p(n_total), _stream()))
     return dict(losses=losses, loc_t=loc_t, conf_t=conf_t, sel=sel, n_total=n_total, loss_c_all=lca, partial=partial,
                 loc=loc, conf=conf)
 

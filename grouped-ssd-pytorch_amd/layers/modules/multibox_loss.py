@@ -16,9 +16,9 @@ from data.config import v2 as cfg
 
 class _MultiBoxLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, loc, conf, priors, tg, n_gt, threshold, negpos_ratio, variance):
+    def forward(ctx, loc, conf, priors, tg, n_gt, threshold, negpos_ratio, variance, global_n=False):
         st = ops.multibox_loss_forward(loc.detach(), conf.detach(), priors, tg, n_gt, threshold, negpos_ratio,
-                                       variance)
+                                       variance, global_n=global_n)
         ctx.st = st
         losses = st['losses']
         return losses[0], losses[1]
@@ -26,7 +26,7 @@ class _MultiBoxLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_l, g_c):
         dloc, dconf = ops.multibox_loss_backward(ctx.st, g_l, g_c)
-        return dloc, dconf, None, None, None, None, None, None
+        return dloc, dconf, None, None, None, None, None, None, None
 
 
 class MultiBoxLoss(nn.Module):
@@ -43,6 +43,9 @@ class MultiBoxLoss(nn.Module):
         self.negpos_ratio = neg_pos
         self.neg_overlap = neg_overlap
         self.variance = cfg['variance']
+        # extension (not in the reference): one process per GPU keeps the reference's per-replica normaliser N by default; True
+        # all-reduces N over the ranks so that the data-parallel mean of the losses / gradients equals the single (world x B)-image batch
+        self.global_normalizer = False
 
     def forward(self, predictions, targets):
         loc_data, conf_data, priors = predictions
@@ -52,4 +55,5 @@ class MultiBoxLoss(nn.Module):
             priors = priors.to(loc_data.device)
         tg, n_gt = ops.pack_targets(targets, loc_data.device)
         return _MultiBoxLossFn.apply(loc_data, conf_data, priors.detach().contiguous(), tg, n_gt, float(self.threshold),
-                                     int(self.negpos_ratio), (float(self.variance[0]), float(self.variance[1])))
+                                     int(self.negpos_ratio), (float(self.variance[0]), float(self.variance[1])),
+                                     bool(self.global_normalizer))

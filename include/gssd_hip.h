@@ -205,7 +205,8 @@ int gssd_l2norm_bf16(const void* x, const float* weight, void* out, int64_t pixe
 /* U[g][xi][co][ci] = (G g G^T)_xi of the packed K-major weights [Cout][tap*cin_g + ci] (row stride `row_stride`).
  * Winograd shapes: cin_g % 16 == 0 and cout_g % 32 == 0, or (one group) any cout_g >= 24 -- U's rows per group are then
  * padded with zeros to a multiple of the kernel's channel block; gssd_winograd_weight_elems (HOST) returns the float
- * count of U, or -1 for other shapes.  The same packer serves the data gradient (weights packed by
+ * count of the buffer the packer fills, or -1 for other shapes: the fp32 U followed -- for the shapes csrc/conv_wino_x6.hip takes
+ * (cin_g % 16 == 0, cout_g >= 24) -- by U's three bf16 planes in that kernel's staging order (two bf16 per counted float).  The same packer serves the data gradient (weights packed by
  * gssd_pack_conv_weight_dgrad). */
 long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g);
 int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
@@ -544,6 +545,11 @@ int gssd_hnm_loss(const float* loc, const float* conf, const float* loc_t, const
                   int xmax_n, int B, int P, int C, int negpos_ratio, uint8_t* sel, double* partial, float* loss_c_all,
                   gssd_stream_t stream);
 int gssd_loss_finalize(const double* partial, int B, float* losses, double* n_total, gssd_stream_t stream);
+/* multibox_loss.py:117 with N taken over every rank's images (opt-in, MultiBoxLoss.global_normalizer): n_global = the all-reduced
+ * (summed) n_total of gssd_loss_finalize; losses = world * local sums / n_global, *n_total = n_global / world -- the mean over ranks of these
+ * losses, and of the gradients gssd_loss_backward forms with this n_total, equals the single (world x B)-image batch. */
+int gssd_loss_finalize_global(const double* partial, int B, const double* n_global, int world, float* losses, double* n_total,
+                              gssd_stream_t stream);
 /* d(loss_l + loss_c)/d(loc, conf) scaled by grad_l, grad_c (device scalars) / N. */
 int gssd_loss_backward(const float* loc, const float* conf, const float* loc_t, const int64_t* conf_t,
                        const uint8_t* sel, const double* n_total, const float* grad_l, const float* grad_c, int B,
@@ -674,9 +680,12 @@ const char* gssd_plan_fn_name(int index);
 int gssd_plan_fn_index(const char* name); /* -1: not an entry point the runner can launch */
 int gssd_plan_fn_nargs(int index);        /* parameters before the stream */
 int gssd_plan_op_size(void);              /* sizeof(gssd_plan_op) as built */
+/* Threading: callable from several host threads at once (the events behind WAIT ops come from a per-device ring whose slots are handed
+   out, recorded and waited on under a mutex); the ring is chosen by the device that owns the awaited stream, so the caller's current
+   device need not be the plan's.  The launches themselves need the plan's device current, as every other entry point does. */
 int gssd_plan_run(const gssd_plan_op* ops, int n_ops, const gssd_stream_t* streams, int n_streams, int* failed_at);
 
-/* 1 when gssd_conv2d_nhwc_f32 runs the descriptor on the three-plane Winograd kernel (csrc/conv_wino_x6.hip; GSSD_WINO_X6=1 only) */
+/* 1 when gssd_conv2d_nhwc_f32 runs the descriptor on the three-plane Winograd kernel (csrc/conv_wino_x6.hip; on by default above its size gate; GSSD_WINO_X6=0 never, =2 every shape it can take) */
 int gssd_conv_wino_x6_takes(const gssd_conv_desc* d);
 
 #ifdef __cplusplus

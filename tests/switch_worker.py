@@ -1,4 +1,5 @@
-"""Subprocess of tests/test_gpu_switches.py: one GSSD++ training step (forward + MultiBoxLoss + backward) at batch 4 in the dtype
+"""Subprocess of tests/test_gpu_switches.py: one GSSD++ training step (forward + MultiBoxLoss + backward) at batch 4 (or argv[2]: the
+size-gated kernels -- conv_wino_x6, conv_x6 on the 19 x 19 maps, the 256 x 128 bf16 tiles -- take launches only at larger batches) in the dtype
 given on the command line, under whatever GSSD_* ablation switches the parent put into the environment (they are read once per
 process).  Prints one JSON line: sampled outputs, losses, gradient norms and samples, and which kernel instances the plan launched."""
 import json
@@ -22,8 +23,9 @@ def main():
     net.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1111))
     net = net.to(dev).train()
     net.compute_dtype = dtype
-    x = synth.synth_images(4, seed=5).to(dev)
-    tg = synth.synth_targets(4, seed=5)
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    x = synth.synth_images(B, seed=5).to(dev)
+    tg = synth.synth_targets(B, seed=5)
     crit = MultiBoxLoss(2, 0.5, True, 0, True, 3, 0.5, False, True)
     with torch.no_grad():
         for _ in range(3):                      # the third forward replays from hipGraphs (unless GSSD_NO_GRAPH)

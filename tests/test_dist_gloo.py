@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -118,14 +119,18 @@ def _worker_overlap(rank, world, port, out):
     net._engine.grad_segment_skipped = True                # what GssdTrainFn.backward sets when p.grad is not the flat slice
     red.finish()
     assert not red.overlapped_last and net._engine.grad_segment_hook is None
-    assert all(float(p.grad.min()) == float(p.grad.max()) == 15.0 for p in params)
+    assert all(float(p.grad.min()) == float(p.grad.max()) == 5.0 * (world + 1) for p in params)
     out.put(res)
     gd.barrier()
     gd.finish()
 
 
-def test_overlapped_reducer_two_ranks():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize('world', [2, 8])
+def test_overlapped_reducer_ranks(world, tmp_path, monkeypatch):
+    """world 8 = BASELINE configs[3]'s launch shape: the ranges fire last-to-first on every rank and each element is
+    averaged exactly once; the ranks meet through the FileStore rendezvous bench.py's self-launcher uses (gssd/dist.py::init)."""
+    port = _free_port()
+    monkeypatch.setenv('GSSD_DIST_INIT_FILE', str(tmp_path / 'store'))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
@@ -135,5 +140,6 @@ def test_overlapped_reducer_two_ranks():
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
+    mean = (world + 1) / 2.0                    # ranks fill their gradients with rank + 1
     for r in got:
-        assert r[1] and r[2] == r[3] == 1.5 and r[4] == [1.5, 1.5, 1.5]              # every element averaged exactly once, in place
+        assert r[1] and r[2] == r[3] == mean and r[4] == [mean] * 3                  # every element averaged exactly once, in place

@@ -107,8 +107,12 @@ def hip_decisions(plan, dev):
     return dec
 
 
-@pytest.mark.parametrize('name', ['gssd', 'gssdpp'])
-def test_teacher_forced_gradients_all_parameters(dev, name):
+# (gssdpp, 32) -- round 6, VERDICT r5 item 1b: the batch bench.py's `full_step` times.  Only at this size do the data gradients of conv3_2 .. conv4_3
+# run csrc/conv_wino_x6.hip (>= 8 192 Winograd tiles), conv6 / conv7 / fuse_21 / the 19 x 19 Self_Attn convs and the deformable conv's d(cols) GEMM
+# csrc/conv_x6.hip (M >= 4 096), and the wgrad / BatchNorm-backward kernels their batch-32 tilings: the float64 graph costs ~80 GB of host memory
+# and a minute or two of the GPU box's 256 host cores, once.
+@pytest.mark.parametrize('name,B', [('gssd', 4), ('gssdpp', 4), ('gssdpp', 32)])
+def test_teacher_forced_gradients_all_parameters(dev, name, B):
     from models.ssd_multiphase_custom_group import build_ssd
     flags, args = NETS[name]
     net = build_ssd('train', 300, 2, *args)
@@ -116,7 +120,6 @@ def test_teacher_forced_gradients_all_parameters(dev, name):
     sd = synth.synth_state_dict(shapes, seed=1111)
     net.load_state_dict(sd)
     net = net.to(dev).train()
-    B = 4
     x = synth.synth_images(B, seed=9)
     rng = np.random.default_rng(0)
     r1 = torch.from_numpy(rng.normal(size=(B, 8732, 4)).astype(np.float32))
@@ -124,6 +127,17 @@ def test_teacher_forced_gradients_all_parameters(dev, name):
     loc, conf, _ = net(x.to(dev))
     ((loc * r1.to(dev)).sum() + (conf * r2.to(dev)).sum()).backward()
     plan = net._engine._last_plan
+    if B >= 24:
+        # the kernel mix this batch exists for: the three-plane kernels really took their launches, forward and backward
+        fwd_k = {st.tag[0].split('/')[0] for st in plan.steps if st.tag is not None}
+        assert {'conv_wino_x6<64>', 'conv_x6<128>', 'dcn_x6<128x256>', 'flash_attn_x6<64,256>'} <= fwd_k, fwd_k
+        import ctypes as C
+        from gssd import _lib
+        bwd_descs = [a for fn, args in plan._bwd.steps if getattr(fn, '__name__', '') == 'gssd_conv2d_nhwc_f32' for a in args]
+        n_wx6 = sum(_lib.lib.gssd_conv_wino_x6_takes(a) == 1 for a in bwd_descs)
+        n_cx6 = sum(_lib.lib.gssd_conv_x6_takes(a) == 1 for a in bwd_descs)
+        print(f'backward plan at B = {B}: {n_wx6} data-gradient launches on conv_wino_x6, {n_cx6} on conv_x6')
+        assert n_wx6 >= 5 and n_cx6 >= 6, (n_wx6, n_cx6)
     dec = hip_decisions(plan, dev)
     # float64 autograd through the oracle with the HIP path's decisions (spectral norm's u / v: the pre-step values, as the HIP forward used)
     sd64 = {k: (v.double().requires_grad_() if (v.is_floating_point() and not k.endswith(('running_mean', 'running_var', 'weight_u', 'weight_v')))
@@ -161,7 +175,7 @@ def test_teacher_forced_gradients_all_parameters(dev, name):
     print('\n'.join(lines))
     d = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(d):
-        with open(os.path.join(d, f'grad_teacher_forced_{name}.txt'), 'w') as f:
+        with open(os.path.join(d, f'grad_teacher_forced_{name}' + (f'_b{B}' if B != 4 else '') + '.txt'), 'w') as f:
             f.write('\n'.join(lines) + '\n' + '\n'.join(f'{k} {v:.3e}' for k, v in sorted(errs.items(), key=lambda kv: -kv[1])) + '\n')
     assert fw < 1e-4
     assert len(errs) + len(zero_grad) + len(skipped) == len(named)

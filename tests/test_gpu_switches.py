@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 _cache = {}
 
 
-def run(dtype, env):
-    key = (dtype, tuple(sorted(env.items())))
+def run(dtype, env, batch=4):
+    key = (dtype, batch, tuple(sorted(env.items())))
     if key not in _cache:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'switch_worker.py'), dtype], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'switch_worker.py'), dtype, str(batch)], capture_output=True, text=True,
                            timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('SWITCHJSON ')][-1]
@@ -33,8 +33,12 @@ def l2rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def has(o, prefix):
+    return any(k.startswith(prefix) for k in o['kernels'])
+
+
 SWITCHES = [
-    # dtype, environment, what must (not) be in the launched kernel set
+    # dtype, environment (+ optional 'BATCH': a batch at which the switch really changes the kernel set), what must (not) be in the launched kernel set
     ('f32', {'GSSD_NO_GRAPH': '1'}, lambda o, base: o['graphs'] == 0 and base['graphs'] > 0),
     ('f32', {'GSSD_NO_BRANCH_STREAMS': '1'}, lambda o, base: True),
     ('f32', {'GSSD_BWD_STREAMS': '0'}, lambda o, base: True),
@@ -65,13 +69,35 @@ SWITCHES = [
     # the round-3 form of the bf16 training step: the fp32 backward plan on fp32 copies of every stored map
     ('bf16', {'GSSD_BWD_BF16': '0'}, lambda o, base: 'gssd_conv2d_wgrad_bf16' in base['bwd_fns'] and 'gssd_bn_bwd_apply_mixed' in base['bwd_fns']
      and not any(f in o['bwd_fns'] for f in ('gssd_conv2d_wgrad_bf16', 'gssd_bn_bwd_apply_mixed', 'gssd_dcn_im2col_bf16'))),
+    # ---- round 6: the size-gated three-plane kernels, at batch 24 where conv3_1 .. conv4_3 (+ the offset conv) and their data gradients run
+    # csrc/conv_wino_x6.hip (>= 8 192 Winograd tiles) and conv6 / conv7 / the 19 x 19 dgrads run csrc/conv_x6.hip (M >= 4 096): a whole
+    # training step of the batch-32 kernel mix against the same step on the fp32-MFMA kernels
+    ('f32', {'GSSD_WINO_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino_x6') and has(base, 'conv_wino_x6<64>') and has(o, 'conv_wino<64>')),
+    ('f32', {'GSSD_WINO_X6': '2', 'BATCH': 24}, lambda o, base: has(o, 'conv_wino_x6<32>') and not has(base, 'conv_wino_x6<32>')),
+    ('f32', {'GSSD_CONV_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_x6') and has(base, 'conv_x6')),
+    ('f32', {'GSSD_DCN_X6': '0', 'BATCH': 24}, lambda o, base: has(o, 'dcn_fused') and has(base, 'dcn_x6')),
+    ('f32', {'GSSD_WINO_X6': '0', 'GSSD_CONV_X6': '0', 'GSSD_DCN_X6': '0', 'GSSD_FLASH_X6': '0', 'BATCH': 24},
+     lambda o, base: not any(has(o, k) for k in ('conv_wino_x6', 'conv_x6', 'dcn_x6', 'flash_attn_x6'))),
+    # the attention cores of the 38 x 38 blocks on the fp32 matrix cores (csrc/flash_attn.hip) instead of the three-plane form
+    ('f32', {'GSSD_FLASH_X6': '0'}, lambda o, base: not has(o, 'flash_attn_x6') and has(base, 'flash_attn_x6') and has(o, 'flash_attn<')),
+    # the backward as one Python call per launch instead of one gssd_plan_run array per gradient segment (csrc/plan_run.hip)
+    ('f32', {'GSSD_NO_PLAN_RUN': '1'}, lambda o, base: True),
+    ('f32', {'GSSD_BRANCH0_LATE': '0'}, lambda o, base: True),
+    ('f32', {'GSSD_CONV21_WINO': '0'}, lambda o, base: has(o, 'conv_thin<16,32>') and not has(base, 'conv_thin<16,32>')),
+    ('bf16', {'GSSD_STATS_REP': '0'}, lambda o, base: True),
+    # opt-in experiments that stay in the tree (DESIGN 9 "measured and rejected"): 256 x 128 bf16 tiles (>= 8 192 rows: batch 8), the loader /
+    # matrix-wave form of the bf16 deformable conv
+    ('bf16', {'GSSD_BF16_BIG_TILES': '1', 'BATCH': 8}, lambda o, base: has(o, 'conv_bf16<256x128>') and not has(base, 'conv_bf16<256x128>')),
+    ('bf16', {'GSSD_DCN_BF16_V3': '1', 'BATCH': 8}, lambda o, base: True),
 ]
 
 
 @pytest.mark.parametrize('dtype,env,check', SWITCHES, ids=[f"{d}-{'-'.join(f'{k}={v}' for k, v in e.items())}" for d, e, _ in SWITCHES])
 def test_switch_path_agrees_with_default(dtype, env, check):
-    base = run(dtype, {})
-    out = run(dtype, env)
+    env = dict(env)
+    batch = env.pop('BATCH', 4)
+    base = run(dtype, {}, batch)
+    out = run(dtype, env, batch)
     assert check(out, base), (out['kernels'], out['graphs'])
     assert out['graph_replay'] <= (1e-6 if dtype == 'f32' else 0.0) * max(out['loc_max'], 1.0) + 1e-5     # eager == hipGraph replay
     f32 = dtype == 'f32'
