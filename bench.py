@@ -437,7 +437,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                     traffic = None
             ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
             wino = dom.startswith(('conv_wino', 'conv_thin_wino'))
-            x6 = dom.startswith(("dcn_x6", "conv_x6", "conv_wino_x6", "flash_attn_x"))
+            x6 = dom.startswith(("dcn_x6", "conv_x6", "conv_wino_x6", "conv_thin_x6", "flash_attn_x"))
             if dom.startswith('conv_wino_x6'):
                 # Winograd F(2x2,3x3) with three-plane operands: 2.25 x fewer products than the direct conv, six bf16 MFMAs each -- `achieved` /
                 # `frac` are the ISSUED bf16 FLOPs (direct-conv FLOPs x 6 / 2.25) against the bf16 matrix peak

@@ -71,6 +71,7 @@ SIGNATURES = {
     'gssd_conv_x6_pack_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_conv_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
     'gssd_conv_wino_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
+    'gssd_conv_thin_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
     'gssd_plan_fn_count': (c_i, []),
     'gssd_plan_fn_name': (C.c_char_p, [c_i]),
     'gssd_plan_fn_index': (c_i, [C.c_char_p]),

@@ -440,6 +440,10 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
         if (rc != 1) return rc;
     }
     {
+        const int rc = gssd_try_conv_thin_x6(d, s);   // conv1_2 / conv2_1 / conv2_2: patch-staged direct conv, three-plane bf16 operands (round 6)
+        if (rc != 1) return rc;
+    }
+    {
         const int rc = gssd_try_conv_thin_wino(d, s); // conv1_2 (and its dgrad): patch-staged Winograd
         if (rc != 1) return rc;
     }

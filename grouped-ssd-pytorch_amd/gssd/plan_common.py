@@ -89,7 +89,9 @@ def conv_tag(d, real_cin_g=None, bf16=False):
         name = f'conv_wino<{64 if (cout_g % 64 == 0 or (cout_g % 32 != 0 and cout_g > 32)) else 32}>'   # gssd_try_conv_wino
     if name.startswith('conv_wino<') and lib.gssd_conv_wino_x6_takes(C.byref(d)) == 1:
         name = f'conv_wino_x6<{64 if cout_g > 32 else 32}>'      # csrc/conv_wino_x6.hip: the library's own host rule
-    if name.startswith(('conv_wino<', 'conv_wino_x6<')):
+    if not bf16 and lib.gssd_conv_thin_x6_takes(C.byref(d)) == 1:
+        name = f'conv_thin_x6<{d.cin_g},{cout_g}>'               # csrc/conv_thin_x6.hip: first in gssd_conv2d_nhwc_f32's dispatch order
+    if name.startswith(('conv_wino<', 'conv_wino_x6<', 'conv_thin_x6<')):
         # one name per kernel SYMBOL, as rocprofv3 --stats groups them (template <tile, fused input transform, ..., pooled epilogue>)
         name += ('' if d.in_scale else '/plain') + ('/pool2' if d.flags & _lib.CONV_POOL2 else '')
     if bf16 and name.startswith('conv_bf16'):

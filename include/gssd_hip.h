@@ -687,6 +687,11 @@ int gssd_plan_run(const gssd_plan_op* ops, int n_ops, const gssd_stream_t* strea
 
 /* 1 when gssd_conv2d_nhwc_f32 runs the descriptor on the three-plane Winograd kernel (csrc/conv_wino_x6.hip; on by default above its size gate; GSSD_WINO_X6=0 never, =2 every shape it can take) */
 int gssd_conv_wino_x6_takes(const gssd_conv_desc* d);
+/* 1 when gssd_conv2d_nhwc_f32 runs the descriptor on the patch-staged three-plane direct conv (csrc/conv_thin_x6.hip, round 6): the grouped 3x3
+ * trunk layers with 16 -> 16, 16 -> 32 and 32 -> 32 channels per group on maps of >= 75 x 75 pixels -- conv1_2, conv2_1, conv2_2 of
+ * models/ssd_multiphase_custom_group.py:434-460 -- plain or with the fused producer BatchNorm + ReLU / batch sums / GSSD_CONV_POOL2 epilogue
+ * (no residual: their data gradients stay with the fp32 kernels).  GSSD_THIN_X6=0: never. */
+int gssd_conv_thin_x6_takes(const gssd_conv_desc* d);
 
 #ifdef __cplusplus
 }

@@ -618,9 +618,11 @@ def test_conv_winograd_pooled_epilogue(dev, ops, Cin, Cout, H, W, xf):
     scale, shift = gamma * 0.7, torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
     f = lambda t: torch.relu(torch.addcmul(shift.view(1, -1, 1, 1), t, scale.view(1, -1, 1, 1)))
     assert torch.equal(f(want), F.max_pool2d(f(nchw(full.cpu())), 2, 2, 0, ceil_mode=True))
-    # a shape no pooled epilogue exists for is refused loudly, not computed unpooled
+    # a shape no pooled epilogue exists for is refused loudly, not computed unpooled (without Winograd weights only csrc/conv_thin_x6.hip's
+    # shape classes -- conv1_2, conv2_2 -- have one)
     d1, _, _ = ops.make_conv_desc(nhwc(x).to(dev), wp, out, flags=_lib.CONV_POOL2, pool_sign=gd_, **{**kw, 'wgt_wino': None})
-    assert _lib.lib.gssd_conv2d_nhwc_f32(C.byref(d1), st_) == -1
+    if _lib.lib.gssd_conv_thin_x6_takes(C.byref(d1)) == 0:
+        assert _lib.lib.gssd_conv2d_nhwc_f32(C.byref(d1), st_) == -1
 
 
 def test_sa_backward_building_blocks(dev):

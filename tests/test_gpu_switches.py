@@ -73,11 +73,15 @@ SWITCHES = [
     # csrc/conv_wino_x6.hip (>= 8 192 Winograd tiles) and conv6 / conv7 / the 19 x 19 dgrads run csrc/conv_x6.hip (M >= 4 096): a whole
     # training step of the batch-32 kernel mix against the same step on the fp32-MFMA kernels
     ('f32', {'GSSD_WINO_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino_x6') and has(base, 'conv_wino_x6<64>') and has(o, 'conv_wino<64>')),
-    ('f32', {'GSSD_WINO_X6': '2', 'BATCH': 24}, lambda o, base: has(o, 'conv_wino_x6<32>') and not has(base, 'conv_wino_x6<32>')),
+    # (every shape it can take: conv5_x on the 19 x 19 maps -- 2 400 tiles -- move over from conv_wino.hip<64>)
+    ('f32', {'GSSD_WINO_X6': '2', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino<64>') and has(base, 'conv_wino<64>') and has(o, 'conv_wino_x6<64>')),
     ('f32', {'GSSD_CONV_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_x6') and has(base, 'conv_x6')),
     ('f32', {'GSSD_DCN_X6': '0', 'BATCH': 24}, lambda o, base: has(o, 'dcn_fused') and has(base, 'dcn_x6')),
     ('f32', {'GSSD_WINO_X6': '0', 'GSSD_CONV_X6': '0', 'GSSD_DCN_X6': '0', 'GSSD_FLASH_X6': '0', 'BATCH': 24},
      lambda o, base: not any(has(o, k) for k in ('conv_wino_x6', 'conv_x6', 'dcn_x6', 'flash_attn_x6'))),
+    # round 6: conv1_2 / conv2_1 / conv2_2 on the round-5 fp32-MFMA kernels instead of the patch-staged three-plane direct conv (csrc/conv_thin_x6.hip)
+    ('f32', {'GSSD_THIN_X6': '0'}, lambda o, base: not has(o, 'conv_thin_x6') and has(base, 'conv_thin_x6<16,16>') and has(base, 'conv_thin_x6<32,32>')
+     and has(o, 'conv_thin_wino')),
     # the attention cores of the 38 x 38 blocks on the fp32 matrix cores (csrc/flash_attn.hip) instead of the three-plane form
     ('f32', {'GSSD_FLASH_X6': '0'}, lambda o, base: not has(o, 'flash_attn_x6') and has(base, 'flash_attn_x6') and has(o, 'flash_attn<')),
     # the backward as one Python call per launch instead of one gssd_plan_run array per gradient segment (csrc/plan_run.hip)
