@@ -604,6 +604,11 @@ extern "C" int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* dp, gssd_stream_t str
     static const int big = [] { const char* e = getenv("GSSD_BF16_BIG_TILES"); return e ? atoi(e) : 0; }();
     if (big && !d.m_per_image && d.split_k == 1 && M >= 8192 && cout_g % 128 == 0 && d.K % BK == 0 && d.K >= 256 &&
         (d.out_mode == GSSD_OUT_NHWC || (d.out_mode == GSSD_OUT_SPLIT_T && d.split_n % 128 == 0))) {
+        if (big == 2) return launch_cfg<256, 128, 4, 2, 3>(d, M, images, s);     // round 6 sweep: the same tile behind a three-stage ring (144 KB)
+        if (big == 3) return launch_cfg<192, 128, 4, 2, 3>(d, M, images, s);     // 192 rows: 46 208 pixels = 241 row tiles -> 723 / 964 tiles = 2.8 / 3.8 rounds
+        if (big == 4) return launch_cfg<128, 128, 2, 2, 4>(d, M, images, s);     // four stages of 32 KB, four 64 x 64 waves
+        if (big == 5) return launch_cfg<128, 128, 2, 2, 3>(d, M, images, s);
+        if (big == 6) return launch_cfg<128, 128, 4, 2, 4>(d, M, images, s);     // eight 32 x 64 waves
         return launch_cfg<256, 128, 4, 2>(d, M, images, s);      // (256 x 256 on eight waves: 256 registers and 672 bytes of scratch per lane)
     }
     if (cout_g > 64) {

@@ -1,11 +1,11 @@
 """Link decoding on the device (ssd_liverdet/pixel_link/postprocess.py).
 
 ``decode`` = the thresholds of ``mask_to_box`` (:104-121) + ``func`` (:178-234): labelled connected components per image, with their
-pixel count, bounding box and mean positive-class score.  ``mask_to_box`` here returns per image ``[[score, x0, y0, x1, y1], ...]``
-in image pixels from those component boxes.  The reference goes on through cv2 (nearest resize to 300 x 300, findContours,
-minAreaRect, boxPoints; :124-160); cv2 is not part of this image, so that detour is not reproduced: the boxes are the components'
-own axis-aligned bounds under the same nearest-neighbour 75 -> 300 up-scaling (a mask pixel covers a 4 x 4 block), the score is the
-mean over the component's mask pixels, and the reference's min_area / min_height filters act on those boxes."""
+pixel count, bounding box and mean positive-class score.  ``mask_to_box`` returns per image ``[[score, x0, y0, x1, y1], ...]``
+in image pixels.  The reference goes on through cv2 (nearest resize to 300 x 300, findContours, minAreaRect, boxPoints; :124-160); cv2 is not
+part of this image, so that tail is DEFINED in pixel_link/box_geometry.py (round 6): minimum-area enclosing rectangle of each component by
+convex hull + rotating calipers, the reference's filters, integer corners, axis-aligned bounds, bilinear score map -- pinned by closed-form
+cases and a brute-force cross-check (tests/test_pixellink_cpu.py), not by OpenCV outputs (there are none to pin it to)."""
 import torch
 
 import pixel_link.pixel_link_config as config
@@ -33,29 +33,19 @@ def decode(pixel_mask, link_mask, pixel_thres=None, link_thres=None, max_compone
 
 
 def mask_to_box(pixel_mask, link_mask, neighbors=8, img_shape=(300, 300), pixel_thres=None):
+    """postprocess.py:84-161: per image ``[[score, min_x, min_y, max_x, max_y], ...]``.  Components on the device (``decode``), then the
+    reference's host tail as pixel_link/box_geometry.py defines it: nearest-neighbour up-scaling of the label map, the minimum-area enclosing
+    rectangle of each component, its min_height / min_area filters, integer corners clamped into the image and their axis-aligned bounds; the score
+    is the mean of the bilinearly up-scaled positive-class probability over the component's pixels."""
     assert neighbors == 8
-    B, _, H, W = pixel_mask.shape
-    _, comps, ncomp = decode(pixel_mask, link_mask, pixel_thres)
-    nmax = int(ncomp.max())
-    if nmax > comps.shape[1]:
-        # more components than the default statistics table holds (a noisy 75 x 75 map can have > 512): the reference's func()
-        # handles every component, so decode again with the kernel's largest table and refuse to truncate beyond that
-        if nmax > STAT_COMPS_MAX:
-            raise _lib.GssdError(f'pixel_link.postprocess.mask_to_box: {nmax} components in one image; the device keeps statistics '
-                                 f'for at most {STAT_COMPS_MAX} (the label map from decode() is complete, the box table is not)')
-        _, comps, ncomp = decode(pixel_mask, link_mask, pixel_thres, max_components=STAT_COMPS_MAX)
-    comps, ncomp = comps.cpu(), ncomp.cpu()
-    sx, sy = img_shape[0] / W, img_shape[1] / H
+    import numpy as np
+    from pixel_link import box_geometry as G
+    labels, _, _ = decode(pixel_mask, link_mask, pixel_thres)
+    lab = labels.cpu().numpy()
+    logit = pixel_mask.detach().float().cpu().numpy()
+    prob = (1.0 / (1.0 + np.exp((logit[:, 0] - logit[:, 1]).astype(np.float64)))).astype(np.float32)       # Softmax2d, positive class
     out = []
-    for b in range(B):
-        dets = []
-        for c in comps[b, :min(int(ncomp[b]), comps.shape[1])].tolist():
-            n, x0, y0, x1, y1, ssum = c
-            bx0, by0 = int(x0 * sx), int(y0 * sy)
-            bx1, by1 = min(int((x1 + 1) * sx) - 1, img_shape[0] - 1), min(int((y1 + 1) * sy) - 1, img_shape[1] - 1)
-            w, h = bx1 - bx0 + 1, by1 - by0 + 1
-            if min(w, h) < config.min_height or w * h < config.min_area:
-                continue
-            dets.append([ssum / n, bx0, by0, bx1, by1])
-        out.append(dets)
+    for b in range(lab.shape[0]):
+        boxes, scores = G.component_boxes(lab[b], prob[b], (img_shape[1], img_shape[0]), config.min_height, config.min_area)
+        out.append([[s] + bx for s, bx in zip(scores, boxes)])
     return out

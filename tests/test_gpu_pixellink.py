@@ -303,6 +303,11 @@ def test_decode_vs_reference_fixture(dev, golden):
             assert abs(ssum - score[b][ys, xs].sum()) <= 1e-4 * max(1.0, ssum)
     boxes = postprocess.mask_to_box(o1, o2)
     assert len(boxes) == lab.shape[0] and all(len(d) <= int(lab[b].max()) for b, d in enumerate(boxes))
+    # the box tail (pixel_link/box_geometry.py: min-area rectangles of the up-scaled components) on the REFERENCE's label maps gives the same boxes
+    from pixel_link import box_geometry as G, pixel_link_config as cfg
+    for b in range(lab.shape[0]):
+        bx, sc = G.component_boxes(g['dec_labels'][b], score[b], (300, 300), cfg.min_height, cfg.min_area)
+        assert [d[1:] for d in boxes[b]] == bx and np.allclose([d[0] for d in boxes[b]], sc, atol=1e-6)
     # edge cases: nothing positive; everything positive and fully linked -> one component
     z1 = torch.zeros(1, 2, 20, 20, device=dev)
     z1[:, 0] = 5.0
