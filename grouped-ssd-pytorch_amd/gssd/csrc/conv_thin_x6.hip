@@ -25,6 +25,8 @@
 // Not Winograd: the products are those of the direct convolution, so the result is as close to float64 as an exact fp32 FMA chain
 // (tests/test_gpu_thin_x6.py).  GSSD_THIN_X6=0 keeps the round-5 kernels (ablation / A-B).
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,10 +36,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
-#ifndef TX6_TEAMS
-#define TX6_TEAMS 1           // 1 (shipped): two independent 256-thread workgroups per CU.  2 (measured, rejected): one 512-thread workgroup per CU = two four-wave
-#endif                        // TEAMS, each with its own tile and plane buffer, forced into opposite phases by a workgroup-wide barrier per phase: 485 / 235 / 364 us
-                              // against 462 / 216 / 327 (random data, B = 32) -- a phase lasts as long as its longer half (M: 3.3 x S) and the staging team idles
 #ifndef TX6_FENCE
 #define TX6_FENCE 1
 #endif
@@ -64,8 +62,7 @@ namespace {
 __device__ __attribute__((aligned(16))) float g_zero_thin_x6[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPATCH = PH * PW;      // 180 patch pixels
-constexpr int NT_ = 256;                  // threads per team (four waves)
-constexpr int TEAMS = TX6_TEAMS;
+constexpr int NT_ = 256;                  // threads per workgroup (four waves)
 constexpr int NPAD = 192;                 // patch pixels incl. the padding of the staging passes
 constexpr int NPL = 3;
 // input channels staged per workgroup: the whole pixel vector of conv1_2, two groups of conv2_1, one group of conv2_2
@@ -90,6 +87,7 @@ struct ThinX6Params {
     const float* in_pad;     // per input channel: a value the producer transform maps to 0 (out-of-image patch pixels LOAD it: address select)
     const float* pool_sign;  // GSSD_CONV_POOL2: `out` is the pooled raw map, max where pool_sign[c] >= 0 else min
     int B, H, W, tiles_y, tiles_x;
+    int* ctr;                // [slabs][8 XCDs] tile counters, zero before the launch (NULL: static tile shares)
 };
 
 // the split of TWO values at once, planes as packed bf16 pairs (a in the low half): conv_x6.hip::split3_pair
@@ -102,7 +100,7 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
 }
 
 template <int CIN_G, int COUT_G, bool XF, bool POOL>
-__global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(const ThinX6Params p) {
+__global__ __launch_bounds__(NT_, 2) void conv_thin_x6_kernel(const ThinX6Params p) {
     constexpr int CIN = 4 * CIN_G, COUT = 4 * COUT_G;
     constexpr int CW = slab_channels(CIN_G, COUT_G);
     constexpr int UPS = CW / 8;                    // 16-byte units (8 bf16) per staged pixel: 8 / 4
@@ -117,21 +115,18 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
     constexpr int RS = 4 / UNITS;                  // row splits: 1 / 1 / 2
     constexpr int RW = TH / RS;                    // output rows per wave: 8 / 8 / 4
     constexpr int KR = (3 * CIN_G + 31) / 32;      // 32-k steps per input row: 2 / 3
-    extern __shared__ __attribute__((aligned(16))) u16 smem_all[];        // per team [3][NPAD][CW] planes, then per team the scale / shift table [2][CW] floats
-    const int lane = threadIdx.x & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int team = TEAMS == 1 ? 0 : wave_all >> 2;                     // (a workgroup's waves go to the SIMDs cyclically: waves w and w + 4 share one)
-    const int wave = wave_all & 3, tid = threadIdx.x & (NT_ - 1);
-    u16* const planes = smem_all + team * (NPL * PLANE);
-    float* const xtab = reinterpret_cast<float*>(smem_all + TEAMS * NPL * PLANE) + team * (2 * CW);
+    extern __shared__ __attribute__((aligned(16))) u16 planes[];          // [3][NPAD][CW], then the scale / shift table [2][CW] floats, then two ints
+    float* const xtab = reinterpret_cast<float*>(planes + NPL * PLANE);
+    int* const s_next = reinterpret_cast<int*>(xtab + 2 * CW);            // [2]: tiles claimed by thread 0 for the workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
     const int unit = wave % UNITS, rs = wave / UNITS;
     const int gi = unit % NG, ch = unit / NG;
     // XCD-aware persistent order (conv_thin.hip): each XCD works on gridDim / 8 consecutive slots of every sweep
     const int bperm = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int vwg = bperm * TEAMS + team;                 // a team is what a workgroup was: it owns a slab and a tile sequence
-    const int gpi = NGI == 1 ? 0 : vwg % NGI;             // channel slab of this team (fixed: its weights never change)
-    const int wg0 = vwg / NGI, nwg = (int)gridDim.x * TEAMS / NGI;
+    const int gpi = NGI == 1 ? 0 : bperm % NGI;           // channel slab of this workgroup (fixed: its weights never change)
+    const int wg0 = bperm / NGI, nwg = (int)gridDim.x / NGI;
     const int g = gpi * NG + gi;                          // conv group of this wave
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const int ntiles = p.B * tiles_per_img;
@@ -195,7 +190,9 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
         s_py[it] = pp / PW;
         s_px[it] = pp - s_py[it] * PW;
     }
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    // batch sums: fp32 inside a tile (a fixed set of values in a fixed order), fp64 across tiles -- which tiles a workgroup gets is decided at run time,
+    // and a sum of fp32 tile sums in fp64 does not depend on their order at fp32 resolution (the same argument as the fp64 atomics at the end)
+    double sd[4] = {0.0, 0.0, 0.0, 0.0}, qd[4] = {0.0, 0.0, 0.0, 0.0};
 
     f32x4 pre[NIT][2];
     // out-of-image patch pixels load the padding vector instead (zeros, or -- fused producer transform -- the value the transform maps to 0:
@@ -234,28 +231,41 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
         }
     };
 
-    if (wg0 < ntiles) issue_loads(wg0);
-    __syncthreads();                                     // the scale / shift table
+    // Tiles are CLAIMED, not dealt out: `ctr[slab]` (zeroed by the launcher in front of the launch) hands the slab's tiles to whichever workgroup
+    // asks next.  A persistent grid with a static share per workgroup assumes that all of it is resident at once -- two workgroups of this kernel
+    // fill a CU's register file, so on a CU that is busy with another stream's kernel they start only when that kernel ends, and then still run
+    // their whole share: inside the step's hipGraph conv1_2 ran 950 us against 370 us alone, behind the 48 workgroups of the spectral-norm launch
+    // on the side stream (profiles/r06_thin_x6_notes.txt).  Thread 0 claims two tiles ahead; everyone reads the claim behind the barrier that
+    // ends a tile.  p.ctr == NULL (no counter pool yet under a stream capture): the static share.
+    // One counter per (slab, XCD): XCD x (= workgroup id & 7, the dispatch order) claims inside its own eighth of the tile list, so neighbouring
+    // tiles -- which share their halo rows / columns -- still meet in one L2 (a single global counter: conv2_2 244 -> 316 us); the other stream's
+    // workgroups spread over the XCDs evenly, so the eighths end together.
+    const bool xsplit = (gridDim.x & 7) == 0;
+    const int xcd = xsplit ? (int)(blockIdx.x & 7) : 0;
+    const int per = xsplit ? (ntiles + 7) >> 3 : ntiles;
+    const int t_lo = xcd * per, t_hi = min(ntiles, t_lo + per);
+    int* const ctr = p.ctr ? p.ctr + gpi * 8 + xcd : nullptr;
+    auto claim = [&](int stat) -> int {
+        if (!ctr) return stat;
+        const int t = t_lo + atomicAdd(ctr, 1);
+        return t < t_hi ? t : ntiles;
+    };
+    if (tid == 0) {                                      // the first two tiles
+        s_next[0] = claim(wg0);
+        s_next[1] = claim(wg0 + nwg);
+    }
+    __syncthreads();                                     // the scale / shift table, the first tiles
+    int tile = __builtin_amdgcn_readfirstlane(s_next[0]), next = __builtin_amdgcn_readfirstlane(s_next[1]);
+    if (tile < ntiles) issue_loads(tile);
 #ifdef TX6_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
-    // Phases.  A team (TX6_TEAMS=1: the workgroup) alternates S (transform + split + plane writes of its prefetched patch) and M (fragment reads +
-    // MFMAs + epilogue of that tile, with the next tile's loads in flight); a barrier ends every phase.  With TX6_TEAMS=2 team 1 runs ONE PHASE BEHIND
-    // team 0, so that on every SIMD one wave is in its vector-ALU-only phase while the other issues MFMAs (two vector instructions per MFMA of the
-    // OTHER wave are free in isolation, scripts/ubench/mfma_valu_two_waves.hip) -- measured slower than two free-running workgroups, see TX6_TEAMS.
-    const int n_mine = wg0 < ntiles ? (ntiles - wg0 + nwg - 1) / nwg : 0;
-    int n_max = n_mine;
-    if (TEAMS == 2) {
-        const int o0 = (bperm * TEAMS + (team ^ 1)) / NGI;
-        const int n_other = o0 < ntiles ? (ntiles - o0 + nwg - 1) / nwg : 0;
-        n_max = n_other > n_max ? n_other : n_max;
-    }
-    const int nph = 2 * n_max + (TEAMS - 1);
-    for (int ph = 0; ph < nph; ++ph) {
-        const int sph = ph - team;
-        const bool active = sph >= 0 && sph < 2 * n_mine;
-        const int tile = wg0 + (sph >> 1) * nwg;
-        if (active && !(sph & 1)) {
+    while (tile < ntiles) {
+        // the tile after next is claimed a whole tile period ahead: the atomic's round trip (every workgroup of an XCD asks one address) is
+        // never waited for -- claimed at the top of S and stored for everyone at the bottom of M
+        int claimed = ntiles;
+        if (tid == 0 && next < ntiles) claimed = claim(next + nwg);
+        {
         // ---- transform + split + plane writes of the prefetched patch ------------------------------------------------------------------
 #ifdef TX6_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -290,16 +300,18 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
         }
         TSTAMP(1)                                         // transform + split + plane writes
         }
-        if (active && (sph & 1)) {
+        __syncthreads();                                  // the planes are complete
+        {
         const int b = tile / tiles_per_img;
         const int trem = tile - b * tiles_per_img;
         const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
         const int y0 = tyi * TH, x0 = txi * TW;
-        if ((sph >> 1) + 1 < n_mine) issue_loads(tile + nwg);       // the next tile's patch: in flight under this tile's MFMAs
+        if (next < ntiles) issue_loads(next);             // the next tile's patch: in flight under this tile's MFMAs
 
         // ---- input-row-major K loop: patch row rho feeds output rows rho, rho - 1, rho - 2 (dy = 0, 1, 2) -------------------------------
         const int x = x0 + r;
         const int row0 = rs * RW;                       // first output row of this wave inside the tile
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[4];
 #pragma unroll
         for (int rho = 0; rho < RW + 2; ++rho) {
@@ -415,21 +427,38 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sd[c] += (double)ssum[c];
+            qd[c] += (double)ssq[c];
+        }
         TSTAMP(3)                                         // fragment reads + MFMAs + epilogues
         }
-        __syncthreads();          // S: the planes are complete;  M: every wave is done reading them
+        if (tid == 0) s_next[0] = claimed;
+        __syncthreads();          // every wave is done reading the planes; the tile after next is known
         TSTAMP(4)
+        tile = next;
+        next = __builtin_amdgcn_readfirstlane(s_next[0]);
     }
 #ifdef TX6_TIMING
-    if (lane == 0 && wave_all == 1)
+    if (lane == 0 && wave == 1)
         for (int k = 0; k < 5; ++k) atomicAdd(&g_tx6_timing[k], tacc[k]);
-    if (threadIdx.x == 0) atomicAdd(&g_tx6_timing[7], 1ull);
+    if (tid == 0) atomicAdd(&g_tx6_timing[7], 1ull);
 #endif
 
+    if (p.ctr && tid == 0) {
+        // the last workgroup to finish leaves the counters at zero for the slot's next launch (no memset node in front of every launch: a
+        // 6 us node on the step's critical path, three times per step)
+        __threadfence();
+        if (atomicAdd(p.ctr + 32, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i <= 32; ++i) p.ctr[i] = 0;
+            __threadfence();
+        }
+    }
     if (p.stats) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            double s = (double)ssum[c], q = (double)ssq[c];
+            double s = sd[c], q = qd[c];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
                 s += __shfl_xor(s, o, 64);
@@ -442,6 +471,37 @@ __global__ __launch_bounds__(NT_ * TEAMS, 2 / TEAMS) void conv_thin_x6_kernel(co
             }
         }
     }
+}
+
+// Tile counters: per device a pool of 1024 slots of 64 ints (32 tile counters + the count of finished workgroups), created and zeroed by the first
+// launch outside a stream capture; a launch takes the next slot, and its last workgroup leaves the slot zeroed for the next user (a replayed graph
+// always finds its own slot at zero).  GSSD_TX6_DYNAMIC=0, or no pool yet while capturing: NULL = static tile shares.
+int* tx6_counters(hipStream_t stream) {
+    static const bool off = [] { const char* e = getenv("GSSD_TX6_DYNAMIC"); return e && e[0] == '0'; }();
+    if (off) return nullptr;
+    constexpr int SLOTS = 1024;
+    static int* pool[32] = {};
+    static std::atomic<unsigned> next[32];
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return nullptr;
+    if (!pool[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!pool[dev]) {
+            int* q = nullptr;
+            if (hipMalloc(&q, SLOTS * 64 * sizeof(int)) != hipSuccess || hipMemset(q, 0, SLOTS * 64 * sizeof(int)) != hipSuccess ||
+                hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            pool[dev] = q;
+        }
+    }
+    return pool[dev] + 64 * (next[dev].fetch_add(1) % SLOTS);
 }
 
 template <int CIN_G, int COUT_G, bool XF, bool POOL>
@@ -463,7 +523,7 @@ int launch_thin_x6(const gssd_conv_desc& d, hipStream_t stream) {
     p.tiles_y = (d.H + TH - 1) / TH;
     p.tiles_x = (d.W + TW - 1) / TW;
     constexpr int CW = slab_channels(CIN_G, COUT_G);
-    constexpr size_t smem = TEAMS * ((size_t)NPL * NPAD * CW * sizeof(u16) + 2 * CW * sizeof(float));
+    constexpr size_t smem = (size_t)NPL * NPAD * CW * sizeof(u16) + 2 * CW * sizeof(float) + 16;
     auto kern = conv_thin_x6_kernel<CIN_G, COUT_G, XF, POOL>;
     static unsigned attr_mask = 0;     // one bit per device (the attribute is per device)
     if (gssd_attr_needed(&attr_mask)) {
@@ -475,13 +535,11 @@ int launch_thin_x6(const gssd_conv_desc& d, hipStream_t stream) {
     gssd_attr_done(&attr_mask);
     constexpr int NGI = 4 / (CW / CIN_G);
     const long long ntiles = (long long)d.B * p.tiles_y * p.tiles_x;
-    long long grid = 512 / TEAMS;                         // per CU: one workgroup of two teams (or two one-team workgroups)
-#ifdef TX6_TIMING
-    if (getenv("GSSD_TX6_GRID")) grid = atoi(getenv("GSSD_TX6_GRID"));      // (timing build only: one workgroup per CU = the phases' uncontended durations)
-#endif
-    if ((ntiles * NGI + TEAMS - 1) / TEAMS < grid) grid = (ntiles * NGI + TEAMS - 1) / TEAMS;
-    if (NGI > 1 && TEAMS == 1 && grid % NGI) grid += NGI - grid % NGI;      // every slab needs its workgroups
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT_ * TEAMS), smem, stream, p);
+    long long grid = 512;                                 // two workgroups per CU
+    if (ntiles * NGI < grid) grid = ntiles * NGI;
+    if (NGI > 1 && grid % NGI) grid += NGI - grid % NGI;  // every slab needs its workgroups
+    p.ctr = tx6_counters(stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT_), smem, stream, p);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }

@@ -59,10 +59,23 @@ class PlanExecMixin:
     def _run_graphs(self, x, events, only):
         key = tuple(sorted(only)) if only else None
         cache = self.__dict__.setdefault('_graphs', {})
-        if key not in cache:
-            cache[key] = self._capture(x, only)
-        segs = cache[key]
-        self._gx.copy_(x)
+        # Zero-copy input (round 6): a caller that hands over the SAME device buffer step after step (a training loop's pinned staging buffer, the
+        # benchmark's resident batch) gets a graph whose first node reads that buffer in place -- the 138 MB x -> static-buffer copy in front of
+        # every replay was 50 us of an 8.3 ms step.  A pointer seen twice in a row is captured (at most two such graphs per plan); any other
+        # input takes the generic graph over the plan's static input buffer.
+        ptr = x.data_ptr()
+        dkey = ('direct', ptr, key)
+        if dkey not in cache and self.__dict__.get('_last_in_ptr') == ptr and sum(1 for k in cache if isinstance(k, tuple) and k[:1] == ('direct',)) < 2:
+            cache[dkey] = self._capture(x, only, in_ptr=ptr)
+        self.__dict__['_last_in_ptr'] = ptr
+        if dkey in cache:
+            segs = cache[dkey]
+            self._x_keepalive = x
+        else:
+            if key not in cache:
+                cache[key] = self._capture(x, only)
+            segs = cache[key]
+            self._gx.copy_(x)
         stream = torch.cuda.current_stream().cuda_stream
         for kind, obj in segs:
             if kind == 'graph':
@@ -81,15 +94,16 @@ class PlanExecMixin:
             pool[sid] = torch.cuda.Stream(device=self.dev)
         return pool[sid]
 
-    def _capture(self, x, only):
-        """Capture the plan as hipGraph segments over static input / output buffers; the steps named in ``only`` stay eager."""
+    def _capture(self, x, only, in_ptr=None):
+        """Capture the plan as hipGraph segments over static input / output buffers; the steps named in ``only`` stay eager.  ``in_ptr``: the graph
+        reads the input at this address instead of the plan's static input buffer (zero-copy replay, _run_graphs)."""
         B, dev = self.B, self.dev
         if getattr(self, '_gx', None) is None:
             self._gx = torch.empty_like(x)
             self._gloc = torch.zeros(B, self.P, 4, device=dev, dtype=torch.float32)
             self._gconf = torch.zeros(B, self.P, self.nc, device=dev, dtype=torch.float32)
         self._set_outputs(self._gloc, self._gconf)
-        self.steps[self._pack_step].args[0] = self._gx.data_ptr()
+        self.steps[self._pack_step].args[0] = in_ptr if in_ptr is not None else self._gx.data_ptr()
         groups, cur = [], []
         for st in self.steps:
             if only and st.tag is not None and st.tag[0] in only:

@@ -571,7 +571,8 @@ def test_graph_replay_equals_eager(dev, name):
         for it in range(5):
             outs.append(net(x))
     plan = net._engine._last_plan
-    assert plan._runs == 5 and len(plan._graphs) == 1                 # runs 3..5 were graph replays
+    # runs 3..5 were graph replays: run 3 over the plan's static input buffer, runs 4-5 (the same input buffer again) zero-copy
+    assert plan._runs == 5 and sorted(str(k[0]) if isinstance(k, tuple) and k else 'generic' for k in plan._graphs) == ['direct', 'generic']
     # the twin runs the same five training forwards eagerly
     import gssd.plan_common as E          # (plan_exec.run reads the switch through this module)
     E.USE_GRAPH = False
@@ -586,6 +587,14 @@ def test_graph_replay_equals_eager(dev, name):
         assert rel(a[0], b[0]) < 1e-6 and rel(a[1], b[1]) < 1e-6
     for (k, va), (_, vb) in zip(net.state_dict().items(), twin.state_dict().items()):
         assert torch.equal(va, vb), k
+    # the zero-copy graph reads the caller's buffer IN PLACE (new contents at the old address are seen), another buffer takes the generic graph
+    with torch.no_grad():
+        x.mul_(0.5)
+        o_a, r_a = net(x), twin(x)
+        x2 = (x * 1.7).clone()
+        o_b, r_b = net(x2), twin(x2)
+    assert rel(o_a[0], r_a[0]) < 1e-6 and rel(o_a[1], r_a[1]) < 1e-6 and rel(o_b[0], r_b[0]) < 1e-6 and rel(o_b[1], r_b[1]) < 1e-6
+    assert float((o_a[0] - o_b[0]).abs().max()) > 0
     if name == 'gssdpp':
         class EL(list):
             only = {'dcn_x6<128x256>', 'dcn_fused<128x256>'}
@@ -596,7 +605,7 @@ def test_graph_replay_equals_eager(dev, name):
             r6 = twin(x)
         net.__dict__['_events'] = None
         torch.cuda.synchronize()
-        assert len(ev) == 1 and ev[0][1].elapsed_time(ev[0][2]) > 0 and len(plan._graphs) == 2
+        assert len(ev) == 1 and ev[0][1].elapsed_time(ev[0][2]) > 0 and len(plan._graphs) == 3
         assert rel(o6[0], r6[0]) < 1e-6 and rel(o6[1], r6[1]) < 1e-6
 
 
