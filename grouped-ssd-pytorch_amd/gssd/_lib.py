@@ -53,7 +53,7 @@ class SnItem(C.Structure):
 
 
 OUT_NHWC, OUT_TRANSPOSED, OUT_HEADS, OUT_SPLIT_T = 0, 1, 2, 3
-CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES, CONV_POOL2, CONV_RESID_F32 = 1, 2, 4, 8, 16
+CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES, CONV_POOL2, CONV_RESID_F32, CONV_F16_OK = 1, 2, 4, 8, 16, 32
 
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {

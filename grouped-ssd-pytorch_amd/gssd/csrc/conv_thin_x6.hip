@@ -612,7 +612,7 @@ static bool thin_x6_shape(const gssd_conv_desc& d) {
     return d.groups == 4 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.in_stride == 4 * d.cin_g && d.in_ch_off == 0 &&
            d.out_mode == GSSD_OUT_NHWC && d.out_stride == d.Cout && d.out_ch_off == 0 && !d.m_per_image && !d.relu && !d.gate && !d.resid && !d.alpha &&
            !d.out2 && d.split_k <= 1 && d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && ((uintptr_t)d.out % 16) == 0 &&
-           ((uintptr_t)d.in % 16) == 0 && ((uintptr_t)d.wgt % 16) == 0 && (d.flags == 0 || (d.flags == GSSD_CONV_POOL2 && d.pool_sign)) &&
+           ((uintptr_t)d.in % 16) == 0 && ((uintptr_t)d.wgt % 16) == 0 && ((d.flags & ~GSSD_CONV_F16_OK) == 0 || ((d.flags & ~GSSD_CONV_F16_OK) == GSSD_CONV_POOL2 && d.pool_sign)) &&
            (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31) &&
            ((d.cin_g == 16 && (cout_g == 16 || cout_g == 32)) || (d.cin_g == 32 && cout_g == 32));
 }

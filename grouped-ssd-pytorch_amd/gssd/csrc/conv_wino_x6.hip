@@ -29,6 +29,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 #ifndef WX6_KO
@@ -70,6 +72,17 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
     pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
 }
 
+// The two-plane fp16 form (round 6, conv_thin_x6.hip): x = h + l' / 2048, h = fp16(x), l' = fp16((x - h) * 2048) -- |x - h - l' / 2048| <= 2^-24 |x| --
+// and three v_mfma_f32_16x16x32_f16 per product (h h'; h l' + l' h' into a sum that enters with 1 / 2048).  For launches whose input is a BatchNorm +
+// ReLU output (the fused producer transform: the trunk's forward convs) or that the caller marks GSSD_CONV_F16_OK (bounded activations: the DCN
+// offset conv); data gradients keep the bf16 planes (fp16 has no exponent range for them).  GSSD_X6_F16=0: bf16 planes everywhere.
+__device__ __forceinline__ void split2_pair(const float a, const float b, unsigned& ph, unsigned& pl) {
+    const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+    const f32x2 r = (f32x2{a, b} - __builtin_convertvector(h, f32x2)) * 2048.f;
+    ph = __builtin_bit_cast(unsigned, h);
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 struct WinoX6Params {
     const float* in;
     const u16* Ux;           // [groups][cout blocks][chunks][16 xi][3 planes][NB co][32 slots], slot groups swizzled (swz)
@@ -95,10 +108,11 @@ struct Step {                // a step = one 32-channel chunk of one item + the 
 };
 
 // PSEL: out-of-image patch positions are replaced by the padding value with a select (else: the loads already fetched it, WinoX6Params::pad_off)
-template <int NBT, bool XF, int EPI, bool PSEL>      // NB = 16 NBT output channels per workgroup; EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
+template <int NBT, bool XF, int EPI, bool PSEL, bool F16>      // NB = 16 NBT output channels per workgroup; EPI: 0 plain, 1 + residual, 2 pooled raw map (GSSD_CONV_POOL2)
 __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params p) {
-    constexpr int NB = 16 * NBT, TILE = NB * 32, STAGE = XG * NP * TILE, CHUNK = 16 * NP * TILE;
-    constexpr int PWAVE = XG * NP * 512;                             // u16 elements of one tile group's planes of a block: [xi][plane][lane][8]
+    constexpr int NPX = F16 ? 2 : 3;                                 // operand planes of this instance
+    constexpr int NB = 16 * NBT, TILE = NB * 32, STAGE = XG * NPX * TILE, CHUNK = 16 * NPX * TILE;
+    constexpr int PWAVE = XG * NPX * 512;                             // u16 elements of one tile group's planes of a block: [xi][plane][lane][8]
     extern __shared__ __attribute__((aligned(16))) u16 smem[];      // U [2][STAGE] | P [4 tile groups][PWAVE]
     u16* const Pl = smem + 2 * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
     };
     // Winograd row: t = ra + sg * rb, V = t B, three-plane split -> the operand planes of its four xi: quarter q
     // planes of a block as operand dwords: P[xi][plane] = 4 dwords = the lane's 8 k slots (dword 2 * half + e / 2 holds channels e, e + 1)
-    auto make_planes_q = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NP], const int q) {
+    auto make_planes_q = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NPX], const int q) {
         if (WX6_KO & 1) return;
         const int hf = q >> 1, e = 2 * (q & 1);
         float t0[4], t1[4];
@@ -234,26 +248,33 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         const float v1[4] = {t1[0] - t1[2], t1[1] + t1[2], t1[2] - t1[1], t1[1] - t1[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned ph, pm, pl;
-            split3_pair(v0[j], v1[j], ph, pm, pl);
-            P[j][0][2 * hf + (q & 1)] = ph;
-            P[j][1][2 * hf + (q & 1)] = pm;
-            P[j][2][2 * hf + (q & 1)] = pl;
+            if constexpr (F16) {
+                unsigned ph, pl;
+                split2_pair(v0[j], v1[j], ph, pl);
+                P[j][0][2 * hf + (q & 1)] = ph;
+                P[j][1][2 * hf + (q & 1)] = pl;
+            } else {
+                unsigned ph, pm, pl;
+                split3_pair(v0[j], v1[j], ph, pm, pl);
+                P[j][0][2 * hf + (q & 1)] = ph;
+                P[j][1][2 * hf + (q & 1)] = pm;
+                P[j][NPX - 1][2 * hf + (q & 1)] = pl;
+            }
         }
     };
-    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NP]) {
+    auto make_planes = [&](const Row& ra, const Row& rb, const float sg, u32x4 (&P)[4][NPX]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) make_planes_q(ra, rb, sg, P, q);
     };
         u16* const Pw = Pl + wv * PWAVE + lane * 8;
-        auto put_planes = [&](const u32x4 (&P)[4][NP]) {
+        auto put_planes = [&](const u32x4 (&P)[4][NPX]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(Pw + (j * NP + q) * 512) = P[j][q];
+                for (int q = 0; q < NPX; ++q) *reinterpret_cast<u32x4*>(Pw + (j * NPX + q) * 512) = P[j][q];
         };
         // barrier B of the block that is running (its planes are in the consumers' registers), the next block's planes -> LDS, barrier A of the next
-        auto hand_over = [&](const u32x4 (&P)[4][NP]) {
+        auto hand_over = [&](const u32x4 (&P)[4][NPX]) {
             __builtin_amdgcn_s_barrier();                 // B
             put_planes(P);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         Step nxt = cur;
         advance(nxt);
         Row d0, d1, d2, d3, e2;                       // e2: the next step's row 2 (row 2 is the last to die)
-        u32x4 P[4][NP];
+        u32x4 P[4][NPX];
         XfTab xc, xn;
         load_xf(xc, cur);
         load_xf(xn, nxt);
@@ -324,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         for (int nb = 0; nb < NBT; ++nb) ssum[nb] = ssq[nb] = zero4;
         const bool vec = ((p.out_stride | p.out_ch_off | p.cout_g) & 3) == 0 && p.vec_ok;
         const int fo = r * 32 + ((kq ^ swz(r)) << 3);          // fragment offset inside a 16-row block of a tile
-        // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NP * TILE / 512 pieces of 1 KB, consumer wave w moves pieces w, w + 4, ..
+        // U planes of (chunk c, Winograd row i) -> LDS slot: XG * NPX * TILE / 512 pieces of 1 KB, consumer wave w moves pieces w, w + 4, ..
         auto stage_U_part = [&](const int c, const int i, const int slot, const int part) {      // part of NBT (-1: all)
             if (WX6_KO & 4) return;
             const u16* src = Ug + (size_t)c * CHUNK + i * STAGE;
@@ -442,31 +463,31 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
         auto run_row = [&](const int I, const int slot, const int c_next, const int i_next) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the block's U planes have landed
             __builtin_amdgcn_s_barrier();                 // A: everyone's have, the producers' planes are in LDS
-            bf16x8 Pc[4][NP];
+            bf16x8 Pc[4][NPX];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) Pc[j][q] = *reinterpret_cast<const bf16x8*>(Pr + (j * NP + q) * 512);
+                for (int q = 0; q < NPX; ++q) Pc[j][q] = *reinterpret_cast<const bf16x8*>(Pr + (j * NPX + q) * 512);
             const u16* ub = smem + slot * STAGE + fo;
             // the 12 weight fragments of output tile nb + 1 are requested before the 24 MFMAs of tile nb (an LDS read issued right in front of
             // its MFMA costs the wave the LDS latency: 64 such waits per step were ~10 k of the consumer's 23 k cycles); the next block's DMA pieces
             // go out a few per tile
-            bf16x8 u[2][XG][NP];
-            auto frags = [&](const int nb, bf16x8 (&dst)[XG][NP]) {
+            bf16x8 u[2][XG][NPX];
+            auto frags = [&](const int nb, bf16x8 (&dst)[XG][NPX]) {
 #pragma unroll
                 for (int xl = 0; xl < XG; ++xl)
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) {
+                    for (int q = 0; q < NPX; ++q) {
                         if (WX6_KO & 16) asm volatile("" : "=v"(dst[xl][q]));
-                        else dst[xl][q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NP + q) * TILE + nb * 16 * 32);
+                        else dst[xl][q] = *reinterpret_cast<const bf16x8*>(ub + (xl * NPX + q) * TILE + nb * 16 * 32);
                     }
             };
             // the first tile's weight fragments are requested behind the planes' reads (the block's U planes are in LDS since barrier A): LDS
-            // returns in order, so the planes are in registers when at most these XG * NP reads are outstanding -- barrier B does not wait
+            // returns in order, so the planes are in registers when at most these XG * NPX reads are outstanding -- barrier B does not wait
             // for them, and their round trip runs beside it instead of behind it
             frags(0, u[0]);
             if (WX6_KO & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XG * NP) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XG * NPX) : "memory");
             __builtin_amdgcn_s_barrier();                 // B: the plane buffer is free for the next block
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
@@ -475,13 +496,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
                 f32x4 m[XG];
 #pragma unroll
                 for (int xl = 0; xl < XG; ++xl) {
-                    const bf16x8 (&uc)[NP] = u[nb & 1][xl];
+                    const bf16x8 (&uc)[NPX] = u[nb & 1][xl];
                     // six products, smallest first (uc: weight planes, Pc: activation planes), summed from zero
                     f32x4 s6 = zero4;
-                    if (!(WX6_KO & 2)) {
+                    if constexpr (F16) {
+                        // h h' from zero; h l' + l' h' from zero, entering with 1 / 2048
+                        f32x4 sx = zero4;
+                        if (!(WX6_KO & 2)) {
+                            sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, uc[1]), __builtin_bit_cast(f16x8, Pc[xl][0]), sx, 0, 0, 0);
+                            sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, uc[0]), __builtin_bit_cast(f16x8, Pc[xl][1]), sx, 0, 0, 0);
+                            s6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, uc[0]), __builtin_bit_cast(f16x8, Pc[xl][0]), s6, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s6[e] = __builtin_fmaf(sx[e], 1.f / 2048.f, s6[e]);
+                    } else if (!(WX6_KO & 2)) {
                         s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][1], s6, 0, 0, 0);
-                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[2], Pc[xl][0], s6, 0, 0, 0);
-                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][2], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[NPX - 1], Pc[xl][0], s6, 0, 0, 0);
+                        s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][NPX - 1], s6, 0, 0, 0);
                         s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[1], Pc[xl][0], s6, 0, 0, 0);
                         s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][1], s6, 0, 0, 0);
                         s6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uc[0], Pc[xl][0], s6, 0, 0, 0);
@@ -616,6 +647,8 @@ __global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restri
     const int c = ci / 32, wi = ci % 32;
     const int sub = wi >> 4, kq = (wi & 15) >> 2, e = wi & 3;
     const size_t base = ((size_t)(g * ncb + cb) * nchunks + c) * CHUNK + row * 32 + ((kq ^ swz(row & 15)) << 3) + 4 * sub + e;
+    const size_t f16_base = (size_t)groups * ncb * nchunks * CHUNK;          // behind the bf16 planes
+    const size_t base16 = ((size_t)(g * ncb + cb) * nchunks + c) * (16 * 2 * TILE) + row * 32 + ((kq ^ swz(row & 15)) << 3) + 4 * sub + e;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {                         // (G g) G^T
         const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
@@ -627,13 +660,19 @@ __global__ void wino_x6_weight_kernel(const float* __restrict__ w, u16* __restri
             dst[0 * TILE] = __builtin_bit_cast(u16, h);
             dst[1 * TILE] = __builtin_bit_cast(u16, m);
             dst[2 * TILE] = __builtin_bit_cast(u16, l);
+            // the two fp16 planes of the same U (h, (u - h) * 2048), behind all bf16 planes, chunks of 16 x 2 x TILE
+            const _Float16 fh = (_Float16)u[b];
+            const _Float16 fl = (_Float16)((u[b] - (float)fh) * 2048.f);
+            u16* d16 = Ux + f16_base + base16 + (size_t)(a * 4 + b) * 2 * TILE;
+            d16[0 * TILE] = __builtin_bit_cast(u16, fh);
+            d16[1 * TILE] = __builtin_bit_cast(u16, fl);
         }
     }
 }
 
-template <int NBT, bool XF, int EPI, bool PSEL>
-int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
-    constexpr int NB = 16 * NBT;
+template <int NBT, bool XF, int EPI, bool PSEL, bool F16>
+int launch_wino_x6_impl(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
+    constexpr int NB = 16 * NBT, NPX = F16 ? 2 : 3;
     WinoX6Params p;
     p.in = d.in;
     p.Ux = Ux;
@@ -664,8 +703,8 @@ int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t strea
     p.npairs = p.ncb * d.groups;
     p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
     p.pad_off = PSEL ? 0u : wx6_pad_off(d);
-    constexpr size_t smem = (2 * (size_t)XG * NP * NB * 32 + 4 * (size_t)XG * NP * 512) * sizeof(u16);      // two U stages + the planes of a block
-    auto kern = conv_wino_x6_kernel<NBT, XF, EPI, PSEL>;
+    constexpr size_t smem = (2 * (size_t)XG * NPX * NB * 32 + 4 * (size_t)XG * NPX * 512) * sizeof(u16);      // two U stages + the planes of a block
+    auto kern = conv_wino_x6_kernel<NBT, XF, EPI, PSEL, F16>;
     static unsigned attr_mask = 0;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
@@ -684,6 +723,20 @@ int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t strea
     return GSSD_OK;
 }
 
+// the two-plane fp16 form: forward launches behind a fused BatchNorm + ReLU, or marked GSSD_CONV_F16_OK by the caller; never a data gradient (EPI 1)
+template <int NBT, bool XF, int EPI, bool PSEL>
+int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
+    static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
+    if constexpr (EPI != 1) {
+        if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) {
+            const int cout_g = d.Cout / d.groups;
+            const long long nb = cout_g > 32 ? 64 : 32, ncb = (cout_g + nb - 1) / nb, nchunks = (d.cin_g + 31) / 32;
+            return launch_wino_x6_impl<NBT, XF, EPI, PSEL, true>(d, Ux + (long long)d.groups * ncb * nchunks * 16 * NP * nb * 32, stream);
+        }
+    }
+    return launch_wino_x6_impl<NBT, XF, EPI, PSEL, false>(d, Ux, stream);
+}
+
 template <int NBT, bool XF, int EPI>
 int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
     if (XF && wx6_pad_off(d)) return launch_wino_x6_sel<NBT, XF, EPI, false>(d, Ux, stream);
@@ -696,7 +749,7 @@ int launch_wino_x6(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
 long long gssd_wino_x6_plane_elems(int cout_g, int groups, int cin_g) {
     if (cin_g % 16 != 0 || cout_g < 24) return 0;
     const long long NB = wx6_nb(cout_g), ncb = (cout_g + NB - 1) / NB, nchunks = (cin_g + 31) / 32;
-    return (long long)groups * ncb * nchunks * 16 * NP * NB * 32;
+    return (long long)groups * ncb * nchunks * 16 * (NP + 2) * NB * 32;      // three bf16 planes, then two fp16 planes
 }
 
 int gssd_wino_x6_pack(const float* w_packed, void* Ux, int Cout, int groups, int cin_g, int row_stride, hipStream_t stream) {

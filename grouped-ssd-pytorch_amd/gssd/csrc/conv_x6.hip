@@ -978,7 +978,7 @@ extern "C" int gssd_conv_x6_takes(const gssd_conv_desc* dp) {
     const gssd_conv_desc& d = *dp;
     if (!d.wgt_x6 || d.groups <= 0 || d.Cout % d.groups != 0) return 0;
     if (!shape_ok(d.cin_g, d.Cout / d.groups, d.groups)) return 0;
-    if (d.split_k > 1 || (d.flags & ~GSSD_CONV_OUT_F32) || (d.out2 && !d.gate)) return 0;
+    if (d.split_k > 1 || (d.flags & ~(GSSD_CONV_OUT_F32 | GSSD_CONV_F16_OK)) || (d.out2 && !d.gate)) return 0;
     if (d.out_mode == GSSD_OUT_SPLIT_T) {
         // merged Self_Attn projection: columns [0, split_n) NHWC, the rest transposed per image; whole tiles on either side
         const int bn = gssd_conv_x6_tile(d.Cout / d.groups, d.groups, (long long)d.B * d.Ho * d.Wo);

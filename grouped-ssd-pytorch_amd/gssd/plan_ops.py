@@ -366,7 +366,8 @@ class PlanOpsMixin:
                 return ops.winograd_weight(eng._packed[key], 1, cin, out)
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1, out_stride=OMC,
-                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om, flags=_lib.CONV_OUT_F32)
+                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om,
+                                      flags=_lib.CONV_OUT_F32 | (0 if self.bf16 else _lib.CONV_F16_OK))      # (fp32 mode: x is a bounded activation map)
         self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H
         esz = 2.0 if self.bf16 else 4.0

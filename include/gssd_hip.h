@@ -182,6 +182,10 @@ int gssd_conv_x6_takes(const gssd_conv_desc* d);
 /* bf16 entry point: `resid` is an fp32 map of the OUTPUT's geometry (with GSSD_CONV_OUT_F32: the backward of the bf16 storage mode
  * accumulates a data gradient computed on the bf16 matrix cores into an fp32 gradient map).  Default: `resid` has the input's type (bf16). */
 #define GSSD_CONV_RESID_F32 16
+/* fp32 mode: the launch's input is a bounded activation map (a BatchNorm + ReLU output, or maps built from such): the three-plane kernels may run
+ * their two-plane fp16 form (three MFMAs per product; x = h + l' / 2048 to 2^-24) -- csrc/conv_wino_x6.hip, csrc/conv_thin_x6.hip.  Never set on a
+ * data-gradient launch: fp16 has no exponent range for gradients.  Launches with a fused producer BatchNorm + ReLU take the form without it. */
+#define GSSD_CONV_F16_OK 32
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
 int gssd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int cin_g, int KH, int KW, int cin_g_pad, int Kpad,

@@ -2,7 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'grouped-ssd-pytorch_amd'))
 import torch
-from gssd import ops
+from gssd import ops, _lib
+FLAGS = _lib.CONV_F16_OK if os.environ.get('F16OK') else 0      # bounded activations: the two-plane fp16 form of csrc/conv_wino_x6.hip
 dev = torch.device('cuda:0')
 B, G = int(os.environ.get('B', 32)), int(os.environ.get('G', 4))
 shapes = [('conv1_2', 300, 16, 16), ('conv2_1', 150, 16, 32), ('conv2_2', 150, 32, 32), ('conv3_1', 75, 32, 64), ('conv3_2', 75, 64, 64),
@@ -26,7 +27,7 @@ for name, H, cin_g, cout_g in shapes:
         U = ops.winograd_weight(wp, G, cin_g) if wino else None
         out = torch.empty_like(y)
         d, _, _ = ops.make_conv_desc(x, wp, out, B=B, H=H, W=H, in_stride=G * cin_g, cin_g=cin_g, Cout=G * cout_g, groups=G, k=3,
-                                     pad=1, bias=bias, wgt_wino=U)
+                                     pad=1, bias=bias, wgt_wino=U, flags=FLAGS)
         for _ in range(3): ops.run_conv(d)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
