@@ -438,22 +438,28 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             ach_t, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
             wino = dom.startswith(('conv_wino', 'conv_thin_wino'))
             x6 = dom.startswith(("dcn_x6", "conv_x6", "conv_wino_x6", "conv_thin_x6", "flash_attn_x"))
+            # matrix instructions per fp32-equivalent product of the forward launches (round 6): three fp16 ones (v_mfma_f32_16x16x32_f16, same
+            # dense peak as bf16) over fp16 planes; six bf16 ones with GSSD_X6_F16=0 and in the attention core (whose fp16 form is opt-in)
+            f16_form = os.environ.get('GSSD_X6_F16', '1') != '0' and (not dom.startswith('flash_attn_x') or os.environ.get('GSSD_FLASH_X6_F16') == '1')
+            mm = 3 if f16_form else 6
+            form = ('fp16 planes, three v_mfma_f32_16x16x32_f16 per product' if f16_form else 'three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product')
             if dom.startswith('conv_wino_x6'):
-                # Winograd F(2x2,3x3) with three-plane operands: 2.25 x fewer products than the direct conv, six bf16 MFMAs each -- `achieved` /
-                # `frac` are the ISSUED bf16 FLOPs (direct-conv FLOPs x 6 / 2.25) against the bf16 matrix peak
-                iss = ach_t * 6 / 2.25
+                # Winograd F(2x2,3x3) with split operands: 2.25 x fewer products than the direct conv, `mm` MFMAs each -- `achieved` /
+                # `frac` are the ISSUED 16-bit FLOPs (direct-conv FLOPs x mm / 2.25) against the bf16 / fp16 matrix peak
+                iss = ach_t * mm / 2.25
                 roof = dict(bound='mfma', achieved=round(iss, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(iss / PEAK_BF16_TFLOPS, 4),
                             useful_frac=round(ach_t / PEAK_BF16_TFLOPS, 4), direct_conv_tflops=round(ach_t, 2), fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
-                note = 'Winograd F(2x2,3x3), operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product: achieved = ISSUED bf16 FLOPs'
+                roof['mfma_per_product'] = mm
+                note = f'Winograd F(2x2,3x3), fp32 operands as {form}: achieved = ISSUED 16-bit FLOPs'
             elif x6:
-                # three-plane kernels: fp32-equivalent products as six bf16 MFMAs over operands split into three bf16 planes -- `achieved` /
-                # `frac` are the ISSUED bf16 FLOPs (6 x algorithmic) against the bf16 matrix peak; the algorithmic rate has its own name
-                roof = dict(bound='mfma', achieved=round(6 * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                            frac=round(6 * ach_t / PEAK_BF16_TFLOPS, 4), useful_frac=round(ach_t / PEAK_BF16_TFLOPS, 4),
-                            fp32_equivalent_tflops=round(ach_t, 2),
+                # split-operand kernels: fp32-equivalent products as `mm` 16-bit MFMAs over operands split into planes -- `achieved` /
+                # `frac` are the ISSUED 16-bit FLOPs (mm x algorithmic) against the bf16 / fp16 matrix peak; the algorithmic rate has its own name
+                roof = dict(bound='mfma', achieved=round(mm * ach_t, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                            frac=round(mm * ach_t / PEAK_BF16_TFLOPS, 4), useful_frac=round(ach_t / PEAK_BF16_TFLOPS, 4),
+                            mfma_per_product=mm, fp32_equivalent_tflops=round(ach_t, 2),
                             fp32_equivalent_over_fp32_mfma_peak=round(ach_t / PEAK_F32_TFLOPS, 4))
-                note = ('fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate: achieved / frac = ISSUED bf16 FLOPs '
-                        '(pipe occupancy); useful_frac = algorithmic FLOPs / bf16 peak')
+                note = (f'fp32 operands as {form}, fp32 accumulate: achieved / frac = ISSUED 16-bit FLOPs '
+                        '(pipe occupancy); useful_frac = algorithmic FLOPs / that peak')
             elif ach_b / PEAK_HBM_GBS > ach_t / peak_t:
                 roof = dict(bound='hbm', achieved=round(ach_b, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_b / PEAK_HBM_GBS, 4))
                 note = 'algorithmic bytes (in + out + weights) / launch time'
@@ -502,7 +508,9 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
                workload=WORKLOAD[cfg] + (', bf16 storage / bf16 MFMA / fp32 accumulate + BN statistics + loss' if dtype == 'bf16' else ''),
                alg_gflop_per_img=gflop_img, alg_mb_per_img=mb_img,
                whole_path=dict(tflops=round(value * gflop_img / 1e3, 2),
-                               frac_mfma_peak=round(value * gflop_img / 1e3 / (peak_t * world), 4),
+                               frac_mfma_peak=round(value * gflop_img / 1e3 / (peak_t * world), 4),        # fp32 mode: against the fp32 matrix peak (157 TFLOP/s) --
+                               # above 1 since round 6: most of its products run as three fp16 matrix instructions, a pipe 16 x wider
+                               frac_16bit_mfma_peak=round(value * gflop_img / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                                alg_gbs=round(value * mb_img / 1e3, 1),
                                frac_hbm_peak=round(value * mb_img / 1e3 / (PEAK_HBM_GBS * world), 4)),
                host_enqueue_ms_per_step=host_per_rank,

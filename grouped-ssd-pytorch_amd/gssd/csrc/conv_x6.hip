@@ -71,6 +71,20 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
     pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
 }
 
+// Round 6, the three-MFMA form for FORWARD launches on bounded activations (a fused producer BatchNorm + ReLU, or GSSD_CONV_F16_OK set by the
+// caller): three fp16 planes per operand -- h = fp16(x), h6 = h / 64, l6 = fp16((x - h) * 64), x = h + l6 / 64 to 2^-24 |x| -- and the products
+// h h' + l6 h6' + h6 l6' (dcn_x6.hip).  Same planes, LDS images and DMA pieces as the bf16 form, half the matrix instructions.  The packed weights
+// hold both forms (the bf16 planes, then the fp16 planes); data gradients keep the bf16 planes.  GSSD_X6_F16=0: bf16 everywhere.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3h_pair(const float a, const float b, unsigned& ph, unsigned& p6, unsigned& pl) {
+    const f16x2_t h = __builtin_convertvector(f32x2{a, b}, f16x2_t);
+    const f32x2 r = (f32x2{a, b} - __builtin_convertvector(h, f32x2)) * 64.f;
+    ph = __builtin_bit_cast(unsigned, h);
+    p6 = __builtin_bit_cast(unsigned, h * f16x2_t{(_Float16)0.015625f, (_Float16)0.015625f});
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+
 #ifndef X6_V2
 #define X6_V2 1             // round 5's K loop for the 64- / 128-column tiles (conv_x6_v2_kernel); 0: round 4's (conv_x6_kernel, also the 256-column sweep instance)
 #endif
@@ -469,7 +483,7 @@ struct Cfg2 {
     static_assert(BN == 64 || BN == 128, "tiles");
 };
 
-template <int BN, bool XF>
+template <int BN, bool XF, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles,
                                                            const long long plane_elems) {
     using K = Cfg2<BN>;
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
     const int cpc = p.cin_g / BKC;
     const int nchunks = cpc * taps;
     const float* __restrict__ in = p.in + p.in_ch_off + g * p.cin_g;
-    const u16* wslab = reinterpret_cast<const u16*>(p.wgt_x6) + (size_t)by * nchunks * B_STAGE;      // plane 0; plane q at + q * plane_elems
+    const u16* wslab = reinterpret_cast<const u16*>(p.wgt_x6) + (F16 ? 3 * plane_elems : 0) + (size_t)by * nchunks * B_STAGE;      // plane 0; plane q at + q * plane_elems (the fp16 planes lie behind the bf16 planes)
     constexpr bool xf = XF;
 
     f32x4 acc[MT][NT];
@@ -580,8 +594,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
         }
         if (!gok[j]) v = zero4;
         unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pair(v[0], v[1], h0, m0_, l0);
-        split3_pair(v[2], v[3], h1, m1, l1);
+        if constexpr (F16) {
+            split3h_pair(v[0], v[1], h0, m0_, l0);
+            split3h_pair(v[2], v[3], h1, m1, l1);
+        } else {
+            split3_pair(v[0], v[1], h0, m0_, l0);
+            split3_pair(v[2], v[3], h1, m1, l1);
+        }
         if (X6_KO & 32) return;
         u16* Ad = As + a_wr0 + j * 64 * BKC + 4 * hh;
         *reinterpret_cast<u32x2*>(Ad) = u32x2{h0, h1};
@@ -629,12 +648,19 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
 #else
         f32x4 c = acc[i][j];
 #endif
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+        if constexpr (F16) {
+            // planes 0: h, 1: h / 64, 2: (x - h) * 64 -- l6 h6', h6 l6', h h'
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][2]), __builtin_bit_cast(f16x8_t, areg[i][1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][1]), __builtin_bit_cast(f16x8_t, areg[i][2]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][0]), __builtin_bit_cast(f16x8_t, areg[i][0]), c, 0, 0, 0);
+        } else {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+        }
 #if X6_LOCAL_SUM
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] += c[e];
@@ -888,11 +914,17 @@ __global__ void conv_x6_pack_kernel(const float* __restrict__ w, u16* __restrict
         const int tap = chunk % taps, c32 = chunk / taps;
         const int c = c32 * BKC + q * 8 + e;
         const int ng = nt * BN + chan_of_row(row);
+        const float v = ng < cout_g ? w[(size_t)(g * cout_g + ng) * row_stride + tap * cin_g + c] : 0.f;
         __bf16 h, m, l;
-        split3(ng < cout_g ? w[(size_t)(g * cout_g + ng) * row_stride + tap * cin_g + c] : 0.f, h, m, l);
+        split3(v, h, m, l);
         wp[i] = __builtin_bit_cast(u16, h);
         wp[i + total] = __builtin_bit_cast(u16, m);
         wp[i + 2 * total] = __builtin_bit_cast(u16, l);
+        // behind the bf16 planes: the three fp16 planes of the three-MFMA form (h, h / 64, (v - h) * 64)
+        const _Float16 fh = (_Float16)v;
+        wp[i + 3 * total] = __builtin_bit_cast(u16, fh);
+        wp[i + 4 * total] = __builtin_bit_cast(u16, (_Float16)(fh * (_Float16)0.015625f));
+        wp[i + 5 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
     }
 }
 
@@ -916,10 +948,10 @@ int launch(const gssd_conv_desc& d, int M, hipStream_t stream) {
 }
 
 #if X6_V2
-template <int BN, bool XF>
-int launch2(const gssd_conv_desc& d, int M, hipStream_t stream) {
+template <int BN, bool XF, bool F16>
+int launch2_impl(const gssd_conv_desc& d, int M, hipStream_t stream) {
     static unsigned attr_mask = 0;
-    auto kern = conv_x6_v2_kernel<BN, XF>;
+    auto kern = conv_x6_v2_kernel<BN, XF, F16>;
     constexpr int lds = Cfg2<BN>::LDS_BYTES;
     if (gssd_attr_needed(&attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 4096) != hipSuccess) {
@@ -934,6 +966,13 @@ int launch2(const gssd_conv_desc& d, int M, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * d.groups * ntn), dim3(256), lds + (d.in_scale ? 8 * d.cin_g : 0), stream, d, M, ntn, mtiles, plane);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
+}
+// the three-MFMA fp16 form: forward launches on bounded activations only (never a data gradient: no flag, no fused producer transform)
+template <int BN, bool XF>
+int launch2(const gssd_conv_desc& d, int M, hipStream_t stream) {
+    static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
+    if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) return launch2_impl<BN, XF, true>(d, M, stream);
+    return launch2_impl<BN, XF, false>(d, M, stream);
 }
 #endif
 
@@ -958,14 +997,14 @@ extern "C" long long gssd_conv_x6_weight_elems(int Cout, int groups, int cin_g, 
     if (Cout <= 0 || groups <= 0 || Cout % groups != 0 || taps <= 0 || !(BN == 64 || BN == 128 || BN == 256)) return -1;
     if (!shape_ok(cin_g, Cout / groups, groups)) return -1;
     const int cout_g = Cout / groups;
-    return 3ll * groups * ((cout_g + BN - 1) / BN) * BN * taps * cin_g;
+    return 6ll * groups * ((cout_g + BN - 1) / BN) * BN * taps * cin_g;      // three bf16 planes, then three fp16 planes
 }
 
 extern "C" int gssd_conv_x6_pack_weight(const float* w_packed, void* w_x6, int Cout, int groups, int cin_g, int taps, int row_stride, int BN,
                                         gssd_stream_t stream) {
     const long long n = gssd_conv_x6_weight_elems(Cout, groups, cin_g, taps, BN);
     GSSD_CHECK_ARG(w_packed && w_x6 && n > 0 && row_stride >= taps * cin_g);
-    const long long total = n / 3;
+    const long long total = n / 6;
     hipLaunchKernelGGL(conv_x6_pack_kernel, dim3((int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w_packed, reinterpret_cast<u16*>(w_x6), Cout, groups, cin_g, taps, row_stride, BN, total);
     GSSD_CHECK_LAUNCH();

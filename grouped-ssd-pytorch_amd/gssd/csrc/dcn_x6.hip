@@ -75,6 +75,22 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // the same split of TWO values at once, planes as packed bf16 pairs (a in the low half): one v_cvt_pk_bf16_f32 per plane and PAIR, and the
 // packed result is the operand dword (the element-wise form converts every element alone and then once more to pack: 7 converts per pair)
+// Round 6, the three-MFMA form (conv_thin_x6.hip) for a kernel whose accumulator count leaves no room for a second set: THREE fp16 planes per
+// operand -- h = fp16(x), h6 = h / 64 (exact), l6 = fp16((x - h) * 64): x = h + l6 / 64 to 2^-24 |x| -- and the three products
+// h h' + l6 h6' + h6 l6' into ONE accumulator (the scale 2^6 sits half on either operand of the two cross terms, so that neither a residual nor a
+// down-scaled leading plane leaves fp16's normal range for operands between 4e-3 and 1e3; below that the ABSOLUTE error stays under 5e-10).
+// Same planes, same LDS images, same DMA pieces as the bf16 form; half the matrix instructions.  GSSD_X6_F16=0: the bf16 planes.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3h_pair(const float a, const float b, unsigned& ph, unsigned& p6, unsigned& pl) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f16x2_t h = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);
+    const f32x2_t r = (f32x2_t{a, b} - __builtin_convertvector(h, f32x2_t)) * 64.f;
+    ph = __builtin_bit_cast(unsigned, h);
+    p6 = __builtin_bit_cast(unsigned, h * f16x2_t{(_Float16)0.015625f, (_Float16)0.015625f});
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+
 __device__ __forceinline__ void split3_pair(const float a, const float b, unsigned& ph, unsigned& pm, unsigned& pl) {
     ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
     const float ra = a - __builtin_bit_cast(float, ph << 16), rb = b - __builtin_bit_cast(float, ph & 0xffff0000u);
@@ -115,6 +131,7 @@ __device__ unsigned long long g_x6_timing[8];
     if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(VM), "n"(LGKM) : "memory");           \
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(VM), "n"(LGKM) : "memory")
 
+template <bool F16>
 __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const u16* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
@@ -300,8 +317,13 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
                         // the blend of dcn_fused.hip: the same four products, the same order
                         ve[e] = gv[j][0][hh][e] * gw[j][0] + gv[j][1][hh][e] * gw[j][1] + gv[j][2][hh][e] * gw[j][2] + gv[j][3][hh][e] * gw[j][3];
                     unsigned h0, m0_, l0, h1, m1, l1;
-                    split3_pair(ve[0], ve[1], h0, m0_, l0);
-                    split3_pair(ve[2], ve[3], h1, m1, l1);
+                    if constexpr (F16) {
+                        split3h_pair(ve[0], ve[1], h0, m0_, l0);
+                        split3h_pair(ve[2], ve[3], h1, m1, l1);
+                    } else {
+                        split3_pair(ve[0], ve[1], h0, m0_, l0);
+                        split3_pair(ve[2], ve[3], h1, m1, l1);
+                    }
                     pln[j][hh][0] = u32x2{h0, h1};
                     pln[j][hh][1] = u32x2{m0_, m1};
                     pln[j][hh][2] = u32x2{l0, l1};
@@ -427,12 +449,19 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
         auto mma_row = [&](int i, int j, int which) {
             if (X6_KO & 2) return;
             f32x4 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+            if constexpr (F16) {
+                // planes 0: h, 1: h / 64, 2: (x - h) * 64 -- l6 h6', h6 l6', h h'
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][2]), __builtin_bit_cast(f16x8_t, areg[i][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][1]), __builtin_bit_cast(f16x8_t, areg[i][2]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, breg[which][0]), __builtin_bit_cast(f16x8_t, areg[i][0]), c, 0, 0, 0);
+            } else {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][2], areg[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][1], areg[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[which][0], areg[i][0], c, 0, 0, 0);
+            }
             acc[i][j] = c;
         };
         X6_BARRIER(0, 0);                                    // P1
@@ -523,7 +552,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
 #undef X6_BARRIER
 
 // OIHW fp32 [Cout][C][3][3] -> three bf16 planes, each [n_tiles][chunks][BN staging rows][32] with the slot swizzle; rows beyond Cout zero
-__global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int C, int dg, long long total) {
+__global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int C, int dg, long long total, int f16) {
     const int cpg = C / dg, cpc = cpg / BKC, nchunks = dg * cpc * 9;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7);
@@ -536,8 +565,16 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
         const int tap = chunk % 9, cc = chunk / 9;                                // chunk = ((group * cpc + channel block) * 9 + tap)
         const int c = cc * BKC + q * 8 + e;
         const int n = nt * BN + chan_of_row(row);
+        const float v = n < Cout ? w[((size_t)n * C + c) * 9 + tap] : 0.f;
+        if (f16) {                 // the three fp16 planes of the three-MFMA form: h, h / 64, (v - h) * 64
+            const _Float16 fh = (_Float16)v;
+            wp[i] = __builtin_bit_cast(u16, fh);
+            wp[i + total] = __builtin_bit_cast(u16, (_Float16)(fh * (_Float16)0.015625f));
+            wp[i + 2 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
+            continue;
+        }
         __bf16 h, m, l;
-        split3(n < Cout ? w[((size_t)n * C + c) * 9 + tap] : 0.f, h, m, l);
+        split3(v, h, m, l);
         wp[i] = __builtin_bit_cast(u16, h);
         wp[i + total] = __builtin_bit_cast(u16, m);
         wp[i + 2 * total] = __builtin_bit_cast(u16, l);
@@ -555,6 +592,12 @@ extern "C" int gssd_dcn_x6_timing_read(unsigned long long* out8) {       // debu
 }
 #endif
 
+// GSSD_X6_F16=0: bf16 planes and six MFMAs per product; read once -- the packed weights and the kernel instance have to agree
+static bool dcn_x6_f16() {
+    static const bool on = [] { const char* e = getenv("GSSD_X6_F16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" long long gssd_dcn_packed_weight_elems_x6(int Cout, int C) {          // bf16 elements (three planes)
     if (Cout <= 0 || C <= 0 || C % BKC != 0) return -1;
     return 3ll * ((Cout + BN - 1) / BN) * BN * 9 * C;
@@ -564,7 +607,7 @@ extern "C" int gssd_dcn_pack_weight_x6(const float* w_oihw, void* w_packed, int 
     GSSD_CHECK_ARG(w_oihw && w_packed && Cout > 0 && C > 0 && dg > 0 && C % dg == 0 && (C / dg) % BKC == 0);
     const long long total = gssd_dcn_packed_weight_elems_x6(Cout, C) / 3;
     hipLaunchKernelGGL(dcn_pack_weight_x6_kernel, dim3((int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), w_oihw, reinterpret_cast<u16*>(w_packed), Cout, C, dg, total);
+                       as_stream(stream), w_oihw, reinterpret_cast<u16*>(w_packed), Cout, C, dg, total, dcn_x6_f16() ? 1 : 0);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
@@ -578,16 +621,16 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     GSSD_CHECK_ARG(Mll < (1ll << 30) && Mll * C < (1ll << 32));          // 30-bit pixel index + 2 flag bits; 32-bit element offsets
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
-    static unsigned attr_mask = 0;
-    const auto kernel = dcn_x6_kernel;
+    static unsigned attr_mask[2] = {0, 0};
+    const auto kernel = dcn_x6_f16() ? dcn_x6_kernel<true> : dcn_x6_kernel<false>;
     constexpr int NTHREADS = THREADS;
-    if (gssd_attr_needed(&attr_mask)) {
+    if (gssd_attr_needed(&attr_mask[dcn_x6_f16()])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", LDS_BYTES);
             return GSSD_ELAUNCH;
         }
-        gssd_attr_done(&attr_mask);
+        gssd_attr_done(&attr_mask[dcn_x6_f16()]);
     }
     int blocks;
     if (X6_MAP) {

@@ -14,11 +14,13 @@
 //                                 registers; the six products of a tile are summed from zero and added to the running output by the vector
 //                                 ALU (the bf16 MFMA's adder truncates); softmax, running maximum and row sums are fp32 as before.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 namespace {
@@ -41,6 +43,9 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 
 // rows x cols fp32 (row stride ld_in) -> three bf16 planes [rows][cols_out] (plane stride `plane`); perm32: column c of the output holds input
 // column 32 t + perm(c % 32) (the key order of the value product); columns >= cols are zero.  One thread = 8 output columns = 16 bytes per plane.
+// F16 (round 6): TWO fp16 planes instead -- h = fp16(x), l' = fp16((x - h) * 2048), x = h + l' / 2048 to 2^-24 |x| -- for the three-MFMA form of
+// the core (conv_thin_x6.hip): theta, phi and g are projections of normalised activations, far inside fp16's range.
+template <bool F16>
 __global__ void split_planes_kernel(const float* __restrict__ in, u16* __restrict__ out, long long rows, int cols, int ld_in, int cols_out,
                                     long long plane, int perm32) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -59,27 +64,35 @@ __global__ void split_planes_kernel(const float* __restrict__ in, u16* __restric
             c = (c & ~31) + 16 * (ee >> 2) + 4 * kq + (ee & 3);
         }
         const float v = c < cols ? src[c] : 0.f;
-        __bf16 a, b, d;
-        split3(v, a, b, d);
-        h[e] = a;
-        m[e] = b;
-        l[e] = d;
+        if (F16) {
+            const _Float16 fh = (_Float16)v;
+            const _Float16 fl = (_Float16)((v - (float)fh) * 2048.f);
+            h[e] = __builtin_bit_cast(__bf16, fh);
+            m[e] = __builtin_bit_cast(__bf16, fl);
+        } else {
+            __bf16 a, b, d;
+            split3(v, a, b, d);
+            h[e] = a;
+            m[e] = b;
+            l[e] = d;
+        }
     }
     u16* dst = out + row * cols_out + 8 * u;
     *reinterpret_cast<bf16x8*>(dst) = h;
     *reinterpret_cast<bf16x8*>(dst + plane) = m;
-    *reinterpret_cast<bf16x8*>(dst + 2 * plane) = l;
+    if (!F16) *reinterpret_cast<bf16x8*>(dst + 2 * plane) = l;
 }
 
 // tpp: planes of theta | phi [3][B][N][2D]; gp: planes of g^T [3][B][C2][Np32] (keys permuted inside 32-blocks); out [B][N][C2] fp32
 // NW waves per workgroup = 16 NW queries: every workgroup streams ALL keys / values of its image through LDS, so the L2 -> LDS traffic per query
 // falls with NW (four waves: 2.0 GB per N = 1444 launch = the bound, 346 us; twelve waves = 192 queries: exactly one round of 8 x 32 workgroups)
-template <int D, int C2, int BKV, int NW>
+template <int D, int C2, int BKV, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __restrict__ tpp, const u16* __restrict__ gp,
                                                                                float* __restrict__ out, int N, int Np32, int qtiles,
                                                                                long long tp_plane, long long g_plane,
                                                                                float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    constexpr int NPX = F16 ? 2 : 3;                      // operand planes of this instance
     constexpr int UK = D / 8, UV = BKV / 8;               // 16-byte units per K row / V row
     constexpr int SWK = (UK < 8 ? UK : 8) - 1;            // K rows are >= 64 bytes: unit' = unit ^ (row & SWK)
     constexpr int KT = BKV / 16, KB = BKV / 32, CT = C2 / 16, DI = D / 32;
@@ -95,11 +108,11 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
     const u16* gb = gp + (size_t)b * C2 * Np32;
 
     // query fragments (B operand): lane (q, kq) holds theta[q][32 i + 8 kq .. + 7] of every plane
-    bf16x8 qf[DI][NP];
+    bf16x8 qf[DI][NPX];
 #pragma unroll
     for (int i = 0; i < DI; ++i)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        for (int pl = 0; pl < NPX; ++pl) {
             if (q < N) qf[i][pl] = *reinterpret_cast<const bf16x8*>(tpb + pl * tp_plane + (size_t)q * (2 * D) + 32 * i + 8 * kq);
             else
 #pragma unroll
@@ -112,16 +125,16 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + BKV - 1) / BKV;
-    constexpr int STAGE = NP * (K_PLANE + V_PLANE);           // u16 elements per stage; two stages: the next tile lands under this tile's MFMAs
+    constexpr int STAGE = NPX * (K_PLANE + V_PLANE);           // u16 elements per stage; two stages: the next tile lands under this tile's MFMAs
     // the DMA pieces of a tile, one at a time: piece slot j of this wave = K pieces first (KW per wave), then V pieces (VW per wave).  In the
     // loop they are dealt out between the MFMA groups of the running tile (round 5: a wave issues in order, and the vector memory path takes
     // one 1-KiB piece per 16 cycles per CU -- a burst of 60 pieces at the top of a tile held back every wave's MFMAs for up to ~1 000 cycles)
-    constexpr int K_RPP = 64 / UK, K_PIECES = NP * BKV / K_RPP, V_RPP = 64 / UV, V_PIECES = NP * C2 / V_RPP;
+    constexpr int K_RPP = 64 / UK, K_PIECES = NPX * BKV / K_RPP, V_RPP = 64 / UV, V_PIECES = NPX * C2 / V_RPP;
     constexpr int KW = (K_PIECES + NW - 1) / NW, VW = (V_PIECES + NW - 1) / NW;
     auto stage_piece = [&](const int t, const int buf, const int j) {
         const int key0 = t * BKV;
         u16* const Kd = smem + buf * STAGE;
-        u16* const Vd = Kd + NP * K_PLANE;
+        u16* const Vd = Kd + NPX * K_PLANE;
         if (j < KW) {   // K tile: BKV rows of D bf16 per plane; piece = 1 KiB = 64 / UK rows
             const int row_in = lane / UK, slot = lane % UK;
             const int piece = j * NW + wave;
@@ -154,26 +167,36 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
         const int tn = t + 1 < ntiles ? t + 1 : t;             // past the end: the last tile again, into the stage nobody reads any more
         if (!FX6_SPREAD && t + 1 < ntiles) stage(t + 1, buf ^ 1);
         const u16* const Ks = smem + buf * STAGE;
-        const u16* const Vs = Ks + NP * K_PLANE;
+        const u16* const Vs = Ks + NPX * K_PLANE;
 
         // ---- S^T = K . Q^T: six products per 32 channels, smallest first; the tile's terms summed in one accumulator ---------------
         f32x4 s[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int row = kt * 16 + r;
-            f32x4 acc = zero4;
+            f32x4 acc = zero4, accx = zero4;
 #pragma unroll
             for (int i = 0; i < DI; ++i) {
-                bf16x8 kf[NP];
+                bf16x8 kf[NPX];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
+                for (int pl = 0; pl < NPX; ++pl)
                     kf[pl] = *reinterpret_cast<const bf16x8*>(Ks + pl * K_PLANE + row * D + (((4 * i + kq) ^ (row & SWK)) << 3));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2], qf[i][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], acc, 0, 0, 0);
+                if constexpr (F16) {
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[1]), __builtin_bit_cast(f16x8, qf[i][0]), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[i][1]), accx, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[i][0]), acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[NPX - 1], qf[i][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][NPX - 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], acc, 0, 0, 0);
+                }
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(accx[e], 1.f / 2048.f, acc[e]);
             }
             s[kt] = acc;
             // K pieces of the next tile behind the logits of this one
@@ -200,19 +223,44 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
-        bf16x8 pb[KB][NP];
+        bf16x8 pb[KB][NPX];
+        if constexpr (F16) {
+            // the probabilities go through the matrix cores scaled by 1024 (undone with the row sum at the end): fp16 keeps 11 bits only down to
+            // 6e-5, and a softmax over 1 444 keys has many smaller terms.  Pairs at a time, planes as packed dwords (conv_thin_x6.hip::split2_pair)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb) {
+                u32x4 ph, pl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float p = __expf(s[2 * kb + (e >> 2)][e & 3] - m_new);
-                psum += p;
-                __bf16 h, m, l;
-                split3(p, h, m, l);
-                pb[kb][0][e] = h;
-                pb[kb][1][e] = m;
-                pb[kb][2][e] = l;
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const float p0 = __expf(s[2 * kb + (e2 >> 1)][(2 * e2) & 3] - m_new), p1 = __expf(s[2 * kb + (e2 >> 1)][(2 * e2 + 1) & 3] - m_new);
+                    psum += p0;
+                    psum += p1;
+                    const f32x2 ps = f32x2{p0, p1} * 1024.f;
+                    const f16x2 h = __builtin_convertvector(ps, f16x2);
+                    const f32x2 rr = (ps - __builtin_convertvector(h, f32x2)) * 2048.f;
+                    ph[e2] = __builtin_bit_cast(unsigned, h);
+                    pl[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, f16x2));
+                }
+                pb[kb][0] = __builtin_bit_cast(bf16x8, ph);
+                pb[kb][1] = __builtin_bit_cast(bf16x8, pl);
             }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __expf(s[2 * kb + (e >> 2)][e & 3] - m_new);
+                    psum += p;
+                    __bf16 h, m, l;
+                    split3(p, h, m, l);
+                    pb[kb][0][e] = h;
+                    pb[kb][1][e] = m;
+                    pb[kb][NPX - 1][e] = l;
+                }
+        }
         l_run = l_run * alpha + psum;
         m_run = m_new;
         if (__any(alpha != 1.f)) {                                // the running maximum usually stops moving after a few tiles
@@ -223,22 +271,29 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int row = c * 16 + r;
-            f32x4 acc = zero4;
+            f32x4 acc = zero4, accx = zero4;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                bf16x8 vf[NP];
+                bf16x8 vf[NPX];
                 const int unit = (4 * kb + kq) ^ (BKV == 32 ? ((row & 8) ? 3 : 0) : (row & 7));
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(Vs + pl * V_PLANE + row * BKV + (unit << 3));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pb[kb][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2], pb[kb][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pb[kb][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][0], acc, 0, 0, 0);
+                for (int pl = 0; pl < NPX; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(Vs + pl * V_PLANE + row * BKV + (unit << 3));
+                if constexpr (F16) {
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[1]), __builtin_bit_cast(f16x8, pb[kb][0]), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[0]), __builtin_bit_cast(f16x8, pb[kb][1]), accx, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[0]), __builtin_bit_cast(f16x8, pb[kb][0]), acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pb[kb][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[NPX - 1], pb[kb][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][NPX - 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pb[kb][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pb[kb][0], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[c][e] += acc[e];
+            for (int e = 0; e < 4; ++e) o[c][e] += F16 ? __builtin_fmaf(accx[e], 1.f / 2048.f, acc[e]) : acc[e];
+            if (F16 && (c & 1)) __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from hoisting the value fragments of many tiles: the twelve-wave form has 168 registers)
             // V pieces of the next tile: VW of them dealt out over the first three quarters of the value tiles
             if (FX6_SPREAD)
 #pragma unroll
@@ -252,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_run;
+    const float inv = (F16 ? 1.f / 1024.f : 1.f) / l_run;          // (F16: the probabilities went through the matrix cores scaled by 1024)
     if (lse != nullptr && q < N && kq == 0) lse[(size_t)b * N + q] = m_run + logf(l_run);
     if (q < N) {
         float* dst = out + ((size_t)b * N + q) * C2 + 4 * kq;
@@ -261,11 +316,11 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_x6_kernel(const u16* __
     }
 }
 
-template <int D, int C2, int BKV, int NW>
+template <int D, int C2, int BKV, int NW, bool F16>
 int launch_x6(const u16* tpp, const u16* gp, float* out, int B, int N, int Np32, float* lse, hipStream_t stream) {
-    constexpr int smem = 2 * NP * (BKV * D + C2 * BKV) * (int)sizeof(u16);      // two stages
+    constexpr int smem = 2 * (F16 ? 2 : 3) * (BKV * D + C2 * BKV) * (int)sizeof(u16);      // two stages
     static unsigned attr_mask = 0;
-    auto kern = flash_attn_x6_kernel<D, C2, BKV, NW>;
+    auto kern = flash_attn_x6_kernel<D, C2, BKV, NW, F16>;
     if (gssd_attr_needed(&attr_mask) &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", smem);
@@ -306,16 +361,21 @@ extern "C" int gssd_self_attn_core_x6_f32(const float* tp, const float* gT, floa
     u16* tpp = reinterpret_cast<u16*>(ws);
     const long long tp_plane = (long long)B * N * 2 * D, g_plane = (long long)B * C2 * Np32;
     u16* gp = tpp + NP * tp_plane;
+    // two fp16 planes, three MFMAs per product: built and measured in round 6 -- 313.7 vs 318.1 us (the core is bound by streaming every key / value
+    // through LDS per workgroup and by the exponentials, not by the matrix pipe; the twelve-wave instance spills 34 registers) -- opt-in only
+    static const bool f16 = [] { const char* e = getenv("GSSD_FLASH_X6_F16"); return e && e[0] == '1'; }();
     {
         const long long n = (long long)B * N * (2 * D / 8);
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tp, tpp, (long long)B * N, 2 * D, 2 * D, 2 * D,
-                           tp_plane, 0);
+        if (f16) hipLaunchKernelGGL(split_planes_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tp, tpp, (long long)B * N, 2 * D, 2 * D, 2 * D, tp_plane, 0);
+        else hipLaunchKernelGGL(split_planes_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tp, tpp, (long long)B * N, 2 * D, 2 * D, 2 * D, tp_plane, 0);
         GSSD_CHECK_LAUNCH();
     }
     {
         const long long n = (long long)B * C2 * (Np32 / 8);
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gT, gp, (long long)B * C2, N, Np, Np32, g_plane, 1);
+        if (f16) hipLaunchKernelGGL(split_planes_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gT, gp, (long long)B * C2, N, Np, Np32, g_plane, 1);
+        else hipLaunchKernelGGL(split_planes_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gT, gp, (long long)B * C2, N, Np, Np32, g_plane, 1);
         GSSD_CHECK_LAUNCH();
     }
-    return N > 1024 ? launch_x6<64, 256, 32, 12>(tpp, gp, out, B, N, Np32, lse, s) : launch_x6<64, 256, 32, 4>(tpp, gp, out, B, N, Np32, lse, s);
+    if (f16) return N > 1024 ? launch_x6<64, 256, 32, 12, true>(tpp, gp, out, B, N, Np32, lse, s) : launch_x6<64, 256, 32, 4, true>(tpp, gp, out, B, N, Np32, lse, s);
+    return N > 1024 ? launch_x6<64, 256, 32, 12, false>(tpp, gp, out, B, N, Np32, lse, s) : launch_x6<64, 256, 32, 4, false>(tpp, gp, out, B, N, Np32, lse, s);
 }

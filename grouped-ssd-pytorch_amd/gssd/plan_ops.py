@@ -140,7 +140,7 @@ class PlanOpsMixin:
                                          stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                          stats=st if self.training else None,
                                          in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
-                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2, pool_sign=bn.weight.detach(), stats_rep=srep)
+                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2 | (0 if self.bf16 else _lib.CONV_F16_OK), pool_sign=bn.weight.detach(), stats_rep=srep)
             self._add(self.conv_fn, (C.byref(d),), keep=d)
             sc, sh = self._buf(Cout), self._buf(Cout)
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
@@ -157,7 +157,8 @@ class PlanOpsMixin:
                                      stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U, wgt_x6=X6,
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
-                                     in_pad=in_xf[2] if in_xf else None, stats_rep=srep)
+                                     in_pad=in_xf[2] if in_xf else None, stats_rep=srep,
+                                     flags=0 if self.bf16 else _lib.CONV_F16_OK)      # fp32 mode, forward launches on activation maps: the x6 kernels' fp16 planes
         self._add(self.conv_fn, (C.byref(d),), keep=d)
         rec = dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho, Cout=Cout,
                    desc=d, stats=st, stats_rep=srep, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
@@ -264,14 +265,14 @@ class PlanOpsMixin:
         d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg, wgt_x6=x6_tpg,
                       out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=not flat,
                       in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np,
-                      flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else 0))
+                      flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else _lib.CONV_F16_OK))      # (fp32 mode: x is an activation map)
         x6_o = None
         if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(1, C2, Cc, 1, B * N):
             def build_x6o(out, bn=ops.x6_tile(Cc, 1, B * N)):
                 return ops.x6_weight(sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2), 1, C2, 1, bn, out)
             x6_o = eng._pack(name + f'.o.x6@{ops.x6_tile(Cc, 1, B * N)}', build_x6o)
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
-                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2, wgt_x6=x6_o)
+                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2, wgt_x6=x6_o, flags=0 if self.bf16 else _lib.CONV_F16_OK)
         fn = self.conv_fn
         if C4 % 64 == 0:
             self._add(fn, (C.byref(d1),), keep=(d1, w_tpg, b_tpg))

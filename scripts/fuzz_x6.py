@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'grouped-ssd-pytorch_amd'))
 import numpy as np
 import torch
-from gssd import ops
+from gssd import ops, _lib
 dev = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
@@ -65,13 +65,14 @@ for it in range(n_cases if 'conv' in legs else 0):
         sc = torch.from_numpy((rng.random(g * cin_g) + 0.5).astype(np.float32)).to(dev)
         sh = torch.from_numpy((rng.normal(size=g * cin_g) * 0.3).astype(np.float32)).to(dev)
         kw = dict(in_scale=sc, in_shift=sh, in_pad=-sh / sc - 1.0)
-    y6 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, x6=True, **kw)
+    f16ok = (not xf) and rng.random() < 0.5                    # plain launches: bf16 planes (data gradients) or, flagged, fp16 planes (forward)
+    y6 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, x6=True, **kw, **(dict(flags=_lib.CONV_F16_OK) if f16ok else {}))
     y32 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, **kw)
     torch.cuda.synchronize()
     e = float((y6 - y32).abs().max() / y32.abs().max())
     worst = max(worst, e)
     ok = torch.isfinite(y6).all() and e < 2e-5
-    print(f'conv B {B} {H}x{W} cin_g {cin_g} cout_g {cout_g} g {g} k {k} pad {pad} dil {dil} stride {stride} xf {xf}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
+    print(f'conv B {B} {H}x{W} cin_g {cin_g} cout_g {cout_g} g {g} k {k} pad {pad} dil {dil} stride {stride} xf {xf} f16 {xf or f16ok}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
     assert ok
 if 'conv' in legs:
     print(f'conv_x6: {n_cases} shapes, worst rel {worst:.2e}')

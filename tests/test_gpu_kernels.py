@@ -979,8 +979,11 @@ def test_conv_x6_matches_float64(shape):
     b = torch.randn(Cout, generator=gen).to(dev)
     sc, sh = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)
     pdv = -sh / sc - 1.0
-    for xf in (False, True):
-        kw = dict(in_scale=sc, in_shift=sh, in_pad=pdv) if xf else {}
+    # plain (bf16 planes, six MFMAs: what data gradients run), plain + GSSD_CONV_F16_OK and the fused input transform (fp16 planes, three MFMAs:
+    # the forward's launches; GSSD_X6_F16=0 -- test_x6_kernels_bf16_planes below -- runs all three on the bf16 planes)
+    from gssd import _lib
+    for xf, f16ok in ((False, False), (False, True), (True, False)):
+        kw = dict(in_scale=sc, in_shift=sh, in_pad=pdv) if xf else (dict(flags=_lib.CONV_F16_OK) if f16ok else {})
         xin = F.relu(x.double() * sc.double() + sh.double()) if xf else x.double()
         ref = F.conv2d(xin.permute(0, 3, 1, 2), w.double(), b.double(), stride, pad, dil, g).permute(0, 2, 3, 1)
         st6 = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)
@@ -988,7 +991,8 @@ def test_conv_x6_matches_float64(shape):
         y32 = ops.conv2d_nhwc(x, w, b, stride, pad, dil, g, **kw)
         e6 = float((y6.double() - ref).abs().max() / ref.abs().max())
         e32 = float((y32.double() - ref).abs().max() / ref.abs().max())
-        assert e6 < 2e-6 and e6 <= 1.5 * e32 + 1e-7, (xf, e6, e32)
+        print(f'conv_x6 {shape} xf {xf} f16ok {f16ok}: x6 {e6:.2e} fp32 {e32:.2e}')
+        assert e6 < 2e-6 and e6 <= 1.5 * e32 + 1e-7, (xf, f16ok, e6, e32)
         n_px = ref.shape[0] * ref.shape[1] * ref.shape[2]           # fp32 partial sums per tile: errors relative to sum |v|, not to the sum
         assert float((st6[:Cout] - ref.sum((0, 1, 2))).abs().max()) < 2e-7 * n_px * float(ref.abs().max())
         assert float((st6[Cout:] - (ref * ref).sum((0, 1, 2))).abs().max()) < 2e-7 * n_px * float(ref.abs().max()) ** 2
@@ -1034,6 +1038,18 @@ def test_conv_x6_epilogues_match_igemm(B, H, Cc):
     for a, b in zip(res['ref'], res['x6']):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
+@pytest.mark.gpu
+def test_x6_kernels_bf16_planes():
+    """GSSD_X6_F16=0: the x6 kernels' forward launches on the three bf16 planes (round 5's form, what the data gradients always run) -- the same
+    kernel tests in a child process."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', os.path.join(root, 'tests', 'test_gpu_kernels.py'), os.path.join(root, 'tests', 'test_gpu_thin_x6.py'),
+                        '-k', 'test_conv_x6_matches_float64 or test_dcn_x6_matches_fused or test_conv_x6_epilogues or test_conv_thin_x6_forms'],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, GSSD_X6_F16='0'))
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -82,6 +82,10 @@ SWITCHES = [
     # round 6: conv1_2 / conv2_1 / conv2_2 on the round-5 fp32-MFMA kernels instead of the patch-staged three-plane direct conv (csrc/conv_thin_x6.hip)
     ('f32', {'GSSD_THIN_X6': '0'}, lambda o, base: not has(o, 'conv_thin_x6') and has(base, 'conv_thin_x6<16,16>') and has(base, 'conv_thin_x6<32,32>')
      and has(o, 'conv_thin_wino')),
+    # the x6 kernels' forward launches on three bf16 planes / six MFMAs (round 5's form) instead of the fp16 planes / three MFMAs; and the attention
+    # core's opt-in fp16 form
+    ('f32', {'GSSD_X6_F16': '0', 'BATCH': 24}, lambda o, base: has(o, 'conv_x6') and has(o, 'dcn_x6') and has(o, 'conv_wino_x6')),
+    ('f32', {'GSSD_FLASH_X6_F16': '1'}, lambda o, base: has(o, 'flash_attn_x6')),
     # the attention cores of the 38 x 38 blocks on the fp32 matrix cores (csrc/flash_attn.hip) instead of the three-plane form
     ('f32', {'GSSD_FLASH_X6': '0'}, lambda o, base: not has(o, 'flash_attn_x6') and has(base, 'flash_attn_x6') and has(o, 'flash_attn<')),
     # the backward as one Python call per launch instead of one gssd_plan_run array per gradient segment (csrc/plan_run.hip)
