@@ -586,13 +586,13 @@ int launch_thin_x6_impl(const gssd_conv_desc& d, hipStream_t stream) {
     return GSSD_OK;
 }
 
-// the two-plane fp16 form for launches whose input is a BatchNorm + ReLU output (fused producer transform); GSSD_X6_F16=0: bf16 planes everywhere
+// the two-plane fp16 form for launches whose input is a BatchNorm + ReLU output (fused producer transform, or GSSD_CONV_F16_OK); GSSD_X6_F16=0: bf16 planes everywhere
 template <int CIN_G, int COUT_G, bool XF, bool POOL>
 int launch_thin_x6(const gssd_conv_desc& d, hipStream_t stream) {
     static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
-    if constexpr (XF) {
-        if (!f16_off) return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, true>(d, stream);
-    }
+    // (flagged plain launches too: a training forward reads the materialised activation map where the no-backward forward applies the transform on
+    // read -- the same form in both keeps the two plans' arithmetic identical)
+    if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, true>(d, stream);
     return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, false>(d, stream);
 }
 

@@ -91,7 +91,8 @@ SWITCHES = [
     # the backward as one Python call per launch instead of one gssd_plan_run array per gradient segment (csrc/plan_run.hip)
     ('f32', {'GSSD_NO_PLAN_RUN': '1'}, lambda o, base: True),
     ('f32', {'GSSD_BRANCH0_LATE': '0'}, lambda o, base: True),
-    ('f32', {'GSSD_CONV21_WINO': '0'}, lambda o, base: has(o, 'conv_thin<16,32>') and not has(base, 'conv_thin<16,32>')),
+    # (conv2_1 belongs to conv_thin_x6 since round 6: the round-5 choice between its two fp32 kernels only exists with that one off)
+    ('f32', {'GSSD_CONV21_WINO': '0', 'GSSD_THIN_X6': '0'}, lambda o, base: has(o, 'conv_thin<16,32>') and not has(base, 'conv_thin<16,32>')),
     ('bf16', {'GSSD_STATS_REP': '0'}, lambda o, base: True),
     # opt-in experiments that stay in the tree (DESIGN 9 "measured and rejected"): 256 x 128 bf16 tiles (>= 8 192 rows: batch 8), the loader /
     # matrix-wave form of the bf16 deformable conv

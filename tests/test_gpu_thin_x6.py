@@ -87,6 +87,17 @@ def test_conv_thin_x6_forms_vs_float64(case):
     print(f'{case} plain: thin_x6 vs float64 {e6:.2e}; fp32-MFMA implicit GEMM {e32:.2e}')
     assert e6 < 1e-6 and e6 <= 1.5 * e32 + 1e-7
 
+    # ---- the same launch flagged GSSD_CONV_F16_OK (a forward launch on a materialised activation map): two fp16 planes, three MFMAs per product -----
+    y_f16 = torch.full((B, H, W, Cout), float('nan'), device=dev)
+    stats_f16 = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    launch(y_f16, stats=stats_f16, flags=_lib.CONV_F16_OK)
+    ef = rel(y_f16.cpu(), ref)
+    print(f'{case} plain, fp16 planes: {ef:.2e}')
+    assert ef < 1e-6 and ef <= 1.5 * e32 + 1e-7 and stat_err(stats_f16, 0, ref) < 2e-7
+    yp = torch.full((B, (H + 1) // 2, (W + 1) // 2, Cout), float('nan'), device=dev)
+    launch(yp, flags=_lib.CONV_POOL2 | _lib.CONV_F16_OK, pool_sign=torch.ones(Cout, device=dev))
+    assert torch.equal(yp, F.max_pool2d(y_f16.permute(0, 3, 1, 2), 2, 2, 0, ceil_mode=True).permute(0, 2, 3, 1))
+
     # ---- fused producer BatchNorm + ReLU, scales of both signs; zero padding AFTER the transform -------------------------------------
     scv = torch.from_numpy(rng.uniform(0.2, 1.5, size=Cin).astype(np.float32)) * torch.from_numpy(rng.choice([-1.0, 1.0], size=Cin).astype(np.float32))
     shv = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
