@@ -131,11 +131,12 @@ __device__ unsigned long long g_x6_timing[8];
     if (X6_KO & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(VM), "n"(LGKM) : "memory");           \
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(VM), "n"(LGKM) : "memory")
 
-template <bool F16>
+template <bool F16, int KSPLIT>
 __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restrict__ x, const float* __restrict__ om,
                                                           const u16* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int H, int W, int C, int dg, int om_stride,
                                                           int Cout, int ntn, int mtiles, long long plane_elems) {
+    constexpr int ksplit = KSPLIT;          // (a template parameter: as a run-time value it cost the one-part launch 7 %, 1.36 -> 1.46 ms)
     extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
     u16* const As = smem_h;                                   // [3][BM][32]
     u16* const Bh = smem_h + NP * A_STAGE;                    // [X | Y][2][3][BN / 2][32]
@@ -143,9 +144,14 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
     int* const tabp = reinterpret_cast<int*>(tabw + TAB_N);                                   // [9][BM] corner position + step flags
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int mt, nt;
+    // Split K (round 6): `ksplit` workgroups share a tile, each with dg / ksplit deformable groups of the K loop; their sums meet in the zero-filled
+    // output by fp32 atomic adds.  With two parts (the bias rides on part 0) the result does not depend on the order: 0 + a is exact, a + b = b + a.
+    // Why: small batches (46 row tiles at batch 4, 256 CUs) fill twice as many CUs; the launcher splits only while one round holds all parts.
+    int mt, nt, kz;
     {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = blockIdx.x & 7;
+        const int slot = (int)(blockIdx.x >> 3) / ksplit;
+        kz = (int)(blockIdx.x >> 3) % ksplit;
 #ifndef X6_MAP
 #define X6_MAP 1         // 1: the column tiles of a row tile on the SAME XCD (consecutive slots: its x lines come out of one L2; same-box A/B
                          // 1.856 vs 1.882 - 1.894 ms); 0: on neighbouring XCDs (each XCD streams one column tile's weight planes)
@@ -165,8 +171,9 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
     if (mt >= mtiles) return;
     const int m0 = mt * BM;
     const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;
-    const int nchunks = dg * cpc * 9;
-    const u16* wslab = wp + (size_t)nt * nchunks * B_STAGE;      // plane 0; plane p at + p * plane_elems
+    const int d0 = kz * (dg / ksplit);                           // this workgroup's deformable groups: d0 .. d0 + dg / ksplit - 1
+    const int nchunks = (dg / ksplit) * cpc * 9;
+    const u16* wslab = wp + ((size_t)nt * dg + d0) * cpc * 9 * B_STAGE;      // plane 0; plane p at + p * plane_elems
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #ifdef X6_TIMING
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memrealtime();
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
             for (int k = 0; k < 4; ++k) gv[j][k][0] = gv[j][k][1] = zero4;
         }
         f32x4 gw_next[2] = {zero4, zero4};                   // the weights travel with the requests: read from the table when they are issued
-        int ld_tap = 0, ld_cc = 0, ld_d = 0;                // the chunk the next corner requests are for
+        int ld_tap = 0, ld_cc = 0, ld_d = d0;                // the chunk the next corner requests are for
         int pos_next[2] = {0, 0};
         auto table_read = [&]() {                            // the table entries of the chunk requested next (LDS reads: issued early)
 #pragma unroll
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
         constexpr int ND = (X6_KO & 4) ? 0 : DPH, NL = (X6_KO & 8) ? 0 : 16;
 
         // prologue: table of group 0; corners of chunk 0 -> planes -> stage; X half of chunk 0; corners of chunk 1 requested
-        tab_load(0);
+        tab_load(d0);
         tab_finish();
         X6_BARRIER(0, 0);                                    // P1: the table (only the loaders read it)
         table_read();
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
         corners();                                           // chunk 1
         advance_ld();
         X6_BARRIER(NL, 0);                                   // P2
-        int tb_next = cpc * 9, tb_d = 1;                     // first chunk of the next group, and the group
+        int tb_next = cpc * 9, tb_d = d0 + 1;                     // first chunk of the next group, and the group
         // A loader's iteration: [DMA pieces: Y of chunk it, X of chunk it + 1] [chunk it + 1's corners have landed: blend + split into
         // registers] [first cell's corner requests of chunk it + 2] M(it) [plane writes] [second cell's requests] E(it).  The 28 requests of a
         // wave are ~1.3 us of the vector memory path per chunk (scripts/ubench/vmem_rates.hip: 52 / 39 B per clock for pieces / corner
@@ -523,13 +530,17 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
             const int n0 = nt * BN + wn * WTN + 32 * u + 8 * kq;
             float bv[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) bv[c] = (bias && n0 + c < Cout) ? bias[n0 + c] : 0.f;
+            for (int c = 0; c < 8; ++c) bv[c] = (bias && kz == 0 && n0 + c < Cout) ? bias[n0 + c] : 0.f;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = m0 + wm * WTM + i * 16 + r;
                 if (m >= M) continue;
                 float* dst = out + (size_t)m * Cout + n0;
-                if (n0 + 8 <= Cout) {
+                if (ksplit > 1) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (n0 + c < Cout) atomicAdd(dst + c, acc[i][2 * u + (c >> 2)][c & 3] + bv[c]);
+                } else if (n0 + 8 <= Cout) {
                     *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][2 * u][0] + bv[0], acc[i][2 * u][1] + bv[1], acc[i][2 * u][2] + bv[2], acc[i][2 * u][3] + bv[3]};
                     *reinterpret_cast<f32x4*>(dst + 4) =
                         f32x4{acc[i][2 * u + 1][0] + bv[4], acc[i][2 * u + 1][1] + bv[5], acc[i][2 * u + 1][2] + bv[6], acc[i][2 * u + 1][3] + bv[7]};
@@ -621,20 +632,36 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
     GSSD_CHECK_ARG(Mll < (1ll << 30) && Mll * C < (1ll << 32));          // 30-bit pixel index + 2 flag bits; 32-bit element offsets
     const int M = (int)Mll;
     const int ntn = (Cout + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
-    static unsigned attr_mask[2] = {0, 0};
-    const auto kernel = dcn_x6_f16() ? dcn_x6_kernel<true> : dcn_x6_kernel<false>;
+    static unsigned attr_mask[4] = {0, 0, 0, 0};
     constexpr int NTHREADS = THREADS;
-    if (gssd_attr_needed(&attr_mask[dcn_x6_f16()])) {
+    // two parts per tile while ONE round of the CUs holds them all (GSSD_DCN_X6_SPLITK=0: one part).  Measured (scripts/bench_dcn_x6.py): batch 4,
+    // 46 tiles: 0.79 -> 0.38 ms with four parts (not used: run-to-run bits); batch 32, 361 tiles = 1.41 rounds: two parts (2.82 rounds) are 5 % SLOWER, 1.82 against 1.72 ms --
+    // the launch is bound by the request rate of the shared vector-memory / L2 path, not by the CUs of the half-empty second round.
+    static const bool no_split = [] { const char* e = getenv("GSSD_DCN_X6_SPLITK"); return e && e[0] == '0'; }();
+    int ksplit = 1;
+    if (!no_split && X6_MAP) {
+        int dev = 0, ncu = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        if (dg % 2 == 0 && (long long)mtiles * ntn * 2 <= ncu) ksplit = 2;      // (two parts only: four would finish in any order, (a + b) + c != (a + c) + b)
+        if (ksplit > 1 && hipMemsetAsync(out, 0, (size_t)M * Cout * sizeof(float), as_stream(stream)) != hipSuccess) {
+            gssd_set_error("gssd_dcn_forward_x6: hipMemsetAsync of the output failed");
+            return GSSD_ELAUNCH;
+        }
+    }
+    const auto kernel = ksplit == 2 ? (dcn_x6_f16() ? dcn_x6_kernel<true, 2> : dcn_x6_kernel<false, 2>) : (dcn_x6_f16() ? dcn_x6_kernel<true, 1> : dcn_x6_kernel<false, 1>);
+    const int ai = (dcn_x6_f16() ? 1 : 0) + 2 * (ksplit - 1);
+    if (gssd_attr_needed(&attr_mask[ai])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             gssd_set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", LDS_BYTES);
             return GSSD_ELAUNCH;
         }
-        gssd_attr_done(&attr_mask[dcn_x6_f16()]);
+        gssd_attr_done(&attr_mask[ai]);
     }
     int blocks;
     if (X6_MAP) {
-        blocks = (mtiles + 7) / 8 * 8 * ntn;
+        blocks = (mtiles + 7) / 8 * 8 * ntn * ksplit;
     } else if (8 % ntn == 0) {
         const int per = 8 / ntn;
         blocks = ((mtiles + per - 1) / per) * 8;

@@ -282,40 +282,94 @@ __global__ __launch_bounds__(1024) void spectral_norm_kernel(const gssd_sn_item*
     for (int i = tid; i < R; i += blockDim.x) su[i] = it.u[i];
     for (int i = tid; i < Cc; i += blockDim.x) sv[i] = it.v[i];
     __syncthreads();
+    const bool vec = ((Cc | R) & 3) == 0 && (Cc >> 2) <= (int)blockDim.x && (((uintptr_t)it.w) & 15) == 0;
     if (do_iter) {
-        // v = W^T u : thread per column, rows serial (coalesced across threads)
         float nrm = 0.f;
-        for (int c = tid; c < Cc; c += blockDim.x) {
-            // eight independent partial sums keep eight loads in flight per thread (one workgroup owns the whole matrix)
-            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            int rr = 0;
-            for (; rr + 8 <= R; rr += 8) {
+        if (vec) {
+            // v = W^T u (round 6): thread -> (four columns, one of S row slices), eight 16-byte loads in flight per thread, the slices' partial sums
+            // meet in LDS in slice order.  One workgroup owns a matrix (three dependent passes), so its time is the latency of its load chains: the
+            // thread-per-column form walked all R rows per thread (512 x 1024: 64 dependent rounds of eight 4-byte loads, 414 us for the 48 matrices
+            // of GSSD++ -- long enough beside the trunk's first layers to slow their persistent workgroups, profiles/r06_thin_x6_notes.txt).
+            float* part = red + 16;                    // [S][Cc], S * Cc <= 4 * blockDim.x
+            const int nq = Cc >> 2, S = (int)blockDim.x / nq;
+            const int cq = tid % nq, rs = tid / nq;
+            if (rs < S) {
+                f32x4 a8[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) a8[q] += it.w[(size_t)(rr + q) * Cc + c] * su[rr + q];
+                for (int q = 0; q < 8; ++q) a8[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* wc = it.w + 4 * cq;
+                int rr = rs;
+                for (; rr + 7 * S < R; rr += 8 * S) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a8[q] += *reinterpret_cast<const f32x4*>(wc + (size_t)(rr + q * S) * Cc) * su[rr + q * S];
+                }
+                for (; rr < R; rr += S) a8[0] += *reinterpret_cast<const f32x4*>(wc + (size_t)rr * Cc) * su[rr];
+                *reinterpret_cast<f32x4*>(part + rs * Cc + 4 * cq) = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             }
-            for (; rr < R; ++rr) a8[0] += it.w[(size_t)rr * Cc + c] * su[rr];
-            const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-            sv[c] = acc;
-            nrm += acc * acc;
+            __syncthreads();
+            for (int c = tid; c < Cc; c += blockDim.x) {
+                float acc = part[c];
+                for (int sl = 1; sl < S; ++sl) acc += part[sl * Cc + c];
+                sv[c] = acc;
+                nrm += acc * acc;
+            }
+        } else {
+            // thread per column, rows serial (coalesced across threads)
+            for (int c = tid; c < Cc; c += blockDim.x) {
+                // eight independent partial sums keep eight loads in flight per thread (one workgroup owns the whole matrix)
+                float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int rr = 0;
+                for (; rr + 8 <= R; rr += 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a8[q] += it.w[(size_t)(rr + q) * Cc + c] * su[rr + q];
+                }
+                for (; rr < R; ++rr) a8[0] += it.w[(size_t)rr * Cc + c] * su[rr];
+                const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+                sv[c] = acc;
+                nrm += acc * acc;
+            }
         }
         nrm = block_sum(nrm, red);
         const float inv = 1.f / fmaxf(sqrtf(nrm), eps);
         for (int c = tid; c < Cc; c += blockDim.x) sv[c] *= inv;
         __syncthreads();
     }
-    // t = W v : one wave per row
+    // t = W v : one wave per row (vec: four rows at a time, 16-byte loads -- four independent chains per lane)
     float sig = 0.f, nrm2 = 0.f;
-    for (int rr = wave; rr < R; rr += nw) {
-        float acc = 0.f;
-        for (int c = lane; c < Cc; c += 64) acc += it.w[(size_t)rr * Cc + c] * sv[c];
-        acc = wave_sum(acc);
+    auto row_done = [&](int rr, float acc) {
         if (do_iter) {
-            if (lane == 0) {
-                su[rr] = acc;     // un-normalised W v
-                nrm2 += acc * acc;
-            }
-        } else if (lane == 0) {
+            su[rr] = acc;     // un-normalised W v
+            nrm2 += acc * acc;
+        } else {
             sig += su[rr] * acc;
+        }
+    };
+    if (vec) {
+        for (int r0 = wave * 4; r0 < R; r0 += nw * 4) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < Cc; c += 256) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(sv + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (r0 + q < R) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(it.w + (size_t)(r0 + q) * Cc + c);
+                        acc[q] += (w4[0] * v4[0] + w4[1] * v4[1]) + (w4[2] * v4[2] + w4[3] * v4[3]);
+                    }
+                }
+            }
+            // (su[r0 + q] is read by row_done before it is overwritten: the same lane, program order)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t = wave_sum(acc[q]);
+                if (lane == 0 && r0 + q < R) row_done(r0 + q, t);
+            }
+        }
+    } else {
+        for (int rr = wave; rr < R; rr += nw) {
+            float acc = 0.f;
+            for (int c = lane; c < Cc; c += 64) acc += it.w[(size_t)rr * Cc + c] * sv[c];
+            acc = wave_sum(acc);
+            if (lane == 0) row_done(rr, acc);
         }
     }
     if (do_iter) {
@@ -476,7 +530,7 @@ extern "C" int gssd_spectral_norm_f32(const gssd_sn_item* items_dev, int n, int 
                                       gssd_stream_t stream) {
     GSSD_CHECK_ARG(items_dev && n > 0);
     // rows + cols <= 1536 for every Self_Attn conv of the path (512 x 1024 is the largest); --feature_scale 2 doubles both (3072)
-    const size_t smem = (4096 + 16) * sizeof(float);
+    const size_t smem = (4096 + 16 + 4096) * sizeof(float);          // u | v | reduction slots | the row slices' partial sums
     hipLaunchKernelGGL(spectral_norm_kernel, dim3(n), dim3(1024), smem, as_stream(stream), items_dev,
                        do_power_iteration, eps);
     GSSD_CHECK_LAUNCH();

@@ -6,7 +6,9 @@ import torch
 from gssd import ops
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-B, H, C, dg, Cout = 32, 38, 1024, 4, 512
+# argv: B C Cout (the GSSD++ launch: 32 x 38 x 38 pixels, 2048 = x | SA-base channels, 256 outputs)
+B, C, Cout = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 2048, 256)))
+H, dg = 38, 4
 x = torch.randn(B, H, H, C, device=dev)
 om = torch.randn(B, H, H, 27 * dg, device=dev) * 0.5
 w = torch.randn(Cout, C, 3, 3, device=dev) * 0.02

@@ -428,7 +428,8 @@ def test_l2norm_softmax_slicecat(dev, ops, golden):
 def test_spectral_norm(dev, ops, do_iter):
     rng = np.random.default_rng(5)
     items, refs = [], []
-    for (r, c) in ((64, 512), (256, 512), (512, 256), (128, 1024), (512, 1024), (32, 256)):
+    # (the last three: three row slices with idle threads; shapes the 16-byte form does not take)
+    for (r, c) in ((64, 512), (256, 512), (512, 256), (128, 1024), (512, 1024), (32, 256), (36, 1028), (30, 52), (33, 50)):
         w = torch.from_numpy(rng.normal(0, 0.05, size=(r, c, 1, 1)).astype(np.float32))
         u = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=r).astype(np.float32)), dim=0)
         v = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=c).astype(np.float32)), dim=0)
@@ -1050,6 +1051,20 @@ def test_x6_kernels_bf16_planes():
                         '-k', 'test_conv_x6_matches_float64 or test_dcn_x6_matches_fused or test_conv_x6_epilogues or test_conv_thin_x6_forms'],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, GSSD_X6_F16='0'))
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_dcn_x6_one_part_per_tile():
+    """GSSD_DCN_X6_SPLITK=0: launches of fewer tiles than CUs (every kernel test's) split the K loop over two workgroups per tile that meet in
+    the output by atomic adds; the one-part form (what batch 32 runs) against the same references, in a child process."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSSD_DCN_X6_SPLITK='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-k', 'test_dcn_x6_matches_fused'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_x6.py'), '8', '5', 'dcn'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'dcn_x6: 8 shapes' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

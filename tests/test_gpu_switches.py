@@ -57,6 +57,8 @@ SWITCHES = [
     ('f32', {'GSSD_DCN_STREAMK': '0'}, lambda o, base: True),
     # the deformable conv on the fp32 matrix cores (csrc/dcn_fused.hip) instead of the three-plane bf16 form (csrc/dcn_x6.hip)
     ('f32', {'GSSD_DCN_X6': '0'}, lambda o, base: any(k.startswith('dcn_fused') for k in o['kernels']) and any(k.startswith('dcn_x6') for k in base['kernels'])),
+    # one workgroup per tile of the three-plane deformable conv (at batch 4 the default splits its K loop in two: csrc/dcn_x6.hip)
+    ('f32', {'GSSD_DCN_X6_SPLITK': '0'}, lambda o, base: has(o, 'dcn_x6')),
     # the fp32-MFMA kernels (conv_igemm / gemm_slot) instead of the three-plane bf16 conv (csrc/conv_x6.hip) on the launches it takes
     ('f32', {'GSSD_CONV_X6': '0'}, lambda o, base: not any(k.startswith('conv_x6') for k in o['kernels']) and any(k.startswith('conv_x6') for k in base['kernels'])),
     ('bf16', {'GSSD_NO_CONV_FLAT': '1'}, lambda o, base: not any(k.startswith('conv_flat_bf16') for k in o['kernels'])
