@@ -487,7 +487,17 @@ template <int BN, bool XF, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc p, const int M, const int ntn, const int mtiles,
                                                            const long long plane_elems) {
     using K = Cfg2<BN>;
-    constexpr int WTM = 64, WTN = K::WTN, MT = K::MT, NT = K::NT, NTH = K::NTH, NG = K::NG, DPW = K::DPW, NY = K::NY, PH = K::PH;
+    // F16: TWO planes travel through LDS and the weight DMA -- h and l6 = (x - h) * 64; h6 = h / 64 is made from h in registers behind the fragment
+    // reads (four packed multiplies per fragment).  Why: at three planes a chunk moves 144 KB through the CU's LDS port (fragment reads 96, plane
+    // writes 24, DMA 24) = 1 125 cycles at 128 B per cycle against 768 cycles of MFMAs; two planes: 96 KB = 750.  The LDS images keep their
+    // three-plane strides; the piece counts of the schedule below follow NPL.  Measured (scripts/bench_conv_x6.py, same box): 64-column tiles
+    // -20 % (conv3_1 241 -> 193 us, conv3_2 396 -> 324); 128-column tiles +2 .. +5 % on 3x3 launches (conv4_2 229 -> 241, the packed multiplies
+    // sit between twice as many MFMAs per fragment read) -- those keep the third plane in LDS.  fp16 plane order in memory: h, l6, h6.
+    constexpr int NPL = (F16 && BN == 64) ? 2 : NP;
+    constexpr int WTM = 64, WTN = K::WTN, MT = K::MT, NT = K::NT, NTH = K::NTH, NG = K::NG;
+    constexpr int PH = NPL * K::HB_ROWS / 16;             // 1-KiB pieces per half: 12 / 6 (F16: 8 / 4)
+    constexpr int DPW = 2 * PH / 4;                       // pieces per wave and iteration: 6 / 3 (4 / 2)
+    constexpr int NY = (PH + 3) / 4;                      // the wave's first NY pieces cover its share of the Y half: 3 / 2 (2 / 1)
     constexpr int HB_PLANE = K::HB_PLANE, HB_ELEMS = K::HB_ELEMS, B_STAGE = BN * BKC;
     extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
     u16* const As = smem_h;                                   // [3][BM][32]
@@ -604,8 +614,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
         if (X6_KO & 32) return;
         u16* Ad = As + a_wr0 + j * 64 * BKC + 4 * hh;
         *reinterpret_cast<u32x2*>(Ad) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(Ad + A_STAGE) = u32x2{m0_, m1};
-        *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = u32x2{l0, l1};
+        if constexpr (F16) {
+            *reinterpret_cast<u32x2*>(Ad + A_STAGE) = u32x2{l0, l1};
+            if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = u32x2{m0_, m1};
+        } else {
+            *reinterpret_cast<u32x2*>(Ad + A_STAGE) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(Ad + 2 * A_STAGE) = u32x2{l0, l1};
+        }
     };
     // piece q (0 .. DPW - 1) of this wave in an iteration: the first PH pieces of the iteration's list are the Y half of chunk cy, the rest the
     // X half of chunk cx; piece = (plane, wave column, column tile inside the half)
@@ -622,8 +637,28 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
     };
 
     bf16x8 areg[MT][NP], breg[2][NP];
+    // F16: LDS planes (h, l6) -> registers [0] and [2]; [1] = h / 64 (exact; where it leaves fp16's normal range the product it enters is below
+    // 2^-24 of the leading one)
+    auto derive = [&](bf16x8& h6, const bf16x8& h) {
+        const f16x8_t sc = {(_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f,
+                            (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f};
+        h6 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8_t, h) * sc);
+    };
     auto a_load_row = [&](int i) {
         const u16* Ab = As + (wm * WTM + i * 16) * BKC + fo;
+        if constexpr (F16) {
+            if (X6_KO & 16) {
+                asm volatile("" : "=v"(areg[i][0]));
+                asm volatile("" : "=v"(areg[i][2]));
+            } else {
+                areg[i][0] = *reinterpret_cast<const bf16x8*>(Ab);
+                areg[i][2] = *reinterpret_cast<const bf16x8*>(Ab + A_STAGE);
+                if constexpr (NPL == 3) areg[i][1] = *reinterpret_cast<const bf16x8*>(Ab + 2 * A_STAGE);
+            }
+            if constexpr (NPL == 2) derive(areg[i][1], areg[i][0]);
+            else if (X6_KO & 16) asm volatile("" : "=v"(areg[i][1]));
+            return;
+        }
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             if (X6_KO & 16) asm volatile("" : "=v"(areg[i][pl]));
@@ -632,6 +667,19 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
     };
     auto b_load = [&](int which, int half, int parity, int jj) {
         const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * NTH * 16 + jj * 16) * BKC + fo;
+        if constexpr (F16) {
+            if (X6_KO & 16) {
+                asm volatile("" : "=v"(breg[which][0]));
+                asm volatile("" : "=v"(breg[which][2]));
+            } else {
+                breg[which][0] = *reinterpret_cast<const bf16x8*>(Bb);
+                breg[which][2] = *reinterpret_cast<const bf16x8*>(Bb + HB_PLANE);
+                if constexpr (NPL == 3) breg[which][1] = *reinterpret_cast<const bf16x8*>(Bb + 2 * HB_PLANE);
+            }
+            if constexpr (NPL == 2) derive(breg[which][1], breg[which][0]);
+            else if (X6_KO & 16) asm volatile("" : "=v"(breg[which][1]));
+            return;
+        }
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             if (X6_KO & 16) asm volatile("" : "=v"(breg[which][pl]));
@@ -723,15 +771,17 @@ __global__ __launch_bounds__(256, 2) void conv_x6_v2_kernel(const gssd_conv_desc
                     mma_row(i, NTH + jj, jj & 1);
                     if (!LAST) {
                         if (NTH == 2) {
-                            if (gidx < 3) dma_piece(gidx, cy, cx, par);
+                            if (gidx < NY) dma_piece(gidx, cy, cx, par);
                             if (gidx < 4) load_req(gidx);
-                            if (gidx >= 4 && gidx < 7) dma_piece(gidx - 1, cy, cx, par);
+                            if (gidx >= 4 && gidx < 4 + DPW - NY) dma_piece(gidx - 4 + NY, cy, cx, par);
                         } else {
-                            if (gidx < 3) dma_piece(gidx, cy, cx, par);
+                            // (the pieces behind the wave's Y share follow the loads of their group: B2's count leaves exactly them in flight)
+                            if (gidx < NY) dma_piece(gidx, cy, cx, par);
                             if (gidx < 2) {
                                 load_req(2 * gidx);
                                 load_req(2 * gidx + 1);
                             }
+                            if (gidx >= NY && gidx < DPW) dma_piece(gidx, cy, cx, par);
                         }
                         if (jj + 1 == NTH) a_load_row(i);    // chunk it's planes, in place behind the row's last use
                     }
@@ -920,11 +970,11 @@ __global__ void conv_x6_pack_kernel(const float* __restrict__ w, u16* __restrict
         wp[i] = __builtin_bit_cast(u16, h);
         wp[i + total] = __builtin_bit_cast(u16, m);
         wp[i + 2 * total] = __builtin_bit_cast(u16, l);
-        // behind the bf16 planes: the three fp16 planes of the three-MFMA form (h, h / 64, (v - h) * 64)
+        // behind the bf16 planes: the fp16 planes of the three-MFMA form -- h, (v - h) * 64, h / 64 (64-column tiles make the last one in registers)
         const _Float16 fh = (_Float16)v;
         wp[i + 3 * total] = __builtin_bit_cast(u16, fh);
-        wp[i + 4 * total] = __builtin_bit_cast(u16, (_Float16)(fh * (_Float16)0.015625f));
-        wp[i + 5 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
+        wp[i + 4 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
+        wp[i + 5 * total] = __builtin_bit_cast(u16, (_Float16)(fh * (_Float16)0.015625f));
     }
 }
 

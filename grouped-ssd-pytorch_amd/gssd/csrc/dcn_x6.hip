@@ -110,7 +110,6 @@ constexpr int NTH = NT / 2, NG = NTH * MT;
 constexpr int TAB_N = 9 * BM;
 constexpr int LDS_BYTES = (NP * A_STAGE + 4 * HB_ELEMS) * 2 + TAB_N * 16 + TAB_N * 4;
 constexpr int TPT = (TAB_N + LTHREADS - 1) / LTHREADS;
-constexpr int DPH = 24 / LW;                          // DMA pieces per loader wave and half
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(MT == 4 && (NT == 4 || NT == 8) && BN == 256, "written for 128 x 256 tiles, eight or four matrix waves");
 #ifdef X6_TIMING
@@ -311,6 +310,9 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
             }
         };
         // blend + split of the thread's 16 column values into packed plane dwords (registers); written behind the barrier
+        // (F16: two planes travel through LDS -- h and l6; the matrix waves make h6 = h / 64 from h in registers: a third fewer plane writes, fragment
+        // reads and weight DMA pieces on a launch bound by its memory side)
+        constexpr int NPL = F16 ? 2 : NP;                    // planes in LDS / in the packed weights
         u32x2 pln[2][2][NP];                                 // [cell][channel half][plane]
         auto blend_all = [&]() {
             if (X6_KO & 1) return;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
                         split3_pair(ve[2], ve[3], h1, m1, l1);
                     }
                     pln[j][hh][0] = u32x2{h0, h1};
-                    pln[j][hh][1] = u32x2{m0_, m1};
+                    pln[j][hh][1] = F16 ? u32x2{l0, l1} : u32x2{m0_, m1};
                     pln[j][hh][2] = u32x2{l0, l1};
                 }
         };
@@ -343,10 +345,11 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         *reinterpret_cast<u32x2*>(As + pl * A_STAGE + a_wr0 + j * 64 * BKC + 4 * hh) = pln[j][hh][pl];
         };
-        // weight planes of (chunk, half) -> half buffer (half, parity): 24 1-KiB pieces (plane, wave column, j & 1), six per loader wave
+        // weight planes of (chunk, half) -> half buffer (half, parity): 24 (F16: 16) 1-KiB pieces (plane, wave column, j & 1), six (four) per loader wave
+        constexpr int DPH = 8 * NPL / LW;
         auto dma_half = [&](int chunk, int half, int parity) {
             if (X6_KO & 4) return;
             u16* dst = Bh + (half * 2 + parity) * HB_ELEMS;
@@ -436,8 +439,26 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = zero4;
         bf16x8 areg[MT][NP], breg[2][NP];
+        // F16: LDS planes (h, l6) -> registers [0] and [2]; [1] = h / 64 (exact: a power of two; below fp16's normal range the product it enters
+        // is below 2^-24 of the leading one anyway)
+        auto derive = [&](bf16x8& h6, const bf16x8& h) {
+            const f16x8_t s = {(_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f,
+                               (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f, (_Float16)0.015625f};
+            h6 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8_t, h) * s);
+        };
         auto a_load_row = [&](int i) {
             const u16* Ab = As + (wm * WTM + i * 16) * BKC + fo;
+            if constexpr (F16) {
+                if (X6_KO & 16) {
+                    asm volatile("" : "=v"(areg[i][0]));
+                    asm volatile("" : "=v"(areg[i][2]));
+                } else {
+                    areg[i][0] = *reinterpret_cast<const bf16x8*>(Ab);
+                    areg[i][2] = *reinterpret_cast<const bf16x8*>(Ab + A_STAGE);
+                }
+                derive(areg[i][1], areg[i][0]);
+                return;
+            }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 if (X6_KO & 16) asm volatile("" : "=v"(areg[i][pl]));
@@ -446,6 +467,17 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
         };
         auto b_load = [&](int which, int half, int parity, int jj) {
             const u16* Bb = Bh + (half * 2 + parity) * HB_ELEMS + (wn * NTH * 16 + jj * 16) * BKC + fo;
+            if constexpr (F16) {
+                if (X6_KO & 16) {
+                    asm volatile("" : "=v"(breg[which][0]));
+                    asm volatile("" : "=v"(breg[which][2]));
+                } else {
+                    breg[which][0] = *reinterpret_cast<const bf16x8*>(Bb);
+                    breg[which][2] = *reinterpret_cast<const bf16x8*>(Bb + HB_PLANE);
+                }
+                derive(breg[which][1], breg[which][0]);
+                return;
+            }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 if (X6_KO & 16) asm volatile("" : "=v"(breg[which][pl]));
@@ -580,8 +612,7 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
         if (f16) {                 // the three fp16 planes of the three-MFMA form: h, h / 64, (v - h) * 64
             const _Float16 fh = (_Float16)v;
             wp[i] = __builtin_bit_cast(u16, fh);
-            wp[i + total] = __builtin_bit_cast(u16, (_Float16)(fh * (_Float16)0.015625f));
-            wp[i + 2 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
+            wp[i + total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));       // (h / 64 is made in registers)
             continue;
         }
         __bf16 h, m, l;

@@ -4,6 +4,7 @@ allocator / stream owner here; every computation happens in the HIP kernels.  No
 a non-CUDA tensor raises."""
 import ctypes as C
 
+import os
 import torch
 
 from . import _lib
@@ -213,11 +214,19 @@ def x6_tile(cout_g, groups, M):
     return int(lib.gssd_conv_x6_tile(cout_g, groups, M))
 
 
-def x6_wanted(k, cin_g, cout_g, groups, M, winograd=False):
-    """Launches the engine hands to csrc/conv_x6.hip (fp32 mode): not the Winograd shapes (the same speed there), at least 128 output
-    channels per group and 256 k, M = B Ho Wo >= 4096 (19 x 19 maps at batch 32, 38 x 38 at batch 4) -- measured with scripts/bench_conv_x6.py: conv6 306 -> 174 us,
-    conv7 84 -> 56, the fuse convs 208 -> 166, the Self_Attn output convs 143-175 -> ~90."""
-    return (not winograd) and cin_g % 32 == 0 and cout_g >= 128 and cout_g % 8 == 0 and k * k * cin_g >= 256 and M >= 4096
+X6_F16 = os.environ.get('GSSD_X6_F16', '1') != '0'        # csrc/conv_x6.hip & co.: forward launches on fp16 planes, three MFMAs per product
+
+
+def x6_wanted(k, cin_g, cout_g, groups, M, winograd=False, forward=False):
+    """Launches the engine hands to csrc/conv_x6.hip (fp32 mode): at least 128 output channels per group and 256 k, M = B Ho Wo >= 4096 (19 x 19
+    maps at batch 32, 38 x 38 at batch 4) -- measured with scripts/bench_conv_x6.py: conv6 306 -> 174 us, conv7 84 -> 56, the fuse convs
+    208 -> 166, the Self_Attn output convs 143-175 -> ~90.  Not the Winograd shapes (the same speed there with bf16 planes; the large ones belong to
+    csrc/conv_wino_x6.hip) -- except, round 6, FORWARD launches on maps too small for conv_wino_x6 (conv5_x at batch 32, M = 11 552): the fp16-plane
+    form runs them in 76 us against fp32 Winograd's 100 (their data gradients: 97 against 101, left where they were)."""
+    ok = cin_g % 32 == 0 and cout_g >= 128 and cout_g % 8 == 0 and k * k * cin_g >= 256 and M >= 4096
+    if winograd:
+        return ok and forward and X6_F16 and M < 16384
+    return ok
 
 
 def x6_weight(w_packed, groups, cin_g, taps, bn, out=None):

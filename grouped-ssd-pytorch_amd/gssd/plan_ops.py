@@ -117,7 +117,7 @@ class PlanOpsMixin:
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
         X6 = None
-        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None):
+        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None, forward=True):
             def build_x6(out, key=name + '.w', groups=groups, cin_g=cin_g, taps=k * k, bn=ops.x6_tile(Cout // groups, groups, B * Ho * Ho)):
                 return ops.x6_weight(self.eng._packed[key], groups, cin_g, taps, bn, out)
             X6 = self.eng._pack(name + f'.x6@{ops.x6_tile(Cout // groups, groups, B * Ho * Ho)}', build_x6)       # the tile is part of the packed layout: part of the key       # (after '.w' as well)
