@@ -83,13 +83,16 @@ def test_conv_x6_host_rules():
     from gssd import _lib, ops
     lib = _lib.lib
     assert [lib.gssd_conv_x6_tile(c, 4, 46208) for c in (32, 64, 96, 128, 216, 256, 1024)] == [64, 64, 128, 128, 128, 128, 128]
-    # 3 planes x groups x ceil(cout_g / tile) x tile x taps x cin_g bf16 elements; -1 for shapes the kernel does not take
-    assert lib.gssd_conv_x6_weight_elems(1024, 4, 128, 9, 128) == 3 * 4 * 2 * 128 * 9 * 128
-    assert lib.gssd_conv_x6_weight_elems(216, 1, 512, 9, 128) == 3 * 1 * 2 * 128 * 9 * 512          # 216 -> two 128-column tiles, zero rows
+    # (3 bf16 + 3 fp16 planes, round 6) x groups x ceil(cout_g / tile) x tile x taps x cin_g 16-bit elements; -1 for shapes the kernel does not take
+    assert lib.gssd_conv_x6_weight_elems(1024, 4, 128, 9, 128) == 6 * 4 * 2 * 128 * 9 * 128
+    assert lib.gssd_conv_x6_weight_elems(216, 1, 512, 9, 128) == 6 * 1 * 2 * 128 * 9 * 512          # 216 -> two 128-column tiles, zero rows
     assert lib.gssd_conv_x6_weight_elems(512, 1, 48, 1, 128) == -1                                    # cin_g % 32 != 0
     assert lib.gssd_conv_x6_weight_elems(512, 1, 64, 1, 96) == -1                                     # not a tile width
     assert ops.x6_wanted(1, 512, 512, 1, 46208) and ops.x6_wanted(3, 128, 256, 4, 11552)
     assert not ops.x6_wanted(3, 128, 128, 4, 46208, winograd=True) and not ops.x6_wanted(1, 512, 64, 1, 46208) and not ops.x6_wanted(1, 512, 512, 1, 3200)
+    # Winograd shapes: only forward launches on maps too small for conv_wino_x6 (conv5_x at batch 32), and only on the fp16 planes
+    assert ops.x6_wanted(3, 128, 128, 4, 11552, winograd=True, forward=True) == ops.X6_F16
+    assert not ops.x6_wanted(3, 128, 128, 4, 11552, winograd=True) and not ops.x6_wanted(3, 128, 128, 4, 46208, winograd=True, forward=True)
     buf = torch.zeros(64, dtype=torch.float32)             # any 16-byte aligned host address: takes() only inspects the descriptor
 
     def desc(**kw):
