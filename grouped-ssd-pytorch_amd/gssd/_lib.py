@@ -144,6 +144,7 @@ SIGNATURES = {
     'gssd_dcn_packed_weight_elems_x6': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_x6': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_forward_x6': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_dcn_forward_x6_ex': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_packed_weight_elems': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_streamk': (c_i, [c_i]),

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(NT_, 2) void conv_thin_x6_kernel(const ThinX6Params
     // asks next.  A persistent grid with a static share per workgroup assumes that all of it is resident at once -- two workgroups of this kernel
     // fill a CU's register file, so on a CU that is busy with another stream's kernel they start only when that kernel ends, and then still run
     // their whole share: inside the step's hipGraph conv1_2 ran 950 us against 370 us alone, behind the 48 workgroups of the spectral-norm launch
-    // on the side stream (profiles/r06_thin_x6_notes.txt).  Thread 0 claims two tiles ahead; everyone reads the claim behind the barrier that
+    // on the side stream (profiles/r06_thin_x6_notes.txt; the same scheme in conv_thin_bf16.hip, whose tiles take ~8 us, LOST: 137 -> 233 us for
+    // conv1_1 -- 768 workgroups' returning atomics on eight addresses, whatever the tiles per claim; it keeps its static shares).  Thread 0 claims two tiles ahead; everyone reads the claim behind the barrier that
     // ends a tile.  p.ctr == NULL (no counter pool yet under a stream capture): the static share.
     // One counter per (slab, XCD): XCD x (= workgroup id & 7, the dispatch order) claims inside its own eighth of the tile list, so neighbouring
     // tiles -- which share their halo rows / columns -- still meet in one L2 (a single global counter: conv2_2 244 -> 316 us); the other stream's
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(NT_, 2) void conv_thin_x6_kernel(const ThinX6Params
         const int t = t_lo + atomicAdd(ctr, 1);
         return t < t_hi ? t : ntiles;
     };
-    if (tid == 0) {                                      // the first two tiles
+    if (tid == 0) {                                      // the first two tiles (a static first tile -- no atomic in front of the first loads -- measured the same)
         s_next[0] = claim(wg0);
         s_next[1] = claim(wg0 + nwg);
     }
@@ -586,13 +587,11 @@ int launch_thin_x6_impl(const gssd_conv_desc& d, hipStream_t stream) {
     return GSSD_OK;
 }
 
-// the two-plane fp16 form for launches whose input is a BatchNorm + ReLU output (fused producer transform, or GSSD_CONV_F16_OK); GSSD_X6_F16=0: bf16 planes everywhere
+// the two-plane fp16 form for launches the caller flags GSSD_CONV_F16_OK (operands inside fp16's range; never inferred from the descriptor); GSSD_X6_F16=0: bf16 planes everywhere
 template <int CIN_G, int COUT_G, bool XF, bool POOL>
 int launch_thin_x6(const gssd_conv_desc& d, hipStream_t stream) {
     static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
-    // (flagged plain launches too: a training forward reads the materialised activation map where the no-backward forward applies the transform on
-    // read -- the same form in both keeps the two plans' arithmetic identical)
-    if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, true>(d, stream);
+    if (!f16_off && (d.flags & GSSD_CONV_F16_OK)) return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, true>(d, stream);
     return launch_thin_x6_impl<CIN_G, COUT_G, XF, POOL, false>(d, stream);
 }
 

@@ -723,12 +723,12 @@ int launch_wino_x6_impl(const gssd_conv_desc& d, const u16* Ux, hipStream_t stre
     return GSSD_OK;
 }
 
-// the two-plane fp16 form: forward launches behind a fused BatchNorm + ReLU, or marked GSSD_CONV_F16_OK by the caller; never a data gradient (EPI 1)
+// the two-plane fp16 form: launches marked GSSD_CONV_F16_OK by the caller (operands inside fp16's range; never inferred); never a data gradient (EPI 1)
 template <int NBT, bool XF, int EPI, bool PSEL>
 int launch_wino_x6_sel(const gssd_conv_desc& d, const u16* Ux, hipStream_t stream) {
     static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
     if constexpr (EPI != 1) {
-        if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) {
+        if (!f16_off && (d.flags & GSSD_CONV_F16_OK)) {
             const int cout_g = d.Cout / d.groups;
             const long long nb = cout_g > 32 ? 64 : 32, ncb = (cout_g + nb - 1) / nb, nchunks = (d.cin_g + 31) / 32;
             return launch_wino_x6_impl<NBT, XF, EPI, PSEL, true>(d, Ux + (long long)d.groups * ncb * nchunks * 16 * NP * nb * 32, stream);

@@ -71,7 +71,7 @@ __device__ __forceinline__ void split3_pair(const float a, const float b, unsign
     pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
 }
 
-// Round 6, the three-MFMA form for FORWARD launches on bounded activations (a fused producer BatchNorm + ReLU, or GSSD_CONV_F16_OK set by the
+// Round 6, the three-MFMA form for FORWARD launches on bounded activations (GSSD_CONV_F16_OK set by the
 // caller): three fp16 planes per operand -- h = fp16(x), h6 = h / 64, l6 = fp16((x - h) * 64), x = h + l6 / 64 to 2^-24 |x| -- and the products
 // h h' + l6 h6' + h6 l6' (dcn_x6.hip).  Same planes, LDS images and DMA pieces as the bf16 form, half the matrix instructions.  The packed weights
 // hold both forms (the bf16 planes, then the fp16 planes); data gradients keep the bf16 planes.  GSSD_X6_F16=0: bf16 everywhere.
@@ -1017,11 +1017,11 @@ int launch2_impl(const gssd_conv_desc& d, int M, hipStream_t stream) {
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
-// the three-MFMA fp16 form: forward launches on bounded activations only (never a data gradient: no flag, no fused producer transform)
+// the three-MFMA fp16 form: only launches the CALLER flags GSSD_CONV_F16_OK (operands inside fp16's range: include/gssd_hip.h) -- never inferred
 template <int BN, bool XF>
 int launch2(const gssd_conv_desc& d, int M, hipStream_t stream) {
     static const bool f16_off = [] { const char* e = getenv("GSSD_X6_F16"); return e && e[0] == '0'; }();
-    if (!f16_off && (XF || (d.flags & GSSD_CONV_F16_OK))) return launch2_impl<BN, XF, true>(d, M, stream);
+    if (!f16_off && (d.flags & GSSD_CONV_F16_OK)) return launch2_impl<BN, XF, true>(d, M, stream);
     return launch2_impl<BN, XF, false>(d, M, stream);
 }
 #endif

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(THREADS, 1) void dcn_x6_kernel(const float* __restr
     const int HW = H * W, cpg = C / dg, cpc = cpg / BKC;
     const int d0 = kz * (dg / ksplit);                           // this workgroup's deformable groups: d0 .. d0 + dg / ksplit - 1
     const int nchunks = (dg / ksplit) * cpc * 9;
-    const u16* wslab = wp + ((size_t)nt * dg + d0) * cpc * 9 * B_STAGE;      // plane 0; plane p at + p * plane_elems
+    const u16* wslab = wp + (F16 ? 3 * plane_elems : 0) + ((size_t)nt * dg + d0) * cpc * 9 * B_STAGE;      // plane 0; plane p at + p * plane_elems (the fp16 planes lie behind the bf16 planes)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #ifdef X6_TIMING
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memrealtime();
@@ -609,11 +609,10 @@ __global__ void dcn_pack_weight_x6_kernel(const float* __restrict__ w, u16* __re
         const int c = cc * BKC + q * 8 + e;
         const int n = nt * BN + chan_of_row(row);
         const float v = n < Cout ? w[((size_t)n * C + c) * 9 + tap] : 0.f;
-        if (f16) {                 // the three fp16 planes of the three-MFMA form: h, h / 64, (v - h) * 64
+        if (f16) {                 // behind the three bf16 planes: the two fp16 planes of the three-MFMA form, h and (v - h) * 64 (h / 64 is made in registers)
             const _Float16 fh = (_Float16)v;
-            wp[i] = __builtin_bit_cast(u16, fh);
-            wp[i + total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));       // (h / 64 is made in registers)
-            continue;
+            wp[i + 3 * total] = __builtin_bit_cast(u16, fh);
+            wp[i + 4 * total] = __builtin_bit_cast(u16, (_Float16)((v - (float)fh) * 64.f));
         }
         __bf16 h, m, l;
         split3(v, h, m, l);
@@ -640,22 +639,25 @@ static bool dcn_x6_f16() {
     return on;
 }
 
-extern "C" long long gssd_dcn_packed_weight_elems_x6(int Cout, int C) {          // bf16 elements (three planes)
+extern "C" long long gssd_dcn_packed_weight_elems_x6(int Cout, int C) {          // 16-bit elements: three bf16 planes, then two fp16 planes
     if (Cout <= 0 || C <= 0 || C % BKC != 0) return -1;
-    return 3ll * ((Cout + BN - 1) / BN) * BN * 9 * C;
+    return 5ll * ((Cout + BN - 1) / BN) * BN * 9 * C;
 }
 
 extern "C" int gssd_dcn_pack_weight_x6(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream) {
     GSSD_CHECK_ARG(w_oihw && w_packed && Cout > 0 && C > 0 && dg > 0 && C % dg == 0 && (C / dg) % BKC == 0);
-    const long long total = gssd_dcn_packed_weight_elems_x6(Cout, C) / 3;
+    const long long total = gssd_dcn_packed_weight_elems_x6(Cout, C) / 5;
     hipLaunchKernelGGL(dcn_pack_weight_x6_kernel, dim3((int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), w_oihw, reinterpret_cast<u16*>(w_packed), Cout, C, dg, total, dcn_x6_f16() ? 1 : 0);
+                       as_stream(stream), w_oihw, reinterpret_cast<u16*>(w_packed), Cout, C, dg, total, 1);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
 }
 
-extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H,
-                                   int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream) {
+// flags & GSSD_CONV_F16_OK: x, the blended samples and the weights lie inside fp16's range (|v| < 65 504; full precision from 4e-3 up) -- the
+// caller's promise, e.g. activations behind a train-mode BatchNorm: three fp16 MFMAs per product instead of six bf16 ones.  Never inferred.
+extern "C" int gssd_dcn_forward_x6_ex(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H,
+                                      int W, int C, int dg, int om_stride, int Cout, int flags, gssd_stream_t stream) {
+    const bool f16 = dcn_x6_f16() && (flags & GSSD_CONV_F16_OK);
     GSSD_CHECK_ARG(x && om && w_packed && out && B > 0 && H > 0 && W > 0 && C > 0 && dg > 0 && Cout > 0 && Cout % 8 == 0);
     GSSD_CHECK_ARG(C % dg == 0 && (C / dg) % BKC == 0 && om_stride >= 27 * dg);
     GSSD_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)out % 16) == 0);
@@ -680,8 +682,8 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
             return GSSD_ELAUNCH;
         }
     }
-    const auto kernel = ksplit == 2 ? (dcn_x6_f16() ? dcn_x6_kernel<true, 2> : dcn_x6_kernel<false, 2>) : (dcn_x6_f16() ? dcn_x6_kernel<true, 1> : dcn_x6_kernel<false, 1>);
-    const int ai = (dcn_x6_f16() ? 1 : 0) + 2 * (ksplit - 1);
+    const auto kernel = ksplit == 2 ? (f16 ? dcn_x6_kernel<true, 2> : dcn_x6_kernel<false, 2>) : (f16 ? dcn_x6_kernel<true, 1> : dcn_x6_kernel<false, 1>);
+    const int ai = (f16 ? 1 : 0) + 2 * (ksplit - 1);
     if (gssd_attr_needed(&attr_mask[ai])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
@@ -700,7 +702,12 @@ extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* 
         blocks = ((mtiles * ntn + 7) / 8) * 8;
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NTHREADS), LDS_BYTES, as_stream(stream), x, om, reinterpret_cast<const u16*>(w_packed), bias,
-                       out, M, H, W, C, dg, om_stride, Cout, ntn, mtiles, gssd_dcn_packed_weight_elems_x6(Cout, C) / 3);
+                       out, M, H, W, C, dg, om_stride, Cout, ntn, mtiles, gssd_dcn_packed_weight_elems_x6(Cout, C) / 5);
     GSSD_CHECK_LAUNCH();
     return GSSD_OK;
+}
+
+extern "C" int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H,
+                                   int W, int C, int dg, int om_stride, int Cout, gssd_stream_t stream) {
+    return gssd_dcn_forward_x6_ex(x, om, w_packed, bias, out, B, H, W, C, dg, om_stride, Cout, 0, stream);
 }

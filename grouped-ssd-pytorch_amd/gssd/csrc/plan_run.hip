@@ -114,6 +114,7 @@ const PlanFn g_plan_fns[] = {
     GSSD_PLAN_FN(gssd_dcn_streamk_reset),
     GSSD_PLAN_FN(gssd_dcn_pack_weight_x6),
     GSSD_PLAN_FN(gssd_dcn_forward_x6),
+    GSSD_PLAN_FN(gssd_dcn_forward_x6_ex),
     GSSD_PLAN_FN(gssd_dcn_pack_weight_bf16),
     GSSD_PLAN_FN(gssd_dcn_forward_bf16),
     GSSD_PLAN_FN(gssd_dcn_col2im_f32),

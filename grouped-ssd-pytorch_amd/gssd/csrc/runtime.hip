@@ -12,7 +12,7 @@ void gssd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int gssd_abi_version(void) { return 7; }
+extern "C" int gssd_abi_version(void) { return 8; }
 extern "C" int gssd_conv_desc_size(void) { return (int)sizeof(gssd_conv_desc); }
 extern "C" const char* gssd_last_error(void) { return g_err; }
 extern "C" const char* gssd_build_arch(void) { return "gfx950"; }

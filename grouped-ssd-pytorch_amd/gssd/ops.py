@@ -399,8 +399,9 @@ def dcn_forward(x, om, w_oihw, bias, dg, w_packed=None):
     return out
 
 
-def dcn_forward_x6(x, om, w_oihw, bias, dg):
-    """The same op through csrc/dcn_x6.hip (fp32 in / out, three-plane bf16 split on the bf16 matrix cores)."""
+def dcn_forward_x6(x, om, w_oihw, bias, dg, f16ok=False):
+    """The same op through csrc/dcn_x6.hip (fp32 in / out, three-plane bf16 split on the bf16 matrix cores; ``f16ok``: the caller's promise that x
+    and the weights lie inside fp16's range -- GSSD_CONV_F16_OK -- fp16 planes, three MFMAs per product)."""
     _need_cuda(x, om, w_oihw)
     B, H, W, Cc = x.shape
     w = w_oihw.detach().contiguous().float()
@@ -411,7 +412,8 @@ def dcn_forward_x6(x, om, w_oihw, bias, dg):
     wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
     check(lib.gssd_dcn_pack_weight_x6(_p(w), _p(wp), Cout, Cc, dg, _stream()))
     out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
-    check(lib.gssd_dcn_forward_x6(_p(x), _p(om), _p(wp), _p(bias), _p(out), B, H, W, Cc, dg, om.shape[-1], Cout, _stream()))
+    check(lib.gssd_dcn_forward_x6_ex(_p(x), _p(om), _p(wp), _p(bias), _p(out), B, H, W, Cc, dg, om.shape[-1], Cout,
+                                     _lib.CONV_F16_OK if f16ok else 0, _stream()))
     return out
 
 

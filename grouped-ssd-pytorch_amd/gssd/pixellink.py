@@ -30,6 +30,10 @@ class PixelLinkEngine(GssdEngine):
 
 
 class _PlanPixelLink(_Plan):
+    # PixelLink++'s VGG trunk is conv + ReLU without BatchNorm (model.py:40-77): nothing bounds its activation maps, so its launches never carry
+    # GSSD_CONV_F16_OK (the split-operand kernels keep their bf16 planes)
+    f16_ok = 0
+
     def backward_plan(self):
         if self._bwd is None:
             from .backward import PixelLinkBackwardPlan

@@ -10,6 +10,14 @@ from .plan_common import DCN_X6, HEAD_OFF, MBOX, SN_STREAM, USE_CONV_X6, USE_FLA
 
 
 class PlanOpsMixin:
+    @property
+    def f16_ok(self):
+        """_lib.CONV_F16_OK for the forward launches of an fp32-mode, TRAIN-mode network, else 0: train-mode BatchNorm (batch statistics) bounds every
+        activation map by |gamma| sqrt(n) + |beta|, far inside fp16's range, so the split-operand kernels may use their fp16 planes (three MFMAs per
+        product).  Eval mode normalises with running statistics, which bound nothing (tests/test_gpu_pixellink.py's synthetic eval graph reaches
+        1e12): those launches keep the bf16 planes (include/gssd_hip.h: GSSD_CONV_F16_OK)."""
+        return _lib.CONV_F16_OK if (not getattr(self, 'bf16', False) and getattr(self, 'training', False)) else 0
+
     def _conv_act(self, name, conv, x, H, Cin, groups):
         """(grouped) conv + bias + ReLU in ONE launch (ReLU in the conv epilogue): the batch_norm=False layers."""
         B = self.B
@@ -117,7 +125,7 @@ class PlanOpsMixin:
             U = self.eng._pack(name + '.U', build_u)          # registered after '.w', so refreshed after it
         Ho = (H + 2 * p - dl * (k - 1) - 1) // s + 1
         X6 = None
-        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None, forward=True):
+        if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(k, cin_g, Cout // groups, groups, B * Ho * Ho, winograd=U is not None, forward=bool(self.f16_ok)):
             def build_x6(out, key=name + '.w', groups=groups, cin_g=cin_g, taps=k * k, bn=ops.x6_tile(Cout // groups, groups, B * Ho * Ho)):
                 return ops.x6_weight(self.eng._packed[key], groups, cin_g, taps, bn, out)
             X6 = self.eng._pack(name + f'.x6@{ops.x6_tile(Cout // groups, groups, B * Ho * Ho)}', build_x6)       # the tile is part of the packed layout: part of the key       # (after '.w' as well)
@@ -140,7 +148,7 @@ class PlanOpsMixin:
                                          stride=s, pad=p, dil=dl, bias=conv.bias.detach(), wgt_wino=U,
                                          stats=st if self.training else None,
                                          in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
-                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2 | (0 if self.bf16 else _lib.CONV_F16_OK), pool_sign=bn.weight.detach(), stats_rep=srep)
+                                         in_pad=in_xf[2] if in_xf else None, flags=_lib.CONV_POOL2 | self.f16_ok, pool_sign=bn.weight.detach(), stats_rep=srep)
             self._add(self.conv_fn, (C.byref(d),), keep=d)
             sc, sh = self._buf(Cout), self._buf(Cout)
             self._add(lib.gssd_bn_finalize_bf16 if self.bf16 else lib.gssd_bn_finalize_f32,
@@ -158,7 +166,7 @@ class PlanOpsMixin:
                                      stats=st if self.training else None,
                                      in_scale=in_xf[0] if in_xf else None, in_shift=in_xf[1] if in_xf else None,
                                      in_pad=in_xf[2] if in_xf else None, stats_rep=srep,
-                                     flags=0 if self.bf16 else _lib.CONV_F16_OK)      # fp32 mode, forward launches on activation maps: the x6 kernels' fp16 planes
+                                     flags=self.f16_ok)      # fp32 mode, train-mode network: forward launches on activation maps may use the x6 kernels' fp16 planes
         self._add(self.conv_fn, (C.byref(d),), keep=d)
         rec = dict(name=name, conv=conv, bn=bn, x_in=x, in_xf=in_xf, H=H, Cin=Cin, groups=groups, raw=raw, Ho=Ho, Cout=Cout,
                    desc=d, stats=st, stats_rep=srep, pool=pool, relu=relu, k=k, stride=s, pad=p, dil=dl)
@@ -265,14 +273,14 @@ class PlanOpsMixin:
         d1, _, _ = mk(x, w_tpg, tp, B=B, H=H, W=H, in_stride=Cc, cin_g=Cc, Cout=C4 + C2, bias=b_tpg, alpha=a_tpg, wgt_x6=x6_tpg,
                       out_mode=_lib.OUT_SPLIT_T, out_b=gT, split_n=C4, out_stride=C4, out_b_stride=Np, m_per_image=not flat,
                       in_batch_stride=N * Cc, out_batch_stride=N * C4, outb_batch_stride=C2 * Np,
-                      flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else _lib.CONV_F16_OK))      # (fp32 mode: x is an activation map)
+                      flags=_lib.CONV_OUT_F32 | (_lib.CONV_OUTB_BF16_PERM32 if self.bf16 else self.f16_ok))
         x6_o = None
         if not self.bf16 and USE_CONV_X6 and ops.x6_wanted(1, C2, Cc, 1, B * N):
             def build_x6o(out, bn=ops.x6_tile(Cc, 1, B * N)):
                 return ops.x6_weight(sa.snconv1x1_attn.weight_orig.detach().view(Cc, C2), 1, C2, 1, bn, out)
             x6_o = eng._pack(name + f'.o.x6@{ops.x6_tile(Cc, 1, B * N)}', build_x6o)
         d5, _, _ = mk(ag, w_o, out, B=B, H=H, W=H, in_stride=C2, cin_g=C2, Cout=Cc, bias=sa.snconv1x1_attn.bias.detach(),
-                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2, wgt_x6=x6_o, flags=0 if self.bf16 else _lib.CONV_F16_OK)
+                      alpha=a_o, gate=sa.sigma.detach(), resid=x, out2=out2, wgt_x6=x6_o, flags=self.f16_ok)
         fn = self.conv_fn
         if C4 % 64 == 0:
             self._add(fn, (C.byref(d1),), keep=(d1, w_tpg, b_tpg))
@@ -368,12 +376,13 @@ class PlanOpsMixin:
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1, out_stride=OMC,
                                       bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om,
-                                      flags=_lib.CONV_OUT_F32 | (0 if self.bf16 else _lib.CONV_F16_OK))      # (fp32 mode: x is a bounded activation map)
+                                      flags=_lib.CONV_OUT_F32 | self.f16_ok)
         self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H
         esz = 2.0 if self.bf16 else 4.0
-        self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_x6 if DCN_X6 else lib.gssd_dcn_forward_f32,
-                  (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout),
+        self._add(lib.gssd_dcn_forward_bf16 if self.bf16 else lib.gssd_dcn_forward_x6_ex if DCN_X6 else lib.gssd_dcn_forward_f32,
+                  (x.data_ptr(), om.data_ptr(), w_main.data_ptr(), m.bias.data_ptr(), out.data_ptr(), B, H, H, Cin, dg, OMC, Cout) +
+                  ((self.f16_ok,) if DCN_X6 and not self.bf16 else ()),
                   keep=w_main, tag=('dcn_bf16<128x256>' if self.bf16 else 'dcn_x6<128x256>' if DCN_X6 else 'dcn_fused<128x256>', 2.0 * M * Cout * 9 * Cin,
                                     esz * (M * (Cin + Cout) + Cout * 9 * Cin) + 4.0 * M * 27 * dg))
         if not self.bf16 and not DCN_X6:

@@ -182,9 +182,13 @@ int gssd_conv_x6_takes(const gssd_conv_desc* d);
 /* bf16 entry point: `resid` is an fp32 map of the OUTPUT's geometry (with GSSD_CONV_OUT_F32: the backward of the bf16 storage mode
  * accumulates a data gradient computed on the bf16 matrix cores into an fp32 gradient map).  Default: `resid` has the input's type (bf16). */
 #define GSSD_CONV_RESID_F32 16
-/* fp32 mode: the launch's input is a bounded activation map (a BatchNorm + ReLU output, or maps built from such): the three-plane kernels may run
- * their two-plane fp16 form (three MFMAs per product; x = h + l' / 2048 to 2^-24) -- csrc/conv_wino_x6.hip, csrc/conv_thin_x6.hip.  Never set on a
- * data-gradient launch: fp16 has no exponent range for gradients.  Launches with a fused producer BatchNorm + ReLU take the form without it. */
+/* fp32 mode, the CALLER's promise: every operand of this launch -- the input map (after the fused producer BatchNorm + ReLU, if any) and the
+ * weights -- lies inside fp16's range (|v| < 65 504; full precision for 4e-3 <= |v|, below that the absolute error stays under 5e-10).  The
+ * split-operand kernels (csrc/conv_x6.hip, conv_wino_x6.hip, conv_thin_x6.hip, dcn_x6.hip) then split into fp16 planes and issue three MFMAs per
+ * product instead of six (x = h + l / 2^k to 2^-24 |x|).  It is NEVER inferred from the descriptor: a value beyond the range becomes inf.  The
+ * engine sets it on forward launches of a train-mode network (batch-statistics BatchNorm bounds |y| by |gamma| sqrt(n) + |beta|), never in eval
+ * mode (running statistics bound nothing) and never on a data-gradient launch (fp16 has no exponent range for gradients).  GSSD_X6_F16=0 (environment)
+ * ignores it. */
 #define GSSD_CONV_F16_OK 32
 int gssd_conv2d_nhwc_bf16(const gssd_conv_desc* d, gssd_stream_t stream);
 /* OIHW fp32 -> packed bf16 rows [Cout][Kpad] (cin_g_pad, Kpad multiples of 8); fp32 -> bf16 array cast (round to nearest even) */
@@ -448,6 +452,10 @@ long long gssd_dcn_packed_weight_elems_x6(int Cout, int C);
 int gssd_dcn_pack_weight_x6(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
 int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H, int W, int C,
                         int dg, int om_stride, int Cout, gssd_stream_t stream);
+/* the same with `flags`: GSSD_CONV_F16_OK = x, its bilinear samples and the weights lie inside fp16's range (see the flag) -> fp16 planes, three
+ * MFMAs per product (w_packed holds both forms: 3 bf16 + 2 fp16 planes).  Round 6, ABI 8. */
+int gssd_dcn_forward_x6_ex(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H, int W, int C,
+                           int dg, int om_stride, int Cout, int flags, gssd_stream_t stream);
 long long gssd_dcn_packed_weight_elems_bf16(int Cout, int C);
 int gssd_dcn_pack_weight_bf16(const float* w_oihw, void* w_packed, int Cout, int C, int dg, gssd_stream_t stream);
 int gssd_dcn_forward_bf16(const void* x, const float* om, const void* w_packed, const float* bias, void* out, int B, int H, int W,

@@ -5,7 +5,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'grouped-ssd-pytorch_amd'))
 import torch
 import torch.nn.functional as F
-from gssd import ops
+from gssd import ops, _lib
+F16OK = 0 if os.environ.get('F16OK') == '0' else _lib.CONV_F16_OK      # as a train-mode forward flags its launches (F16OK=0: bf16 planes, an eval-mode forward / a data gradient)
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 B = 32
@@ -28,7 +29,7 @@ for name, H, Cin, Cout, g, k, pad, dil in SHAPES:
     for tag, kw in (('default' + ('(wino)' if wino else ''), dict(winograd=wino)), ('x6', dict(x6=True))):
         stats = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)
         keep = []
-        d = ops.conv2d_nhwc(x, w, b, 1, pad, dil, g, stats=stats, in_scale=sc, in_shift=sh, in_pad=pdv, _keep=keep, **kw)
+        d = ops.conv2d_nhwc(x, w, b, 1, pad, dil, g, stats=stats, in_scale=sc, in_shift=sh, in_pad=pdv, _keep=keep, flags=F16OK, **kw)
         out = keep[-1]
         for _ in range(3): ops.run_conv(d)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

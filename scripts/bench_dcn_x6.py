@@ -14,10 +14,11 @@ om = torch.randn(B, H, H, 27 * dg, device=dev) * 0.5
 w = torch.randn(Cout, C, 3, 3, device=dev) * 0.02
 bias = torch.randn(Cout, device=dev)
 ref = ops.dcn_forward(x, om, w, bias, dg)
-got = ops.dcn_forward_x6(x, om, w, bias, dg)
+got = ops.dcn_forward_x6(x, om, w, bias, dg, f16ok=True)
 print('max |x6 - fused| / max|fused| =', float((got - ref).abs().max() / ref.abs().max()), ' L2 rel', float((got - ref).norm() / ref.norm()))
 wp = ops.dcn_pack_weight(w, dg)
-for name, fn in (('dcn_fused (fp32 MFMA)', lambda: ops.dcn_forward(x, om, w, bias, dg, w_packed=wp)), ('dcn_x6 incl. weight split', lambda: ops.dcn_forward_x6(x, om, w, bias, dg))):
+for name, fn in (('dcn_fused (fp32 MFMA)', lambda: ops.dcn_forward(x, om, w, bias, dg, w_packed=wp)), ('dcn_x6 bf16 planes incl. weight split', lambda: ops.dcn_forward_x6(x, om, w, bias, dg)),
+                 ('dcn_x6 fp16 planes (GSSD_CONV_F16_OK) incl. weight split', lambda: ops.dcn_forward_x6(x, om, w, bias, dg, f16ok=True))):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

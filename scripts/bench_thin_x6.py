@@ -25,7 +25,7 @@ for name, H, Cin, Cout, pool in (('conv1_2', 300, 64, 64, True), ('conv2_1', 150
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
     d, _, _ = ops.make_conv_desc(buf[:B * H * H * Cin].view(B, H, H, Cin), wp, out, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin // 4, Cout=Cout, groups=4, k=3, pad=1,
                                  bias=b, stats=stats, wgt_wino=U, in_scale=sc, in_shift=sh, in_pad=buf[B * H * H * Cin:],
-                                 flags=_lib.CONV_POOL2 if pool else 0, pool_sign=torch.ones(Cout, device=dev) if pool else None)
+                                 flags=(_lib.CONV_POOL2 if pool else 0) | (0 if os.environ.get('F16OK') == '0' else _lib.CONV_F16_OK), pool_sign=torch.ones(Cout, device=dev) if pool else None)
     takes = _lib.lib.gssd_conv_thin_x6_takes(C.byref(d))
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):

@@ -22,6 +22,7 @@ for it in range(n_cases if 'dcn' in legs else 0):
     om = torch.from_numpy(rng.normal(0, float(rng.choice([0.3, 1.5, 4.0])), size=(B, H, W, 27 * dg)).astype(np.float32)).to(dev)
     w = torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cc, 3, 3)).astype(np.float32)).to(dev)
     b = torch.from_numpy(rng.normal(size=Cout).astype(np.float32)).to(dev)
+    f16 = bool(rng.random() < 0.5)              # GSSD_CONV_F16_OK: the fp16-plane form (a train-mode forward's) or the bf16 planes
     if H != W:
         # ops.dcn_forward takes square maps only through its convenience wrapper: use the C ABI for both
         from gssd._lib import lib, check
@@ -33,15 +34,16 @@ for it in range(n_cases if 'dcn' in legs else 0):
         ref = torch.full((B, H, W, Cout), float('nan'), device=dev)
         got = torch.full((B, H, W, Cout), float('nan'), device=dev)
         check(lib.gssd_dcn_forward_f32(x.data_ptr(), om.data_ptr(), wp.data_ptr(), b.data_ptr(), ref.data_ptr(), B, H, W, Cc, dg, 27 * dg, Cout, s))
-        check(lib.gssd_dcn_forward_x6(x.data_ptr(), om.data_ptr(), wp6.data_ptr(), b.data_ptr(), got.data_ptr(), B, H, W, Cc, dg, 27 * dg, Cout, s))
+        check(lib.gssd_dcn_forward_x6_ex(x.data_ptr(), om.data_ptr(), wp6.data_ptr(), b.data_ptr(), got.data_ptr(), B, H, W, Cc, dg, 27 * dg, Cout,
+                                         _lib.CONV_F16_OK if f16 else 0, s))
     else:
         ref = ops.dcn_forward(x, om, w, b, dg)
-        got = ops.dcn_forward_x6(x, om, w, b, dg)
+        got = ops.dcn_forward_x6(x, om, w, b, dg, f16ok=f16)
     torch.cuda.synchronize()
     e = float((got - ref).abs().max() / ref.abs().max())
     worst = max(worst, e)
     ok = torch.isfinite(got).all() and e < 2e-5
-    print(f'dcn  B {B} {H}x{W} C {Cc} dg {dg} Cout {Cout}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
+    print(f'dcn  B {B} {H}x{W} C {Cc} dg {dg} Cout {Cout} f16 {f16}: rel {e:.2e}' + ('' if ok else '   <-- FAIL'), flush=True)
     assert ok
 if 'dcn' in legs:
     print(f'dcn_x6: {n_cases} shapes, worst rel {worst:.2e}')

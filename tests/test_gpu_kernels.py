@@ -942,10 +942,12 @@ def test_dcn_streamk_is_placement_independent(dev, ops):
     assert lib.gssd_dcn_streamk_status(None) & ~2 == 0
 
 
-def test_dcn_x6_matches_fused(dev, ops):
-    """csrc/dcn_x6.hip (experiment, GSSD_DCN_X6=1): the fp32 deformable conv with every operand as the exact sum of three bf16 planes and six
-    bf16 MFMAs per product -- fp32-equivalent: it must agree with the fp32-MFMA kernel to fp32 summation-order noise and with the
-    float64 evaluation as well as that kernel does.  Shapes with a ragged last pixel tile and a masked channel tile."""
+@pytest.mark.parametrize('f16ok', [False, True], ids=['bf16_planes', 'fp16_planes'])
+def test_dcn_x6_matches_fused(dev, ops, f16ok):
+    """csrc/dcn_x6.hip: the fp32 deformable conv with every operand as the exact sum of three bf16 planes and six bf16 MFMAs per product --
+    or, flagged GSSD_CONV_F16_OK by the caller (a train-mode forward), of fp16 planes and three MFMAs -- fp32-equivalent: it must agree with the
+    fp32-MFMA kernel to fp32 summation-order noise and with the float64 evaluation as well as that kernel does.  Shapes with a ragged last
+    pixel tile and a masked channel tile."""
     rng = np.random.default_rng(77)
     for (B, Cc, H, dg, Cout) in ((2, 128, 13, 4, 136), (1, 256, 19, 1, 512), (3, 128, 11, 2, 264), (1, 192, 9, 2, 40),
                                   (1, 32, 7, 1, 8)):     # 1, 8, 2, 3, 1 channel blocks per tap; the last: nine chunks in all
@@ -954,7 +956,7 @@ def test_dcn_x6_matches_fused(dev, ops):
         w = torch.from_numpy(rng.normal(0, 0.05, size=(Cout, Cc, 3, 3)).astype(np.float32)).to(dev)
         b = torch.from_numpy(rng.normal(size=Cout).astype(np.float32)).to(dev)
         ref = ops.dcn_forward(x, om, w, b, dg)
-        got = ops.dcn_forward_x6(x, om, w, b, dg)
+        got = ops.dcn_forward_x6(x, om, w, b, dg, f16ok=f16ok)
         o1, o2, m = torch.chunk(nchw(om.cpu()).double(), 3, dim=1)
         r64 = O.dcn_v2_conv(nchw(x.cpu()).double(), torch.cat((o1, o2), 1), torch.sigmoid(m), w.cpu().double(), b.cpu().double(), 1, 1, 1, dg)
         e_x6, e_f = rel(nchw(got), r64), rel(nchw(ref), r64)
@@ -980,11 +982,13 @@ def test_conv_x6_matches_float64(shape):
     b = torch.randn(Cout, generator=gen).to(dev)
     sc, sh = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)
     pdv = -sh / sc - 1.0
-    # plain (bf16 planes, six MFMAs: what data gradients run), plain + GSSD_CONV_F16_OK and the fused input transform (fp16 planes, three MFMAs:
-    # the forward's launches; GSSD_X6_F16=0 -- test_x6_kernels_bf16_planes below -- runs all three on the bf16 planes)
+    # bf16 planes, six MFMAs (eval-mode forwards, every data gradient) and, flagged GSSD_CONV_F16_OK, fp16 planes, three MFMAs (a train-mode
+    # forward's launches) -- each plain and with the fused input transform
     from gssd import _lib
-    for xf, f16ok in ((False, False), (False, True), (True, False)):
-        kw = dict(in_scale=sc, in_shift=sh, in_pad=pdv) if xf else (dict(flags=_lib.CONV_F16_OK) if f16ok else {})
+    for xf, f16ok in ((False, False), (False, True), (True, False), (True, True)):
+        kw = dict(in_scale=sc, in_shift=sh, in_pad=pdv) if xf else {}
+        if f16ok:
+            kw['flags'] = _lib.CONV_F16_OK
         xin = F.relu(x.double() * sc.double() + sh.double()) if xf else x.double()
         ref = F.conv2d(xin.permute(0, 3, 1, 2), w.double(), b.double(), stride, pad, dil, g).permute(0, 2, 3, 1)
         st6 = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)

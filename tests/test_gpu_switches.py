@@ -75,8 +75,9 @@ SWITCHES = [
     # csrc/conv_wino_x6.hip (>= 8 192 Winograd tiles) and conv6 / conv7 / the 19 x 19 dgrads run csrc/conv_x6.hip (M >= 4 096): a whole
     # training step of the batch-32 kernel mix against the same step on the fp32-MFMA kernels
     ('f32', {'GSSD_WINO_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino_x6') and has(base, 'conv_wino_x6<64>') and has(o, 'conv_wino<64>')),
-    # (every shape it can take: conv5_x on the 19 x 19 maps -- 2 400 tiles -- move over from conv_wino.hip<64>)
-    ('f32', {'GSSD_WINO_X6': '2', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino<64>') and has(base, 'conv_wino<64>') and has(o, 'conv_wino_x6<64>')),
+    # (every shape it can take: conv5_x on the 19 x 19 maps -- 2 400 tiles -- move over from conv_wino.hip<64>; with the fp16 planes off, or the
+    # train-mode forward runs them on conv_x6 since round 6)
+    ('f32', {'GSSD_WINO_X6': '2', 'GSSD_X6_F16': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_wino<64>') and has(o, 'conv_wino_x6<64>')),
     ('f32', {'GSSD_CONV_X6': '0', 'BATCH': 24}, lambda o, base: not has(o, 'conv_x6') and has(base, 'conv_x6')),
     ('f32', {'GSSD_DCN_X6': '0', 'BATCH': 24}, lambda o, base: has(o, 'dcn_fused') and has(base, 'dcn_x6')),
     ('f32', {'GSSD_WINO_X6': '0', 'GSSD_CONV_X6': '0', 'GSSD_DCN_X6': '0', 'GSSD_FLASH_X6': '0', 'BATCH': 24},
@@ -84,6 +85,8 @@ SWITCHES = [
     # round 6: conv1_2 / conv2_1 / conv2_2 on the round-5 fp32-MFMA kernels instead of the patch-staged three-plane direct conv (csrc/conv_thin_x6.hip)
     ('f32', {'GSSD_THIN_X6': '0'}, lambda o, base: not has(o, 'conv_thin_x6') and has(base, 'conv_thin_x6<16,16>') and has(base, 'conv_thin_x6<32,32>')
      and has(o, 'conv_thin_wino')),
+    # static tile shares instead of claimed tiles in the persistent thin trunk kernels of the fp32 mode (csrc/conv_thin_x6.hip)
+    ('f32', {'GSSD_TX6_DYNAMIC': '0'}, lambda o, base: has(o, 'conv_thin_x6')),
     # the x6 kernels' forward launches on three bf16 planes / six MFMAs (round 5's form) instead of the fp16 planes / three MFMAs; and the attention
     # core's opt-in fp16 form
     ('f32', {'GSSD_X6_F16': '0', 'BATCH': 24}, lambda o, base: has(o, 'conv_x6') and has(o, 'dcn_x6') and has(o, 'conv_wino_x6')),

@@ -111,6 +111,16 @@ def test_conv_thin_x6_forms_vs_float64(case):
     e = rel(y_xf.cpu(), refx)
     print(f'{case} fused producer BatchNorm + ReLU: {e:.2e}')
     assert e < 1e-6 and stat_err(stats_xf, 0, refx) < 2e-7
+    # ... and as a train-mode forward launches it: flagged GSSD_CONV_F16_OK (fp16 planes); its pooled form = the pooled image of this launch
+    y_xf16 = torch.full((B, H, W, Cout), float('nan'), device=dev)
+    stats_xf16 = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    launch(y_xf16, stats=stats_xf16, flags=_lib.CONV_F16_OK, **xf)
+    e = rel(y_xf16.cpu(), refx)
+    print(f'{case} fused producer BatchNorm + ReLU, fp16 planes: {e:.2e}')
+    assert e < 1e-6 and stat_err(stats_xf16, 0, refx) < 2e-7
+    yp = torch.full((B, (H + 1) // 2, (W + 1) // 2, Cout), float('nan'), device=dev)
+    launch(yp, flags=_lib.CONV_POOL2 | _lib.CONV_F16_OK, pool_sign=torch.ones(Cout, device=dev), **xf)
+    assert torch.equal(yp, F.max_pool2d(y_xf16.permute(0, 3, 1, 2), 2, 2, 0, ceil_mode=True).permute(0, 2, 3, 1))
 
     # ---- pooled-raw epilogue: max / min by the sign of the consumer BatchNorm's weight, batch sums of the FULL map -------------------------
     gamma = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))

@@ -25,15 +25,16 @@ pytestmark = pytest.mark.gpu
 _cache = {}
 
 
-def run_worker(mode):
-    if mode not in _cache:
+def run_worker(mode, f16ok=False):
+    key = (mode, f16ok)
+    if key not in _cache:
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'wino_x6_worker.py')], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, GSSD_WINO_X6=mode))
+                           env=dict(os.environ, GSSD_WINO_X6=mode, WX6_TEST_F16OK='1' if f16ok else '0'))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('WINOX6JSON ')][-1]
-        _cache[mode] = json.loads(line[len('WINOX6JSON '):])
-        assert _cache[mode]['mode'] == mode
-    return _cache[mode]
+        _cache[key] = json.loads(line[len('WINOX6JSON '):])
+        assert _cache[key]['mode'] == mode
+    return _cache[key]
 
 
 def x6_can_take(case):
@@ -42,8 +43,11 @@ def x6_can_take(case):
     return (Cin // g) % 16 == 0 and Cout // g >= 24
 
 
-def test_conv_winograd_x6_every_form_vs_float64_and_fp32_kernel():
-    x6, f32 = run_worker('2'), run_worker('0')
+@pytest.mark.parametrize('f16ok', [False, True], ids=['bf16_planes', 'fp16_planes'])
+def test_conv_winograd_x6_every_form_vs_float64_and_fp32_kernel(f16ok):
+    """f16ok: every forward launch carries GSSD_CONV_F16_OK -- the kernel's two-plane fp16 form (round 6: what a train-mode forward runs); the data
+    gradients keep the three bf16 planes either way."""
+    x6, f32 = run_worker('2', f16ok), run_worker('0')
     assert len(x6['results']) == len(f32['results']) >= 11
     lines = []
     for a, b in zip(x6['results'], f32['results']):
@@ -73,7 +77,7 @@ def test_conv_winograd_x6_every_form_vs_float64_and_fp32_kernel():
     assert taken >= 70, taken
     d = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(d):
-        with open(os.path.join(d, 'wino_x6_forms.txt'), 'w') as f:
+        with open(os.path.join(d, 'wino_x6_forms_fp16.txt' if f16ok else 'wino_x6_forms.txt'), 'w') as f:
             f.write('\n'.join(lines) + '\n')
 
 
@@ -104,7 +108,7 @@ def test_conv_winograd_x6_default_host_rule(case):
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
     sc, sh = scv.to(dev), shv.to(dev)
     d, _, _ = ops.make_conv_desc(xd, wp, y, B=B, H=H, W=H, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=g, k=3, pad=1, bias=b.to(dev), wgt_wino=U,
-                                 stats=stats, in_scale=sc, in_shift=sh, in_pad=(-sh / sc - 1.0))
+                                 stats=stats, in_scale=sc, in_shift=sh, in_pad=(-sh / sc - 1.0), flags=_lib.CONV_F16_OK)      # (as a train-mode forward flags it)
     assert _lib.lib.gssd_conv_wino_x6_takes(C.byref(d)) == 1
     ops.run_conv(d)
     e = float((y.cpu().double() - ref).abs().max() / ref.abs().max())

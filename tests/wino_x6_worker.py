@@ -59,6 +59,8 @@ def main():
         kw = dict(B=B, H=H, W=W, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=g, k=3, stride=1, pad=1, bias=b.to(dev), wgt_wino=U)
 
         def launch(inp, o, **extra):
+            # WX6_TEST_F16OK=1: every forward launch carries GSSD_CONV_F16_OK (the fp16-plane form of the kernel; the data gradients never do)
+            extra['flags'] = extra.get('flags', 0) | (_lib.CONV_F16_OK if os.environ.get('WX6_TEST_F16OK') == '1' else 0)
             d, _, _ = ops.make_conv_desc(inp, wp, o, **{**kw, **extra})
             takes = int(lib.gssd_conv_wino_x6_takes(C.byref(d)))
             _lib.check(lib.gssd_conv2d_nhwc_f32(C.byref(d), st))
@@ -142,7 +144,7 @@ def main():
                 torch.cuda.synchronize()
                 record('dgrad_resid' if with_resid else 'dgrad', dx, dref + existing.double() if with_resid else dref, takes)
         res.append(out)
-    print('WINOX6JSON ' + json.dumps(dict(mode=os.environ.get('GSSD_WINO_X6', ''), results=res)))
+    print('WINOX6JSON ' + json.dumps(dict(mode=os.environ.get('GSSD_WINO_X6', ''), f16ok=os.environ.get('WX6_TEST_F16OK', ''), results=res)))
 
 
 if __name__ == '__main__':
