@@ -52,3 +52,7 @@ f=$(find $R/gpurun_out/${tag}_prof_fsb -name '*kernel_trace.csv' | head -1)
 python3 bench.py --detail gpurun_out/${tag}_gssd_b32_bf16_fullstep_detail.json --config gssd --dtype bf16 --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --full-step 8 > gpurun_out/${tag}_gssd_b32_bf16_fullstep.json 2>> gpurun_out/${tag}_bench.err
 GSSD_BWD_BF16=0 python3 bench.py --detail gpurun_out/${tag}_gssdpp_b32_bf16_fullstep_round3_backward_detail.json --dtype bf16 --steps 20 --warmup 5 --steady 0 --cpu-sample 0 --no-input-stage --no-secondary --no-events --full-step 8 > gpurun_out/${tag}_gssdpp_b32_bf16_fullstep_round3_backward.json 2>> gpurun_out/${tag}_bench.err
 python3 scripts/bench_wgrad_bf16.py > gpurun_out/${tag}_wgrad_bf16.txt 2>/dev/null
+# the driver's own command line
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail gpurun_out/${tag}_driver_command_bench_detail.json > gpurun_out/${tag}_driver_command_bench.json 2>/dev/null
+# keep the merge small: the raw rocprofv3 output directories stay on the box
+rm -rf gpurun_out/${tag}_prof_* gpurun_out/${tag}_cp_*
