@@ -84,9 +84,11 @@ def _roof(r, note=True):
     out = _pick(r, ROOF_KEYS)
     if r.get('source'):
         out['measured'] = ('HIP events inside the timed region' if 'inside the timed region' in r['source'] else
-                           'HIP events in a pass of its own behind the timed region' if 'of their own' in r['source'] else 'survey passes')
+                           'HIP event nodes inside the hipGraph, replays of their own behind the timed region' if 'of their own' in r['source'] else 'survey passes')
     if note and r.get('note'):
         out['note'] = str(r['note'])[:160]
+    if r.get('alone'):
+        out['alone'] = _pick(r['alone'], ('avg_launch_us', 'frac', 'useful_frac'))
     if r.get('next'):
         out['next'] = [_pick(q, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'ms_per_step', 'avg_launch_us')) for q in r['next']]
     return out
@@ -222,7 +224,18 @@ def cpu_baseline(cfg_name, sample_b, seed, twin=None):
 
 
 class EventList(list):
-    only = None
+    only = None       # kernel instances bracketed by HIP events around EAGER launches (the plan's hipGraph is cut around them)
+    nodes = None      # kernel instances bracketed by event-record NODES inside the replayed hipGraph (gssd/plan_exec.py::NodeEvent)
+
+
+class _Ms:
+    """a time stamp in ms with torch.cuda.Event's elapsed_time(): samples read from graph event nodes right after their replay"""
+
+    def __init__(self, ms):
+        self.ms = ms
+
+    def elapsed_time(self, other):
+        return other.ms - self.ms
 
 
 def aggregate(evs):
@@ -372,7 +385,7 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             prime = None
             if ev is not None:
                 prime = EventList()
-                prime.only = ev.only
+                prime.only, prime.nodes = ev.only, ev.nodes
             net.__dict__['_events'] = prime
             step()
         torch.cuda.synchronize()
@@ -386,11 +399,22 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
     dt = time.perf_counter() - t0
     net.__dict__['_events'] = None
     if events is not None and not inside:
+        # event-record nodes INSIDE the step's hipGraph (round 6): the launches keep their place in the graph and their neighbours on the other
+        # branches -- the same conditions as the timed region and as a rocprofv3 trace of it (bracketing them eagerly cut the graph around every
+        # launch and timed each one ALONE: conv_x6<128> 97 us against 147 us in the trace).  The nodes hold the last replay's times: every replay
+        # of this pass is followed by a sync and a read.
+        events.only, events.nodes = None, {top}
         primed(events)
+        samples = EventList()
         for _ in range(a.steps):
+            ev = EventList()
+            ev.nodes = {top}
+            net.__dict__['_events'] = ev
             step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            samples.extend((tag, _Ms(0.0), _Ms(e0.elapsed_time(e1))) for tag, e0, e1 in ev)
         net.__dict__['_events'] = None
+        events = samples
     per_rank = [round(1e3 * t / a.steps, 3) for t in gd.gather_over_ranks(dt, dev)]
     loss = (float(ll), float(lc))
     if not all(map(lambda v: v == v and abs(v) != float('inf'), loss)):
@@ -480,8 +504,14 @@ def measure(cfg, a, dev, gd, rank, world, dtype='f32'):
             return roof
         dom = max(agg, key=lambda k: agg[k][1])
         roof = make_roof(dom, agg[dom], 'HIP events around every launch of this instance inside the timed region' if inside else
-                         f'HIP events around every launch of this instance in {a.steps} steps of their own right behind the timed region '
-                         f'({sagg[dom][0] // 2} launches per step: bracketing them inside the region would cut its hipGraph that many times)')
+                         f'HIP event-record nodes around every launch of this instance INSIDE the replayed hipGraph, in {a.steps} steps of their own right '
+                         f'behind the timed region ({sagg[dom][0] // 2} launches per step; each replay followed by a sync that reads the nodes)')
+        if not inside and dom in sagg:
+            # the same launches timed ALONE (eager survey passes: nothing else on the chip) beside the in-graph figure: inside the step's graph a
+            # launch shares the CUs with the other branches' kernels, so its own duration -- what rocprofv3 reports too -- is longer
+            alone = make_roof(dom, sagg[dom], 'untimed survey passes')
+            roof['alone'] = dict(avg_launch_us=alone['avg_launch_us'], frac=alone['frac'], useful_frac=alone.get('useful_frac'),
+                                 note='every launch bracketed eagerly, nothing else running')
         roof['next'] = [make_roof(k, sagg[k], 'untimed survey passes') for k in (runner_up or []) if k in sagg]
     # the HBM-side companion of `roofline`: the heaviest of the byte-bound trunk layers (the patch-staged thin kernels of conv1_1 ..
     # conv2_2: arithmetic intensity below the ridge in both storage modes), from the untimed survey passes' per-launch HIP events

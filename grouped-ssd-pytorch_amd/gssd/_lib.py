@@ -58,6 +58,10 @@ CONV_OUT_F32, CONV_OUTB_BF16_PERM32, CONV_HEADS_SLICES, CONV_POOL2, CONV_RESID_F
 # name -> (restype, argtypes); mirrors include/gssd_hip.h one to one
 SIGNATURES = {
     'gssd_abi_version': (c_i, []),
+    'gssd_event_create': (c_i, [C.POINTER(C.c_void_p)]),
+    'gssd_event_destroy': (c_i, [c_fp]),
+    'gssd_event_record_node': (c_i, [c_fp, c_fp]),
+    'gssd_event_elapsed_ms': (c_i, [c_fp, c_fp, C.POINTER(C.c_float)]),
     'gssd_conv_desc_size': (c_i, []),
     'gssd_last_error': (C.c_char_p, []),
     'gssd_build_arch': (C.c_char_p, []),

@@ -64,6 +64,7 @@ int plan_thunk(const uint64_t* a, gssd_stream_t s) {
 
 #define GSSD_PLAN_FN(f) PlanFn{#f, plan_nargs(&f), &plan_thunk<&f>}
 const PlanFn g_plan_fns[] = {
+    GSSD_PLAN_FN(gssd_event_record_node),
     GSSD_PLAN_FN(gssd_pack_input_nhwc),
     GSSD_PLAN_FN(gssd_unpack_nhwc_to_nchw),
     GSSD_PLAN_FN(gssd_pack_conv_weight),

@@ -40,6 +40,16 @@ const char* gssd_last_error(void);
 /* name of the GPU architecture the library was built for ("gfx950") */
 const char* gssd_build_arch(void);
 
+/* Timing events that survive hipGraph capture (round 6, ABI 8): gssd_event_record_node() records `ev` on `stream`; under stream capture it becomes
+ * an event-record NODE of the graph (hipEventRecordExternal), so a caller that replays its step from a hipGraph can still time single launches
+ * INSIDE the replay, beside whatever runs on the graph's other branches -- bench.py's roofline measurement of kernels launched many times per
+ * step.  After a replay has finished, gssd_event_elapsed_ms() gives the time between two of them in that replay. */
+typedef void* gssd_event_t; /* hipEvent_t */
+int gssd_event_create(gssd_event_t* ev);
+int gssd_event_destroy(gssd_event_t ev);
+int gssd_event_record_node(gssd_event_t ev, gssd_stream_t stream);
+int gssd_event_elapsed_ms(gssd_event_t start, gssd_event_t stop, float* ms);
+
 /* ------------------------------------------------------------------------------------------
  * Layout packing
  * ------------------------------------------------------------------------------------------ */
