@@ -224,7 +224,7 @@ int gssd_l2norm_bf16(const void* x, const float* weight, void* out, int64_t pixe
  * Winograd shapes: cin_g % 16 == 0 and cout_g % 32 == 0, or (one group) any cout_g >= 24 -- U's rows per group are then
  * padded with zeros to a multiple of the kernel's channel block; gssd_winograd_weight_elems (HOST) returns the float
  * count of the buffer the packer fills, or -1 for other shapes: the fp32 U followed -- for the shapes csrc/conv_wino_x6.hip takes
- * (cin_g % 16 == 0, cout_g >= 24) -- by U's three bf16 planes in that kernel's staging order (two bf16 per counted float).  The same packer serves the data gradient (weights packed by
+ * (cin_g % 16 == 0, cout_g >= 24) -- by U's three bf16 planes and, round 6, its two fp16 planes (h and (v - h) * 2048: the GSSD_CONV_F16_OK form) in that kernel's staging order (two 16-bit values per counted float).  The same packer serves the data gradient (weights packed by
  * gssd_pack_conv_weight_dgrad). */
 long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g);
 int gssd_winograd_weight_f32(const float* w_packed, float* U, int Cout, int groups, int cin_g, int row_stride,
