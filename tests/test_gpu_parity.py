@@ -607,6 +607,25 @@ def test_graph_replay_equals_eager(dev, name):
         torch.cuda.synchronize()
         assert len(ev) == 1 and ev[0][1].elapsed_time(ev[0][2]) > 0 and len(plan._graphs) == 3
         assert rel(o6[0], r6[0]) < 1e-6 and rel(o6[1], r6[1]) < 1e-6
+        # round 6: event-record NODES inside the replayed graph (gssd_event_record_node; bench.py's measurement of kernels launched many times per
+        # step): nothing is cut out of the graph, every launch of the named instances gets a (start, stop) pair that holds the last replay's times
+        tags = sorted({st.tag[0] for st in plan.steps if st.tag is not None and st.tag[0].startswith('conv_igemm')})
+        n_launch = sum(1 for st in plan.steps if st.tag is not None and st.tag[0] in tags[:2])
+
+        class EN(list):
+            only, nodes = None, set(tags[:2])
+        for _ in range(2):
+            ev = EN()
+            net.__dict__['_events'] = ev
+            with torch.no_grad():
+                o7 = net(x)
+                r7 = twin(x)
+            torch.cuda.synchronize()
+            ms = [e0.elapsed_time(e1) for _, e0, e1 in ev]
+            assert len(ev) == n_launch >= 2 and all(0 < t < 50 for t in ms), (len(ev), n_launch, ms)
+            assert rel(o7[0], r7[0]) < 1e-6 and rel(o7[1], r7[1]) < 1e-6
+        net.__dict__['_events'] = None
+        assert len(plan._graphs) == 4
 
 
 @pytest.mark.parametrize('name', ['gssdpp', 'vanilla'])
