@@ -266,3 +266,21 @@ def test_bench_stdout_line_is_short_and_parses(tmp_path):
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and len(r.stdout.strip().splitlines()) == 1 and len(last) < 8192
     assert json.loads(last)['value'] == full['value']
+
+
+def test_fp16_planes_are_flagged_only_for_train_mode_fp32_plans():
+    """gssd/plan_ops.py::PlanOpsMixin.f16_ok: GSSD_CONV_F16_OK goes on forward launches of a train-mode, fp32-mode plan only (batch-statistics
+    BatchNorm bounds the activations); eval mode, the bf16 storage mode and PixelLink's plan (a trunk without BatchNorm) never flag."""
+    from gssd import _lib
+    from gssd.plan_ops import PlanOpsMixin
+    from gssd.pixellink import _PlanPixelLink
+
+    class P(PlanOpsMixin):
+        def __init__(self, training, bf16):
+            self.training, self.bf16 = training, bf16
+    assert P(True, False).f16_ok == _lib.CONV_F16_OK == 32
+    assert P(False, False).f16_ok == 0 and P(True, True).f16_ok == 0 and P(False, True).f16_ok == 0
+    assert _PlanPixelLink.f16_ok == 0
+    # the header documents the promise the flag makes
+    hdr = open(os.path.join(ROOT, 'include', 'gssd_hip.h')).read()
+    assert '#define GSSD_CONV_F16_OK 32' in hdr and 'NEVER inferred' in hdr and 'gssd_dcn_forward_x6_ex' in hdr
