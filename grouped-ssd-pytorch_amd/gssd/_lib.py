@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [
         ('in_', c_fp), ('wgt', c_fp), ('bias', c_fp), ('out', c_fp), ('out_b', c_fp), ('alpha', c_fp),
         ('gate', c_fp), ('resid', c_fp), ('out2', c_fp), ('in_scale', c_fp), ('in_shift', c_fp), ('in_pad', c_fp),
-        ('stats', c_fp), ('wgt_wino', c_fp), ('pool_sign', c_fp), ('wgt_x6', c_fp),
+        ('stats', c_fp), ('wgt_wino', c_fp), ('pool_sign', c_fp), ('wgt_x6', c_fp), ('wgt_patch', c_fp),
         ('B', c_i), ('H', c_i), ('W', c_i), ('in_stride', c_i), ('in_ch_off', c_i), ('Ho', c_i), ('Wo', c_i),
         ('Cout', c_i), ('groups', c_i), ('cin_g', c_i), ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad', c_i),
         ('dil', c_i), ('K', c_i), ('wgt_row_stride', c_i), ('out_stride', c_i), ('out_ch_off', c_i),
@@ -148,6 +148,9 @@ SIGNATURES = {
     'gssd_dcn_packed_weight_elems_x6': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_x6': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_forward_x6': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    'gssd_conv_patch_x6_weight_elems': (C.c_longlong, [c_i, c_i]),
+    'gssd_conv_patch_x6_pack_weight': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    'gssd_conv_patch_x6_takes': (c_i, [C.POINTER(ConvDesc)]),
     'gssd_dcn_forward_x6_ex': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     'gssd_dcn_packed_weight_elems': (C.c_longlong, [c_i, c_i]),
     'gssd_dcn_pack_weight_f32': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),

@@ -90,6 +90,8 @@ int gssd_wino_x6_pack(const float* w_packed, void* Ux, int Cout, int groups, int
 bool gssd_wino_x6_enabled();                                             // GSSD_WINO_X6=0 switches it off
 bool gssd_wino_x6_wanted(const gssd_conv_desc& d);                        // the shapes it takes by default (GSSD_WINO_X6=2: all it can)
 int gssd_launch_conv_wino_x6(const gssd_conv_desc& d, const void* Ux, hipStream_t stream);
+// conv_patch_x6.hip: dense 3x3 convs with many input channels and <= 128 outputs, fp16 planes (GSSD_CONV_F16_OK launches with wgt_patch); else 1
+int gssd_try_conv_patch_x6(const gssd_conv_desc& d, hipStream_t stream);
 // conv_thin_x6.hip: conv1_2 / conv2_1 / conv2_2 shape classes on the bf16 matrix cores with three-plane operands; else returns 1
 int gssd_try_conv_thin_x6(const gssd_conv_desc& d, hipStream_t stream);
 // conv_thin_wino.hip: conv1_2's shape class (4 x 16 -> 16 channels, large map) with Winograd weights; else returns 1

@@ -435,6 +435,10 @@ extern "C" int gssd_conv2d_nhwc_f32(const gssd_conv_desc* dp, gssd_stream_t stre
     const int M = (int)Mll;
     const int cout_g = d.Cout / d.groups;
     hipStream_t s = as_stream(stream);
+    if (d.wgt_patch) {
+        const int rc = gssd_try_conv_patch_x6(d, s);  // many input channels, <= 128 outputs, GSSD_CONV_F16_OK: patch-staged direct conv on fp16 planes (round 6)
+        if (rc != 1) return rc;
+    }
     if (d.wgt_x6) {
         const int rc = gssd_try_conv_x6(d, s);        // fp32-equivalent products on the bf16 matrix cores (caller packed wgt_x6)
         if (rc != 1) return rc;

@@ -71,6 +71,7 @@ const PlanFn g_plan_fns[] = {
     GSSD_PLAN_FN(gssd_pack_conv_weights_batched),
     GSSD_PLAN_FN(gssd_conv2d_nhwc_f32),
     GSSD_PLAN_FN(gssd_conv_x6_pack_weight),
+    GSSD_PLAN_FN(gssd_conv_patch_x6_pack_weight),
     GSSD_PLAN_FN(gssd_conv2d_nhwc_bf16),
     GSSD_PLAN_FN(gssd_pack_conv_weight_bf16),
     GSSD_PLAN_FN(gssd_cast_f32_bf16),

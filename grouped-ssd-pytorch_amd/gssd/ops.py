@@ -163,7 +163,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
                    stats=None, alpha=None, gate=None, resid=None, out2=None, out_b=None, split_n=0,
                    m_per_image=False, in_batch_stride=0, wgt_batch_stride=0, out_batch_stride=0,
                    outb_batch_stride=0, out_off=0, outb_off=0, wgt_row_stride=None, split_k=1, in_scale=None,
-                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None, stats_rep=0, wgt_x6=None):
+                   in_shift=None, in_pad=None, wgt_wino=None, out_b_stride=0, flags=0, pool_sign=None, stats_rep=0, wgt_x6=None, wgt_patch=None):
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     K = k * k * cin_g
@@ -180,6 +180,7 @@ def make_conv_desc(inp, wgt, out, *, B, H, W, in_stride, cin_g, Cout, groups=1, 
     d.in_scale, d.in_shift, d.in_pad = _p(in_scale), _p(in_shift), _p(in_pad)
     d.wgt_wino = _p(wgt_wino)
     d.wgt_x6 = _p(wgt_x6)
+    d.wgt_patch = _p(wgt_patch)
     d.stats_rep = int(stats_rep)
     d.pool_sign = _p(pool_sign)
     d.out_b_stride = out_b_stride
@@ -241,6 +242,18 @@ def x6_weight(w_packed, groups, cin_g, taps, bn, out=None):
     return out
 
 
+def patch_x6_weight(w_packed, cin, out=None):
+    """Packed K-major fp32 weights [Cout][9*cin] -> the two fp16 planes of csrc/conv_patch_x6.hip (int16 tensor)."""
+    Cout = w_packed.shape[0]
+    if out is None:
+        n = int(lib.gssd_conv_patch_x6_weight_elems(Cout, cin))
+        if n <= 0:
+            raise _lib.GssdError(f'not a conv_patch_x6 shape: Cout {Cout}, cin {cin}')
+        out = torch.empty(n, device=w_packed.device, dtype=torch.int16)
+    check(lib.gssd_conv_patch_x6_pack_weight(_p(w_packed), _p(out), Cout, cin, w_packed.stride(0), _stream()))
+    return out
+
+
 def winograd_weight(w_packed, groups, cin_g, out=None):
     """Packed K-major 3x3 weights [Cout][9*cin_g] -> U[g][16][cout_pad][cin_g] (G g G^T)."""
     Cout = w_packed.shape[0]
@@ -253,7 +266,7 @@ def winograd_weight(w_packed, groups, cin_g, out=None):
     return out
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None, winograd=False, x6=False, _keep=None, **kw):
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=False, stats=None, winograd=False, x6=False, patch=False, _keep=None, **kw):
     """Convenience one-shot conv for tests: x NHWC [B,H,W,Cin], weight OIHW; returns NHWC."""
     _need_cuda(x, w_oihw)
     B, H, W, Cin = x.shape
@@ -265,12 +278,17 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=Fal
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     U = winograd_weight(wp, groups, cin_g) if winograd else None
     X6 = x6_weight(wp, groups, cin_g, k * k, x6_tile(Cout // groups, groups, B * Ho * Wo)) if x6 else None
+    if patch:
+        kw['wgt_patch'] = patch_x6_weight(wp, cin_g)
+        kw['flags'] = kw.get('flags', 0) | _lib.CONV_F16_OK | _lib.CONV_OUT_F32
     d, _, _ = make_conv_desc(x, wp, out, B=B, H=H, W=W, in_stride=Cin, cin_g=cin_g, Cout=Cout, groups=groups, k=k,
                              stride=stride, pad=pad, dil=dil, bias=bias, relu=relu, stats=stats, wgt_wino=U, wgt_x6=X6, **kw)
+    if patch and lib.gssd_conv_patch_x6_takes(C.byref(d)) != 1:
+        raise _lib.GssdError('conv2d_nhwc(patch=True): csrc/conv_patch_x6.hip does not take this descriptor')
     if x6 and lib.gssd_conv_x6_takes(C.byref(d)) != 1:
         raise _lib.GssdError('conv2d_nhwc(x6=True): csrc/conv_x6.hip does not take this descriptor')
     if _keep is not None:
-        _keep.extend([d, wp, U, X6, out])
+        _keep.extend([d, wp, U, X6, out, kw.get('wgt_patch')])
         return d
     run_conv(d)
     return out

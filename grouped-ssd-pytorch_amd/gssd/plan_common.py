@@ -16,6 +16,7 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
+USE_PATCH_X6 = os.environ.get('GSSD_PATCH_X6', '1') != '0'    # csrc/conv_patch_x6.hip for the DCN offset conv of a train-mode fp32 forward
 USE_CONV_X6 = os.environ.get('GSSD_CONV_X6', '1') != '0'      # csrc/conv_x6.hip for the launches ops.x6_wanted names (fp32 mode)
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
 # fp32 mode: the deformable conv on the bf16 matrix cores with three-plane (fp32-equivalent) operands, csrc/dcn_x6.hip;
@@ -68,6 +69,9 @@ def conv_tag(d, real_cin_g=None, bf16=False):
             and (d.out_mode == _lib.OUT_NHWC or (d.out_mode == _lib.OUT_SPLIT_T and d.split_n % 128 == 0))):
         inst = '256x128'                                 # csrc/conv_bf16.hip: opt-in experiment (measured slower, round 5)
     name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
+    if not bf16 and d.wgt_patch and lib.gssd_conv_patch_x6_takes(C.byref(d)) == 1:      # first in gssd_conv2d_nhwc_f32's dispatch order
+        M6 = d.B * d.Ho * d.Wo
+        return ('conv_patch_x6<128>', 2.0 * M6 * d.Cout * 9 * d.cin_g, 4.0 * (d.B * d.H * d.W * d.cin_g + M6 * d.Cout + d.Cout * 9 * d.cin_g))
     if not bf16 and d.wgt_x6 and lib.gssd_conv_x6_takes(C.byref(d)) == 1:
         M6 = d.B * d.Ho * d.Wo
         flops = 2.0 * M6 * d.Cout * d.KH * d.KW * d.cin_g

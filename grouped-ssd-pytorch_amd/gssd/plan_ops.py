@@ -6,7 +6,7 @@ import os
 import torch
 from . import _lib, ops
 from ._lib import lib
-from .plan_common import DCN_X6, HEAD_OFF, MBOX, SN_STREAM, USE_CONV_X6, USE_FLASH_X6, USE_WINOGRAD
+from .plan_common import DCN_X6, HEAD_OFF, MBOX, SN_STREAM, USE_CONV_X6, USE_FLASH_X6, USE_PATCH_X6, USE_WINOGRAD
 
 
 class PlanOpsMixin:
@@ -374,8 +374,14 @@ class PlanOpsMixin:
             def build_u(out, key=f'dcn_list.{li}.om.w', cin=Cin):
                 return ops.winograd_weight(eng._packed[key], 1, cin, out)
             u_om = eng._pack(f'dcn_list.{li}.om.U', build_u)
+        p_om = None
+        if self.f16_ok and USE_PATCH_X6 and lib.gssd_conv_patch_x6_weight_elems(27 * dg, Cin) > 0:
+            # train-mode fp32 forward: the patch-staged direct conv on fp16 planes (csrc/conv_patch_x6.hip: 1024 -> 108 channels, 483 -> 398 us)
+            def build_p(out, key=f'dcn_list.{li}.om.w', cin=Cin):
+                return ops.patch_x6_weight(eng._packed[key], cin, out)
+            p_om = eng._pack(f'dcn_list.{li}.om.px6', build_p)
         d1, _, _ = ops.make_conv_desc(x, w_om, om, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=27 * dg, k=3, pad=1, out_stride=OMC,
-                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om,
+                                      bias=m.conv_offset_mask.bias.detach(), wgt_wino=u_om, wgt_patch=p_om,
                                       flags=_lib.CONV_OUT_F32 | self.f16_ok)
         self._add(self.conv_fn, (C.byref(d1),), keep=d1)
         M = B * H * H

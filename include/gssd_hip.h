@@ -122,6 +122,9 @@ typedef struct gssd_conv_desc {
     const void* wgt_x6;    /* optional three-plane bf16 form of `wgt` (gssd_conv_x6_pack_weight, tile gssd_conv_x6_tile): plain-epilogue
                               convs with cin_g % 32 == 0 then run csrc/conv_x6.hip (fp32-equivalent products on the bf16 matrix cores,
                               see gssd_conv_x6_takes); NULL = never.  fp32 entry point only */
+    const void* wgt_patch; /* optional two fp16 planes of `wgt` in the order of csrc/conv_patch_x6.hip (gssd_conv_patch_x6_pack_weight): dense 3x3 /
+                              stride 1 / pad 1 convs with cin % 32 == 0 and <= 128 outputs (the DCN offset conv) that carry GSSD_CONV_F16_OK
+                              run there (gssd_conv_patch_x6_takes); NULL = never.  fp32 entry point only.  Round 6, ABI 8 */
     int B, H, W;        /* input geometry */
     int in_stride;      /* floats between consecutive input pixels */
     int in_ch_off;      /* first input channel used */
@@ -464,6 +467,11 @@ int gssd_dcn_forward_x6(const float* x, const float* om, const void* w_packed, c
                         int dg, int om_stride, int Cout, gssd_stream_t stream);
 /* the same with `flags`: GSSD_CONV_F16_OK = x, its bilinear samples and the weights lie inside fp16's range (see the flag) -> fp16 planes, three
  * MFMAs per product (w_packed holds both forms: 3 bf16 + 2 fp16 planes).  Round 6, ABI 8. */
+/* csrc/conv_patch_x6.hip (round 6): patch-staged direct 3x3 conv for many input channels and few (<= 128) outputs, fp16 planes (GSSD_CONV_F16_OK
+ * launches only).  weight_elems: 16-bit elements of the packed planes (-1: not a shape of the kernel); pack from the K-major fp32 rows. */
+long long gssd_conv_patch_x6_weight_elems(int Cout, int C);
+int gssd_conv_patch_x6_pack_weight(const float* w_packed, void* out, int Cout, int C, int row_stride, gssd_stream_t stream);
+int gssd_conv_patch_x6_takes(const gssd_conv_desc* d);
 int gssd_dcn_forward_x6_ex(const float* x, const float* om, const void* w_packed, const float* bias, float* out, int B, int H, int W, int C,
                            int dg, int om_stride, int Cout, int flags, gssd_stream_t stream);
 long long gssd_dcn_packed_weight_elems_bf16(int Cout, int C);

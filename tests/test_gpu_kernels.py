@@ -1046,6 +1046,31 @@ def test_conv_x6_epilogues_match_igemm(B, H, Cc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 19, 64, 108), (1, 38, 128, 24), (3, 9, 32, 128), (1, 17, 96, 36), (2, 8, 256, 4)])
+def test_conv_patch_x6_matches_float64(shape):
+    """csrc/conv_patch_x6.hip (round 6): the patch-staged direct 3x3 conv for many input channels and few outputs (the DCN offset conv, fp16 planes,
+    GSSD_CONV_F16_OK launches) is as close to a float64 convolution as the fp32-MFMA implicit GEMM -- ragged tiles in both directions (W = H + 3),
+    one to eight 32-channel chunks, output channel counts that end inside a 16-channel tile and inside a wave's 32, bias, ReLU."""
+    import torch.nn.functional as F
+    from gssd import ops
+    B, H, Cin, Cout = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, H + 3, Cin, generator=gen).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05).to(dev)
+    b = torch.randn(Cout, generator=gen).to(dev)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), 1, 1).permute(0, 2, 3, 1)
+    yp = ops.conv2d_nhwc(x, w, b, 1, 1, 1, 1, patch=True)
+    y32 = ops.conv2d_nhwc(x, w, b, 1, 1, 1, 1)
+    ep = float((yp.double() - ref).abs().max() / ref.abs().max())
+    e32 = float((y32.double() - ref).abs().max() / ref.abs().max())
+    print(f'conv_patch_x6 {shape}: {ep:.2e}; fp32-MFMA implicit GEMM {e32:.2e}')
+    assert torch.isfinite(yp).all() and ep < 2e-6 and ep <= 1.5 * e32 + 1e-7
+    yr = ops.conv2d_nhwc(x, w, b, 1, 1, 1, 1, patch=True, relu=True)
+    torch.testing.assert_close(yr, torch.relu(yp), rtol=0, atol=0)
+
+
+@pytest.mark.gpu
 def test_x6_kernels_bf16_planes():
     """GSSD_X6_F16=0: the x6 kernels' forward launches on the three bf16 planes (round 5's form, what the data gradients always run) -- the same
     kernel tests in a child process."""
