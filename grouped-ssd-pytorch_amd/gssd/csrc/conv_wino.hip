@@ -555,8 +555,11 @@ int launch_wino(const gssd_conv_desc& d, hipStream_t stream) {
 int gssd_try_conv_wino(const gssd_conv_desc& d, hipStream_t stream) {
     if (!d.wgt_wino) return 1;
     const int cout_g = d.Cout / d.groups;
+    // (GSSD_OUT_HEADS: only the form conv_wino_x6.hip takes -- one reduction slice, no batch sums / residual / pooling, both sides of split_n whole quads)
+    const bool heads = d.out_mode == GSSD_OUT_HEADS && d.out_b && d.split_k <= 1 && !d.stats && !d.resid && !(d.flags & GSSD_CONV_POOL2) &&
+                       d.split_n % 4 == 0 && (d.Cout - d.split_n) % 4 == 0 && gssd_wino_x6_plane_elems(cout_g, d.groups, d.cin_g) > 0 && gssd_wino_x6_wanted(d);
     const bool ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.cin_g % 16 == 0 && wino_nb(cout_g, d.groups) != 0 &&
-                    d.out_mode == GSSD_OUT_NHWC && !d.alpha && !d.gate && !d.out2 && !d.relu && d.split_k <= 1 && !d.m_per_image &&
+                    (d.out_mode == GSSD_OUT_NHWC || heads) && !d.alpha && !d.gate && !d.out2 && !d.relu && d.split_k <= 1 && !d.m_per_image &&
                     d.in_stride % 4 == 0 && d.in_ch_off % 4 == 0 && ((uintptr_t)d.wgt_wino % 16) == 0 &&
                     (long long)d.B * d.H * d.W * d.in_stride < (1ll << 30);     // 32-bit BYTE offsets into the input
     if (!ok) return 1;
@@ -590,8 +593,10 @@ extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g)
 extern "C" int gssd_conv_wino_x6_takes(const gssd_conv_desc* d) {
     if (!d || !d->wgt_wino || !gssd_wino_x6_enabled()) return 0;
     const int cout_g = d->Cout / d->groups;
+    const bool heads = d->out_mode == GSSD_OUT_HEADS && d->out_b && d->split_k <= 1 && !d->stats && !d->resid && !(d->flags & GSSD_CONV_POOL2) &&
+                       d->split_n % 4 == 0 && (d->Cout - d->split_n) % 4 == 0;
     const bool ok = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->cin_g % 16 == 0 && wino_nb(cout_g, d->groups) != 0 &&
-                    d->out_mode == GSSD_OUT_NHWC && !d->alpha && !d->gate && !d->out2 && !d->relu && d->split_k <= 1 && !d->m_per_image &&
+                    (d->out_mode == GSSD_OUT_NHWC || heads) && !d->alpha && !d->gate && !d->out2 && !d->relu && d->split_k <= 1 && !d->m_per_image &&
                     d->in_stride % 4 == 0 && d->in_ch_off % 4 == 0 && (long long)d->B * d->H * d->W * d->in_stride < (1ll << 30);
     if (!ok || ((d->flags & GSSD_CONV_POOL2) && (d->resid || !d->pool_sign))) return 0;
     return gssd_wino_x6_plane_elems(cout_g, d->groups, d->cin_g) > 0 && gssd_wino_x6_wanted(*d);

@@ -100,6 +100,10 @@ struct WinoX6Params {
     int ncb, nchunks, npairs, gx;
     int vec_ok;
     unsigned pad_off;
+    // GSSD_OUT_HEADS (round 6: the 38 x 38 multibox head): channels [0, split_n) -> out, the rest -> out_b, each at its source's offset inside an image's priors
+    float* out_b;
+    int heads, split_n;
+    long long out_bs, outb_bs, out_off, outb_off;
 };
 
 struct Step {                // a step = one 32-channel chunk of one item + the item's patch origin / validity mask of this lane's tile
@@ -387,12 +391,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) v[a][c2] = Y[a][c2][nb] + bia;
+                    // (GSSD_OUT_HEADS: this quad of channels lies on one side of split_n -- both sides are multiples of four)
+                    const int nq = n0 + nb * 16 + kq * 4;
+                    float* const obase = (p.heads && nq >= p.split_n) ? p.out_b : p.out;
                     auto put = [&](size_t o, const f32x4& val) {
-                        if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(p.out + o) = val;
+                        if (vec && nrem >= 4) *reinterpret_cast<f32x4*>(obase + o) = val;
                         else
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (j < nrem) p.out[o + j] = val[j];
+                                if (j < nrem) obase[o + j] = val[j];
                     };
                     if (EPI == 2) {
                         // GSSD_CONV_POOL2: a Winograd tile IS a pooling window; batch sums in the order of the unpooled epilogue
@@ -426,7 +433,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_x6_kernel(const WinoX6Params
 #pragma unroll
                             for (int c2 = 0; c2 < 2; ++c2) {
                                 if ((a == 1 && !y1) || (c2 == 1 && !x1)) continue;
-                                const size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
+                                size_t o = o00 + nb * 16 + ((size_t)a * p.W + c2) * p.out_stride;
+                                if (p.heads) {
+                                    const size_t pix = (size_t)(y + a) * p.W + x + c2;
+                                    o = nq < p.split_n ? (size_t)b * p.out_bs + p.out_off + pix * p.split_n + nq
+                                                       : (size_t)b * p.outb_bs + p.outb_off + pix * (p.Cout - p.split_n) + (nq - p.split_n);
+                                }
                                 f32x4 val = v[a][c2];
                                 if (EPI == 1) {
                                     if (vec && nrem >= 4) val += *reinterpret_cast<const f32x4*>(p.resid + o);
@@ -701,7 +713,15 @@ int launch_wino_x6_impl(const gssd_conv_desc& d, const u16* Ux, hipStream_t stre
     p.ncb = (p.cout_g + NB - 1) / NB;
     p.nchunks = (d.cin_g + 31) / 32;
     p.npairs = p.ncb * d.groups;
+    p.heads = d.out_mode == GSSD_OUT_HEADS;
+    p.out_b = d.out_b;
+    p.split_n = d.split_n;
+    p.out_bs = d.out_batch_stride;
+    p.outb_bs = d.outb_batch_stride;
+    p.out_off = d.out_off;
+    p.outb_off = d.outb_off;
     p.vec_ok = (((uintptr_t)d.out | (uintptr_t)d.bias | (uintptr_t)d.resid | (uintptr_t)p.pool_sign) & 15) == 0;
+    if (p.heads) p.vec_ok = p.vec_ok && (((uintptr_t)d.out_b & 15) == 0) && ((d.out_batch_stride | d.outb_batch_stride | d.out_off | d.outb_off | d.split_n | (d.Cout - d.split_n)) & 3) == 0;
     p.pad_off = PSEL ? 0u : wx6_pad_off(d);
     constexpr size_t smem = (2 * (size_t)XG * NPX * NB * 32 + 4 * (size_t)XG * NPX * 512) * sizeof(u16);      // two U stages + the planes of a block
     auto kern = conv_wino_x6_kernel<NBT, XF, EPI, PSEL, F16>;
@@ -780,6 +800,10 @@ bool gssd_wino_x6_wanted(const gssd_conv_desc& d) {
     if (mode == 0) return false;
     if (mode == 2) return true;
     const int cout_g = d.Cout / d.groups;
+    // the multibox head of a large map (round 6: 38 x 38, 24 = 16 loc | 8 conf channels of 512): flagged GSSD_CONV_F16_OK, 95 us against 173 us on the
+    // fp32-MFMA implicit GEMM with its split-K slices; the 19 x 19 head stays there (217 vs 178 us)
+    if (d.out_mode == GSSD_OUT_HEADS)
+        return (d.flags & GSSD_CONV_F16_OK) && d.groups == 1 && cout_g >= 24 && d.cin_g >= 32 && (long long)d.B * ((d.H + 1) / 2) * ((d.W + 1) / 2) >= 8192;
     // whole 64-channel blocks, or at least 80 % of the padded ones: the dense DCN offset conv (1024 -> 108 channels = two blocks with 20 padding
     // rows) lost with the first producers (651 vs 601 us) and wins since the pair-wise split: 527 vs 575 us (512 -> 108: 277 vs 316)
     const int padded = (cout_g + 63) / 64 * 64;

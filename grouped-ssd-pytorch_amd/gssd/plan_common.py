@@ -16,6 +16,7 @@ FUSE_NAMES = ['11', '21', '31', '41', '51', '61']
 
 # Winograd F(2x2,3x3) for the compute-bound 3x3 trunk layers (csrc/conv_wino.hip); GSSD_NO_WINOGRAD=1 keeps the direct
 # implicit GEMM everywhere (ablation / cross-check).
+USE_HEADS_WINO = os.environ.get('GSSD_HEADS_WINO', '1') != '0'  # the 38 x 38 multibox head of a train-mode fp32 forward on csrc/conv_wino_x6.hip
 USE_PATCH_X6 = os.environ.get('GSSD_PATCH_X6', '1') != '0'    # csrc/conv_patch_x6.hip for the DCN offset conv of a train-mode fp32 forward
 USE_CONV_X6 = os.environ.get('GSSD_CONV_X6', '1') != '0'      # csrc/conv_x6.hip for the launches ops.x6_wanted names (fp32 mode)
 USE_WINOGRAD = os.environ.get('GSSD_NO_WINOGRAD', '0') != '1'
@@ -91,8 +92,11 @@ def conv_tag(d, real_cin_g=None, bf16=False):
     elif (d.wgt_wino and ops.winograd_eligible(d.KH, d.stride, d.pad, d.dil, d.cin_g, cout_g, d.groups) and not d.m_per_image
           and d.split_k <= 1 and not d.relu):
         name = f'conv_wino<{64 if (cout_g % 64 == 0 or (cout_g % 32 != 0 and cout_g > 32)) else 32}>'   # gssd_try_conv_wino
+    igemm_name = ('conv_bf16<' if bf16 else 'conv_igemm<') + inst + '>'
     if name.startswith('conv_wino<') and lib.gssd_conv_wino_x6_takes(C.byref(d)) == 1:
         name = f'conv_wino_x6<{64 if cout_g > 32 else 32}>'      # csrc/conv_wino_x6.hip: the library's own host rule
+    elif name.startswith('conv_wino<') and d.out_mode == _lib.OUT_HEADS:
+        name = igemm_name                                        # (the fp32 Winograd kernel has no heads epilogue: gssd_try_conv_wino hands it on)
     if not bf16 and lib.gssd_conv_thin_x6_takes(C.byref(d)) == 1:
         name = f'conv_thin_x6<{d.cin_g},{cout_g}>'               # csrc/conv_thin_x6.hip: first in gssd_conv2d_nhwc_f32's dispatch order
     if name.startswith(('conv_wino<', 'conv_wino_x6<', 'conv_thin_x6<')):

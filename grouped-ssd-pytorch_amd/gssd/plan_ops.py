@@ -6,7 +6,7 @@ import os
 import torch
 from . import _lib, ops
 from ._lib import lib
-from .plan_common import DCN_X6, HEAD_OFF, MBOX, SN_STREAM, USE_CONV_X6, USE_FLASH_X6, USE_PATCH_X6, USE_WINOGRAD
+from .plan_common import DCN_X6, HEAD_OFF, MBOX, SN_STREAM, USE_CONV_X6, USE_FLASH_X6, USE_HEADS_WINO, USE_PATCH_X6, USE_WINOGRAD
 
 
 class PlanOpsMixin:
@@ -59,13 +59,22 @@ class PlanOpsMixin:
             return out
         wp = eng._pack(f'heads.{i}.w', build_w)
         bp = eng._pack(f'heads.{i}.b', build_b)
+        split = (ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K, target_blocks=256, max_split=8)
+                 if self.bf16 else ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K))
+        U = None
+        if (self.f16_ok and USE_WINOGRAD and USE_HEADS_WINO and nloc % 4 == 0 and nconf % 4 == 0 and B * ((Hs + 1) // 2) ** 2 >= 8192
+                and ops.winograd_eligible(3, 1, 1, 1, Cs, nloc + nconf, 1)):
+            # train-mode fp32 forward, large map (38 x 38 at batch >= 23): Winograd on fp16 planes with the heads' two-destination epilogue
+            # (csrc/conv_wino_x6.hip: 95 us against 173 us for the implicit GEMM and its two reduction slices); one slice
+            def build_u(out, key=f'heads.{i}.w', cin=Cs):
+                return ops.winograd_weight(eng._packed[key], 1, cin, out)
+            U = eng._pack(f'heads.{i}.U', build_u)
+            split = 1
         d, _, _ = ops.make_conv_desc(s, wp, None, B=B, H=Hs, W=Hs, in_stride=Cs, cin_g=Cs, Cout=nloc + nconf, k=3,
                                      pad=1, bias=bp, out_mode=_lib.OUT_HEADS, out_b=None, split_n=nloc,
                                      out_batch_stride=self.P * 4, outb_batch_stride=self.P * self.nc,
-                                     out_off=off * 4, outb_off=off * self.nc,
-                                     split_k=(ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K, target_blocks=256, max_split=8)
-                                              if self.bf16 else ops.auto_split_k(B * Hs * Hs, nloc + nconf, 1, K)),
-                                     flags=_lib.CONV_OUT_F32)
+                                     out_off=off * 4, outb_off=off * self.nc, split_k=split, wgt_wino=U,
+                                     flags=_lib.CONV_OUT_F32 | (self.f16_ok if U is not None else 0))
         self.head_descs.append(d)
         self._add(self.conv_fn, (C.byref(d),), keep=d)
         self.rec.append(('head', dict(i=i, src=s, H=Hs, C=Cs, A=A, off=off, loc=lw, conf=cw, K=K)))

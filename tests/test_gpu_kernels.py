@@ -1071,6 +1071,48 @@ def test_conv_patch_x6_matches_float64(shape):
 
 
 @pytest.mark.gpu
+def test_conv_wino_x6_heads_epilogue():
+    """csrc/conv_wino_x6.hip with GSSD_OUT_HEADS (round 6: the 38 x 38 multibox head of a train-mode forward): the merged loc | conf conv writes its
+    channels [0, split_n) into loc and the rest into conf, each at the source's offset inside an image's priors -- against the implicit GEMM's heads
+    epilogue on the same descriptor (and float64 on a slice).  >= 8 192 Winograd tiles and the GSSD_CONV_F16_OK flag are the host rule."""
+    import ctypes
+    import torch.nn.functional as F
+    from gssd import ops, _lib
+    lib = _lib.lib
+    dev = torch.device('cuda:0')
+    B, H, Cin, A, nc = 6, 75, 64, 4, 2
+    nloc, nconf = 4 * A, nc * A
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(B, H, H, Cin, generator=gen).to(dev)
+    w = (torch.randn(nloc + nconf, Cin, 3, 3, generator=gen) * 0.05).to(dev)
+    b = torch.randn(nloc + nconf, generator=gen).to(dev)
+    wp = ops.pack_weight(w)
+    U = ops.winograd_weight(wp, 1, Cin)
+    P = H * H * A + 40                                   # this source's priors sit behind 10 others' (40 = 10 x A)
+    res = {}
+    for tag in ('wino', 'igemm'):
+        loc = torch.full((B, P, 4), float('nan'), device=dev)
+        conf = torch.full((B, P, nc), float('nan'), device=dev)
+        d, _, _ = ops.make_conv_desc(x, wp, loc, B=B, H=H, W=H, in_stride=Cin, cin_g=Cin, Cout=nloc + nconf, k=3, pad=1, bias=b,
+                                     out_mode=_lib.OUT_HEADS, out_b=conf, split_n=nloc, out_batch_stride=P * 4, outb_batch_stride=P * nc,
+                                     out_off=10 * 4, outb_off=10 * nc, wgt_wino=U if tag == 'wino' else None,
+                                     flags=_lib.CONV_OUT_F32 | (_lib.CONV_F16_OK if tag == 'wino' else 0))
+        assert lib.gssd_conv_wino_x6_takes(ctypes.byref(d)) == (1 if tag == 'wino' else 0)
+        ops.run_conv(d)
+        torch.cuda.synchronize()
+        res[tag] = (loc, conf)
+    for a, c in zip(res['wino'], res['igemm']):
+        assert torch.equal(torch.isnan(a), torch.isnan(c))                 # the same elements written (the other sources' priors untouched)
+        m = ~torch.isnan(c)
+        assert float((a[m] - c[m]).abs().max() / c[m].abs().max()) < 2e-5
+    ref = F.conv2d(x[:1].double().permute(0, 3, 1, 2), w.double(), b.double(), 1, 1).permute(0, 2, 3, 1)      # [1, H, H, 24]
+    loc0 = res['wino'][0][0, 10:10 + H * H * A].reshape(H, H, nloc).double().cpu()
+    conf0 = res['wino'][1][0, 10:10 + H * H * A].reshape(H, H, nconf).double().cpu()
+    assert float((loc0 - ref[0, :, :, :nloc].cpu()).abs().max() / ref.abs().max()) < 2e-5
+    assert float((conf0 - ref[0, :, :, nloc:].cpu()).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_x6_kernels_bf16_planes():
     """GSSD_X6_F16=0: the x6 kernels' forward launches on the three bf16 planes (round 5's form, what the data gradients always run) -- the same
     kernel tests in a child process."""
