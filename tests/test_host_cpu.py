@@ -24,7 +24,7 @@ def test_abi_exports_match_header():
         assert hasattr(raw, name), name
     assert _lib.lib.gssd_abi_version() == 8 and _lib.lib.gssd_build_arch() == b'gfx950'
     # struct layout agrees with the header's field order / C packing rules
-    assert ctypes.sizeof(_lib.ConvDesc) == 16 * 8 + 27 * 4 + 4 + 6 * 8 == _lib.lib.gssd_conv_desc_size()   # (27 ints + 4 bytes of padding)
+    assert ctypes.sizeof(_lib.ConvDesc) == 17 * 8 + 27 * 4 + 4 + 6 * 8 == _lib.lib.gssd_conv_desc_size()   # (17 pointers since wgt_patch; 27 ints + 4 bytes of padding)
     assert ctypes.sizeof(_lib.SnItem) == 4 * 8 + 2 * 4
 
 
