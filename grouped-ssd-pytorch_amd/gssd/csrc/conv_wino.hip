@@ -593,7 +593,8 @@ extern "C" long long gssd_winograd_weight_elems(int Cout, int groups, int cin_g)
 extern "C" int gssd_conv_wino_x6_takes(const gssd_conv_desc* d) {
     if (!d || !d->wgt_wino || !gssd_wino_x6_enabled()) return 0;
     const int cout_g = d->Cout / d->groups;
-    const bool heads = d->out_mode == GSSD_OUT_HEADS && d->out_b && d->split_k <= 1 && !d->stats && !d->resid && !(d->flags & GSSD_CONV_POOL2) &&
+    const bool heads = d->out_mode == GSSD_OUT_HEADS && d->split_k <= 1      // (out / out_b may still be unset when a plan names its kernels)
+                       && !d->stats && !d->resid && !(d->flags & GSSD_CONV_POOL2) &&
                        d->split_n % 4 == 0 && (d->Cout - d->split_n) % 4 == 0;
     const bool ok = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->cin_g % 16 == 0 && wino_nb(cout_g, d->groups) != 0 &&
                     (d->out_mode == GSSD_OUT_NHWC || heads) && !d->alpha && !d->gate && !d->out2 && !d->relu && d->split_k <= 1 && !d->m_per_image &&

@@ -288,7 +288,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, dil=1, groups=1, relu=Fal
     if x6 and lib.gssd_conv_x6_takes(C.byref(d)) != 1:
         raise _lib.GssdError('conv2d_nhwc(x6=True): csrc/conv_x6.hip does not take this descriptor')
     if _keep is not None:
-        _keep.extend([d, wp, U, X6, out, kw.get('wgt_patch')])
+        _keep.extend([d, wp, U, X6, kw.get('wgt_patch'), out])           # (the output last: callers read keep[-1])
         return d
     run_conv(d)
     return out
