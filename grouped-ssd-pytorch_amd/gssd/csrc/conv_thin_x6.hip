@@ -606,6 +606,17 @@ static bool thin_x6_enabled() {
     return on;
 }
 
+// conv3_1 (32 -> 64 channels per group, 75 x 75; round 6, late): four waves = the group's four 16-channel output tiles; GSSD_THIN_X6_CONV31=0: conv_wino_x6
+// (fp16 planes only -- flagged launches: the three-plane bf16 instance of this shape spills)
+static bool thin_x6_conv31() {
+    static const bool on = [] {
+        const char* e = getenv("GSSD_THIN_X6_CONV31");
+        const char* f = getenv("GSSD_X6_F16");
+        return !(e && e[0] == '0') && !(f && f[0] == '0');
+    }();
+    return on;
+}
+
 static bool thin_x6_shape(const gssd_conv_desc& d) {
     const int cout_g = d.groups > 0 ? d.Cout / d.groups : 0;
     return d.groups == 4 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.dil == 1 && d.in_stride == 4 * d.cin_g && d.in_ch_off == 0 &&
@@ -613,7 +624,7 @@ static bool thin_x6_shape(const gssd_conv_desc& d) {
            !d.out2 && d.split_k <= 1 && d.wgt_row_stride == 9 * d.cin_g && d.H * d.W >= 75 * 75 && ((uintptr_t)d.out % 16) == 0 &&
            ((uintptr_t)d.in % 16) == 0 && ((uintptr_t)d.wgt % 16) == 0 && ((d.flags & ~GSSD_CONV_F16_OK) == 0 || ((d.flags & ~GSSD_CONV_F16_OK) == GSSD_CONV_POOL2 && d.pool_sign)) &&
            (long long)d.B * d.H * d.W * d.in_stride < (1ll << 31) &&
-           ((d.cin_g == 16 && (cout_g == 16 || cout_g == 32)) || (d.cin_g == 32 && cout_g == 32));
+           ((d.cin_g == 16 && (cout_g == 16 || cout_g == 32)) || (d.cin_g == 32 && (cout_g == 32 || (cout_g == 64 && (d.flags & GSSD_CONV_F16_OK) && thin_x6_conv31()))));
 }
 
 extern "C" int gssd_conv_thin_x6_takes(const gssd_conv_desc* d) { return d && thin_x6_enabled() && thin_x6_shape(*d) ? 1 : 0; }
@@ -630,6 +641,7 @@ int gssd_try_conv_thin_x6(const gssd_conv_desc& d, hipStream_t stream) {
     TX6_CASE(16, 16)
     TX6_CASE(16, 32)
     TX6_CASE(32, 32)
+    TX6_CASE(32, 64)
 #undef TX6_CASE
     return 1;
 }

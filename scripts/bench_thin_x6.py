@@ -10,7 +10,7 @@ from gssd import ops, _lib
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 g = torch.Generator().manual_seed(3)
-for name, H, Cin, Cout, pool in (('conv1_2', 300, 64, 64, True), ('conv2_1', 150, 64, 128, False), ('conv2_2', 150, 128, 128, True)):
+for name, H, Cin, Cout, pool in (('conv1_2', 300, 64, 64, True), ('conv2_1', 150, 64, 128, False), ('conv2_2', 150, 128, 128, True), ('conv3_1', 75, 128, 256, False)):
     x = torch.randn(B, H, H, Cin, generator=g).to(dev)
     w = (torch.randn(Cout, Cin // 4, 3, 3, generator=g) * 0.1).to(dev)
     b = torch.randn(Cout, generator=g).to(dev)

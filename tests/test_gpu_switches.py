@@ -89,6 +89,8 @@ SWITCHES = [
     ('f32', {'GSSD_TX6_DYNAMIC': '0'}, lambda o, base: has(o, 'conv_thin_x6')),
     # the 38 x 38 multibox head on the implicit GEMM with reduction slices instead of conv_wino_x6's heads epilogue (>= 8 192 Winograd tiles: batch 24)
     ('f32', {'GSSD_HEADS_WINO': '0', 'BATCH': 24}, lambda o, base: has(o, 'conv_igemm<128x32>') and has(base, 'conv_wino_x6<32>')),
+    # conv3_1 on the Winograd kernels instead of conv_thin_x6<32,64>
+    ('f32', {'GSSD_THIN_X6_CONV31': '0'}, lambda o, base: has(base, 'conv_thin_x6<32,64>') and not has(o, 'conv_thin_x6<32,64>')),
     # the DCN offset conv on conv_wino_x6 / conv_wino instead of the patch-staged direct conv on fp16 planes (csrc/conv_patch_x6.hip)
     ('f32', {'GSSD_PATCH_X6': '0'}, lambda o, base: not has(o, 'conv_patch_x6') and has(base, 'conv_patch_x6')),
     # the x6 kernels' forward launches on three bf16 planes / six MFMAs (round 5's form) instead of the fp16 planes / three MFMAs; and the attention

@@ -140,6 +140,56 @@ def test_conv_thin_x6_forms_vs_float64(case):
         assert rel(yp.cpu(), pool_by_sign(r64)) < 1e-6, name
 
 
+@pytest.mark.parametrize('case', [(2, 75, 75), (1, 83, 90)])
+def test_conv_thin_x6_conv3_1_class(case):
+    """conv3_1's shape class (4 x 32 -> 64 channels, round 6): taken only with GSSD_CONV_F16_OK (its three-plane bf16 instance spills) -- plain, with the
+    fused producer BatchNorm + ReLU, batch sums, pooled epilogue -- against float64 and the fp32 Winograd / implicit-GEMM kernels."""
+    from gssd import ops, _lib
+    lib = _lib.lib
+    B, H, W = case
+    Cin, Cout, g = 128, 256, 4
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(sum(case))
+    x = torch.from_numpy(rng.normal(0.1, 1.0, size=(B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, size=(Cout, Cin // g, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = ops.pack_weight(w.to(dev))
+    kw = dict(B=B, H=H, W=W, in_stride=Cin, cin_g=Cin // g, Cout=Cout, groups=g, k=3, stride=1, pad=1, bias=b.to(dev))
+    n_px = B * H * W
+
+    def launch(o, expect, **extra):
+        d, _, _ = ops.make_conv_desc(xd, wp, o, **{**kw, **extra})
+        assert lib.gssd_conv_thin_x6_takes(C.byref(d)) == expect
+        _lib.check(lib.gssd_conv2d_nhwc_f32(C.byref(d), st))
+        torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1, 1, g).permute(0, 2, 3, 1).contiguous()
+    y32 = torch.empty(B, H, W, Cout, device=dev)
+    launch(y32, 0)                                                     # unflagged: the fp32-MFMA implicit GEMM
+    y = torch.full((B, H, W, Cout), float('nan'), device=dev)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    launch(y, 1, stats=stats, flags=_lib.CONV_F16_OK)
+    e6, e32 = rel(y.cpu(), ref), rel(y32.cpu(), ref)
+    print(f'{case} conv3_1 class: thin_x6 {e6:.2e}; implicit GEMM {e32:.2e}')
+    assert torch.isfinite(y).all() and e6 < 1e-6 and e6 <= 1.5 * e32 + 1e-7
+    s = stats.cpu()
+    assert float((s[:Cout] - ref.sum((0, 1, 2))).abs().max() / (n_px * float(ref.abs().max()))) < 2e-7
+    assert float((s[Cout:] - (ref * ref).sum((0, 1, 2))).abs().max() / (n_px * float(ref.abs().max()) ** 2)) < 2e-7
+    scv = torch.from_numpy(rng.uniform(0.2, 1.5, size=Cin).astype(np.float32)) * torch.from_numpy(rng.choice([-1.0, 1.0], size=Cin).astype(np.float32))
+    shv = torch.from_numpy(rng.normal(size=Cin).astype(np.float32))
+    pdv = torch.where(scv > 0, torch.full_like(scv, -3.0e38), torch.full_like(scv, 3.0e38))
+    act64 = torch.relu(torch.addcmul(shv.double().view(1, -1, 1, 1), x.double(), scv.double().view(1, -1, 1, 1)))
+    refx = F.conv2d(act64, w.double(), b.double(), 1, 1, 1, g).permute(0, 2, 3, 1).contiguous()
+    xf = dict(in_scale=scv.to(dev), in_shift=shv.to(dev), in_pad=pdv.to(dev))
+    yx = torch.full((B, H, W, Cout), float('nan'), device=dev)
+    launch(yx, 1, flags=_lib.CONV_F16_OK, **xf)
+    assert rel(yx.cpu(), refx) < 1e-6
+    yp = torch.full((B, (H + 1) // 2, (W + 1) // 2, Cout), float('nan'), device=dev)
+    launch(yp, 1, flags=_lib.CONV_POOL2 | _lib.CONV_F16_OK, pool_sign=torch.ones(Cout, device=dev), **xf)
+    assert torch.equal(yp, F.max_pool2d(yx.permute(0, 3, 1, 2), 2, 2, 0, ceil_mode=True).permute(0, 2, 3, 1))
+
+
 def test_round5_kernels_of_these_layers_still_pass_with_the_switch_off():
     """GSSD_THIN_X6=0 (the switch row of tests/test_gpu_switches.py runs a whole training step in that mode): the kernel-level tests of
     conv_thin_wino.hip / conv_wino.hip<32> / conv_thin.hip on the shapes this kernel now takes by default."""
