@@ -14,9 +14,11 @@ class PlanOpsMixin:
     def f16_ok(self):
         """_lib.CONV_F16_OK for the forward launches of an fp32-mode, TRAIN-mode network, else 0: train-mode BatchNorm (batch statistics) bounds every
         activation map by |gamma| sqrt(n) + |beta|, far inside fp16's range, so the split-operand kernels may use their fp16 planes (three MFMAs per
-        product).  Eval mode normalises with running statistics, which bound nothing (tests/test_gpu_pixellink.py's synthetic eval graph reaches
+        product).  Eval mode normalises with running statistics, which bound nothing, and so does a graph built with batch_norm=False (tests/test_gpu_pixellink.py's synthetic eval graph reaches
         1e12): those launches keep the bf16 planes (include/gssd_hip.h: GSSD_CONV_F16_OK)."""
-        return _lib.CONV_F16_OK if (not getattr(self, 'bf16', False) and getattr(self, 'training', False)) else 0
+        net = getattr(getattr(self, 'eng', None), 'net', None)
+        bn = bool(getattr(net, 'batch_norm', False))          # (a graph without BatchNorm -- batch_norm=False, the vanilla SSD -- bounds nothing either)
+        return _lib.CONV_F16_OK if (bn and not getattr(self, 'bf16', False) and getattr(self, 'training', False)) else 0
 
     def _conv_act(self, name, conv, x, H, Cin, groups):
         """(grouped) conv + bias + ReLU in ONE launch (ReLU in the conv epilogue): the batch_norm=False layers."""

@@ -275,11 +275,15 @@ def test_fp16_planes_are_flagged_only_for_train_mode_fp32_plans():
     from gssd.plan_ops import PlanOpsMixin
     from gssd.pixellink import _PlanPixelLink
 
+    import types
+
     class P(PlanOpsMixin):
-        def __init__(self, training, bf16):
+        def __init__(self, training, bf16, batch_norm=True):
             self.training, self.bf16 = training, bf16
+            self.eng = types.SimpleNamespace(net=types.SimpleNamespace(batch_norm=batch_norm))
     assert P(True, False).f16_ok == _lib.CONV_F16_OK == 32
     assert P(False, False).f16_ok == 0 and P(True, True).f16_ok == 0 and P(False, True).f16_ok == 0
+    assert P(True, False, batch_norm=False).f16_ok == 0
     assert _PlanPixelLink.f16_ok == 0
     # the header documents the promise the flag makes
     hdr = open(os.path.join(ROOT, 'include', 'gssd_hip.h')).read()
